@@ -1,0 +1,92 @@
+"""Cross-check of the oracle's hand-written forward/backward (oracle/net.py, oracle/layers.py)
+against an independent implementation: torch CPU float64 ops + autograd.  This is a sanity
+check of the restatement, not a reference pin (the reference ships no tests)."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from oracle import layers as L
+from oracle.net import TimeSlicedAttentionNet
+
+
+def torch_forward(net, params, x, y, seed, step):
+    """Same network written with torch.nn.functional (channels-first inside)."""
+    B = x.shape[0]
+    dt = torch.float64
+    xt = torch.from_numpy(x).to(dt)
+    xp = F.pad(xt, (10, 10))
+    frames = xp.unfold(1, 40, 20)                     # [B, 800, 40]
+    h = frames.permute(0, 2, 1)                       # [B, 40, 800]
+    W = params['conv1d_1/kernel']                     # [3, 40, 128]
+    h = F.conv1d(h, W.permute(2, 1, 0), stride=2)
+
+    def bn_relu6(h, idx):
+        g = params['batch_normalization_%d/gamma' % idx]
+        b = params['batch_normalization_%d/beta' % idx]
+        h = F.batch_norm(h, None, None, g, b, training=True, eps=1e-3)
+        return torch.clamp(h, 0, 6)
+    h = bn_relu6(h, 1)
+    for i, blk in enumerate(net.blocks):
+        w = params['depthwise_conv2d_%d/depthwise_kernel' % (i + 1)].reshape(3, blk['cin'])
+        hp = F.pad(h, blk['pad'])
+        h = F.conv1d(hp, w.t().unsqueeze(1), stride=blk['stride'], groups=blk['cin'])
+        Wp = params['conv1d_%d/kernel' % (i + 2)].reshape(blk['cin'], blk['cout'])
+        h = F.conv1d(h, Wp.t().unsqueeze(2))
+        h = bn_relu6(h, i + 2)
+    a = h.permute(0, 2, 1)                            # [B, T, C]
+    T, C = net.T, net.C
+    m1 = torch.from_numpy(L.dropout_mask(L.dropout_key(seed, step, 1), B * T * C, 0.6).reshape(B, T * C)).to(dt)
+    m2 = torch.from_numpy(L.dropout_mask(L.dropout_key(seed, step, 2), B * 2 * C, 0.6).reshape(B, 2 * C)).to(dt)
+    fd = a.reshape(B, T * C) * m1 / 0.6
+    att = torch.softmax(fd @ params['dense_1/kernel'] + params['dense_1/bias'], dim=1)
+    xa = a * att[:, :, None]
+    feat = torch.cat([xa.max(dim=1).values, a.mean(dim=1)], dim=1) * m2 / 0.6
+    p = torch.softmax(feat @ params['dense_2/kernel'], dim=1)
+    yt = torch.from_numpy(y).to(dt)
+    ysm = yt * 0.9 + 0.1 / y.shape[1]
+    logits = torch.log(torch.clamp(p, 1e-7, 1 - 1e-7))
+    loss = -(ysm * torch.log_softmax(logits, dim=1)).sum(dim=1).mean()
+    reg = sum(1e-5 * (v ** 2).sum() for k, v in params.items() if k.endswith('kernel'))
+    return p, loss, reg
+
+
+def test_param_count_matches_reference_readme_and_survey():
+    net = TimeSlicedAttentionNet()
+    assert net.count_params() == 1198601          # SURVEY B.1; README.md:14 "roughly 1.250.000"
+    assert sum(v.size for v in net.params.values()) == 1191433
+    assert [b['Lout'] for b in net.blocks] == [397, 199, 197, 99, 97, 49, 47, 24, 22, 11, 9]
+    assert net.blocks[9]['pad'] == (0, 1)          # right-biased SAME padding at L=22
+
+
+def test_oracle_grads_match_torch_autograd():
+    net = TimeSlicedAttentionNet(dtype=np.float64)
+    rng = np.random.RandomState(3)
+    # de-trivialise BN affine params so their gradients are exercised
+    for k in net.params:
+        if k.endswith('gamma'):
+            net.params[k] = (1.0 + 0.1 * rng.randn(*net.params[k].shape)).astype(np.float32)
+        if k.endswith('beta') or k.endswith('bias'):
+            net.params[k] = (0.1 * rng.randn(*net.params[k].shape)).astype(np.float32)
+    B = 3
+    x = (rng.randn(B, 16000) * 0.0774).astype(np.float64)
+    y = np.eye(12)[[2, 0, 7]]
+    loss, p, grads, _ = net.loss_and_grads(x, y, seed=11, step=5)
+    tparams = {k: torch.tensor(v.astype(np.float64), requires_grad=True) for k, v in net.params.items()}
+    pt, tloss, treg = torch_forward(net, tparams, x, y, 11, 5)
+    (tloss + treg).backward()
+    np.testing.assert_allclose(p, pt.detach().numpy(), rtol=1e-9, atol=1e-12)
+    assert abs(loss - tloss.item()) < 1e-10
+    assert abs(net.reg_loss() - treg.item()) < 1e-10
+    for k, g in grads.items():
+        tg = tparams[k].grad.numpy().reshape(g.shape)
+        scale = max(np.abs(tg).max(), 1e-12)
+        assert np.abs(g - tg).max() / scale < 1e-8, k
+
+
+def test_inference_uses_moving_stats():
+    net = TimeSlicedAttentionNet(dtype=np.float64)
+    x = np.random.RandomState(1).randn(2, 16000) * 0.05
+    p1 = net.forward(x, training=False)
+    p2 = net.forward(x[:1], training=False)
+    np.testing.assert_allclose(p1[:1], p2, rtol=1e-10)
+    np.testing.assert_allclose(p1.sum(axis=1), 1.0, rtol=1e-12)
