@@ -1,0 +1,229 @@
+/* libkws_hip.so - C ABI of the MI355X (gfx950) keyword-spotting hot path.
+ *
+ * The reference (see--/speech_recognition) has no FFI of its own: its hot path is Python that
+ * lowers to TensorFlow-1.4 / Keras-2.1.2 ops.  Each entry point below replaces the
+ * ops behind one reference call site, cited as file:line under the reference checkout.
+ *
+ * Conventions
+ *  - plain C, no exceptions across the ABI; every function returns 0 (KWS_OK) or a negative
+ *    KWS_E_* code; kws_last_error() returns a thread-local message for the last failure.
+ *  - every tensor argument is a raw DEVICE pointer owned by the caller (e.g. the data_ptr() of a
+ *    PyTorch-ROCm tensor); the library never frees or retains it.  Exceptions are the *_create
+ *    functions, whose table arguments are HOST pointers copied once into a plan.
+ *  - work is enqueued on `stream` (a hipStream_t passed as void*) and not synchronised.
+ *  - layout is channels-last row-major fp32 [B, L, C] (= Keras channels_last), so Keras-named
+ *    weights load without transposes: conv1d/kernel [k, Cin, Cout], depthwise_kernel [1,3,C,1],
+ *    dense/kernel [in, out].
+ *  - functions are re-entrant: no global mutable state besides the thread-local error string.
+ */
+#ifndef KWS_HIP_H_
+#define KWS_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KWS_OK 0
+#define KWS_E_INVALID (-1)   /* bad argument / unsupported shape */
+#define KWS_E_HIP (-2)       /* a HIP runtime call failed */
+#define KWS_E_WORKSPACE (-3) /* caller workspace too small */
+
+#define KWS_ABI_VERSION 1
+
+int kws_abi_version(void);
+const char* kws_last_error(void);
+/* name of the device the calling thread is bound to; "" if no HIP device is usable */
+int kws_device_name(char* buf, int cap);
+
+/* ------------------------------------------------------------------------------------------
+ * a2  augment graph: decode_wav -> multiply -> tf_roll -> multiply/add -> reshape
+ *     reference input_data.py:334-359, utils.py:56-73
+ *   out[b,t] = bg_vol[b] * noise[noise_off[b] + t] + fg_vol[b] * bank[clip_idx[b], (t - shift[b]) mod L]
+ * bank: [n_clips, L] resident clip bank (f32, or int16 PCM scaled by 1/32768 like DecodeWav).
+ * noise: 1-D concatenation of the background recordings (input_data.py:274-309); noise_off are
+ * absolute start samples (input_data.py:484-487); noise may be NULL when every bg_vol is 0.
+ * ---------------------------------------------------------------------------------------- */
+int kws_augment_f32(const float* bank, int64_t n_clips, int L, const int32_t* clip_idx,
+                    const float* fg_vol, const int32_t* shift, const float* noise,
+                    int64_t noise_len, const int64_t* noise_off, const float* bg_vol,
+                    float* out, int B, void* stream);
+int kws_augment_i16(const int16_t* bank, int64_t n_clips, int L, const int32_t* clip_idx,
+                    const float* fg_vol, const int32_t* shift, const float* noise,
+                    int64_t noise_len, const int64_t* noise_off, const float* bg_vol,
+                    float* out, int B, void* stream);
+
+/* a17 TTA transforms, reference make_submission.py:125-134.
+ * kind: 0 copy, 1 np.roll(X,-1500,axis=1), 2 1.2*X, 3 clip(1.1*X,-1,1), 4 0.9*X */
+int kws_tta_transform(const float* x, float* out, int B, int L, int kind, void* stream);
+/* mean of n_terms probability tensors / divisor, argmax; make_submission.py:137-146 */
+int kws_tta_combine(const float* const* probs, int n_terms, float divisor, float* out_probs,
+                    int32_t* out_argmax, int B, int C, void* stream);
+
+/* a18 32->12 head, reference freeze_graph_32_classes.py:55-69.
+ * map[i] in [0,12): output slot of input class i (slot 1 = max over all classes mapped to 1). */
+int kws_head32to12(const float* p_in, int C_in, const int32_t* map, int C_out, float* p_out,
+                   int B, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a3-a5  STFT -> |X| -> mel -> log -> DCT   (one table-driven kernel for both feature paths)
+ *     path B: reference input_data.py:361-381 (tf.contrib.signal.stft, abs, tensordot mel,
+ *             log(+1e-6), mfccs_from_log_mel_spectrograms[..., :K])
+ *     path A: reference audio.py:15-23 (audio_spectrogram magnitude_squared -> mfcc)
+ * Host tables (copied into the plan): window[frame_len], mel[n_bins * n_mel] row-major
+ * (n_bins = fft_len/2+1), dct[n_mel * n_out] row-major.  fft_len must be 512.
+ * out_kind: 0 = DCT features [B,F,n_out] (mfcc_), 1 = magnitude spectrogram [B,F,257]
+ * (spectrogram_, input_data.py:366), 2 = log-mel [B,F,n_mel].
+ * ---------------------------------------------------------------------------------------- */
+typedef struct kws_stft_plan kws_stft_plan_t;
+int kws_stft_plan_create(int frame_len, int frame_step, int fft_len, int n_mel, int n_out,
+                         const float* window, const float* mel, const float* dct,
+                         float log_offset, float log_floor, kws_stft_plan_t** plan);
+int kws_stft_plan_destroy(kws_stft_plan_t* plan);
+int kws_stft_num_frames(const kws_stft_plan_t* plan, int L);
+int kws_stft_mel_f32(const kws_stft_plan_t* plan, const float* x, int B, int L, float* out,
+                     int out_kind, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a7+a8, a10  GEMM family on f32 MFMA (v_mfma_f32_32x32x2_f32)
+ *   C[M,N] = A[M,K] * W[K,N]          pointwise Conv1D(1x1)  reference model.py:48-49
+ *   with a gathered A it is frame+Conv1D(k3,s2) (model.py:805-808) / Conv1D(64,3) (model.py:1450)
+ *   / the stride-2 1x1 shortcut (model.py:1431-1432):
+ *   A[(b,t), j*cin + c] = X[b*x_batch_stride + t*stride_t + j*stride_j + c + base_off], 0 outside
+ *   [0, x_len) of clip b.
+ * stats (optional, may be NULL): per-row-tile partial sums for BatchNorm, finalised by
+ * kws_bn_stats_finalize (a11).  part must hold 2 * kws_gemm_num_row_tiles(M) * N floats.
+ * ---------------------------------------------------------------------------------------- */
+int kws_gemm_num_row_tiles(int64_t M);
+int kws_gemm_nn_f32(const float* A, const float* W, float* C, int64_t M, int K, int N,
+                    float* stats_part, void* stream);
+typedef struct {
+  int L_out;             /* rows per clip */
+  int cin;               /* channels per tap */
+  int taps;              /* K = taps * cin */
+  int stride_t;          /* element stride between consecutive output rows */
+  int stride_j;          /* element stride between taps */
+  int base_off;          /* offset of (t=0, j=0, c=0), may be negative (SAME padding) */
+  int x_len;             /* valid elements per clip */
+  int64_t x_batch_stride;
+} kws_gather_t;
+int kws_gemm_gather_f32(const float* X, const kws_gather_t* g, const float* W, float* C, int B,
+                        int N, float* stats_part, void* stream);
+/* dW[K,N] = A^T[K,M] * G[M,N] (Conv2DBackpropFilter of the 1x1 conv); deterministic split-M:
+ * workspace floats >= kws_gemm_tn_workspace_floats(M,K,N). */
+int64_t kws_gemm_tn_workspace_floats(int64_t M, int K, int N);
+int kws_gemm_tn_f32(const float* A, const float* G, float* dW, int64_t M, int K, int N,
+                    float* workspace, void* stream);
+int kws_gemm_tn_gather_f32(const float* X, const kws_gather_t* g, const float* G, float* dW, int B,
+                           int N, float* workspace, void* stream);
+int kws_transpose_f32(const float* in, float* out, int rows, int cols, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a11  BatchNormalization (training: biased batch moments over (B,L); eps 1e-3; momentum .99)
+ *      + Activation(relu6), reference model.py:46-51, 809-810; constants SURVEY D.2.
+ * The normalise+ReLU6 is never materialised: it is applied on load by the consumer through the
+ * per-channel (scale, shift) these functions produce.
+ * bn layout: float[4*C] = scale | shift | mean | rstd.
+ * ---------------------------------------------------------------------------------------- */
+int kws_bn_stats_finalize(const float* stats_part, int n_tiles, int64_t count, int C,
+                          const float* gamma, const float* beta, float eps, float momentum,
+                          float* moving_mean, float* moving_var, float* bn, void* stream);
+int kws_bn_infer_prepare(const float* gamma, const float* beta, const float* moving_mean,
+                         const float* moving_var, float eps, int C, float* bn, void* stream);
+/* elementwise y -> relu6(scale*y+shift): only used by tests and by inference outputs */
+int kws_bn_relu6_apply(const float* y, const float* bn, float* out, int64_t rows, int C, int relu6,
+                       void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a9  DepthwiseConv2D((1,3)) on [B,1,L,C], reference model.py:34-44, with the producer's
+ *     BN+ReLU6 applied on load (bn may be NULL: input used as is).
+ *   z[b,t,c] = sum_j w[j,c] * act(y[b, s*t + j - pad_l, c])      (0 outside [0,L_in))
+ * bwd (DepthwiseConv2dNativeBackpropInput/Filter + ReluGrad + the BatchNorm reduction, a15):
+ *   g[b,u,c]  = relu6'(.) * sum_j w[j,c] dz[b,(u+pad_l-j)/s,c]
+ *   part      = per-block partial sums of (g, g*xhat, dw0, dw1, dw2), finalised by kws_dw_bwd_finalize.
+ * ---------------------------------------------------------------------------------------- */
+int kws_dwconv_fwd_f32(const float* y, const float* bn, const float* w, float* z, int B, int L_in,
+                       int L_out, int C, int stride, int pad_l, void* stream);
+int64_t kws_dwconv_bwd_part_floats(int B, int L_in, int C);
+int kws_dwconv_bwd_f32(const float* dz, const float* y, const float* bn, const float* w, float* g,
+                       float* part, int B, int L_in, int L_out, int C, int stride, int pad_l,
+                       void* stream);
+/* reduces part -> dw[3,C] (may be NULL), dgamma[C], dbeta[C], and coef[2*C] = (c1, c2) used by
+ * kws_bn_bwd_apply; n_parts = part floats / (5*C) */
+int kws_dw_bwd_finalize(const float* part, int n_parts, int64_t count, int C, const float* gamma,
+                        const float* bn, float* dw, float* dgamma, float* dbeta, float* coef,
+                        void* stream);
+/* dy = gamma*rstd*(g - c1 - xhat*c2), in place on g (BatchNorm backward through batch stats) */
+int kws_bn_bwd_apply(float* g, const float* y, const float* bn, const float* gamma,
+                     const float* coef, int64_t rows, int C, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a14  optimizers on one flat parameter buffer, reference model.py:834 (RMSprop(lr=1e-3)) and
+ *      model.py:96,110 (SGD momentum); constants SURVEY D.5.  g_eff = grad*grad_scale + 2*l2[i]*p
+ *      (l2[i] = per-element kernel_regularizer coefficient, 0 for BN/bias).
+ * ---------------------------------------------------------------------------------------- */
+int kws_rmsprop_step(float* p, const float* grad, float* acc, const float* l2, int64_t n, float lr,
+                     float rho, float eps, float grad_scale, void* stream);
+int kws_sgd_momentum_step(float* p, const float* grad, float* vel, const float* l2, int64_t n,
+                          float lr, float momentum, float grad_scale, void* stream);
+/* out[0] = sum_i l2[i]*p[i]^2 (Keras regularisation loss) */
+int kws_l2_loss(const float* p, const float* l2, int64_t n, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Network programs: the whole forward / forward+backward of one model as a sequence of the
+ * kernels above, launched natively (no Python between layers).
+ *   KWS_NET_TS_ATTENTION: conv_1d_time_sliced_with_attention_model, reference model.py:775-838
+ *   KWS_NET_LOG_MFCC:     conv_1d_log_mfcc_model, reference model.py:1400-1479
+ * The net handle holds only the host-side layer table.  Parameters live in ONE flat f32 buffer
+ * (trainable, Keras layer order) + one flat state buffer (BN moving mean/variance), both owned by
+ * the caller; kws_net_tensor_info enumerates the Keras-named tensors inside them.
+ * ---------------------------------------------------------------------------------------- */
+#define KWS_NET_TS_ATTENTION 1
+#define KWS_NET_LOG_MFCC 2
+typedef struct kws_net kws_net_t;
+typedef struct {
+  int kind;
+  int num_classes;
+  int filter_mult;        /* TS_ATTENTION only */
+  int input_size;         /* 16000 (raw) or spectrogram_length*num_features */
+  int spectrogram_length; /* LOG_MFCC only */
+  int num_features;       /* LOG_MFCC only */
+} kws_net_config_t;
+typedef struct {
+  char name[64];
+  int64_t offset; /* float offset inside the params (is_state=0) or state (is_state=1) buffer */
+  int64_t size;
+  int ndim;
+  int64_t shape[4];
+  int is_state;
+  float l2;       /* kernel_regularizer coefficient (0 if none) */
+  int fan_in, fan_out; /* Glorot fans, 0 for non-kernels */
+  float init;     /* constant initial value for non-kernels */
+} kws_tensor_info_t;
+
+int kws_net_create(const kws_net_config_t* cfg, kws_net_t** net);
+int kws_net_destroy(kws_net_t* net);
+int64_t kws_net_num_params(const kws_net_t* net);
+int64_t kws_net_num_state(const kws_net_t* net);
+int kws_net_num_tensors(const kws_net_t* net);
+int kws_net_tensor_info(const kws_net_t* net, int idx, kws_tensor_info_t* info);
+int64_t kws_net_workspace_bytes(const kws_net_t* net, int max_batch, int training);
+/* inference (K.learning_phase()=0): moving statistics, no dropout. probs [B, num_classes] */
+int kws_net_predict(const kws_net_t* net, const float* params, const float* state, const float* x,
+                    int B, float* probs, void* workspace, int64_t workspace_bytes, void* stream);
+/* one train_on_batch minus the optimizer: forward with batch statistics + dropout, loss
+ * (a13: utils.py:87-108 for TS_ATTENTION, categorical_crossentropy for LOG_MFCC), backward,
+ * BN moving-average update of `state`.  grads: flat buffer laid out like params (data-loss
+ * gradient only, scaled by 1/loss_batch; L2 is folded into the optimizer).
+ * metrics (device float[4]): sum of per-sample data loss, number of correct argmax, 0, 0.
+ * row_offset: global index of row 0 (dropout counter offset for data-parallel shards). */
+int kws_net_train_fwd_bwd(const kws_net_t* net, const float* params, float* state, const float* x,
+                          const float* y_onehot, int B, float* grads, float* probs, float* metrics,
+                          uint64_t seed, uint32_t step, int64_t row_offset, int loss_batch,
+                          void* workspace, int64_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KWS_HIP_H_ */

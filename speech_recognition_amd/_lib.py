@@ -1,0 +1,135 @@
+"""ctypes binding of libkws_hip.so (the C ABI declared in include/kws_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing or a call fails, a
+KwsError is raised.  PyTorch-ROCm is used only to own device memory and streams; every
+pointer handed to the library is a tensor's ``data_ptr()``.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkws_hip.so")
+
+KWS_NET_TS_ATTENTION = 1
+KWS_NET_LOG_MFCC = 2
+
+
+class KwsError(RuntimeError):
+    pass
+
+
+class GatherDesc(ctypes.Structure):
+    _fields_ = [("L_out", ctypes.c_int), ("cin", ctypes.c_int), ("taps", ctypes.c_int),
+                ("stride_t", ctypes.c_int), ("stride_j", ctypes.c_int), ("base_off", ctypes.c_int),
+                ("x_len", ctypes.c_int), ("x_batch_stride", ctypes.c_int64)]
+
+
+class NetConfig(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int), ("num_classes", ctypes.c_int), ("filter_mult", ctypes.c_int),
+                ("input_size", ctypes.c_int), ("spectrogram_length", ctypes.c_int),
+                ("num_features", ctypes.c_int)]
+
+
+class TensorInfo(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 64), ("offset", ctypes.c_int64), ("size", ctypes.c_int64),
+                ("ndim", ctypes.c_int), ("shape", ctypes.c_int64 * 4), ("is_state", ctypes.c_int),
+                ("l2", ctypes.c_float), ("fan_in", ctypes.c_int), ("fan_out", ctypes.c_int),
+                ("init", ctypes.c_float)]
+
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_I64 = ctypes.c_int64
+_F = ctypes.c_float
+
+# name -> (restype, argtypes); every symbol include/kws_hip.h declares
+SIGNATURES = {
+    "kws_abi_version": (_I, []),
+    "kws_last_error": (ctypes.c_char_p, []),
+    "kws_device_name": (_I, [ctypes.c_char_p, _I]),
+    "kws_augment_f32": (_I, [_P, _I64, _I, _P, _P, _P, _P, _I64, _P, _P, _P, _I, _P]),
+    "kws_augment_i16": (_I, [_P, _I64, _I, _P, _P, _P, _P, _I64, _P, _P, _P, _I, _P]),
+    "kws_tta_transform": (_I, [_P, _P, _I, _I, _I, _P]),
+    "kws_tta_combine": (_I, [ctypes.POINTER(_P), _I, _F, _P, _P, _I, _I, _P]),
+    "kws_head32to12": (_I, [_P, _I, _P, _I, _P, _I, _P]),
+    "kws_stft_plan_create": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _F, _F, ctypes.POINTER(_P)]),
+    "kws_stft_plan_destroy": (_I, [_P]),
+    "kws_stft_num_frames": (_I, [_P, _I]),
+    "kws_stft_mel_f32": (_I, [_P, _P, _I, _I, _P, _I, _P]),
+    "kws_gemm_num_row_tiles": (_I, [_I64]),
+    "kws_gemm_nn_f32": (_I, [_P, _P, _P, _I64, _I, _I, _P, _P]),
+    "kws_gemm_gather_f32": (_I, [_P, ctypes.POINTER(GatherDesc), _P, _P, _I, _I, _P, _P]),
+    "kws_gemm_tn_workspace_floats": (_I64, [_I64, _I, _I]),
+    "kws_gemm_tn_f32": (_I, [_P, _P, _P, _I64, _I, _I, _P, _P]),
+    "kws_gemm_tn_gather_f32": (_I, [_P, ctypes.POINTER(GatherDesc), _P, _P, _I, _I, _P, _P]),
+    "kws_transpose_f32": (_I, [_P, _P, _I, _I, _P]),
+    "kws_bn_stats_finalize": (_I, [_P, _I, _I64, _I, _P, _P, _F, _F, _P, _P, _P, _P]),
+    "kws_bn_infer_prepare": (_I, [_P, _P, _P, _P, _F, _I, _P, _P]),
+    "kws_bn_relu6_apply": (_I, [_P, _P, _P, _I64, _I, _I, _P]),
+    "kws_dwconv_fwd_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "kws_dwconv_bwd_part_floats": (_I64, [_I, _I, _I]),
+    "kws_dwconv_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "kws_dw_bwd_finalize": (_I, [_P, _I, _I64, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "kws_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _I64, _I, _P]),
+    "kws_rmsprop_step": (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _P]),
+    "kws_sgd_momentum_step": (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _P]),
+    "kws_l2_loss": (_I, [_P, _P, _I64, _P, _P]),
+    "kws_net_create": (_I, [ctypes.POINTER(NetConfig), ctypes.POINTER(_P)]),
+    "kws_net_destroy": (_I, [_P]),
+    "kws_net_num_params": (_I64, [_P]),
+    "kws_net_num_state": (_I64, [_P]),
+    "kws_net_num_tensors": (_I, [_P]),
+    "kws_net_tensor_info": (_I, [_P, _I, ctypes.POINTER(TensorInfo)]),
+    "kws_net_workspace_bytes": (_I64, [_P, _I, _I]),
+    "kws_net_predict": (_I, [_P, _P, _P, _P, _I, _P, _P, _I64, _P]),
+    "kws_net_train_fwd_bwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, ctypes.c_uint64, ctypes.c_uint32,
+                                   _I64, _I, _P, _I64, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libkws_hip.so (built in-tree by __graft_entry__.build() / csrc/Makefile)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise KwsError("libkws_hip.so not found at %s - build it with "
+                       "`python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(there is no CPU fallback)" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    if lib.kws_abi_version() != 1:
+        raise KwsError("libkws_hip.so ABI version %d, expected 1" % lib.kws_abi_version())
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().kws_last_error()
+        raise KwsError("%s failed (%d): %s" % (what or "libkws_hip call", rc,
+                                               msg.decode() if msg else "?"))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr(stream=None):
+    import torch
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return ctypes.c_void_p(s.cuda_stream)
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    check(rc, name)

@@ -1,0 +1,195 @@
+// BatchNormalization bookkeeping kernels (SURVEY 8a row a11 and its part of a15).
+// The heavy passes live in the producers/consumers (GEMM epilogue statistics, depthwise kernels
+// applying scale/shift on load); what is left here are the per-channel finalisations, which reduce
+// the per-tile partial sums in a FIXED order (double accumulation) so results are bit-reproducible.
+#include "common.h"
+
+namespace {
+
+// part[n_tiles][2][C] -> bn[4C] = scale | shift | mean | rstd ; moving stats update in place.
+__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ part, int n_tiles,
+                                                                double inv_count, int C,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float eps,
+                                                                float one_minus_momentum, float* moving_mean,
+                                                                float* moving_var, float* __restrict__ bn) {
+  __shared__ double red[2][8][32];
+  const int cg = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cg;
+  double s = 0.0, ss = 0.0;
+  if (c < C) {
+    for (int t = rg; t < n_tiles; t += 8) {
+      s += (double)part[((int64_t)t * 2 + 0) * C + c];
+      ss += (double)part[((int64_t)t * 2 + 1) * C + c];
+    }
+  }
+  red[0][rg][cg] = s;
+  red[1][rg][cg] = ss;
+  __syncthreads();
+  if (rg == 0 && c < C) {
+    s = 0.0;
+    ss = 0.0;
+    for (int r = 0; r < 8; ++r) {
+      s += red[0][r][cg];
+      ss += red[1][r][cg];
+    }
+    const double mean = s * inv_count;
+    double var = ss * inv_count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float meanf = (float)mean, varf = (float)var;
+    const float scale = gamma[c] * rstd;
+    bn[c] = scale;
+    bn[C + c] = beta[c] - meanf * scale;
+    bn[2 * C + c] = meanf;
+    bn[3 * C + c] = rstd;
+    if (moving_mean) {
+      // AssignMovingAvg: m -= (m - batch) * (1 - momentum); biased variance
+      moving_mean[c] = moving_mean[c] - (moving_mean[c] - meanf) * one_minus_momentum;
+      moving_var[c] = moving_var[c] - (moving_var[c] - varf) * one_minus_momentum;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_infer_prepare_kernel(const float* gamma, const float* beta,
+                                                               const float* mm, const float* mv, float eps, int C,
+                                                               float* bn) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float rstd = 1.0f / sqrtf(mv[c] + eps);
+  const float scale = gamma[c] * rstd;
+  bn[c] = scale;
+  bn[C + c] = beta[c] - mm[c] * scale;
+  bn[2 * C + c] = mm[c];
+  bn[3 * C + c] = rstd;
+}
+
+__global__ __launch_bounds__(256) void bn_relu6_apply_kernel(const float* __restrict__ y, const float* __restrict__ bn,
+                                                             float* __restrict__ out, int64_t n4, int C, int relu6) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const int c = (int)((i * 4) % C);
+  const float4 v = reinterpret_cast<const float4*>(y)[i];
+  const float4 sc = *reinterpret_cast<const float4*>(bn + c);
+  const float4 sh = *reinterpret_cast<const float4*>(bn + C + c);
+  float4 o = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
+  if (relu6) o = make_float4(relu6f(o.x), relu6f(o.y), relu6f(o.z), relu6f(o.w));
+  reinterpret_cast<float4*>(out)[i] = o;
+}
+
+// part[n_parts][5][C] -> dgamma, dbeta, dw[3][C], coef[2C] = (sum g / n, sum g*xhat / n)
+__global__ __launch_bounds__(256) void dw_bwd_finalize_kernel(const float* __restrict__ part, int n_parts,
+                                                              double inv_count, int C, float* dw, float* dgamma,
+                                                              float* dbeta, float* coef) {
+  __shared__ double red[5][8][32];
+  const int cg = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cg;
+  double s[5] = {0, 0, 0, 0, 0};
+  if (c < C) {
+    for (int t = rg; t < n_parts; t += 8) {
+#pragma unroll
+      for (int q = 0; q < 5; ++q) s[q] += (double)part[((int64_t)t * 5 + q) * C + c];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 5; ++q) red[q][rg][cg] = s[q];
+  __syncthreads();
+  if (rg == 0 && c < C) {
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      double a = 0.0;
+      for (int r = 0; r < 8; ++r) a += red[q][r][cg];
+      s[q] = a;
+    }
+    if (dbeta) dbeta[c] = (float)s[0];
+    if (dgamma) dgamma[c] = (float)s[1];
+    if (coef) {
+      coef[c] = (float)(s[0] * inv_count);
+      coef[C + c] = (float)(s[1] * inv_count);
+    }
+    if (dw) {
+      dw[c] = (float)s[2];
+      dw[C + c] = (float)s[3];
+      dw[2 * C + c] = (float)s[4];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ g, const float* __restrict__ y,
+                                                           const float* __restrict__ bn, const float* __restrict__ gamma,
+                                                           const float* __restrict__ coef, int64_t n4, int C) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const int c = (int)((i * 4) % C);
+  const float4 gv = reinterpret_cast<const float4*>(g)[i];
+  const float4 yv = reinterpret_cast<const float4*>(y)[i];
+  const float4 mean = *reinterpret_cast<const float4*>(bn + 2 * C + c);
+  const float4 rstd = *reinterpret_cast<const float4*>(bn + 3 * C + c);
+  const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
+  const float4 c1 = *reinterpret_cast<const float4*>(coef + c);
+  const float4 c2 = *reinterpret_cast<const float4*>(coef + C + c);
+  float4 o;
+  o.x = ga.x * rstd.x * (gv.x - c1.x - (yv.x - mean.x) * rstd.x * c2.x);
+  o.y = ga.y * rstd.y * (gv.y - c1.y - (yv.y - mean.y) * rstd.y * c2.y);
+  o.z = ga.z * rstd.z * (gv.z - c1.z - (yv.z - mean.z) * rstd.z * c2.z);
+  o.w = ga.w * rstd.w * (gv.w - c1.w - (yv.w - mean.w) * rstd.w * c2.w);
+  reinterpret_cast<float4*>(g)[i] = o;
+}
+
+}  // namespace
+
+extern "C" {
+
+int kws_bn_stats_finalize(const float* stats_part, int n_tiles, int64_t count, int C, const float* gamma,
+                          const float* beta, float eps, float momentum, float* moving_mean, float* moving_var,
+                          float* bn, void* stream) {
+  KWS_REQUIRE(stats_part && gamma && beta && bn, "bn_stats_finalize: NULL pointer");
+  KWS_REQUIRE(n_tiles > 0 && count > 0 && C > 0, "bn_stats_finalize: bad sizes");
+  KWS_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), "bn_stats_finalize: moving stats must both be set");
+  const float omm = (float)(1.0 - (double)momentum);
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((unsigned)ceil_div(C, 32)), dim3(256), 0, (hipStream_t)stream,
+                     stats_part, n_tiles, 1.0 / (double)count, C, gamma, beta, eps, omm, moving_mean, moving_var, bn);
+  KWS_LAUNCH_CHECK("bn_stats_finalize_kernel");
+  return KWS_OK;
+}
+
+int kws_bn_infer_prepare(const float* gamma, const float* beta, const float* moving_mean, const float* moving_var,
+                         float eps, int C, float* bn, void* stream) {
+  KWS_REQUIRE(gamma && beta && moving_mean && moving_var && bn && C > 0, "bn_infer_prepare: bad arguments");
+  hipLaunchKernelGGL(bn_infer_prepare_kernel, dim3((unsigned)ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream,
+                     gamma, beta, moving_mean, moving_var, eps, C, bn);
+  KWS_LAUNCH_CHECK("bn_infer_prepare_kernel");
+  return KWS_OK;
+}
+
+int kws_bn_relu6_apply(const float* y, const float* bn, float* out, int64_t rows, int C, int relu6, void* stream) {
+  KWS_REQUIRE(y && bn && out && rows > 0 && C > 0 && C % 4 == 0, "bn_relu6_apply: bad arguments");
+  const int64_t n4 = rows * C / 4;
+  hipLaunchKernelGGL(bn_relu6_apply_kernel, dim3((unsigned)ceil_div64(n4, 256)), dim3(256), 0, (hipStream_t)stream, y,
+                     bn, out, n4, C, relu6);
+  KWS_LAUNCH_CHECK("bn_relu6_apply_kernel");
+  return KWS_OK;
+}
+
+int kws_dw_bwd_finalize(const float* part, int n_parts, int64_t count, int C, const float* gamma, const float* bn,
+                        float* dw, float* dgamma, float* dbeta, float* coef, void* stream) {
+  (void)gamma;
+  (void)bn;
+  KWS_REQUIRE(part && n_parts > 0 && count > 0 && C > 0, "dw_bwd_finalize: bad arguments");
+  hipLaunchKernelGGL(dw_bwd_finalize_kernel, dim3((unsigned)ceil_div(C, 32)), dim3(256), 0, (hipStream_t)stream, part,
+                     n_parts, 1.0 / (double)count, C, dw, dgamma, dbeta, coef);
+  KWS_LAUNCH_CHECK("dw_bwd_finalize_kernel");
+  return KWS_OK;
+}
+
+int kws_bn_bwd_apply(float* g, const float* y, const float* bn, const float* gamma, const float* coef, int64_t rows,
+                     int C, void* stream) {
+  KWS_REQUIRE(g && y && bn && gamma && coef && rows > 0 && C > 0 && C % 4 == 0, "bn_bwd_apply: bad arguments");
+  const int64_t n4 = rows * C / 4;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)ceil_div64(n4, 256)), dim3(256), 0, (hipStream_t)stream, g, y,
+                     bn, gamma, coef, n4, C);
+  KWS_LAUNCH_CHECK("bn_bwd_apply_kernel");
+  return KWS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,252 @@
+// Depthwise 3-tap convolution along time, channels-last, with the producer's BatchNorm+ReLU6
+// applied on load.  HBM-bound: every thread owns one float4 of
+// channels (16-B coalesced loads across the C dimension) and walks a short run of time steps so the
+// three taps are reused from registers.
+#include "common.h"
+
+namespace {
+
+constexpr int TT = 8;  // time steps per thread
+
+__device__ __forceinline__ float4 f4_fma(float4 a, float4 b, float4 c) {
+  return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
+}
+__device__ __forceinline__ float4 f4_mul(float4 a, float4 b) {
+  return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w);
+}
+__device__ __forceinline__ float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+template <int S, bool HAS_BN>
+__global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict__ y, const float* __restrict__ bn,
+                                                         const float* __restrict__ w, float* __restrict__ z,
+                                                         int B, int Lin, int Lout, int C, int pad_l, int nchunks) {
+  const int C4 = C >> 2;
+  const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int c4 = (int)(id % C4);
+  const int64_t rest = id / C4;
+  const int chunk = (int)(rest % nchunks);
+  const int64_t b = rest / nchunks;
+  if (b >= B) return;
+  const int c = c4 * 4;
+  float4 sc = f4_zero(), sh = f4_zero();
+  if (HAS_BN) {
+    sc = *reinterpret_cast<const float4*>(bn + c);
+    sh = *reinterpret_cast<const float4*>(bn + C + c);
+  }
+  const float4 w0 = *reinterpret_cast<const float4*>(w + c);
+  const float4 w1 = *reinterpret_cast<const float4*>(w + C + c);
+  const float4 w2 = *reinterpret_cast<const float4*>(w + 2 * C + c);
+  const float* yb = y + b * (int64_t)Lin * C + c;
+  float* zb = z + b * (int64_t)Lout * C + c;
+  auto act = [&](int u) -> float4 {
+    if (u < 0 || u >= Lin) return f4_zero();
+    float4 v = *reinterpret_cast<const float4*>(yb + (int64_t)u * C);
+    if (HAS_BN) {
+      v.x = relu6f(fmaf(v.x, sc.x, sh.x));
+      v.y = relu6f(fmaf(v.y, sc.y, sh.y));
+      v.z = relu6f(fmaf(v.z, sc.z, sh.z));
+      v.w = relu6f(fmaf(v.w, sc.w, sh.w));
+    }
+    return v;
+  };
+  const int t0 = chunk * TT;
+  float4 a0 = f4_zero(), a1 = f4_zero(), a2;
+#pragma unroll
+  for (int i = 0; i < TT; ++i) {
+    const int t = t0 + i;
+    if (t >= Lout) break;
+    const int u = S * t - pad_l;
+    if (S == 1) {
+      if (i == 0) {
+        a0 = act(u);
+        a1 = act(u + 1);
+      }
+      a2 = act(u + 2);
+    } else {
+      if (i == 0) a0 = act(u);
+      a1 = act(u + 1);
+      a2 = act(u + 2);
+    }
+    float4 o = f4_mul(w0, a0);
+    o = f4_fma(w1, a1, o);
+    o = f4_fma(w2, a2, o);
+    *reinterpret_cast<float4*>(zb + (int64_t)t * C) = o;
+    if (S == 1) {
+      a0 = a1;
+      a1 = a2;
+    } else {
+      a0 = a2;
+    }
+  }
+}
+
+// Backward: one thread per (clip, run of TT input positions, float4 of channels).
+// part[block][5][C] = per-block sums of (g, g*xhat, dz*a@tap0, dz*a@tap1, dz*a@tap2).
+template <int S, bool HAS_BN>
+__global__ __launch_bounds__(256) void dwconv_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ y,
+                                                         const float* __restrict__ bn, const float* __restrict__ w,
+                                                         float* __restrict__ g, float* __restrict__ part, int B,
+                                                         int Lin, int Lout, int C, int pad_l, int nchunks, int R) {
+  __shared__ float red[5][256 * 4];
+  const int C4 = C >> 2;
+  const int tid = threadIdx.x;
+  const int r = tid / C4, c4 = tid - r * C4;
+  const int c = c4 * 4;
+  const int64_t unit = (int64_t)blockIdx.x * R + r;
+  const int64_t b = unit / nchunks;
+  const int chunk = (int)(unit - b * nchunks);
+  float4 sg = f4_zero(), sgx = f4_zero(), sw0 = f4_zero(), sw1 = f4_zero(), sw2 = f4_zero();
+  if (b < B) {
+    float4 sc = f4_zero(), sh = f4_zero(), mean = f4_zero(), rstd = f4_zero();
+    if (HAS_BN) {
+      sc = *reinterpret_cast<const float4*>(bn + c);
+      sh = *reinterpret_cast<const float4*>(bn + C + c);
+      mean = *reinterpret_cast<const float4*>(bn + 2 * C + c);
+      rstd = *reinterpret_cast<const float4*>(bn + 3 * C + c);
+    }
+    const float4 w0 = *reinterpret_cast<const float4*>(w + c);
+    const float4 w1 = *reinterpret_cast<const float4*>(w + C + c);
+    const float4 w2 = *reinterpret_cast<const float4*>(w + 2 * C + c);
+    const float* yb = y + b * (int64_t)Lin * C + c;
+    float* gb = g + b * (int64_t)Lin * C + c;
+    const float* dzb = dz + b * (int64_t)Lout * C + c;
+    auto ldz = [&](int t) -> float4 {
+      if (t < 0 || t >= Lout) return f4_zero();
+      return *reinterpret_cast<const float4*>(dzb + (int64_t)t * C);
+    };
+    const int u0 = chunk * TT;
+    float4 d0 = f4_zero(), d1 = f4_zero(), d2 = f4_zero();  // dz at taps 0,1,2 of the current u
+#pragma unroll
+    for (int i = 0; i < TT; ++i) {
+      const int u = u0 + i;
+      if (u >= Lin) break;
+      const int base = u + pad_l;  // tap j reads dz[(base - j)/S] when divisible
+      if (S == 1) {
+        if (i == 0) {
+          d1 = ldz(base - 1);
+          d2 = ldz(base - 2);
+        } else {
+          d2 = d1;
+          d1 = d0;
+        }
+        d0 = ldz(base);
+      } else {
+        if ((base & 1) == 0) {
+          d0 = ldz(base >> 1);
+          d1 = f4_zero();
+          d2 = ldz((base >> 1) - 1);
+        } else {
+          d0 = f4_zero();
+          d1 = ldz((base - 1) >> 1);
+          d2 = f4_zero();
+        }
+      }
+      const float4 yv = *reinterpret_cast<const float4*>(yb + (int64_t)u * C);
+      float4 a = yv, mk = make_float4(1.f, 1.f, 1.f, 1.f), xh = f4_zero();
+      if (HAS_BN) {
+        const float4 pre = make_float4(fmaf(yv.x, sc.x, sh.x), fmaf(yv.y, sc.y, sh.y), fmaf(yv.z, sc.z, sh.z),
+                                       fmaf(yv.w, sc.w, sh.w));
+        a = make_float4(relu6f(pre.x), relu6f(pre.y), relu6f(pre.z), relu6f(pre.w));
+        mk = make_float4((pre.x > 0.f && pre.x <= 6.f) ? 1.f : 0.f, (pre.y > 0.f && pre.y <= 6.f) ? 1.f : 0.f,
+                         (pre.z > 0.f && pre.z <= 6.f) ? 1.f : 0.f, (pre.w > 0.f && pre.w <= 6.f) ? 1.f : 0.f);
+        xh = make_float4((yv.x - mean.x) * rstd.x, (yv.y - mean.y) * rstd.y, (yv.z - mean.z) * rstd.z,
+                         (yv.w - mean.w) * rstd.w);
+      }
+      float4 da = f4_mul(w0, d0);
+      da = f4_fma(w1, d1, da);
+      da = f4_fma(w2, d2, da);
+      const float4 gv = f4_mul(da, mk);
+      *reinterpret_cast<float4*>(gb + (int64_t)u * C) = gv;
+      sg.x += gv.x; sg.y += gv.y; sg.z += gv.z; sg.w += gv.w;
+      sgx = f4_fma(gv, xh, sgx);
+      sw0 = f4_fma(d0, a, sw0);
+      sw1 = f4_fma(d1, a, sw1);
+      sw2 = f4_fma(d2, a, sw2);
+    }
+  }
+  *reinterpret_cast<float4*>(&red[0][tid * 4]) = sg;
+  *reinterpret_cast<float4*>(&red[1][tid * 4]) = sgx;
+  *reinterpret_cast<float4*>(&red[2][tid * 4]) = sw0;
+  *reinterpret_cast<float4*>(&red[3][tid * 4]) = sw1;
+  *reinterpret_cast<float4*>(&red[4][tid * 4]) = sw2;
+  __syncthreads();
+  // fixed-order reduction over the R rows of this block: thread (q, channel)
+  for (int o = tid; o < 5 * C; o += blockDim.x) {
+    const int q = o / C, ch = o - q * C;
+    float s = 0.f;
+    for (int rr = 0; rr < R; ++rr) s += red[q][(rr * C4) * 4 + ch];
+    part[((int64_t)blockIdx.x * 5 + q) * C + ch] = s;
+  }
+}
+
+struct BwdGeom {
+  int nchunks, R, block;
+  int64_t grid;
+};
+BwdGeom bwd_geom(int B, int Lin, int C) {
+  BwdGeom g;
+  const int C4 = C / 4;
+  g.nchunks = ceil_div(Lin, TT);
+  g.R = 256 / C4;
+  if (g.R < 1) g.R = 1;
+  g.block = g.R * C4;
+  g.grid = ceil_div64((int64_t)B * g.nchunks, g.R);
+  return g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int kws_dwconv_fwd_f32(const float* y, const float* bn, const float* w, float* z, int B, int L_in, int L_out,
+                       int C, int stride, int pad_l, void* stream) {
+  KWS_REQUIRE(y && w && z, "dwconv_fwd: NULL pointer");
+  KWS_REQUIRE(B > 0 && L_in > 0 && L_out > 0 && C > 0 && C % 4 == 0, "dwconv_fwd: bad shape B=%d L=%d->%d C=%d",
+              B, L_in, L_out, C);
+  KWS_REQUIRE(stride == 1 || stride == 2, "dwconv_fwd: stride %d unsupported", stride);
+  KWS_REQUIRE(pad_l >= 0 && stride * (L_out - 1) + 2 - pad_l < L_in + 2, "dwconv_fwd: geometry reads past padding");
+  const int nchunks = ceil_div(L_out, TT);
+  const int64_t threads = (int64_t)B * nchunks * (C / 4);
+  const int64_t grid = ceil_div64(threads, 256);
+  KWS_REQUIRE(grid < 0x7FFFFFFF, "dwconv_fwd: grid too large");
+  dim3 g((unsigned)grid), b(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (stride == 1) {
+    if (bn) hipLaunchKernelGGL((dwconv_fwd_kernel<1, true>), g, b, 0, st, y, bn, w, z, B, L_in, L_out, C, pad_l, nchunks);
+    else hipLaunchKernelGGL((dwconv_fwd_kernel<1, false>), g, b, 0, st, y, bn, w, z, B, L_in, L_out, C, pad_l, nchunks);
+  } else {
+    if (bn) hipLaunchKernelGGL((dwconv_fwd_kernel<2, true>), g, b, 0, st, y, bn, w, z, B, L_in, L_out, C, pad_l, nchunks);
+    else hipLaunchKernelGGL((dwconv_fwd_kernel<2, false>), g, b, 0, st, y, bn, w, z, B, L_in, L_out, C, pad_l, nchunks);
+  }
+  KWS_LAUNCH_CHECK("dwconv_fwd_kernel");
+  return KWS_OK;
+}
+
+int64_t kws_dwconv_bwd_part_floats(int B, int L_in, int C) {
+  if (B <= 0 || L_in <= 0 || C <= 0 || C % 4 != 0 || C > 1024) return 0;
+  const BwdGeom g = bwd_geom(B, L_in, C);
+  return g.grid * 5 * C;
+}
+
+int kws_dwconv_bwd_f32(const float* dz, const float* y, const float* bn, const float* w, float* g, float* part,
+                       int B, int L_in, int L_out, int C, int stride, int pad_l, void* stream) {
+  KWS_REQUIRE(dz && y && w && g && part, "dwconv_bwd: NULL pointer");
+  KWS_REQUIRE(B > 0 && L_in > 0 && L_out > 0 && C > 0 && C % 4 == 0 && C <= 1024,
+              "dwconv_bwd: bad shape B=%d L=%d->%d C=%d", B, L_in, L_out, C);
+  KWS_REQUIRE(stride == 1 || stride == 2, "dwconv_bwd: stride %d unsupported", stride);
+  const BwdGeom ge = bwd_geom(B, L_in, C);
+  KWS_REQUIRE(ge.grid < 0x7FFFFFFF, "dwconv_bwd: grid too large");
+  dim3 gr((unsigned)ge.grid), b((unsigned)ge.block);
+  hipStream_t st = (hipStream_t)stream;
+  if (stride == 1) {
+    if (bn) hipLaunchKernelGGL((dwconv_bwd_kernel<1, true>), gr, b, 0, st, dz, y, bn, w, g, part, B, L_in, L_out, C, pad_l, ge.nchunks, ge.R);
+    else hipLaunchKernelGGL((dwconv_bwd_kernel<1, false>), gr, b, 0, st, dz, y, bn, w, g, part, B, L_in, L_out, C, pad_l, ge.nchunks, ge.R);
+  } else {
+    if (bn) hipLaunchKernelGGL((dwconv_bwd_kernel<2, true>), gr, b, 0, st, dz, y, bn, w, g, part, B, L_in, L_out, C, pad_l, ge.nchunks, ge.R);
+    else hipLaunchKernelGGL((dwconv_bwd_kernel<2, false>), gr, b, 0, st, dz, y, bn, w, g, part, B, L_in, L_out, C, pad_l, ge.nchunks, ge.R);
+  }
+  KWS_LAUNCH_CHECK("dwconv_bwd_kernel");
+  return KWS_OK;
+}
+
+}  // extern "C"

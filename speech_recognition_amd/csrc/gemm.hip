@@ -1,0 +1,537 @@
+// f32 MFMA GEMM family for the pointwise / first convolutions.
+//
+//   NN : C[M,N]  = A[M,K] * W[K,N]          forward (A = activations, optionally gathered) and
+//                                            dgrad (A = dY, W = W^T)
+//   TN : dW[K,N] = A^T[K,M] * G[M,N]        wgrad, split over M, partial slabs reduced in a fixed
+//                                            order (bit-reproducible, no float atomics)
+//
+// gfx950 mapping: v_mfma_f32_32x32x2_f32 (exact f32, 64 cycles/SIMD), 256-thread workgroups =
+// 4 waves, each wave owns TMxTN 32x32 accumulator tiles.  Operands are staged global -> VGPR ->
+// LDS with a register prefetch of the next K-tile (one barrier per K-tile).  The A tile is kept
+// row-major with a 4-float row pad so that one ds_read_b128 per lane fetches 4 consecutive k of
+// its row conflict-free; the k order inside an 8-wide group is permuted consistently for A and B
+// (lane half h owns k = 8q+4h+r), which the MFMA sum does not care about.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int BK = 32;        // K-tile
+constexpr int LDA = BK + 4;   // padded A-tile row (floats); 144 B keeps 16-B alignment
+constexpr int NXCD = 8;
+
+struct NNArgs {
+  const float* A;
+  const float* W;
+  float* C;
+  int64_t M;
+  int K, N;
+  float* stats;  // [m_tiles][2][N] or nullptr
+  kws_gather_t g;
+  int m_tiles, n_tiles;
+};
+
+__device__ __forceinline__ float4 ld4_or_zero(const float* p, bool ok) {
+  return ok ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// gathered load of 4 consecutive elements starting at element index pos of one clip
+__device__ __forceinline__ float4 gather4(const float* xb, int pos, int x_len) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (pos >= 0 && pos + 3 < x_len) {
+    const float* p = xb + pos;
+    if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+      v = *reinterpret_cast<const float4*>(p);
+    } else if ((reinterpret_cast<uintptr_t>(p) & 7) == 0) {
+      float2 lo = *reinterpret_cast<const float2*>(p);
+      float2 hi = *reinterpret_cast<const float2*>(p + 2);
+      v = make_float4(lo.x, lo.y, hi.x, hi.y);
+    } else {
+      v = make_float4(p[0], p[1], p[2], p[3]);
+    }
+  } else {
+    if (pos >= 0 && pos < x_len) v.x = xb[pos];
+    if (pos + 1 >= 0 && pos + 1 < x_len) v.y = xb[pos + 1];
+    if (pos + 2 >= 0 && pos + 2 < x_len) v.z = xb[pos + 2];
+    if (pos + 3 >= 0 && pos + 3 < x_len) v.w = xb[pos + 3];
+  }
+  return v;
+}
+
+template <int BM, int BN, int WM, int WN, bool GATHER, bool STATS>
+__global__ __launch_bounds__(256) void gemm_nn_kernel(NNArgs p) {
+  constexpr int TM = BM / WM / 32;
+  constexpr int TN = BN / WN / 32;
+  constexpr int A_F4 = BM * BK / 4 / 256;
+  constexpr int B_F4 = BK * BN / 4 / 256;
+  constexpr int BN4 = BN / 4;
+  static_assert(WM * WN == 4, "4 waves");
+  static_assert(A_F4 >= 1 && B_F4 >= 1, "tile too small");
+  __shared__ __attribute__((aligned(16))) float smem[2 * (BM * LDA + BK * BN)];
+  constexpr int STAGE = BM * LDA + BK * BN;  // floats per pipeline stage: A tile then B tile
+
+  // XCD-aware tile order: blocks b and b+8 share an XCD (observed round-robin dispatch), so the
+  // n-tiles of one row panel are given to consecutive slots of ONE XCD and hit its L2.
+  const int bid = blockIdx.x;
+  const int xcd = bid % NXCD;
+  const int slot = bid / NXCD;
+  const int tile_n = slot % p.n_tiles;
+  const int tile_m = (slot / p.n_tiles) * NXCD + xcd;
+  if (tile_m >= p.m_tiles) return;  // whole workgroup leaves together
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int li = lane & 31, lh = lane >> 5;
+  const int64_t m0 = (int64_t)tile_m * BM;
+  const int n0 = tile_n * BN;
+  const int K = p.K, N = p.N;
+  const int64_t M = p.M;
+
+  // per-thread A row bookkeeping (rows do not change across K-tiles)
+  const float* a_row[A_F4];
+  bool a_ok[A_F4];
+  int a_t[A_F4];
+#pragma unroll
+  for (int r = 0; r < A_F4; ++r) {
+    const int idx = tid + r * 256;
+    const int row = idx >> 3;
+    const int64_t gm = m0 + row;
+    a_ok[r] = gm < M;
+    if (GATHER) {
+      const int64_t b = a_ok[r] ? gm / p.g.L_out : 0;
+      a_t[r] = a_ok[r] ? (int)(gm - b * p.g.L_out) : 0;
+      a_row[r] = p.A + b * p.g.x_batch_stride;
+    } else {
+      a_t[r] = 0;
+      a_row[r] = p.A + (a_ok[r] ? gm : 0) * (int64_t)K;
+    }
+  }
+
+  float4 ra[A_F4], rb[B_F4];
+  auto load_global = [&](int k0) {
+#pragma unroll
+    for (int r = 0; r < A_F4; ++r) {
+      const int idx = tid + r * 256;
+      const int gk = k0 + (idx & 7) * 4;
+      if (GATHER) {
+        if (a_ok[r] && gk < K) {
+          const int j = gk / p.g.cin;
+          const int c = gk - j * p.g.cin;
+          ra[r] = gather4(a_row[r], a_t[r] * p.g.stride_t + j * p.g.stride_j + c + p.g.base_off, p.g.x_len);
+        } else {
+          ra[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      } else {
+        ra[r] = ld4_or_zero(a_row[r] + gk, a_ok[r] && gk < K);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < B_F4; ++r) {
+      const int idx = tid + r * 256;
+      const int row = idx / BN4, c4 = idx % BN4;
+      const int gk = k0 + row, gn = n0 + c4 * 4;
+      rb[r] = ld4_or_zero(p.W + (int64_t)gk * N + gn, gk < K && gn < N);
+    }
+  };
+  auto store_lds = [&](int buf) {
+#pragma unroll
+    for (int r = 0; r < A_F4; ++r) {
+      const int idx = tid + r * 256;
+      *reinterpret_cast<float4*>(&smem[buf * STAGE + (idx >> 3) * LDA + (idx & 7) * 4]) = ra[r];
+    }
+#pragma unroll
+    for (int r = 0; r < B_F4; ++r) {
+      const int idx = tid + r * 256;
+      *reinterpret_cast<float4*>(&smem[buf * STAGE + BM * LDA + (idx / BN4) * BN + (idx % BN4) * 4]) = rb[r];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+  const int nk = (K + BK - 1) / BK;
+  load_global(0);
+  store_lds(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) load_global((kt + 1) * BK);
+    const float* cA = smem + cur * STAGE + (wm * TM * 32 + li) * LDA + lh * 4;
+    const float* cB = smem + cur * STAGE + BM * LDA + (lh * 4) * BN + wn * TN * 32 + li;
+#pragma unroll
+    for (int q = 0; q < BK / 8; ++q) {
+      float4 a[TM];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const float4*>(cA + i * 32 * LDA + q * 8);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float b[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = cB[(q * 8 + r) * BN + j * 32];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const float av = r == 0 ? a[i].x : (r == 1 ? a[i].y : (r == 2 ? a[i].z : a[i].w));
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[j], acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+    if (kt + 1 < nk) store_lds(cur ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (v&3) + 8*(v>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * TN * 32 + j * 32 + li;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int64_t row = m0 + wm * TM * 32 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh;
+        if (row < M && col < N) p.C[row * N + col] = acc[i][j][v];
+      }
+    }
+  }
+
+  if (STATS) {
+    // BatchNorm partial sums of this row tile (rows >= M are exact zeros and add nothing).
+    float* red = smem;  // [2][WM][BN]
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float s = 0.f, ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const float x = acc[i][j][v];
+          s += x;
+          ss += x * x;
+        }
+      s += __shfl_xor(s, 32);
+      ss += __shfl_xor(ss, 32);
+      if (lh == 0) {
+        const int c = wn * TN * 32 + j * 32 + li;
+        red[(0 * WM + wm) * BN + c] = s;
+        red[(1 * WM + wm) * BN + c] = ss;
+      }
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < N) {
+      float s = 0.f, ss = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) {
+        s += red[(0 * WM + w) * BN + tid];
+        ss += red[(1 * WM + w) * BN + tid];
+      }
+      p.stats[((int64_t)tile_m * 2 + 0) * N + n0 + tid] = s;
+      p.stats[((int64_t)tile_m * 2 + 1) * N + n0 + tid] = ss;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct TNArgs {
+  const float* A;   // [M,K] or gathered X
+  const float* G;   // [M,N]
+  float* ws;        // [S][K][N]
+  int64_t M;
+  int K, N;
+  int64_t chunk;    // rows per split (multiple of 32)
+  int k_tiles, n_tiles;
+  kws_gather_t g;
+};
+
+constexpr int MS = 32;  // rows of M per LDS stage
+
+template <int BKO, int BNO, bool GATHER>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs p) {
+  constexpr int TK = BKO / 2 / 32;
+  constexpr int TN = BNO / 2 / 32;
+  constexpr int Z_F4 = MS * BKO / 4 / 256;
+  constexpr int G_F4 = MS * BNO / 4 / 256;
+  constexpr int BKO4 = BKO / 4, BNO4 = BNO / 4;
+  __shared__ __attribute__((aligned(16))) float smem[2 * MS * (BKO + BNO)];
+  constexpr int STAGE = MS * (BKO + BNO);  // floats per pipeline stage: Z tile then G tile
+
+  const int tile = blockIdx.x;
+  const int tile_k = tile / p.n_tiles, tile_n = tile % p.n_tiles;
+  const int split = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wk = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const int k0 = tile_k * BKO, n0 = tile_n * BNO;
+  const int K = p.K, N = p.N;
+  const int64_t m_begin = (int64_t)split * p.chunk;
+  const int64_t m_end = (m_begin + p.chunk < p.M) ? m_begin + p.chunk : p.M;
+
+  float4 rz[Z_F4], rg[G_F4];
+  auto load_global = [&](int64_t mb) {
+#pragma unroll
+    for (int r = 0; r < Z_F4; ++r) {
+      const int idx = tid + r * 256;
+      const int row = idx / BKO4, c4 = idx % BKO4;
+      const int64_t gm = mb + row;
+      const int gk = k0 + c4 * 4;
+      const bool ok = gm < m_end && gk < K;
+      if (GATHER) {
+        if (ok) {
+          const int64_t b = gm / p.g.L_out;
+          const int t = (int)(gm - b * p.g.L_out);
+          const int j = gk / p.g.cin;
+          const int c = gk - j * p.g.cin;
+          rz[r] = gather4(p.A + b * p.g.x_batch_stride,
+                          t * p.g.stride_t + j * p.g.stride_j + c + p.g.base_off, p.g.x_len);
+        } else {
+          rz[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      } else {
+        rz[r] = ld4_or_zero(p.A + (ok ? gm : 0) * (int64_t)K + gk, ok);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < G_F4; ++r) {
+      const int idx = tid + r * 256;
+      const int row = idx / BNO4, c4 = idx % BNO4;
+      const int64_t gm = mb + row;
+      const int gn = n0 + c4 * 4;
+      const bool ok = gm < m_end && gn < N;
+      rg[r] = ld4_or_zero(p.G + (ok ? gm : 0) * (int64_t)N + gn, ok);
+    }
+  };
+  auto store_lds = [&](int buf) {
+#pragma unroll
+    for (int r = 0; r < Z_F4; ++r) {
+      const int idx = tid + r * 256;
+      *reinterpret_cast<float4*>(&smem[buf * STAGE + (idx / BKO4) * BKO + (idx % BKO4) * 4]) = rz[r];
+    }
+#pragma unroll
+    for (int r = 0; r < G_F4; ++r) {
+      const int idx = tid + r * 256;
+      *reinterpret_cast<float4*>(&smem[buf * STAGE + MS * BKO + (idx / BNO4) * BNO + (idx % BNO4) * 4]) = rg[r];
+    }
+  };
+
+  f32x16 acc[TK][TN];
+#pragma unroll
+  for (int i = 0; i < TK; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+  const int stages = (int)((m_end - m_begin + MS - 1) / MS);
+  if (stages > 0) {
+    load_global(m_begin);
+    store_lds(0);
+  }
+  __syncthreads();
+  for (int st = 0; st < stages; ++st) {
+    const int cur = st & 1;
+    if (st + 1 < stages) load_global(m_begin + (int64_t)(st + 1) * MS);
+    const float* cZ = smem + cur * STAGE + lh * BKO + wk * TK * 32 + li;
+    const float* cG = smem + cur * STAGE + MS * BKO + lh * BNO + wn * TN * 32 + li;
+#pragma unroll
+    for (int s = 0; s < MS / 2; ++s) {
+      float a[TK], b[TN];
+#pragma unroll
+      for (int i = 0; i < TK; ++i) a[i] = cZ[(2 * s) * BKO + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = cG[(2 * s) * BNO + j * 32];
+#pragma unroll
+      for (int i = 0; i < TK; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (st + 1 < stages) store_lds(cur ^ 1);
+    __syncthreads();
+  }
+
+  float* out = p.ws + (int64_t)split * K * N;
+#pragma unroll
+  for (int i = 0; i < TK; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * TN * 32 + j * 32 + li;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int row = k0 + wk * TK * 32 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh;
+        if (row < K && col < N) out[(int64_t)row * N + col] = acc[i][j][v];
+      }
+    }
+}
+
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* ws, float* out, int64_t n4, int S) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const float4* w = reinterpret_cast<const float4*>(ws);
+  float4 s = w[i];
+  for (int k = 1; k < S; ++k) {
+    const float4 v = w[(int64_t)k * n4 + i];
+    s.x += v.x;
+    s.y += v.y;
+    s.z += v.z;
+    s.w += v.w;
+  }
+  reinterpret_cast<float4*>(out)[i] = s;
+}
+
+__global__ __launch_bounds__(256) void transpose_kernel(const float* in, float* out, int rows, int cols) {
+  __shared__ float tile[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const int y = by + r, x = bx + tx;
+    tile[r][tx] = (y < rows && x < cols) ? in[(int64_t)y * cols + x] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int y = bx + r, x = by + tx;  // out is [cols][rows]
+    if (y < cols && x < rows) out[(int64_t)y * rows + x] = tile[tx][r];
+  }
+}
+
+// split heuristic of the TN kernel: enough workgroups to fill 256 CUs, slabs no larger than needed
+struct TNPlan {
+  int bko;  // 128 or 64 (square tiles)
+  int k_tiles, n_tiles, S;
+  int64_t chunk;
+};
+TNPlan tn_plan(int64_t M, int K, int N) {
+  TNPlan pl;
+  pl.bko = (K % 128 == 0 && N % 128 == 0) ? 128 : 64;
+  pl.k_tiles = ceil_div(K, pl.bko);
+  pl.n_tiles = ceil_div(N, pl.bko);
+  const int tiles = pl.k_tiles * pl.n_tiles;
+  int64_t S = ceil_div64(1024, tiles);
+  const int64_t maxS = M / 256 > 1 ? M / 256 : 1;
+  if (S > maxS) S = maxS;
+  if (S < 1) S = 1;
+  int64_t chunk = ceil_div64(ceil_div64(M, S), MS) * MS;
+  if (chunk < MS) chunk = MS;
+  pl.chunk = chunk;
+  pl.S = (int)ceil_div64(M > 0 ? M : 1, chunk);
+  return pl;
+}
+
+template <bool GATHER>
+int launch_nn(const NNArgs& a0, hipStream_t st) {
+  NNArgs a = a0;
+  const bool wide = (a.N % 128 == 0);
+  const int BN = wide ? 128 : 64;
+  a.m_tiles = (int)ceil_div64(a.M, 128);
+  a.n_tiles = ceil_div(a.N, BN);
+  const int64_t slots = ceil_div64(a.m_tiles, NXCD) * a.n_tiles;
+  const int64_t grid = slots * NXCD;
+  if (grid <= 0 || grid > 0x7FFFFFFF) {
+    kws_set_error("gemm_nn: grid %lld out of range", (long long)grid);
+    return KWS_E_INVALID;
+  }
+  const bool stats = a.stats != nullptr;
+  dim3 g((unsigned)grid), b(256);
+  if (wide) {
+    if (stats) hipLaunchKernelGGL((gemm_nn_kernel<128, 128, 2, 2, GATHER, true>), g, b, 0, st, a);
+    else hipLaunchKernelGGL((gemm_nn_kernel<128, 128, 2, 2, GATHER, false>), g, b, 0, st, a);
+  } else {
+    if (stats) hipLaunchKernelGGL((gemm_nn_kernel<128, 64, 2, 2, GATHER, true>), g, b, 0, st, a);
+    else hipLaunchKernelGGL((gemm_nn_kernel<128, 64, 2, 2, GATHER, false>), g, b, 0, st, a);
+  }
+  KWS_LAUNCH_CHECK("gemm_nn_kernel");
+  return KWS_OK;
+}
+
+template <bool GATHER>
+int launch_tn(TNArgs a, float* dW, hipStream_t st) {
+  const TNPlan pl = tn_plan(a.M, a.K, a.N);
+  a.chunk = pl.chunk;
+  a.k_tiles = pl.k_tiles;
+  a.n_tiles = pl.n_tiles;
+  dim3 g((unsigned)(pl.k_tiles * pl.n_tiles), (unsigned)pl.S), b(256);
+  if (pl.bko == 128) hipLaunchKernelGGL((gemm_tn_kernel<128, 128, GATHER>), g, b, 0, st, a);
+  else hipLaunchKernelGGL((gemm_tn_kernel<64, 64, GATHER>), g, b, 0, st, a);
+  KWS_LAUNCH_CHECK("gemm_tn_kernel");
+  const int64_t n4 = (int64_t)a.K * a.N / 4;
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)ceil_div64(n4, 256)), dim3(256), 0, st, a.ws, dW, n4, pl.S);
+  KWS_LAUNCH_CHECK("reduce_slabs_kernel");
+  return KWS_OK;
+}
+
+int check_gather(const kws_gather_t* g, int B, int N) {
+  KWS_REQUIRE(g != nullptr, "gather descriptor is NULL");
+  KWS_REQUIRE(g->L_out > 0 && g->cin > 0 && g->taps > 0 && g->cin % 4 == 0,
+              "gather: need L_out>0, taps>0, cin%%4==0 (cin=%d)", g->cin);
+  KWS_REQUIRE(g->x_len > 0 && g->x_batch_stride >= g->x_len, "gather: bad x_len/x_batch_stride");
+  KWS_REQUIRE(B > 0 && N > 0 && N % 4 == 0, "gather: B=%d N=%d (N%%4 must be 0)", B, N);
+  return KWS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int kws_gemm_num_row_tiles(int64_t M) { return (int)ceil_div64(M, 128); }
+
+int kws_gemm_nn_f32(const float* A, const float* W, float* C, int64_t M, int K, int N, float* stats_part,
+                    void* stream) {
+  KWS_REQUIRE(A && W && C, "gemm_nn: NULL pointer");
+  KWS_REQUIRE(M > 0 && K > 0 && N > 0 && K % 4 == 0 && N % 4 == 0, "gemm_nn: M=%lld K=%d N=%d (K,N %% 4)",
+              (long long)M, K, N);
+  NNArgs a{};
+  a.A = A; a.W = W; a.C = C; a.M = M; a.K = K; a.N = N; a.stats = stats_part;
+  return launch_nn<false>(a, (hipStream_t)stream);
+}
+
+int kws_gemm_gather_f32(const float* X, const kws_gather_t* g, const float* W, float* C, int B, int N,
+                        float* stats_part, void* stream) {
+  KWS_REQUIRE(X && W && C, "gemm_gather: NULL pointer");
+  KWS_TRY(check_gather(g, B, N));
+  NNArgs a{};
+  a.A = X; a.W = W; a.C = C; a.M = (int64_t)B * g->L_out; a.K = g->taps * g->cin; a.N = N;
+  a.stats = stats_part; a.g = *g;
+  return launch_nn<true>(a, (hipStream_t)stream);
+}
+
+int64_t kws_gemm_tn_workspace_floats(int64_t M, int K, int N) {
+  const TNPlan pl = tn_plan(M, K, N);
+  return (int64_t)pl.S * K * N;
+}
+
+int kws_gemm_tn_f32(const float* A, const float* G, float* dW, int64_t M, int K, int N, float* workspace,
+                    void* stream) {
+  KWS_REQUIRE(A && G && dW && workspace, "gemm_tn: NULL pointer");
+  KWS_REQUIRE(M > 0 && K > 0 && N > 0 && K % 4 == 0 && N % 4 == 0, "gemm_tn: M=%lld K=%d N=%d",
+              (long long)M, K, N);
+  TNArgs a{};
+  a.A = A; a.G = G; a.ws = workspace; a.M = M; a.K = K; a.N = N;
+  return launch_tn<false>(a, dW, (hipStream_t)stream);
+}
+
+int kws_gemm_tn_gather_f32(const float* X, const kws_gather_t* g, const float* G, float* dW, int B, int N,
+                           float* workspace, void* stream) {
+  KWS_REQUIRE(X && G && dW && workspace, "gemm_tn_gather: NULL pointer");
+  KWS_TRY(check_gather(g, B, N));
+  TNArgs a{};
+  a.A = X; a.G = G; a.ws = workspace; a.M = (int64_t)B * g->L_out; a.K = g->taps * g->cin; a.N = N;
+  a.g = *g;
+  return launch_tn<true>(a, dW, (hipStream_t)stream);
+}
+
+int kws_transpose_f32(const float* in, float* out, int rows, int cols, void* stream) {
+  KWS_REQUIRE(in && out && rows > 0 && cols > 0, "transpose: bad arguments");
+  dim3 g((unsigned)ceil_div(cols, 32), (unsigned)ceil_div(rows, 32));
+  hipLaunchKernelGGL(transpose_kernel, g, dim3(256), 0, (hipStream_t)stream, in, out, rows, cols);
+  KWS_LAUNCH_CHECK("transpose_kernel");
+  return KWS_OK;
+}
+
+}  // extern "C"

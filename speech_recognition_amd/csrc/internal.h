@@ -1,0 +1,14 @@
+// Launchers shared between translation units of libkws_hip.so (not part of the public C ABI).
+#pragma once
+#include "common.h"
+
+struct kws_ts_tail_args {
+  const float* y; const float* bn; const float* W1; const float* b1; const float* W2; const float* labels;
+  float* probs; float* g; float* part; float* xd; float* fd; float* dl1; float* dl2; float* per_loss;
+  float* per_correct; int B, T, C, NC; uint64_t seed; uint32_t step; float keep_prob; float label_smoothing;
+  int loss_batch; int64_t row_offset; int train;
+};
+int kws_ts_tail_launch(const kws_ts_tail_args* p, hipStream_t st);
+int kws_small_wgrad_launch(const float* X, const float* D, float* out, float* out_bias, int B, int K, int N,
+                           hipStream_t st);
+int kws_metrics_launch(const float* per_loss, const float* per_correct, int B, float* metrics, hipStream_t st);

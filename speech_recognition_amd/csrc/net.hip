@@ -1,0 +1,394 @@
+// Network programs: the forward / forward+backward of one model as a native sequence of kernel
+// launches on one HIP stream (no Python between layers, so the step can also be captured into a
+// hipGraph by the caller).  SURVEY 8a rows a7-a15.
+//
+//   KWS_NET_TS_ATTENTION  conv_1d_time_sliced_with_attention_model   reference model.py:775-838
+//
+// Data flow per depthwise block l (training):
+//   z_l = dw_l( relu6(bn_{l-1}(y_{l-1})) )      BN+ReLU6 applied on load, never materialised
+//   y_l = z_l W_l                                f32 MFMA GEMM, BN statistics in the epilogue
+// Backward keeps two scratch tensors (G: gradient wrt a BN output / pre-BN tensor, DZ: gradient wrt
+// a depthwise output) and walks the blocks in reverse.
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "internal.h"
+
+namespace {
+
+constexpr float BN_EPS = 1e-3f;
+constexpr float BN_MOMENTUM = 0.99f;
+constexpr float L2_COEF = 1e-5f;
+constexpr float DROP_KEEP = 0.6f;     // Dropout(0.4), model.py:819,828
+constexpr float LABEL_SMOOTH = 0.1f;  // model.py:835-836
+
+struct BnRef {
+  int64_t gamma, beta;  // param offsets
+  int64_t mm, mv;       // state offsets
+  int C;
+};
+struct Block {
+  int stride, pad_l, cin, cout, Lin, Lout;
+  int64_t dw, pw;  // param offsets
+  BnRef bn;        // BN after the pointwise conv
+};
+
+}  // namespace
+
+struct kws_net {
+  kws_net_config_t cfg;
+  std::vector<kws_tensor_info_t> tensors;
+  int64_t n_params = 0, n_state = 0;
+  // TS_ATTENTION
+  int L_in = 0;      // samples per clip
+  int L1 = 0, C1 = 0;  // conv1 output
+  int64_t conv1 = 0;
+  BnRef bn1;
+  std::vector<Block> blocks;
+  int T = 0, C = 0, NC = 0;
+  int64_t d1k = 0, d1b = 0, d2k = 0;
+  kws_gather_t gather1;
+};
+
+namespace {
+
+int64_t add_tensor(kws_net* n, const std::string& name, std::vector<int64_t> shape, bool is_state, float l2,
+                   int fan_in, int fan_out, float init) {
+  kws_tensor_info_t t;
+  memset(&t, 0, sizeof(t));
+  snprintf(t.name, sizeof(t.name), "%s", name.c_str());
+  int64_t size = 1;
+  t.ndim = (int)shape.size();
+  for (int i = 0; i < t.ndim; ++i) {
+    t.shape[i] = shape[i];
+    size *= shape[i];
+  }
+  t.size = size;
+  t.is_state = is_state ? 1 : 0;
+  t.l2 = l2;
+  t.fan_in = fan_in;
+  t.fan_out = fan_out;
+  t.init = init;
+  int64_t& cursor = is_state ? n->n_state : n->n_params;
+  t.offset = cursor;
+  cursor += (size + 3) / 4 * 4;  // keep every tensor 16-B aligned inside the flat buffer
+  n->tensors.push_back(t);
+  return t.offset;
+}
+
+BnRef add_bn(kws_net* n, int idx, int C) {
+  BnRef r;
+  const std::string base = "batch_normalization_" + std::to_string(idx) + "/";
+  r.gamma = add_tensor(n, base + "gamma", {C}, false, 0.f, 0, 0, 1.f);
+  r.beta = add_tensor(n, base + "beta", {C}, false, 0.f, 0, 0, 0.f);
+  r.mm = add_tensor(n, base + "moving_mean", {C}, true, 0.f, 0, 0, 0.f);
+  r.mv = add_tensor(n, base + "moving_variance", {C}, true, 0.f, 0, 0, 1.f);
+  r.C = C;
+  return r;
+}
+
+void same_pad(int L, int k, int s, int* Lout, int* pl) {
+  *Lout = (L + s - 1) / s;
+  int p = (*Lout - 1) * s + k - L;
+  if (p < 0) p = 0;
+  *pl = p / 2;  // TF: extra padding goes to the right
+}
+
+int build_ts_attention(kws_net* n) {
+  const kws_net_config_t& c = n->cfg;
+  KWS_REQUIRE(c.num_classes >= 2 && c.num_classes <= 64, "net: num_classes %d out of range", c.num_classes);
+  KWS_REQUIRE(c.filter_mult >= 1 && c.filter_mult <= 2, "net: filter_mult %d unsupported", c.filter_mult);
+  KWS_REQUIRE(c.input_size >= 1600 && c.input_size % 4 == 0, "net: input_size %d unsupported", c.input_size);
+  const int fm = c.filter_mult;
+  n->L_in = c.input_size;
+  // overlapping_time_slice_stack(x, 40, 20) SAME (model.py:805) fused with Conv1D(128,3,strides=2) (model.py:807)
+  int Lf, plf;
+  same_pad(n->L_in, 40, 20, &Lf, &plf);
+  n->L1 = (Lf - 3) / 2 + 1;
+  n->C1 = 128 * fm;
+  n->conv1 = add_tensor(n, "conv1d_1/kernel", {3, 40, n->C1}, false, L2_COEF, 3 * 40, 3 * n->C1, 0.f);
+  n->bn1 = add_bn(n, 1, n->C1);
+  kws_gather_t g;
+  g.L_out = n->L1; g.cin = 40; g.taps = 3; g.stride_t = 2 * 20; g.stride_j = 20; g.base_off = -plf;
+  g.x_len = n->L_in; g.x_batch_stride = n->L_in;
+  n->gather1 = g;
+  static const int spec[11][2] = {{1, 128}, {2, 192}, {1, 192}, {2, 256}, {1, 256}, {2, 320},
+                                  {1, 320}, {2, 384}, {1, 384}, {2, 512}, {1, 512}};  // model.py:812-817
+  int L = n->L1, cin = n->C1;
+  for (int i = 0; i < 11; ++i) {
+    Block b;
+    b.stride = spec[i][0];
+    b.cin = cin;
+    b.cout = spec[i][1] * fm;
+    b.Lin = L;
+    if (b.stride == 2) {
+      same_pad(L, 3, 2, &b.Lout, &b.pad_l);  // _reduce_conv: padding='same'
+    } else {
+      b.Lout = L - 2;  // _context_conv: padding='valid'
+      b.pad_l = 0;
+    }
+    KWS_REQUIRE(b.Lout >= 1, "net: input too short for block %d", i);
+    b.dw = add_tensor(n, "depthwise_conv2d_" + std::to_string(i + 1) + "/depthwise_kernel", {1, 3, cin, 1}, false,
+                      L2_COEF, 3 * cin, 3, 0.f);
+    b.pw = add_tensor(n, "conv1d_" + std::to_string(i + 2) + "/kernel", {1, cin, b.cout}, false, L2_COEF, cin,
+                      b.cout, 0.f);
+    b.bn = add_bn(n, i + 2, b.cout);
+    n->blocks.push_back(b);
+    L = b.Lout;
+    cin = b.cout;
+  }
+  n->T = L;
+  n->C = cin;
+  n->NC = c.num_classes;
+  KWS_REQUIRE(n->T <= 16, "net: %d time steps at the tail (max 16)", n->T);
+  n->d1k = add_tensor(n, "dense_1/kernel", {(int64_t)n->T * n->C, n->T}, false, L2_COEF, n->T * n->C, n->T, 0.f);
+  n->d1b = add_tensor(n, "dense_1/bias", {n->T}, false, 0.f, 0, 0, 0.f);
+  n->d2k = add_tensor(n, "dense_2/kernel", {2 * n->C, n->NC}, false, L2_COEF, 2 * n->C, n->NC, 0.f);
+  return KWS_OK;
+}
+
+// ---- workspace layout ------------------------------------------------------------------------------
+struct Layout {
+  int64_t total = 0;  // bytes
+  std::vector<int64_t> y;   // y[l], l = 0..11 (float offsets)
+  std::vector<int64_t> z;   // z[i], i = 0..10
+  int64_t G = 0, DZ = 0, bn = 0, part = 0, coef = 0, WT = 0, tn = 0;
+  int64_t xd = 0, fd = 0, dl1 = 0, dl2 = 0, per_loss = 0, per_correct = 0;
+  int64_t bn_stride = 0;
+};
+
+struct Bump {
+  int64_t cur = 0;  // in floats
+  int64_t take(int64_t floats) {
+    const int64_t o = cur;
+    cur += (floats + 63) / 64 * 64;  // 256-B granules
+    return o;
+  }
+};
+
+void make_layout(const kws_net* n, int B, bool training, Layout* lo) {
+  Bump bp;
+  const int nb = (int)n->blocks.size();
+  lo->y.assign(nb + 1, 0);
+  lo->z.assign(nb, 0);
+  int64_t max_y = (int64_t)B * n->L1 * n->C1, max_z = 0, max_part = 0, max_dwpart = 0, max_wt = 0, max_tn = 0;
+  int maxC = n->C1;
+  max_part = (int64_t)kws_gemm_num_row_tiles((int64_t)B * n->L1) * 2 * n->C1;
+  max_tn = kws_gemm_tn_workspace_floats((int64_t)B * n->L1, 120, n->C1);
+  for (int i = 0; i < nb; ++i) {
+    const Block& b = n->blocks[i];
+    const int64_t M = (int64_t)B * b.Lout;
+    if (M * b.cout > max_y) max_y = M * b.cout;
+    if (M * b.cin > max_z) max_z = M * b.cin;
+    const int64_t p = (int64_t)kws_gemm_num_row_tiles(M) * 2 * b.cout;
+    if (p > max_part) max_part = p;
+    const int64_t dp = kws_dwconv_bwd_part_floats(B, b.Lin, b.cin);
+    if (dp > max_dwpart) max_dwpart = dp;
+    if ((int64_t)b.cin * b.cout > max_wt) max_wt = (int64_t)b.cin * b.cout;
+    const int64_t t = kws_gemm_tn_workspace_floats(M, b.cin, b.cout);
+    if (t > max_tn) max_tn = t;
+    if (b.cout > maxC) maxC = b.cout;
+  }
+  if (training) {
+    lo->y[0] = bp.take((int64_t)B * n->L1 * n->C1);
+    for (int i = 0; i < nb; ++i) {
+      const Block& b = n->blocks[i];
+      lo->z[i] = bp.take((int64_t)B * b.Lout * b.cin);
+      lo->y[i + 1] = bp.take((int64_t)B * b.Lout * b.cout);
+    }
+    lo->G = bp.take(max_y);
+    lo->DZ = bp.take(max_z);
+    const int64_t tail_part = (int64_t)B * 5 * n->C;
+    lo->part = bp.take(std::max(std::max(max_part, max_dwpart), tail_part));
+    lo->coef = bp.take(2 * maxC);
+    lo->WT = bp.take(max_wt);
+    lo->tn = bp.take(max_tn);
+    lo->xd = bp.take((int64_t)B * n->T * n->C);
+    lo->fd = bp.take((int64_t)B * 2 * n->C);
+    lo->dl1 = bp.take((int64_t)B * n->T);
+    lo->dl2 = bp.take((int64_t)B * n->NC);
+    lo->per_loss = bp.take(B);
+    lo->per_correct = bp.take(B);
+  } else {
+    // inference ping-pong: two y buffers and one z buffer
+    const int64_t ya = bp.take(max_y), yb = bp.take(max_y), zz = bp.take(max_z);
+    lo->y[0] = ya;
+    for (int i = 0; i < nb; ++i) {
+      lo->z[i] = zz;
+      lo->y[i + 1] = (i % 2 == 0) ? yb : ya;
+    }
+    lo->part = bp.take(64);
+  }
+  lo->bn_stride = (4 * maxC + 63) / 64 * 64;
+  lo->bn = bp.take(lo->bn_stride * (nb + 1));
+  lo->total = bp.cur * 4;
+}
+
+}  // namespace
+
+extern "C" {
+
+int kws_net_create(const kws_net_config_t* cfg, kws_net_t** out) {
+  KWS_REQUIRE(cfg && out, "net_create: NULL pointer");
+  kws_net* n = new kws_net();
+  n->cfg = *cfg;
+  int rc;
+  if (cfg->kind == KWS_NET_TS_ATTENTION) {
+    rc = build_ts_attention(n);
+  } else {
+    kws_set_error("net_create: kind %d not supported", cfg->kind);
+    rc = KWS_E_INVALID;
+  }
+  if (rc != KWS_OK) {
+    delete n;
+    return rc;
+  }
+  *out = n;
+  return KWS_OK;
+}
+
+int kws_net_destroy(kws_net_t* net) {
+  delete net;
+  return KWS_OK;
+}
+
+int64_t kws_net_num_params(const kws_net_t* net) { return net ? net->n_params : 0; }
+int64_t kws_net_num_state(const kws_net_t* net) { return net ? net->n_state : 0; }
+int kws_net_num_tensors(const kws_net_t* net) { return net ? (int)net->tensors.size() : 0; }
+
+int kws_net_tensor_info(const kws_net_t* net, int idx, kws_tensor_info_t* info) {
+  KWS_REQUIRE(net && info && idx >= 0 && idx < (int)net->tensors.size(), "net_tensor_info: bad index %d", idx);
+  *info = net->tensors[idx];
+  return KWS_OK;
+}
+
+int64_t kws_net_workspace_bytes(const kws_net_t* net, int max_batch, int training) {
+  if (!net || max_batch <= 0) return 0;
+  Layout lo;
+  make_layout(net, max_batch, training != 0, &lo);
+  return lo.total;
+}
+
+int kws_net_predict(const kws_net_t* net, const float* params, const float* state, const float* x, int B,
+                    float* probs, void* workspace, int64_t workspace_bytes, void* stream) {
+  KWS_REQUIRE(net && params && state && x && probs && workspace && B > 0, "net_predict: bad arguments");
+  Layout lo;
+  make_layout(net, B, false, &lo);
+  if (lo.total > workspace_bytes) {
+    kws_set_error("net_predict: workspace %lld B < %lld B needed for batch %d", (long long)workspace_bytes,
+                  (long long)lo.total, B);
+    return KWS_E_WORKSPACE;
+  }
+  float* ws = (float*)workspace;
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = (int)net->blocks.size();
+  auto bn_at = [&](int l) { return ws + lo.bn + lo.bn_stride * l; };
+  auto prep = [&](const BnRef& r, int l) {
+    return kws_bn_infer_prepare(params + r.gamma, params + r.beta, state + r.mm, state + r.mv, BN_EPS, r.C, bn_at(l),
+                                st);
+  };
+  KWS_TRY(prep(net->bn1, 0));
+  for (int i = 0; i < nb; ++i) KWS_TRY(prep(net->blocks[i].bn, i + 1));
+  KWS_TRY(kws_gemm_gather_f32(x, &net->gather1, params + net->conv1, ws + lo.y[0], B, net->C1, nullptr, st));
+  for (int i = 0; i < nb; ++i) {
+    const Block& b = net->blocks[i];
+    KWS_TRY(kws_dwconv_fwd_f32(ws + lo.y[i], bn_at(i), params + b.dw, ws + lo.z[i], B, b.Lin, b.Lout, b.cin, b.stride,
+                               b.pad_l, st));
+    KWS_TRY(kws_gemm_nn_f32(ws + lo.z[i], params + b.pw, ws + lo.y[i + 1], (int64_t)B * b.Lout, b.cin, b.cout, nullptr,
+                            st));
+  }
+  kws_ts_tail_args t;
+  memset(&t, 0, sizeof(t));
+  t.y = ws + lo.y[nb]; t.bn = bn_at(nb); t.W1 = params + net->d1k; t.b1 = params + net->d1b;
+  t.W2 = params + net->d2k; t.probs = probs; t.B = B; t.T = net->T; t.C = net->C; t.NC = net->NC;
+  t.keep_prob = 1.f; t.loss_batch = 1; t.train = 0;
+  return kws_ts_tail_launch(&t, st);
+}
+
+int kws_net_train_fwd_bwd(const kws_net_t* net, const float* params, float* state, const float* x,
+                          const float* y_onehot, int B, float* grads, float* probs, float* metrics, uint64_t seed,
+                          uint32_t step, int64_t row_offset, int loss_batch, void* workspace, int64_t workspace_bytes,
+                          void* stream) {
+  KWS_REQUIRE(net && params && state && x && y_onehot && grads && probs && metrics && workspace && B > 0,
+              "net_train_fwd_bwd: bad arguments");
+  KWS_REQUIRE(loss_batch >= B, "net_train_fwd_bwd: loss_batch %d < B %d", loss_batch, B);
+  Layout lo;
+  make_layout(net, B, true, &lo);
+  if (lo.total > workspace_bytes) {
+    kws_set_error("net_train_fwd_bwd: workspace %lld B < %lld B needed for batch %d", (long long)workspace_bytes,
+                  (long long)lo.total, B);
+    return KWS_E_WORKSPACE;
+  }
+  float* ws = (float*)workspace;
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = (int)net->blocks.size();
+  auto bn_at = [&](int l) { return ws + lo.bn + lo.bn_stride * l; };
+  float* part = ws + lo.part;
+  float* G = ws + lo.G;
+  float* DZ = ws + lo.DZ;
+  float* coef = ws + lo.coef;
+
+  KWS_HIP(hipMemsetAsync(grads, 0, (size_t)net->n_params * 4, st));
+  // ---------------- forward ----------------
+  {
+    const int64_t M = (int64_t)B * net->L1;
+    KWS_TRY(kws_gemm_gather_f32(x, &net->gather1, params + net->conv1, ws + lo.y[0], B, net->C1, part, st));
+    KWS_TRY(kws_bn_stats_finalize(part, kws_gemm_num_row_tiles(M), M, net->C1, params + net->bn1.gamma,
+                                  params + net->bn1.beta, BN_EPS, BN_MOMENTUM, state + net->bn1.mm, state + net->bn1.mv,
+                                  bn_at(0), st));
+  }
+  for (int i = 0; i < nb; ++i) {
+    const Block& b = net->blocks[i];
+    const int64_t M = (int64_t)B * b.Lout;
+    KWS_TRY(kws_dwconv_fwd_f32(ws + lo.y[i], bn_at(i), params + b.dw, ws + lo.z[i], B, b.Lin, b.Lout, b.cin, b.stride,
+                               b.pad_l, st));
+    KWS_TRY(kws_gemm_nn_f32(ws + lo.z[i], params + b.pw, ws + lo.y[i + 1], M, b.cin, b.cout, part, st));
+    KWS_TRY(kws_bn_stats_finalize(part, kws_gemm_num_row_tiles(M), M, b.cout, params + b.bn.gamma, params + b.bn.beta,
+                                  BN_EPS, BN_MOMENTUM, state + b.bn.mm, state + b.bn.mv, bn_at(i + 1), st));
+  }
+  // ---------------- tail forward + backward ----------------
+  kws_ts_tail_args t;
+  memset(&t, 0, sizeof(t));
+  t.y = ws + lo.y[nb]; t.bn = bn_at(nb); t.W1 = params + net->d1k; t.b1 = params + net->d1b;
+  t.W2 = params + net->d2k; t.labels = y_onehot; t.probs = probs; t.g = G; t.part = part; t.xd = ws + lo.xd;
+  t.fd = ws + lo.fd; t.dl1 = ws + lo.dl1; t.dl2 = ws + lo.dl2; t.per_loss = ws + lo.per_loss;
+  t.per_correct = ws + lo.per_correct; t.B = B; t.T = net->T; t.C = net->C; t.NC = net->NC; t.seed = seed;
+  t.step = step; t.keep_prob = DROP_KEEP; t.label_smoothing = LABEL_SMOOTH; t.loss_batch = loss_batch;
+  t.row_offset = row_offset; t.train = 1;
+  KWS_TRY(kws_ts_tail_launch(&t, st));
+  KWS_TRY(kws_metrics_launch(t.per_loss, t.per_correct, B, metrics, st));
+  KWS_TRY(kws_small_wgrad_launch(t.fd, t.dl2, grads + net->d2k, nullptr, B, 2 * net->C, net->NC, st));
+  KWS_TRY(kws_small_wgrad_launch(t.xd, t.dl1, grads + net->d1k, grads + net->d1b, B, net->T * net->C, net->T, st));
+  {
+    const BnRef& r = net->blocks[nb - 1].bn;
+    KWS_TRY(kws_dw_bwd_finalize(part, B, (int64_t)B * net->T, r.C, nullptr, nullptr, nullptr, grads + r.gamma,
+                                grads + r.beta, coef, st));
+  }
+  // ---------------- backward through the blocks ----------------
+  for (int i = nb - 1; i >= 0; --i) {
+    const Block& b = net->blocks[i];
+    const int64_t M = (int64_t)B * b.Lout;
+    // G = masked gradient wrt bn output of this block -> dy (in place)
+    KWS_TRY(kws_bn_bwd_apply(G, ws + lo.y[i + 1], bn_at(i + 1), params + b.bn.gamma, coef, M, b.cout, st));
+    KWS_TRY(kws_transpose_f32(params + b.pw, ws + lo.WT, b.cin, b.cout, st));
+    KWS_TRY(kws_gemm_nn_f32(G, ws + lo.WT, DZ, M, b.cout, b.cin, nullptr, st));
+    KWS_TRY(kws_gemm_tn_f32(ws + lo.z[i], G, grads + b.pw, M, b.cin, b.cout, ws + lo.tn, st));
+    const BnRef& prev = (i == 0) ? net->bn1 : net->blocks[i - 1].bn;
+    KWS_TRY(kws_dwconv_bwd_f32(DZ, ws + lo.y[i], bn_at(i), params + b.dw, G, part, B, b.Lin, b.Lout, b.cin, b.stride,
+                               b.pad_l, st));
+    const int n_parts = (int)(kws_dwconv_bwd_part_floats(B, b.Lin, b.cin) / (5 * b.cin));
+    KWS_TRY(kws_dw_bwd_finalize(part, n_parts, (int64_t)B * b.Lin, b.cin, nullptr, nullptr, grads + b.dw,
+                                grads + prev.gamma, grads + prev.beta, coef, st));
+  }
+  {
+    const int64_t M = (int64_t)B * net->L1;
+    KWS_TRY(kws_bn_bwd_apply(G, ws + lo.y[0], bn_at(0), params + net->bn1.gamma, coef, M, net->C1, st));
+    KWS_TRY(kws_gemm_tn_gather_f32(x, &net->gather1, G, grads + net->conv1, B, net->C1, ws + lo.tn, st));
+  }
+  return KWS_OK;
+}
+
+}  // extern "C"

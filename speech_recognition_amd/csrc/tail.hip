@@ -1,0 +1,362 @@
+// Attention + pooling + classifier tail of conv_1d_time_sliced_with_attention_model
+// (reference model.py:819-830), its loss (utils.py:87-108) and their backward, fused into one
+// workgroup-per-clip kernel (SURVEY 8a rows a12, a13 and the matching part of a15).
+//
+//   x      = relu6(bn12(y12))                       [T, C]   (BN scale/shift applied on load)
+//   att    = softmax(Dense_T(Dropout(Flatten(x))))  [T]
+//   feat   = [max_t(x * att) ; mean_t(x)]           [2C]
+//   p      = softmax(Dense_NC(Dropout(feat)))       [NC]
+// The per-clip tile (T*C <= 9216 floats) stays in LDS between forward and backward.  Weight
+// gradients need a sum over the batch: the kernel writes the per-clip operands (dropped inputs and
+// logit gradients) and `small_wgrad_kernel` reduces them in a fixed order.
+#include "internal.h"
+
+namespace {
+
+constexpr int MAXT = 16;
+constexpr int MAXNC = 64;
+
+struct TailArgs {
+  const float* y;       // [B, T, C] pre-BN output of the last pointwise conv
+  const float* bn;      // [4C]
+  const float* W1;      // [T*C, T]
+  const float* b1;      // [T]
+  const float* W2;      // [2C, NC]
+  const float* labels;  // [B, NC] one-hot (train)
+  float* probs;         // [B, NC]
+  // train outputs
+  float* g;             // [B, T, C] masked gradient wrt bn12 output
+  float* part;          // [B][5][C] BN-backward partial sums (slots 2..4 zero)
+  float* xd;            // [B, T*C] dropped flatten (operand of dW1)
+  float* fd;            // [B, 2C]  dropped features (operand of dW2)
+  float* dl1;           // [B, T]
+  float* dl2;           // [B, NC]
+  float* per_loss;      // [B]
+  float* per_correct;   // [B]
+  int B, T, C, NC;
+  uint32_t key1, key2, thresh;
+  float inv_keep;
+  float label_smoothing;
+  float inv_loss_batch;
+  int64_t row_offset;
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+  return v;
+}
+
+// sums `nv` (<= NV) per-thread values over the 256-thread block; result broadcast through out[] (LDS).
+// vals is indexed with compile-time constants only (runtime-indexed register arrays go to scratch).
+template <int NV>
+__device__ void block_sum(const float (&vals)[NV], int nv, float* scratch /*[4*MAXNC]*/, float* out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    if (v < nv) {
+      const float s = wave_sum(vals[v]);
+      if (lane == 0) scratch[wave * MAXNC + v] = s;
+    }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < nv) {
+    const int v = threadIdx.x;
+    out[v] = ((scratch[v] + scratch[MAXNC + v]) + scratch[2 * MAXNC + v]) + scratch[3 * MAXNC + v];
+  }
+  __syncthreads();
+}
+
+template <bool TRAIN>
+__global__ __launch_bounds__(256) void ts_tail_kernel(TailArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int T = a.T, C = a.C, NC = a.NC, TC = T * C;
+  float* xs = lds;                 // [TC]
+  float* xd = xs + TC;             // [TC]   dropped x, later dx
+  float* feat = xd + TC;           // [2C]
+  float* dfeat = feat + 2 * C;     // [2C]
+  float* scratch = dfeat + 2 * C;  // [4*MAXNC]
+  float* l1 = scratch + 4 * MAXNC; // [MAXT] logits1 / att
+  float* att = l1 + MAXT;          // [MAXT]
+  float* dl1 = att + MAXT;         // [MAXT]
+  float* datt = dl1 + MAXT;        // [MAXT]
+  float* l2 = datt + MAXT;         // [MAXNC]
+  float* pp = l2 + MAXNC;          // [MAXNC]
+  float* dl2 = pp + MAXNC;         // [MAXNC]
+  float* part16 = dl2 + MAXNC;     // [16*16] partial dot products
+
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x;
+  const float* yb = a.y + (int64_t)b * TC;
+  const uint32_t row = (uint32_t)(a.row_offset + b);
+
+  // ---- x = relu6(bn(y)), dropout 1 -----------------------------------------------------------
+  for (int e = tid; e < TC; e += 256) {
+    const int c = e % C;
+    const float x = relu6f(fmaf(yb[e], a.bn[c], a.bn[C + c]));
+    xs[e] = x;
+    float d = x;
+    if (TRAIN) d = kws_keep(row * (uint32_t)TC + (uint32_t)e, a.key1, a.thresh) ? x * a.inv_keep : 0.f;
+    xd[e] = d;
+    if (TRAIN) a.xd[(int64_t)b * TC + e] = d;
+  }
+  __syncthreads();
+  // ---- logits1 = xd . W1 + b1 : thread (t = tid%16, slice = tid/16) --------------------------
+  {
+    const int t = tid & 15, sl = tid >> 4;
+    float s = 0.f;
+    if (t < T)
+      for (int e = sl; e < TC; e += 16) s = fmaf(xd[e], a.W1[(int64_t)e * T + t], s);
+    part16[sl * 16 + t] = s;
+    __syncthreads();
+    if (tid < T) {
+      float acc = a.b1[tid];
+      for (int k = 0; k < 16; ++k) acc += part16[k * 16 + tid];
+      l1[tid] = acc;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      float m = l1[0];
+      for (int k = 1; k < T; ++k) m = fmaxf(m, l1[k]);
+      float den = 0.f;
+      for (int k = 0; k < T; ++k) {
+        att[k] = expf(l1[k] - m);
+        den += att[k];
+      }
+      for (int k = 0; k < T; ++k) att[k] /= den;
+    }
+    __syncthreads();
+  }
+  // ---- pooling: feat = [max_t x*att ; mean_t x], dropout 2 -----------------------------------
+  for (int c = tid; c < C; c += 256) {
+    float mx = xs[c] * att[0], sm = xs[c];
+    for (int t = 1; t < T; ++t) {
+      mx = fmaxf(mx, xs[t * C + c] * att[t]);
+      sm += xs[t * C + c];
+    }
+    feat[c] = mx;
+    feat[C + c] = sm / (float)T;
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * C; i += 256) {
+    float f = feat[i];
+    if (TRAIN) {
+      f = kws_keep(row * (uint32_t)(2 * C) + (uint32_t)i, a.key2, a.thresh) ? f * a.inv_keep : 0.f;
+      a.fd[(int64_t)b * 2 * C + i] = f;
+    }
+    dfeat[i] = f;  // dropped features (forward use); overwritten by the gradient below
+  }
+  __syncthreads();
+  // ---- logits2 = fd . W2 : thread (k = tid%64, slice = tid/64) -------------------------------
+  {
+    const int k = tid & 63, sl = tid >> 6;
+    float s = 0.f;
+    if (k < NC)
+      for (int i = sl; i < 2 * C; i += 4) s = fmaf(dfeat[i], a.W2[(int64_t)i * NC + k], s);
+    scratch[sl * MAXNC + k] = s;
+    __syncthreads();
+    if (tid < NC) l2[tid] = ((scratch[tid] + scratch[MAXNC + tid]) + scratch[2 * MAXNC + tid]) + scratch[3 * MAXNC + tid];
+    __syncthreads();
+    if (tid == 0) {
+      float m = l2[0];
+      for (int q = 1; q < NC; ++q) m = fmaxf(m, l2[q]);
+      float den = 0.f;
+      for (int q = 0; q < NC; ++q) {
+        pp[q] = expf(l2[q] - m);
+        den += pp[q];
+      }
+      for (int q = 0; q < NC; ++q) pp[q] /= den;
+    }
+    __syncthreads();
+    if (tid < NC) a.probs[(int64_t)b * NC + tid] = pp[tid];
+  }
+  if (!TRAIN) return;
+
+  // ---- loss: softmax-CE on log(clip(p)) with label smoothing (utils.py:100-108) --------------
+  if (tid == 0) {
+    const float eps = 1e-7f;
+    const float* yl = a.labels + (int64_t)b * NC;
+    float S = 0.f, ysum = 0.f;
+    for (int q = 0; q < NC; ++q) S += fminf(fmaxf(pp[q], eps), 1.f - eps);
+    const float logS = logf(S);
+    float loss = 0.f;
+    int am_p = 0, am_y = 0;
+    for (int q = 0; q < NC; ++q) {
+      const float ysm = yl[q] * (1.f - a.label_smoothing) + a.label_smoothing / (float)NC;
+      ysum += ysm;
+      const float pc = fminf(fmaxf(pp[q], eps), 1.f - eps);
+      loss -= ysm * (logf(pc) - logS);
+      if (pp[q] > pp[am_p]) am_p = q;
+      if (yl[q] > yl[am_y]) am_y = q;
+    }
+    a.per_loss[b] = loss;
+    a.per_correct[b] = (am_p == am_y) ? 1.f : 0.f;
+    // dL/dp (clip passes gradient inside [eps, 1-eps]), then softmax backward
+    float dot = 0.f;
+    for (int q = 0; q < NC; ++q) {
+      const float ysm = yl[q] * (1.f - a.label_smoothing) + a.label_smoothing / (float)NC;
+      const float pc = fminf(fmaxf(pp[q], eps), 1.f - eps);
+      const float inside = (pp[q] >= eps && pp[q] <= 1.f - eps) ? 1.f : 0.f;
+      const float dp = (-ysm / pc + ysum / S) * a.inv_loss_batch * inside;
+      dl2[q] = dp;
+      dot += dp * pp[q];
+    }
+    for (int q = 0; q < NC; ++q) dl2[q] = pp[q] * (dl2[q] - dot);
+  }
+  __syncthreads();
+  if (tid < NC) a.dl2[(int64_t)b * NC + tid] = dl2[tid];
+  // ---- dfeat = (W2 . dl2) * mask2 / keep ------------------------------------------------------
+  for (int i = tid; i < 2 * C; i += 256) {
+    float s = 0.f;
+    for (int q = 0; q < NC; ++q) s = fmaf(a.W2[(int64_t)i * NC + q], dl2[q], s);
+    const bool keep = kws_keep(row * (uint32_t)(2 * C) + (uint32_t)i, a.key2, a.thresh);
+    dfeat[i] = keep ? s * a.inv_keep : 0.f;
+  }
+  __syncthreads();
+  // ---- pooling backward: reduce_max splits its gradient equally among ties -------------------
+  float dattl[MAXT];
+#pragma unroll
+  for (int t = 0; t < MAXT; ++t) dattl[t] = 0.f;
+  for (int c = tid; c < C; c += 256) {
+    const float mx = feat[c];
+    int n = 0;
+    for (int t = 0; t < T; ++t) n += (xs[t * C + c] * att[t] == mx) ? 1 : 0;
+    const float share = dfeat[c] / (float)n;
+    const float davg = dfeat[C + c] / (float)T;
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+      if (t < T) {
+        const float xv = xs[t * C + c];
+        const float dxa = (xv * att[t] == mx) ? share : 0.f;
+        xd[t * C + c] = dxa * att[t] + davg;  // xd now holds dx
+        dattl[t] += dxa * xv;
+      }
+    }
+  }
+  block_sum(dattl, T, scratch, datt);
+  if (tid == 0) {
+    float dot = 0.f;
+    for (int t = 0; t < T; ++t) dot += att[t] * datt[t];
+    for (int t = 0; t < T; ++t) dl1[t] = att[t] * (datt[t] - dot);
+  }
+  __syncthreads();
+  if (tid < T) a.dl1[(int64_t)b * T + tid] = dl1[tid];
+  // ---- dx += (W1 . dl1) * mask1 / keep ; g = dx * relu6'(pre) ; BN-backward partial sums ------
+  float* gb = a.g + (int64_t)b * TC;
+  for (int c = tid; c < C; c += 256) {
+    const float sc = a.bn[c], sh = a.bn[C + c], mean = a.bn[2 * C + c], rstd = a.bn[3 * C + c];
+    float sg = 0.f, sgx = 0.f;
+    for (int t = 0; t < T; ++t) {
+      const int e = t * C + c;
+      float s = 0.f;
+      for (int q = 0; q < T; ++q) s = fmaf(a.W1[(int64_t)e * T + q], dl1[q], s);
+      const bool keep = kws_keep(row * (uint32_t)TC + (uint32_t)e, a.key1, a.thresh);
+      const float dx = xd[e] + (keep ? s * a.inv_keep : 0.f);
+      const float yv = yb[e];
+      const float pre = fmaf(yv, sc, sh);
+      const float gv = (pre > 0.f && pre <= 6.f) ? dx : 0.f;
+      gb[e] = gv;
+      sg += gv;
+      sgx = fmaf(gv, (yv - mean) * rstd, sgx);
+    }
+    float* pb = a.part + (int64_t)b * 5 * C;
+    pb[c] = sg;
+    pb[C + c] = sgx;
+    pb[2 * C + c] = 0.f;
+    pb[3 * C + c] = 0.f;
+    pb[4 * C + c] = 0.f;
+  }
+}
+
+// out[K, N] = sum_b X[b, K]^T D[b, N]  (N small); optional bias grad out_b[N] = sum_b D[b, N]
+__global__ __launch_bounds__(256) void small_wgrad_kernel(const float* __restrict__ X, const float* __restrict__ D,
+                                                          float* __restrict__ out, int B, int K, int N) {
+  const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (id >= (int64_t)K * N) return;
+  const int i = (int)(id / N), k = (int)(id - (int64_t)i * N);
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) s = fmaf(X[(int64_t)b * K + i], D[(int64_t)b * N + k], s);
+  out[id] = s;
+}
+__global__ __launch_bounds__(64) void colsum_kernel(const float* __restrict__ D, float* __restrict__ out, int B, int N) {
+  const int k = threadIdx.x;
+  if (k >= N) return;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) s += D[(int64_t)b * N + k];
+  out[k] = s;
+}
+// metrics[0] = sum per_loss, metrics[1] = sum per_correct (fixed order)
+__global__ __launch_bounds__(64) void metrics_kernel(const float* per_loss, const float* per_correct, int B,
+                                                     float* metrics) {
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int b = 0; b < B; ++b) s += (double)per_loss[b];
+    metrics[0] = (float)s;
+  } else if (threadIdx.x == 1) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += per_correct[b];
+    metrics[1] = s;
+  } else if (threadIdx.x < 4) {
+    metrics[threadIdx.x] = 0.f;
+  }
+}
+
+}  // namespace
+
+int kws_ts_tail_launch(const kws_ts_tail_args* p, hipStream_t st) {
+  KWS_REQUIRE(p->T > 0 && p->T <= MAXT && p->NC > 0 && p->NC <= MAXNC && p->C > 0, "ts_tail: bad shape T=%d NC=%d",
+              p->T, p->NC);
+  const int TC = p->T * p->C;
+  const size_t lds_floats = (size_t)2 * TC + 4 * p->C + 4 * MAXNC + 4 * MAXT + 3 * MAXNC + 256;
+  KWS_REQUIRE(lds_floats * 4 <= 160 * 1024, "ts_tail: T*C=%d does not fit LDS", TC);
+  TailArgs a{};
+  a.y = p->y; a.bn = p->bn; a.W1 = p->W1; a.b1 = p->b1; a.W2 = p->W2; a.labels = p->labels; a.probs = p->probs;
+  a.g = p->g; a.part = p->part; a.xd = p->xd; a.fd = p->fd; a.dl1 = p->dl1; a.dl2 = p->dl2;
+  a.per_loss = p->per_loss; a.per_correct = p->per_correct;
+  a.B = p->B; a.T = p->T; a.C = p->C; a.NC = p->NC;
+  a.key1 = kws_dropout_key(p->seed, p->step, 1);
+  a.key2 = kws_dropout_key(p->seed, p->step, 2);
+  a.thresh = kws_dropout_threshold(p->keep_prob);
+  a.inv_keep = (float)(1.0 / (double)p->keep_prob);
+  a.label_smoothing = p->label_smoothing;
+  a.inv_loss_batch = 1.0f / (float)p->loss_batch;
+  a.row_offset = p->row_offset;
+  if (p->train) {
+    static bool attr_set_t = false;
+    if (!attr_set_t && lds_floats * 4 > 64 * 1024) {
+      KWS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ts_tail_kernel<true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_floats * 4)));
+      attr_set_t = true;
+    }
+    hipLaunchKernelGGL((ts_tail_kernel<true>), dim3((unsigned)p->B), dim3(256), lds_floats * 4, st, a);
+  } else {
+    static bool attr_set_i = false;
+    if (!attr_set_i && lds_floats * 4 > 64 * 1024) {
+      KWS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ts_tail_kernel<false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_floats * 4)));
+      attr_set_i = true;
+    }
+    hipLaunchKernelGGL((ts_tail_kernel<false>), dim3((unsigned)p->B), dim3(256), lds_floats * 4, st, a);
+  }
+  KWS_LAUNCH_CHECK("ts_tail_kernel");
+  return KWS_OK;
+}
+
+int kws_small_wgrad_launch(const float* X, const float* D, float* out, float* out_bias, int B, int K, int N,
+                           hipStream_t st) {
+  const int64_t n = (int64_t)K * N;
+  hipLaunchKernelGGL(small_wgrad_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, st, X, D, out, B, K, N);
+  KWS_LAUNCH_CHECK("small_wgrad_kernel");
+  if (out_bias) {
+    KWS_REQUIRE(N <= 64, "small_wgrad: N=%d > 64", N);
+    hipLaunchKernelGGL(colsum_kernel, dim3(1), dim3(64), 0, st, D, out_bias, B, N);
+    KWS_LAUNCH_CHECK("colsum_kernel");
+  }
+  return KWS_OK;
+}
+
+int kws_metrics_launch(const float* per_loss, const float* per_correct, int B, float* metrics, hipStream_t st) {
+  hipLaunchKernelGGL(metrics_kernel, dim3(1), dim3(64), 0, st, per_loss, per_correct, B, metrics);
+  KWS_LAUNCH_CHECK("metrics_kernel");
+  return KWS_OK;
+}
