@@ -209,6 +209,11 @@ int64_t kws_net_num_state(const kws_net_t* net);
 int kws_net_num_tensors(const kws_net_t* net);
 int kws_net_tensor_info(const kws_net_t* net, int idx, kws_tensor_info_t* info);
 int64_t kws_net_workspace_bytes(const kws_net_t* net, int max_batch, int training);
+/* parity/debug view into a workspace laid out for (batch, training): what = 0 pre-BN conv output
+ * y[index] (0 = conv1d_1 .. 11 = conv1d_12), 1 depthwise output z[index], 2 BN table of
+ * batch_normalization_{index+1} (scale|shift|mean|rstd), 3 attention weights [B,T] (training). */
+int kws_net_debug_view(const kws_net_t* net, int batch, int training, int what, int index,
+                       int64_t* offset_floats, int64_t* count);
 /* inference (K.learning_phase()=0): moving statistics, no dropout. probs [B, num_classes] */
 int kws_net_predict(const kws_net_t* net, const float* params, const float* state, const float* x,
                     int B, float* probs, void* workspace, int64_t workspace_bytes, void* stream);

@@ -99,7 +99,13 @@ class TimeSlicedAttentionNet(object):
 
     def _bn_bwd(self, idx, da, cache, grads):
         y, g, stats, pre = cache['bn%d' % idx]
-        dpre = da * L.relu6_mask(pre)
+        mask = L.relu6_mask(pre)
+        override = cache.get('relu_masks')
+        if override is not None and idx in override:
+            # decision-aligned parity: use the mask another implementation actually took (a
+            # pre-activation within rounding of a ReLU6 kink may fall on either side in f32 vs f64)
+            mask = np.asarray(override[idx], dtype=self.dtype).reshape(pre.shape)
+        dpre = da * mask
         dy, dg, db = L.bn_train_bwd(dpre, y, g, stats)
         grads['batch_normalization_%d/gamma' % idx] = dg
         grads['batch_normalization_%d/beta' % idx] = db
@@ -156,11 +162,14 @@ class TimeSlicedAttentionNet(object):
         return sum(L.L2_COEF * float((self._p(k) ** 2).sum()) for k in self.l2_names)
 
     # -- backward --------------------------------------------------------------
-    def loss_and_grads(self, x, y_onehot, seed=0, step=0, drop_offset=0, loss_scale_B=None):
+    def loss_and_grads(self, x, y_onehot, seed=0, step=0, drop_offset=0, loss_scale_B=None,
+                       relu_masks=None, pool_ind=None):
         """Returns (data_loss, probs, grads incl. L2 terms, cache).  loss_scale_B: divide the
-        data-loss gradient by this batch size instead of the local one (data-parallel mean)."""
+        data-loss gradient by this batch size instead of the local one (data-parallel mean).
+        relu_masks {bn index: 0/1 array} / pool_ind [B,T,C] override the discrete decisions of the
+        backward pass (ReLU6 masks, max-pool winners) with those another implementation took."""
         dt = self.dtype
-        cache = {}
+        cache = {'relu_masks': relu_masks}
         p = self.forward(x, training=True, seed=seed, step=step, cache=cache, drop_offset=drop_offset)
         y_onehot = np.asarray(y_onehot, dtype=dt)
         loss, per, dp = L.smooth_cce_fwd_bwd(p, y_onehot, self.label_smoothing)
@@ -176,7 +185,9 @@ class TimeSlicedAttentionNet(object):
         dxmax, dxavg = dfeat[:, :C], dfeat[:, C:]
         # reduce_max gradient: split equally among ties (_MinOrMaxGrad)
         ind = (xa == xmax[:, None, :]).astype(dt)
-        ind /= ind.sum(axis=1, keepdims=True)
+        if pool_ind is not None:
+            ind = np.asarray(pool_ind, dtype=dt).reshape(xa.shape)
+        ind = ind / ind.sum(axis=1, keepdims=True)
         dxa = ind * dxmax[:, None, :]
         da = dxa * att[:, :, None] + dxavg[:, None, :] / dt(T)
         datt = (dxa * a).sum(axis=2)

@@ -81,6 +81,7 @@ SIGNATURES = {
     "kws_net_num_tensors": (_I, [_P]),
     "kws_net_tensor_info": (_I, [_P, _I, ctypes.POINTER(TensorInfo)]),
     "kws_net_workspace_bytes": (_I64, [_P, _I, _I]),
+    "kws_net_debug_view": (_I, [_P, _I, _I, _I, _I, ctypes.POINTER(_I64), ctypes.POINTER(_I64)]),
     "kws_net_predict": (_I, [_P, _P, _P, _P, _I, _P, _P, _I64, _P]),
     "kws_net_train_fwd_bwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, ctypes.c_uint64, ctypes.c_uint32,
                                    _I64, _I, _P, _I64, _P]),

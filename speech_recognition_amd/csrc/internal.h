@@ -5,7 +5,7 @@
 struct kws_ts_tail_args {
   const float* y; const float* bn; const float* W1; const float* b1; const float* W2; const float* labels;
   float* probs; float* g; float* part; float* xd; float* fd; float* dl1; float* dl2; float* per_loss;
-  float* per_correct; int B, T, C, NC; uint64_t seed; uint32_t step; float keep_prob; float label_smoothing;
+  float* per_correct; float* att; int B, T, C, NC; uint64_t seed; uint32_t step; float keep_prob; float label_smoothing;
   int loss_batch; int64_t row_offset; int train;
 };
 int kws_ts_tail_launch(const kws_ts_tail_args* p, hipStream_t st);

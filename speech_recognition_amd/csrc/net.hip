@@ -156,7 +156,7 @@ struct Layout {
   std::vector<int64_t> y;   // y[l], l = 0..11 (float offsets)
   std::vector<int64_t> z;   // z[i], i = 0..10
   int64_t G = 0, DZ = 0, bn = 0, part = 0, coef = 0, WT = 0, tn = 0;
-  int64_t xd = 0, fd = 0, dl1 = 0, dl2 = 0, per_loss = 0, per_correct = 0;
+  int64_t xd = 0, fd = 0, dl1 = 0, dl2 = 0, per_loss = 0, per_correct = 0, att = 0;
   int64_t bn_stride = 0;
 };
 
@@ -212,6 +212,7 @@ void make_layout(const kws_net* n, int B, bool training, Layout* lo) {
     lo->dl2 = bp.take((int64_t)B * n->NC);
     lo->per_loss = bp.take(B);
     lo->per_correct = bp.take(B);
+    lo->att = bp.take((int64_t)B * 16);
   } else {
     // inference ping-pong: two y buffers and one z buffer
     const int64_t ya = bp.take(max_y), yb = bp.take(max_y), zz = bp.take(max_z);
@@ -270,6 +271,36 @@ int64_t kws_net_workspace_bytes(const kws_net_t* net, int max_batch, int trainin
   Layout lo;
   make_layout(net, max_batch, training != 0, &lo);
   return lo.total;
+}
+
+int kws_net_debug_view(const kws_net_t* net, int batch, int training, int what, int index, int64_t* offset_floats,
+                       int64_t* count) {
+  KWS_REQUIRE(net && offset_floats && count && batch > 0, "net_debug_view: bad arguments");
+  Layout lo;
+  make_layout(net, batch, training != 0, &lo);
+  const int nb = (int)net->blocks.size();
+  if (what == 0) {  // pre-BN output y[index], index 0..nb
+    KWS_REQUIRE(index >= 0 && index <= nb, "net_debug_view: y index %d", index);
+    *offset_floats = lo.y[index];
+    *count = index == 0 ? (int64_t)batch * net->L1 * net->C1
+                        : (int64_t)batch * net->blocks[index - 1].Lout * net->blocks[index - 1].cout;
+  } else if (what == 1) {  // depthwise output z[index]
+    KWS_REQUIRE(index >= 0 && index < nb, "net_debug_view: z index %d", index);
+    *offset_floats = lo.z[index];
+    *count = (int64_t)batch * net->blocks[index].Lout * net->blocks[index].cin;
+  } else if (what == 2) {  // bn table (scale|shift|mean|rstd) of BN index
+    KWS_REQUIRE(index >= 0 && index <= nb, "net_debug_view: bn index %d", index);
+    *offset_floats = lo.bn + lo.bn_stride * index;
+    *count = 4 * (index == 0 ? net->C1 : net->blocks[index - 1].cout);
+  } else if (what == 3) {  // attention weights [B, T] (training only)
+    KWS_REQUIRE(training, "net_debug_view: att is a training-only view");
+    *offset_floats = lo.att;
+    *count = (int64_t)batch * net->T;
+  } else {
+    kws_set_error("net_debug_view: unknown view %d", what);
+    return KWS_E_INVALID;
+  }
+  return KWS_OK;
 }
 
 int kws_net_predict(const kws_net_t* net, const float* params, const float* state, const float* x, int B,
@@ -355,7 +386,7 @@ int kws_net_train_fwd_bwd(const kws_net_t* net, const float* params, float* stat
   t.y = ws + lo.y[nb]; t.bn = bn_at(nb); t.W1 = params + net->d1k; t.b1 = params + net->d1b;
   t.W2 = params + net->d2k; t.labels = y_onehot; t.probs = probs; t.g = G; t.part = part; t.xd = ws + lo.xd;
   t.fd = ws + lo.fd; t.dl1 = ws + lo.dl1; t.dl2 = ws + lo.dl2; t.per_loss = ws + lo.per_loss;
-  t.per_correct = ws + lo.per_correct; t.B = B; t.T = net->T; t.C = net->C; t.NC = net->NC; t.seed = seed;
+  t.per_correct = ws + lo.per_correct; t.att = ws + lo.att; t.B = B; t.T = net->T; t.C = net->C; t.NC = net->NC; t.seed = seed;
   t.step = step; t.keep_prob = DROP_KEEP; t.label_smoothing = LABEL_SMOOTH; t.loss_batch = loss_batch;
   t.row_offset = row_offset; t.train = 1;
   KWS_TRY(kws_ts_tail_launch(&t, st));

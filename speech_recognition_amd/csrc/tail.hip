@@ -33,6 +33,7 @@ struct TailArgs {
   float* dl2;           // [B, NC]
   float* per_loss;      // [B]
   float* per_correct;   // [B]
+  float* att_out;       // [B, T] attention weights (debug / parity view), may be NULL
   int B, T, C, NC;
   uint32_t key1, key2, thresh;
   float inv_keep;
@@ -126,6 +127,7 @@ __global__ __launch_bounds__(256) void ts_tail_kernel(TailArgs a) {
       for (int k = 0; k < T; ++k) att[k] /= den;
     }
     __syncthreads();
+    if (TRAIN && a.att_out != nullptr && tid < T) a.att_out[(int64_t)b * T + tid] = att[tid];
   }
   // ---- pooling: feat = [max_t x*att ; mean_t x], dropout 2 -----------------------------------
   for (int c = tid; c < C; c += 256) {
@@ -312,7 +314,7 @@ int kws_ts_tail_launch(const kws_ts_tail_args* p, hipStream_t st) {
   TailArgs a{};
   a.y = p->y; a.bn = p->bn; a.W1 = p->W1; a.b1 = p->b1; a.W2 = p->W2; a.labels = p->labels; a.probs = p->probs;
   a.g = p->g; a.part = p->part; a.xd = p->xd; a.fd = p->fd; a.dl1 = p->dl1; a.dl2 = p->dl2;
-  a.per_loss = p->per_loss; a.per_correct = p->per_correct;
+  a.per_loss = p->per_loss; a.per_correct = p->per_correct; a.att_out = p->att;
   a.B = p->B; a.T = p->T; a.C = p->C; a.NC = p->NC;
   a.key1 = kws_dropout_key(p->seed, p->step, 1);
   a.key2 = kws_dropout_key(p->seed, p->step, 2);

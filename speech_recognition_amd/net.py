@@ -159,6 +159,13 @@ class DeviceNet(object):
                   _lib.stream_ptr(stream))
         return probs
 
+    def debug_view(self, B, what, index, training=True):
+        """Copy of one intermediate tensor of the LAST call with this (B, training) (parity tests)."""
+        off, cnt = ctypes.c_int64(), ctypes.c_int64()
+        _lib.call("kws_net_debug_view", self.handle, B, int(training), what, index, ctypes.byref(off),
+                  ctypes.byref(cnt))
+        return self._ws[off.value:off.value + cnt.value].cpu().numpy()
+
     def l2_loss(self, stream=None):
         _lib.call("kws_l2_loss", _lib.ptr(self.params), _lib.ptr(self.l2), self.n_params,
                   _lib.ptr(self.reg_loss), _lib.stream_ptr(stream))

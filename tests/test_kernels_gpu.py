@@ -14,8 +14,22 @@ from speech_recognition_amd import _lib
 pytestmark = pytest.mark.gpu
 
 
+_KEEP = []
+
+
 def dev(a):
-    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    """Upload; the tensor is kept alive until the end of the test (the library only borrows raw
+    pointers, so a temporary freed before the asynchronous launch runs would be reused)."""
+    t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    _KEEP.append(t)
+    return t
+
+
+@pytest.fixture(autouse=True)
+def _release_uploads():
+    yield
+    torch.cuda.synchronize()
+    del _KEEP[:]
 
 
 def S():

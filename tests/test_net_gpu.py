@@ -1,10 +1,19 @@
 """GPU parity of the whole network program (forward, loss, backward, optimizer, BN moving stats)
 against the CPU oracle.  Bar from BASELINE.json north_star: class indices bit-exact, softmax
-within 1e-3 (we check much tighter where f32 allows)."""
+within 1e-3 (we check 2e-5).
+
+Gradients: the network is piecewise smooth - a pre-activation within f32 rounding of a ReLU6 kink
+(0 or 6), or two max-pool candidates within rounding of each other, may legitimately fall on
+different sides in the f32 device pass and the f64 oracle, and the gradient jumps there (measured:
+one flipped element moves upstream gradients by 3e-3..3e-2 of their max).  The tests therefore read
+the device's own discrete decisions (ReLU6 masks, max-pool winners) back through
+kws_net_debug_view and hand them to the oracle's backward pass; with decisions aligned every one of
+the 51 gradient tensors has to match to 5e-5 of its max."""
 import numpy as np
 import pytest
 import torch
 
+from oracle import layers as OL
 from oracle.net import TimeSlicedAttentionNet
 from speech_recognition_amd import _lib
 from speech_recognition_amd.net import DeviceNet
@@ -12,7 +21,7 @@ from speech_recognition_amd.net import DeviceNet
 pytestmark = pytest.mark.gpu
 
 
-def _pair(num_classes=12, seed=5):
+def _oracle(num_classes=12, seed=5):
     ora = TimeSlicedAttentionNet(num_classes=num_classes, dtype=np.float64)
     rng = np.random.RandomState(seed)
     for k in ora.params:                      # de-trivialise BN affine / bias so their grads matter
@@ -25,6 +34,11 @@ def _pair(num_classes=12, seed=5):
             ora.state[k] = (0.05 * rng.randn(*ora.state[k].shape)).astype(np.float32)
         else:
             ora.state[k] = (1.0 + 0.2 * rng.rand(*ora.state[k].shape)).astype(np.float32)
+    return ora
+
+
+def _pair(num_classes=12, seed=5):
+    ora = _oracle(num_classes, seed)
     net = DeviceNet(_lib.KWS_NET_TS_ATTENTION, num_classes)
     net.set_weights(dict(ora.params, **ora.state))
     return ora, net
@@ -36,6 +50,42 @@ def _batch(B, num_classes, seed):
     lab = rng.randint(0, num_classes, B)
     x = rng.randn(B, 16000) * 0.0774 + 0.05 * np.sin(2 * np.pi * 200.0 * (1 + lab)[:, None] * t[None])
     return x.astype(np.float32), np.eye(num_classes, dtype=np.float32)[lab]
+
+
+def _device_decisions(net, ora, B):
+    """ReLU6 masks of the 12 BN layers and the max-pool winners, recomputed from the device's own
+    pre-BN tensors / BN tables / attention weights with the kernel's f32 arithmetic."""
+    masks = {}
+    pre12 = None
+    shapes = [(B, 399, 128)] + [(B, b['Lout'], b['cout']) for b in ora.blocks]
+    for l in range(12):
+        y = net.debug_view(B, 0, l).reshape(shapes[l])
+        bn = net.debug_view(B, 2, l)
+        C = shapes[l][2]
+        # fmaf(y, scale, shift) rounded once to f32
+        pre = (y.astype(np.float64) * bn[:C].astype(np.float64) + bn[C:2 * C].astype(np.float64)).astype(np.float32)
+        masks[l + 1] = ((pre > 0) & (pre <= 6)).astype(np.float64)
+        pre12 = pre
+    x12 = np.minimum(np.maximum(pre12, np.float32(0)), np.float32(6))
+    att = net.debug_view(B, 3, 0).reshape(B, -1)
+    xa = x12 * att[:, :, None]                      # f32 product, as in ts_tail_kernel
+    ind = (xa == xa.max(axis=1, keepdims=True)).astype(np.float64)
+    return masks, ind
+
+
+def _check_grads(ora, net, x, y, seed, step, B, tol=5e-5, **kw):
+    masks, ind = _device_decisions(net, ora, B)
+    loss, p, grads, cache = ora.loss_and_grads(x.astype(np.float64), y.astype(np.float64), seed=seed, step=step,
+                                               relu_masks=masks, pool_ind=ind, **kw)
+    g = net.grads_dict()
+    flips = sum(int((masks[i] != OL.relu6_mask(cache['bn%d' % i][3])).sum()) for i in range(1, 13))
+    for k, ref in grads.items():
+        if k in ora.l2_names:                   # the HIP path folds L2 into the optimizer
+            ref = ref - 2e-5 * ora.params[k].astype(np.float64)
+        ref = ref.reshape(g[k].shape)
+        err = np.abs(g[k] - ref).max() / max(np.abs(ref).max(), 1e-7)
+        assert err < tol, (k, err, "kink flips: %d" % flips)
+    return loss, p, grads, cache
 
 
 def test_tensor_table_matches_keras_names_and_shapes():
@@ -58,28 +108,20 @@ def test_predict_matches_oracle():
     assert np.array_equal(p.argmax(1), ref.argmax(1))
 
 
-@pytest.mark.parametrize("B", [6, 37])
+@pytest.mark.parametrize("B", [3, 6, 37])
 def test_train_fwd_bwd_matches_oracle(B):
     ora, net = _pair()
     x, y = _batch(B, 12, B)
     probs = net.train_fwd_bwd(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(), seed=1234567, step=3)
     torch.cuda.synchronize()
-    loss, p, grads, cache = ora.loss_and_grads(x.astype(np.float64), y.astype(np.float64), seed=1234567, step=3)
+    loss, p, grads, cache = _check_grads(ora, net, x, y, 1234567, 3, B)
     got = probs.cpu().numpy()
-    assert np.abs(got - p).max() < 2e-5
-    assert np.array_equal(got.argmax(1), p.argmax(1))
+    assert np.abs(got - p).max() < 2e-5          # north_star bar on softmax: 1e-3
+    assert np.array_equal(got.argmax(1), p.argmax(1))   # class indices bit-exact
     m = net.metrics.cpu().numpy()
     assert abs(m[0] / B - loss) < 2e-5
     assert m[1] == (p.argmax(1) == y.argmax(1)).sum()
-    g = net.grads_dict()
-    params64 = {k: v.astype(np.float64) for k, v in ora.params.items()}
-    for k, ref in grads.items():
-        if k in ora.l2_names:                   # the HIP path folds L2 into the optimizer
-            ref = ref - 2e-5 * params64[k]
-        ref = ref.reshape(g[k].shape)
-        scale = max(np.abs(ref).max(), 1e-7)
-        assert np.abs(g[k] - ref).max() / scale < 2e-3, (k, np.abs(g[k] - ref).max() / scale)
-    # BN moving statistics were updated with the batch moments
+    # BN moving statistics were updated with the batch moments (SURVEY D.2)
     w = net.get_weights()
     for idx, (mean, var) in cache['batch_stats'].items():
         mm = ora.state['batch_normalization_%d/moving_mean' % idx].astype(np.float64)
@@ -88,48 +130,74 @@ def test_train_fwd_bwd_matches_oracle(B):
         np.testing.assert_allclose(w['batch_normalization_%d/moving_variance' % idx], mv - (mv - var) * 0.01, rtol=2e-5)
 
 
-def test_train_steps_track_oracle():
-    """Three RMSprop steps: loss / accuracy / weights stay on the oracle's trajectory."""
+@pytest.mark.parametrize("opt", ["sgd", "rmsprop"])
+def test_training_steps_teacher_forced(opt):
+    """Four consecutive train_on_batch steps (BASELINE C1: Keras SGD momentum .9; reference
+    model.py:834: RMSprop 1e-3).  Training is chaotic across ReLU6 kinks and RMSprop's sign-like first
+    steps, so the oracle is re-synchronised to the device weights before every step; what must hold
+    at EVERY step: softmax 2e-5 (bar 1e-3), identical class indices, total loss (data + L2) 5e-5, all
+    gradients (decision-aligned) 5e-5, BN moving statistics, and new weights = the Keras update rule
+    applied to the device's own gradient."""
     ora, net = _pair()
-    ora.init_optimizer('rmsprop')
+    lr = 0.01 if opt == "sgd" else 1e-3
     B = 8
-    for step in range(3):
+    names = [k for k in ora.params]
+    for step in range(4):
+        w0 = net.get_weights()
+        slots0 = net.slots.cpu().numpy()
+        for k in names:
+            ora.params[k] = w0[k].copy()
+        for k in ora.state:
+            ora.state[k] = w0[k].copy()
         x, y = _batch(B, 12, 100 + step)
-        net.train_fwd_bwd(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(), seed=99, step=step)
+        probs = net.train_fwd_bwd(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(), seed=99, step=step)
         reg = net.l2_loss().item()
-        net.rmsprop_step(1e-3)
-        total_ref, acc_ref = ora.train_step(x.astype(np.float64), y.astype(np.float64), 1e-3, seed=99, step=step)
+        g_dev = net.grads_dict()
+        loss, p, grads, cache = _check_grads(ora, net, x, y, 99, step, B)
+        if opt == "sgd":
+            net.sgd_step(lr, 0.9)
+        else:
+            net.rmsprop_step(lr)
+        got = probs.cpu().numpy()
+        assert np.abs(got - p).max() < 2e-5, step
+        assert np.array_equal(got.argmax(1), p.argmax(1))
         m = net.metrics.cpu().numpy()
-        assert abs(m[0] / B + reg - total_ref) < 5e-4, step
-        assert abs(m[1] / B - acc_ref) < 1e-9
-    w = net.get_weights()
-    for k in ('conv1d_1/kernel', 'conv1d_7/kernel', 'dense_2/kernel', 'depthwise_conv2d_3/depthwise_kernel'):
-        # RMSprop's first steps move every weight by ~lr regardless of gradient size, so compare the
-        # displacement direction statistically rather than elementwise
-        d_ref = ora.master[k].reshape(-1) - TimeSlicedAttentionNet().params[k].reshape(-1) if False else None
-        assert np.isfinite(w[k]).all()
+        assert abs(m[0] / B + reg - (loss + ora.reg_loss())) < 5e-5, step
+        w1 = net.get_weights()
+        for k in names:
+            s = net.tensors[k]
+            geff = g_dev[k].astype(np.float64) + 2.0 * s.l2 * w0[k].astype(np.float64)
+            sl = slots0[s.offset:s.offset + s.size].reshape(s.shape).astype(np.float64)
+            if opt == "sgd":
+                ref, _ = OL.sgd_momentum_step(w0[k].astype(np.float64), geff, sl, lr, 0.9)
+            else:
+                ref, _ = OL.rmsprop_step(w0[k].astype(np.float64), geff, sl, lr)
+            np.testing.assert_allclose(w1[k], ref, rtol=0, atol=2e-6, err_msg=k)
+        for idx, (mean, var) in cache['batch_stats'].items():
+            mm = w0['batch_normalization_%d/moving_mean' % idx].astype(np.float64)
+            np.testing.assert_allclose(w1['batch_normalization_%d/moving_mean' % idx], mm - (mm - mean) * 0.01,
+                                       atol=2e-6)
     x, _ = _batch(16, 12, 777)
+    for k in names:
+        ora.params[k] = w1[k]
+    for k in ora.state:
+        ora.state[k] = w1[k]
     p = net.predict(torch.from_numpy(x).cuda()).cpu().numpy()
     ref = ora.forward(x.astype(np.float64), training=False)
-    assert np.abs(p - ref).max() < 1e-3          # north_star tolerance on softmax
+    assert np.abs(p - ref).max() < 2e-5
     assert np.array_equal(p.argmax(1), ref.argmax(1))
 
 
-def test_row_offset_shards_reproduce_full_batch_dropout():
-    """Data-parallel sharding: rows [4,8) of a batch run as their own shard with row_offset=4 see the
-    same dropout masks as inside the full batch (BN stats differ, so only the masks are compared via
-    the dropped-feature path with BN-independent inputs is not possible; check determinism instead)."""
+def test_data_parallel_shard_semantics():
+    """Rows [4,8) of a global batch of 8 run as their own shard (row_offset=4, loss_batch=8): dropout
+    masks are those of the global rows, the loss gradient is scaled by 1/8, results are
+    bit-reproducible run to run (fixed-order reductions everywhere)."""
     ora, net = _pair()
     x, y = _batch(8, 12, 5)
     dx, dy = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
     p1 = net.train_fwd_bwd(dx[4:], dy[4:], seed=3, step=0, row_offset=4, loss_batch=8).clone()
     g1 = net.grads.clone()
     p2 = net.train_fwd_bwd(dx[4:], dy[4:], seed=3, step=0, row_offset=4, loss_batch=8)
-    assert torch.equal(p1, p2)
-    lossA, pA, gradsA, _ = ora.loss_and_grads(x[4:].astype(np.float64), y[4:].astype(np.float64), seed=3, step=0,
-                                               drop_offset=4, loss_scale_B=8)
-    assert np.abs(p1.cpu().numpy() - pA).max() < 2e-5
-    ref = gradsA['dense_2/kernel'] - 2e-5 * ora.params['dense_2/kernel'].astype(np.float64)
-    s = net.tensors['dense_2/kernel']
-    got = g1.cpu().numpy()[s.offset:s.offset + s.size].reshape(s.shape)
-    assert np.abs(got - ref).max() / np.abs(ref).max() < 2e-3
+    assert torch.equal(p1, p2) and torch.equal(g1, net.grads)
+    loss, p, grads, cache = _check_grads(ora, net, x[4:], y[4:], 3, 0, 4, drop_offset=4, loss_scale_B=8)
+    assert np.abs(p1.cpu().numpy() - p).max() < 2e-5
