@@ -37,6 +37,15 @@ const char* kws_last_error(void);
 /* name of the device the calling thread is bound to; "" if no HIP device is usable */
 int kws_device_name(char* buf, int cap);
 
+/* Optional per-kernel-family profiler (measurement only, off by default).  While enabled every
+ * launcher brackets its launch with a hipEvent pair on the launch stream and books the algorithmic
+ * FLOPs/bytes of the call; kws_profile_collect() waits for the events and returns the number of
+ * families, kws_profile_get() reads one (summed device ms, launches, FLOPs, bytes). */
+int kws_profile_enable(int on);
+int kws_profile_collect(void);
+int kws_profile_get(int idx, char* name, int cap, double* ms, int64_t* count, double* flops,
+                    double* bytes);
+
 /* ------------------------------------------------------------------------------------------
  * a2  augment graph: decode_wav -> multiply -> tf_roll -> multiply/add -> reshape
  *     reference input_data.py:334-359, utils.py:56-73
@@ -126,9 +135,13 @@ int kws_transpose_f32(const float* in, float* out, int rows, int cols, void* str
  * per-channel (scale, shift) these functions produce.
  * bn layout: float[4*C] = scale | shift | mean | rstd.
  * ---------------------------------------------------------------------------------------- */
+/* scratch (optional): KWS_REDUCE_SLICES * 2 * C floats (5 * C for kws_dw_bwd_finalize); when given,
+ * long partial lists are folded in two fixed-order stages instead of one serial pass. */
+#define KWS_REDUCE_SLICES 32
 int kws_bn_stats_finalize(const float* stats_part, int n_tiles, int64_t count, int C,
                           const float* gamma, const float* beta, float eps, float momentum,
-                          float* moving_mean, float* moving_var, float* bn, void* stream);
+                          float* moving_mean, float* moving_var, float* bn, float* scratch,
+                          void* stream);
 int kws_bn_infer_prepare(const float* gamma, const float* beta, const float* moving_mean,
                          const float* moving_var, float eps, int C, float* bn, void* stream);
 /* elementwise y -> relu6(scale*y+shift): only used by tests and by inference outputs */
@@ -151,9 +164,8 @@ int kws_dwconv_bwd_f32(const float* dz, const float* y, const float* bn, const f
                        void* stream);
 /* reduces part -> dw[3,C] (may be NULL), dgamma[C], dbeta[C], and coef[2*C] = (c1, c2) used by
  * kws_bn_bwd_apply; n_parts = part floats / (5*C) */
-int kws_dw_bwd_finalize(const float* part, int n_parts, int64_t count, int C, const float* gamma,
-                        const float* bn, float* dw, float* dgamma, float* dbeta, float* coef,
-                        void* stream);
+int kws_dw_bwd_finalize(const float* part, int n_parts, int64_t count, int C, float* dw,
+                        float* dgamma, float* dbeta, float* coef, float* scratch, void* stream);
 /* dy = gamma*rstd*(g - c1 - xhat*c2), in place on g (BatchNorm backward through batch stats) */
 int kws_bn_bwd_apply(float* g, const float* y, const float* bn, const float* gamma,
                      const float* coef, int64_t rows, int C, void* stream);

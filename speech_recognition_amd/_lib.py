@@ -47,6 +47,10 @@ SIGNATURES = {
     "kws_abi_version": (_I, []),
     "kws_last_error": (ctypes.c_char_p, []),
     "kws_device_name": (_I, [ctypes.c_char_p, _I]),
+    "kws_profile_enable": (_I, [_I]),
+    "kws_profile_collect": (_I, []),
+    "kws_profile_get": (_I, [_I, ctypes.c_char_p, _I, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I64),
+                             ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "kws_augment_f32": (_I, [_P, _I64, _I, _P, _P, _P, _P, _I64, _P, _P, _P, _I, _P]),
     "kws_augment_i16": (_I, [_P, _I64, _I, _P, _P, _P, _P, _I64, _P, _P, _P, _I, _P]),
     "kws_tta_transform": (_I, [_P, _P, _I, _I, _I, _P]),
@@ -63,13 +67,13 @@ SIGNATURES = {
     "kws_gemm_tn_f32": (_I, [_P, _P, _P, _I64, _I, _I, _P, _P]),
     "kws_gemm_tn_gather_f32": (_I, [_P, ctypes.POINTER(GatherDesc), _P, _P, _I, _I, _P, _P]),
     "kws_transpose_f32": (_I, [_P, _P, _I, _I, _P]),
-    "kws_bn_stats_finalize": (_I, [_P, _I, _I64, _I, _P, _P, _F, _F, _P, _P, _P, _P]),
+    "kws_bn_stats_finalize": (_I, [_P, _I, _I64, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
     "kws_bn_infer_prepare": (_I, [_P, _P, _P, _P, _F, _I, _P, _P]),
     "kws_bn_relu6_apply": (_I, [_P, _P, _P, _I64, _I, _I, _P]),
     "kws_dwconv_fwd_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "kws_dwconv_bwd_part_floats": (_I64, [_I, _I, _I]),
     "kws_dwconv_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
-    "kws_dw_bwd_finalize": (_I, [_P, _I, _I64, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "kws_dw_bwd_finalize": (_I, [_P, _I, _I64, _I, _P, _P, _P, _P, _P, _P]),
     "kws_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _I64, _I, _P]),
     "kws_rmsprop_step": (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _P]),
     "kws_sgd_momentum_step": (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _P]),
@@ -128,6 +132,21 @@ def stream_ptr(stream=None):
     import torch
     s = stream if stream is not None else torch.cuda.current_stream()
     return ctypes.c_void_p(s.cuda_stream)
+
+
+def profile_collect():
+    """{family: {"ms", "count", "flops", "bytes"}} for everything launched since kws_profile_enable(1)."""
+    lib = load()
+    out = {}
+    n = lib.kws_profile_collect()
+    for i in range(n):
+        name = ctypes.create_string_buffer(64)
+        ms, fl, by = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        cnt = ctypes.c_int64()
+        check(lib.kws_profile_get(i, name, 64, ctypes.byref(ms), ctypes.byref(cnt), ctypes.byref(fl),
+                                  ctypes.byref(by)), "kws_profile_get")
+        out[name.value.decode()] = {"ms": ms.value, "count": cnt.value, "flops": fl.value, "bytes": by.value}
+    return out
 
 
 def call(name, *args):

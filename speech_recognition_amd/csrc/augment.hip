@@ -144,6 +144,7 @@ int launch_augment(const BankT* bank, int64_t n_clips, int L, const int32_t* cli
   KWS_REQUIRE(noise == nullptr || (noise_off != nullptr && noise_len > 0), "augment: noise given without offsets");
   const int L4 = ceil_div(L, 4);
   dim3 g((unsigned)ceil_div(L4, 256), (unsigned)B), b(256);
+  KwsProfScope prof("augment", 3.0 * B * L, (double)B * L * (sizeof(BankT) + 8.0), (hipStream_t)stream);
   hipLaunchKernelGGL((augment_kernel<BankT>), g, b, 0, (hipStream_t)stream, bank, n_clips, L, clip_idx, fg_vol, shift,
                      noise, noise_len, noise_off, bg_vol, out, L4);
   KWS_LAUNCH_CHECK("augment_kernel");

@@ -51,6 +51,30 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __r
   }
 }
 
+// Stage 1 of the two-stage partial-sum reduction: in[n][W] -> out[S][W], slice s sums rows
+// [s*rows_per, (s+1)*rows_per) in ascending order (fixed order => bit-reproducible).  One thread per
+// (column, slice): coalesced across columns, thousands of threads, so the per-tile partials of the big
+// early layers (3000+ tiles) are folded at memory speed instead of by a handful of serial loops.
+__global__ __launch_bounds__(256) void slice_reduce_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                           int n, int W, int rows_per) {
+  const int w = blockIdx.x * 256 + threadIdx.x;
+  const int s = blockIdx.y;
+  if (w >= W) return;
+  const int r0 = s * rows_per;
+  int r1 = r0 + rows_per;
+  if (r1 > n) r1 = n;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int r = r0;
+  for (; r + 3 < r1; r += 4) {
+    a0 += in[(int64_t)r * W + w];
+    a1 += in[(int64_t)(r + 1) * W + w];
+    a2 += in[(int64_t)(r + 2) * W + w];
+    a3 += in[(int64_t)(r + 3) * W + w];
+  }
+  for (; r < r1; ++r) a0 += in[(int64_t)r * W + w];
+  out[(int64_t)s * W + w] = (a0 + a1) + (a2 + a3);
+}
+
 __global__ __launch_bounds__(256) void bn_infer_prepare_kernel(const float* gamma, const float* beta,
                                                                const float* mm, const float* mv, float eps, int C,
                                                                float* bn) {
@@ -136,17 +160,36 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ g
   reinterpret_cast<float4*>(g)[i] = o;
 }
 
+// Folds n partial rows of width W into at most KWS_REDUCE_SLICES rows in `scratch` when that pays.
+int pre_reduce(const float* part, int n, int W, float* scratch, hipStream_t st, const float** out_part, int* out_n) {
+  if (scratch == nullptr || n <= 2 * KWS_REDUCE_SLICES) {
+    *out_part = part;
+    *out_n = n;
+    return KWS_OK;
+  }
+  const int rows_per = ceil_div(n, KWS_REDUCE_SLICES);
+  const int S = ceil_div(n, rows_per);
+  hipLaunchKernelGGL(slice_reduce_kernel, dim3((unsigned)ceil_div(W, 256), (unsigned)S), dim3(256), 0, st, part, scratch,
+                     n, W, rows_per);
+  KWS_LAUNCH_CHECK("slice_reduce_kernel");
+  *out_part = scratch;
+  *out_n = S;
+  return KWS_OK;
+}
+
 }  // namespace
 
 extern "C" {
 
 int kws_bn_stats_finalize(const float* stats_part, int n_tiles, int64_t count, int C, const float* gamma,
                           const float* beta, float eps, float momentum, float* moving_mean, float* moving_var,
-                          float* bn, void* stream) {
+                          float* bn, float* scratch, void* stream) {
   KWS_REQUIRE(stats_part && gamma && beta && bn, "bn_stats_finalize: NULL pointer");
   KWS_REQUIRE(n_tiles > 0 && count > 0 && C > 0, "bn_stats_finalize: bad sizes");
   KWS_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), "bn_stats_finalize: moving stats must both be set");
   const float omm = (float)(1.0 - (double)momentum);
+  KwsProfScope prof("bn_finalize", 0.0, 8.0 * n_tiles * C, (hipStream_t)stream);
+  KWS_TRY(pre_reduce(stats_part, n_tiles, 2 * C, scratch, (hipStream_t)stream, &stats_part, &n_tiles));
   hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((unsigned)ceil_div(C, 32)), dim3(256), 0, (hipStream_t)stream,
                      stats_part, n_tiles, 1.0 / (double)count, C, gamma, beta, eps, omm, moving_mean, moving_var, bn);
   KWS_LAUNCH_CHECK("bn_stats_finalize_kernel");
@@ -171,11 +214,11 @@ int kws_bn_relu6_apply(const float* y, const float* bn, float* out, int64_t rows
   return KWS_OK;
 }
 
-int kws_dw_bwd_finalize(const float* part, int n_parts, int64_t count, int C, const float* gamma, const float* bn,
-                        float* dw, float* dgamma, float* dbeta, float* coef, void* stream) {
-  (void)gamma;
-  (void)bn;
+int kws_dw_bwd_finalize(const float* part, int n_parts, int64_t count, int C, float* dw, float* dgamma, float* dbeta,
+                        float* coef, float* scratch, void* stream) {
   KWS_REQUIRE(part && n_parts > 0 && count > 0 && C > 0, "dw_bwd_finalize: bad arguments");
+  KwsProfScope prof("bn_finalize", 0.0, 20.0 * n_parts * C, (hipStream_t)stream);
+  KWS_TRY(pre_reduce(part, n_parts, 5 * C, scratch, (hipStream_t)stream, &part, &n_parts));
   hipLaunchKernelGGL(dw_bwd_finalize_kernel, dim3((unsigned)ceil_div(C, 32)), dim3(256), 0, (hipStream_t)stream, part,
                      n_parts, 1.0 / (double)count, C, dw, dgamma, dbeta, coef);
   KWS_LAUNCH_CHECK("dw_bwd_finalize_kernel");
@@ -186,6 +229,7 @@ int kws_bn_bwd_apply(float* g, const float* y, const float* bn, const float* gam
                      int C, void* stream) {
   KWS_REQUIRE(g && y && bn && gamma && coef && rows > 0 && C > 0 && C % 4 == 0, "bn_bwd_apply: bad arguments");
   const int64_t n4 = rows * C / 4;
+  KwsProfScope prof("bn_bwd_apply", 6.0 * rows * C, 12.0 * rows * C, (hipStream_t)stream);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)ceil_div64(n4, 256)), dim3(256), 0, (hipStream_t)stream, g, y,
                      bn, gamma, coef, n4, C);
   KWS_LAUNCH_CHECK("bn_bwd_apply_kernel");

@@ -68,3 +68,24 @@ __device__ static inline bool kws_keep(uint32_t idx, uint32_t key, uint32_t thre
 }
 
 __device__ static inline float relu6f(float v) { return fminf(fmaxf(v, 0.0f), 6.0f); }
+
+// ---- optional per-kernel-family profiler (off by default; bench.py turns it on for a few steps) ----
+// When enabled, every launcher brackets its launch with a hipEvent pair on the launch stream and books
+// the algorithmic FLOPs / bytes it was asked to process; kws_profile_get() then reports, per family,
+// the summed device time between the events.  This is the "HIP events on the stream the kernel is
+// launched on" measurement of the roofline numbers.
+bool kws_prof_on();
+void* kws_prof_begin(hipStream_t st);
+void kws_prof_end(void* token, const char* name, double flops, double bytes, hipStream_t st);
+struct KwsProfScope {
+  void* tok;
+  const char* name;
+  double flops, bytes;
+  hipStream_t st;
+  KwsProfScope(const char* n, double f, double b, hipStream_t s) : tok(nullptr), name(n), flops(f), bytes(b), st(s) {
+    if (kws_prof_on()) tok = kws_prof_begin(s);
+  }
+  ~KwsProfScope() {
+    if (tok) kws_prof_end(tok, name, flops, bytes, st);
+  }
+};

@@ -211,6 +211,7 @@ int kws_dwconv_fwd_f32(const float* y, const float* bn, const float* w, float* z
   KWS_REQUIRE(grid < 0x7FFFFFFF, "dwconv_fwd: grid too large");
   dim3 g((unsigned)grid), b(256);
   hipStream_t st = (hipStream_t)stream;
+  KwsProfScope prof("dwconv_fwd", 6.0 * B * L_out * C, 4.0 * ((double)B * L_in * C + (double)B * L_out * C), st);
   if (stride == 1) {
     if (bn) hipLaunchKernelGGL((dwconv_fwd_kernel<1, true>), g, b, 0, st, y, bn, w, z, B, L_in, L_out, C, pad_l, nchunks);
     else hipLaunchKernelGGL((dwconv_fwd_kernel<1, false>), g, b, 0, st, y, bn, w, z, B, L_in, L_out, C, pad_l, nchunks);
@@ -238,6 +239,7 @@ int kws_dwconv_bwd_f32(const float* dz, const float* y, const float* bn, const f
   KWS_REQUIRE(ge.grid < 0x7FFFFFFF, "dwconv_bwd: grid too large");
   dim3 gr((unsigned)ge.grid), b((unsigned)ge.block);
   hipStream_t st = (hipStream_t)stream;
+  KwsProfScope prof("dwconv_bwd", 12.0 * B * L_in * C, 4.0 * (2.0 * B * L_in * C + (double)B * L_out * C), st);
   if (stride == 1) {
     if (bn) hipLaunchKernelGGL((dwconv_bwd_kernel<1, true>), gr, b, 0, st, dz, y, bn, w, g, part, B, L_in, L_out, C, pad_l, ge.nchunks, ge.R);
     else hipLaunchKernelGGL((dwconv_bwd_kernel<1, false>), gr, b, 0, st, dz, y, bn, w, g, part, B, L_in, L_out, C, pad_l, ge.nchunks, ge.R);

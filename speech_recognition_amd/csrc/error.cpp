@@ -39,3 +39,106 @@ int kws_device_name(char* buf, int cap) {
 }
 
 }  // extern "C"
+
+// ---- profiler ----------------------------------------------------------------------------------------
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace {
+struct ProfRec {
+  hipEvent_t a, b;
+  std::string name;
+  double flops, bytes;
+};
+struct ProfAgg {
+  double ms = 0, flops = 0, bytes = 0;
+  long long count = 0;
+};
+std::mutex g_prof_mu;
+bool g_prof_enabled = false;
+std::vector<ProfRec*> g_prof_recs;
+std::vector<std::pair<std::string, ProfAgg>> g_prof_out;
+
+void prof_clear_locked() {
+  for (ProfRec* r : g_prof_recs) {
+    (void)hipEventDestroy(r->a);
+    (void)hipEventDestroy(r->b);
+    delete r;
+  }
+  g_prof_recs.clear();
+}
+}  // namespace
+
+bool kws_prof_on() { return g_prof_enabled; }
+
+void* kws_prof_begin(hipStream_t st) {
+  ProfRec* r = new ProfRec();
+  if (hipEventCreate(&r->a) != hipSuccess || hipEventCreate(&r->b) != hipSuccess) {
+    delete r;
+    return nullptr;
+  }
+  (void)hipEventRecord(r->a, st);
+  return r;
+}
+
+void kws_prof_end(void* token, const char* name, double flops, double bytes, hipStream_t st) {
+  ProfRec* r = static_cast<ProfRec*>(token);
+  (void)hipEventRecord(r->b, st);
+  r->name = name;
+  r->flops = flops;
+  r->bytes = bytes;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof_recs.push_back(r);
+}
+
+extern "C" {
+
+int kws_profile_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (on) {
+    prof_clear_locked();
+    g_prof_out.clear();
+  }
+  g_prof_enabled = on != 0;
+  return KWS_OK;
+}
+
+// Waits for every recorded event, aggregates per family; returns the number of families.
+int kws_profile_collect(void) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  std::map<std::string, ProfAgg> agg;
+  std::vector<std::string> order;
+  for (ProfRec* r : g_prof_recs) {
+    float ms = 0.f;
+    if (hipEventSynchronize(r->b) != hipSuccess || hipEventElapsedTime(&ms, r->a, r->b) != hipSuccess) continue;
+    if (!agg.count(r->name)) order.push_back(r->name);
+    ProfAgg& a = agg[r->name];
+    a.ms += ms;
+    a.flops += r->flops;
+    a.bytes += r->bytes;
+    a.count += 1;
+  }
+  prof_clear_locked();
+  g_prof_out.clear();
+  for (const std::string& n : order) g_prof_out.push_back({n, agg[n]});
+  return (int)g_prof_out.size();
+}
+
+int kws_profile_get(int idx, char* name, int cap, double* ms, int64_t* count, double* flops, double* bytes) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (idx < 0 || idx >= (int)g_prof_out.size() || !name || cap <= 0) {
+    kws_set_error("profile_get: bad index %d", idx);
+    return KWS_E_INVALID;
+  }
+  snprintf(name, cap, "%s", g_prof_out[idx].first.c_str());
+  const ProfAgg& a = g_prof_out[idx].second;
+  if (ms) *ms = a.ms;
+  if (count) *count = a.count;
+  if (flops) *flops = a.flops;
+  if (bytes) *bytes = a.bytes;
+  return KWS_OK;
+}
+
+}  // extern "C"

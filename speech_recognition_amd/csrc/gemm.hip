@@ -488,6 +488,7 @@ int kws_gemm_nn_f32(const float* A, const float* W, float* C, int64_t M, int K, 
               (long long)M, K, N);
   NNArgs a{};
   a.A = A; a.W = W; a.C = C; a.M = M; a.K = K; a.N = N; a.stats = stats_part;
+  KwsProfScope prof("gemm_nn", 2.0 * M * K * N, 4.0 * ((double)M * K + (double)K * N + (double)M * N), (hipStream_t)stream);
   return launch_nn<false>(a, (hipStream_t)stream);
 }
 
@@ -498,6 +499,7 @@ int kws_gemm_gather_f32(const float* X, const kws_gather_t* g, const float* W, f
   NNArgs a{};
   a.A = X; a.W = W; a.C = C; a.M = (int64_t)B * g->L_out; a.K = g->taps * g->cin; a.N = N;
   a.stats = stats_part; a.g = *g;
+  KwsProfScope prof("gemm_nn", 2.0 * a.M * a.K * N, 4.0 * ((double)B * g->x_len + (double)a.K * N + (double)a.M * N), (hipStream_t)stream);
   return launch_nn<true>(a, (hipStream_t)stream);
 }
 
@@ -513,6 +515,7 @@ int kws_gemm_tn_f32(const float* A, const float* G, float* dW, int64_t M, int K,
               (long long)M, K, N);
   TNArgs a{};
   a.A = A; a.G = G; a.ws = workspace; a.M = M; a.K = K; a.N = N;
+  KwsProfScope prof("gemm_tn", 2.0 * M * K * N, 4.0 * ((double)M * K + (double)M * N + (double)K * N), (hipStream_t)stream);
   return launch_tn<false>(a, dW, (hipStream_t)stream);
 }
 
@@ -523,11 +526,13 @@ int kws_gemm_tn_gather_f32(const float* X, const kws_gather_t* g, const float* G
   TNArgs a{};
   a.A = X; a.G = G; a.ws = workspace; a.M = (int64_t)B * g->L_out; a.K = g->taps * g->cin; a.N = N;
   a.g = *g;
+  KwsProfScope prof("gemm_tn", 2.0 * a.M * a.K * N, 4.0 * ((double)B * g->x_len + (double)a.M * N + (double)a.K * N), (hipStream_t)stream);
   return launch_tn<true>(a, dW, (hipStream_t)stream);
 }
 
 int kws_transpose_f32(const float* in, float* out, int rows, int cols, void* stream) {
   KWS_REQUIRE(in && out && rows > 0 && cols > 0, "transpose: bad arguments");
+  KwsProfScope prof("transpose", 0.0, 8.0 * rows * cols, (hipStream_t)stream);
   dim3 g((unsigned)ceil_div(cols, 32), (unsigned)ceil_div(rows, 32));
   hipLaunchKernelGGL(transpose_kernel, g, dim3(256), 0, (hipStream_t)stream, in, out, rows, cols);
   KWS_LAUNCH_CHECK("transpose_kernel");

@@ -9,6 +9,7 @@ struct kws_ts_tail_args {
   int loss_batch; int64_t row_offset; int train;
 };
 int kws_ts_tail_launch(const kws_ts_tail_args* p, hipStream_t st);
+constexpr int KWS_SMALL_WGRAD_SLICES = 32;  // scratch: KWS_SMALL_WGRAD_SLICES * K * N floats
 int kws_small_wgrad_launch(const float* X, const float* D, float* out, float* out_bias, int B, int K, int N,
-                           hipStream_t st);
+                           float* scratch, hipStream_t st);
 int kws_metrics_launch(const float* per_loss, const float* per_correct, int B, float* metrics, hipStream_t st);

@@ -155,7 +155,7 @@ struct Layout {
   int64_t total = 0;  // bytes
   std::vector<int64_t> y;   // y[l], l = 0..11 (float offsets)
   std::vector<int64_t> z;   // z[i], i = 0..10
-  int64_t G = 0, DZ = 0, bn = 0, part = 0, coef = 0, WT = 0, tn = 0;
+  int64_t G = 0, DZ = 0, bn = 0, part = 0, coef = 0, WT = 0, tn = 0, red = 0, swg = 0;
   int64_t xd = 0, fd = 0, dl1 = 0, dl2 = 0, per_loss = 0, per_correct = 0, att = 0;
   int64_t bn_stride = 0;
 };
@@ -204,6 +204,9 @@ void make_layout(const kws_net* n, int B, bool training, Layout* lo) {
     const int64_t tail_part = (int64_t)B * 5 * n->C;
     lo->part = bp.take(std::max(std::max(max_part, max_dwpart), tail_part));
     lo->coef = bp.take(2 * maxC);
+    lo->red = bp.take((int64_t)KWS_REDUCE_SLICES * 5 * maxC);
+    lo->swg = bp.take((int64_t)KWS_SMALL_WGRAD_SLICES *
+                      std::max((int64_t)n->T * n->C * n->T, (int64_t)2 * n->C * n->NC));
     lo->WT = bp.take(max_wt);
     lo->tn = bp.take(max_tn);
     lo->xd = bp.take((int64_t)B * n->T * n->C);
@@ -361,6 +364,7 @@ int kws_net_train_fwd_bwd(const kws_net_t* net, const float* params, float* stat
   float* G = ws + lo.G;
   float* DZ = ws + lo.DZ;
   float* coef = ws + lo.coef;
+  float* red = ws + lo.red;
 
   KWS_HIP(hipMemsetAsync(grads, 0, (size_t)net->n_params * 4, st));
   // ---------------- forward ----------------
@@ -369,7 +373,7 @@ int kws_net_train_fwd_bwd(const kws_net_t* net, const float* params, float* stat
     KWS_TRY(kws_gemm_gather_f32(x, &net->gather1, params + net->conv1, ws + lo.y[0], B, net->C1, part, st));
     KWS_TRY(kws_bn_stats_finalize(part, kws_gemm_num_row_tiles(M), M, net->C1, params + net->bn1.gamma,
                                   params + net->bn1.beta, BN_EPS, BN_MOMENTUM, state + net->bn1.mm, state + net->bn1.mv,
-                                  bn_at(0), st));
+                                  bn_at(0), red, st));
   }
   for (int i = 0; i < nb; ++i) {
     const Block& b = net->blocks[i];
@@ -378,7 +382,7 @@ int kws_net_train_fwd_bwd(const kws_net_t* net, const float* params, float* stat
                                b.pad_l, st));
     KWS_TRY(kws_gemm_nn_f32(ws + lo.z[i], params + b.pw, ws + lo.y[i + 1], M, b.cin, b.cout, part, st));
     KWS_TRY(kws_bn_stats_finalize(part, kws_gemm_num_row_tiles(M), M, b.cout, params + b.bn.gamma, params + b.bn.beta,
-                                  BN_EPS, BN_MOMENTUM, state + b.bn.mm, state + b.bn.mv, bn_at(i + 1), st));
+                                  BN_EPS, BN_MOMENTUM, state + b.bn.mm, state + b.bn.mv, bn_at(i + 1), red, st));
   }
   // ---------------- tail forward + backward ----------------
   kws_ts_tail_args t;
@@ -391,12 +395,13 @@ int kws_net_train_fwd_bwd(const kws_net_t* net, const float* params, float* stat
   t.row_offset = row_offset; t.train = 1;
   KWS_TRY(kws_ts_tail_launch(&t, st));
   KWS_TRY(kws_metrics_launch(t.per_loss, t.per_correct, B, metrics, st));
-  KWS_TRY(kws_small_wgrad_launch(t.fd, t.dl2, grads + net->d2k, nullptr, B, 2 * net->C, net->NC, st));
-  KWS_TRY(kws_small_wgrad_launch(t.xd, t.dl1, grads + net->d1k, grads + net->d1b, B, net->T * net->C, net->T, st));
+  KWS_TRY(kws_small_wgrad_launch(t.fd, t.dl2, grads + net->d2k, nullptr, B, 2 * net->C, net->NC, ws + lo.swg, st));
+  KWS_TRY(kws_small_wgrad_launch(t.xd, t.dl1, grads + net->d1k, grads + net->d1b, B, net->T * net->C, net->T,
+                                 ws + lo.swg, st));
   {
     const BnRef& r = net->blocks[nb - 1].bn;
-    KWS_TRY(kws_dw_bwd_finalize(part, B, (int64_t)B * net->T, r.C, nullptr, nullptr, nullptr, grads + r.gamma,
-                                grads + r.beta, coef, st));
+    KWS_TRY(kws_dw_bwd_finalize(part, B, (int64_t)B * net->T, r.C, nullptr, grads + r.gamma,
+                                grads + r.beta, coef, red, st));
   }
   // ---------------- backward through the blocks ----------------
   for (int i = nb - 1; i >= 0; --i) {
@@ -411,8 +416,8 @@ int kws_net_train_fwd_bwd(const kws_net_t* net, const float* params, float* stat
     KWS_TRY(kws_dwconv_bwd_f32(DZ, ws + lo.y[i], bn_at(i), params + b.dw, G, part, B, b.Lin, b.Lout, b.cin, b.stride,
                                b.pad_l, st));
     const int n_parts = (int)(kws_dwconv_bwd_part_floats(B, b.Lin, b.cin) / (5 * b.cin));
-    KWS_TRY(kws_dw_bwd_finalize(part, n_parts, (int64_t)B * b.Lin, b.cin, nullptr, nullptr, grads + b.dw,
-                                grads + prev.gamma, grads + prev.beta, coef, st));
+    KWS_TRY(kws_dw_bwd_finalize(part, n_parts, (int64_t)B * b.Lin, b.cin, grads + b.dw,
+                                grads + prev.gamma, grads + prev.beta, coef, red, st));
   }
   {
     const int64_t M = (int64_t)B * net->L1;

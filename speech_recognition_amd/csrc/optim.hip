@@ -71,6 +71,7 @@ int kws_rmsprop_step(float* p, const float* grad, float* acc, const float* l2, i
                      float eps, float grad_scale, void* stream) {
   KWS_REQUIRE(p && grad && acc && l2 && n > 0, "rmsprop: bad arguments");
   const int64_t n4 = ceil_div64(n, 4);
+  KwsProfScope prof("optimizer", 8.0 * n, 24.0 * n, (hipStream_t)stream);
   hipLaunchKernelGGL(rmsprop_kernel, dim3((unsigned)ceil_div64(n4, 256)), dim3(256), 0, (hipStream_t)stream, p, grad,
                      acc, l2, n, lr, rho, eps, grad_scale);
   KWS_LAUNCH_CHECK("rmsprop_kernel");
@@ -80,6 +81,7 @@ int kws_rmsprop_step(float* p, const float* grad, float* acc, const float* l2, i
 int kws_sgd_momentum_step(float* p, const float* grad, float* vel, const float* l2, int64_t n, float lr,
                           float momentum, float grad_scale, void* stream) {
   KWS_REQUIRE(p && grad && vel && l2 && n > 0, "sgd: bad arguments");
+  KwsProfScope prof("optimizer", 6.0 * n, 24.0 * n, (hipStream_t)stream);
   hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, (hipStream_t)stream, p, grad, vel,
                      l2, n, lr, momentum, grad_scale);
   KWS_LAUNCH_CHECK("sgd_kernel");
@@ -88,6 +90,7 @@ int kws_sgd_momentum_step(float* p, const float* grad, float* vel, const float* 
 
 int kws_l2_loss(const float* p, const float* l2, int64_t n, float* out, void* stream) {
   KWS_REQUIRE(p && l2 && out && n > 0, "l2_loss: bad arguments");
+  KwsProfScope prof("l2_loss", 3.0 * n, 8.0 * n, (hipStream_t)stream);
   hipLaunchKernelGGL(l2_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, p, l2, n, out);
   KWS_LAUNCH_CHECK("l2_loss_kernel");
   return KWS_OK;

@@ -302,6 +302,10 @@ int kws_stft_mel_f32(const kws_stft_plan_t* plan, const float* x, int B, int L, 
   a.x = x; a.out = out; a.L = L; a.out_kind = out_kind;
   a.F = kws_stft_num_frames(plan, L);
   hipStream_t st = (hipStream_t)stream;
+  const int width = out_kind == 0 ? plan->n_out : (out_kind == 1 ? 257 : plan->n_mel);
+  // ~5 N log2 N for the 256-point complex FFT + split + sparse mel + dense DCT, per frame
+  const double fl = (double)B * a.F * (5.0 * 256 * 8 + 12.0 * 257 + 2.0 * plan->n_w + 2.0 * plan->n_mel * plan->n_out);
+  KwsProfScope prof("stft_mel", fl, 4.0 * ((double)B * L + (double)B * a.F * width), st);
   if (a.F % 14 == 0) {
     a.run_samples = (7 * 2 - 1) * plan->frame_step + plan->frame_len;
     return launch_stft<7, 2>(a, B, st);

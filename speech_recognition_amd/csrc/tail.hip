@@ -270,15 +270,28 @@ __global__ __launch_bounds__(256) void ts_tail_kernel(TailArgs a) {
   }
 }
 
-// out[K, N] = sum_b X[b, K]^T D[b, N]  (N small); optional bias grad out_b[N] = sum_b D[b, N]
+// out[K, N] = sum_b X[b, K]^T D[b, N]  (N small); optional bias grad out_b[N] = sum_b D[b, N].
+// The batch is cut into gridDim.y slices (one partial [K*N] slab each, summed afterwards in slice order)
+// so that B*K*N/256 workgroups share the work instead of K*N/256 serial loops over the whole batch.
 __global__ __launch_bounds__(256) void small_wgrad_kernel(const float* __restrict__ X, const float* __restrict__ D,
-                                                          float* __restrict__ out, int B, int K, int N) {
+                                                          float* __restrict__ out, int B, int K, int N, int rows_per) {
   const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (id >= (int64_t)K * N) return;
   const int i = (int)(id / N), k = (int)(id - (int64_t)i * N);
+  const int b0 = blockIdx.y * rows_per;
+  int b1 = b0 + rows_per;
+  if (b1 > B) b1 = B;
   float s = 0.f;
-  for (int b = 0; b < B; ++b) s = fmaf(X[(int64_t)b * K + i], D[(int64_t)b * N + k], s);
-  out[id] = s;
+  for (int b = b0; b < b1; ++b) s = fmaf(X[(int64_t)b * K + i], D[(int64_t)b * N + k], s);
+  out[(int64_t)blockIdx.y * K * N + id] = s;
+}
+__global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t n,
+                                                       int S) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float s = in[i];
+  for (int k = 1; k < S; ++k) s += in[(int64_t)k * n + i];
+  out[i] = s;
 }
 __global__ __launch_bounds__(64) void colsum_kernel(const float* __restrict__ D, float* __restrict__ out, int B, int N) {
   const int k = threadIdx.x;
@@ -323,6 +336,7 @@ int kws_ts_tail_launch(const kws_ts_tail_args* p, hipStream_t st) {
   a.label_smoothing = p->label_smoothing;
   a.inv_loss_batch = 1.0f / (float)p->loss_batch;
   a.row_offset = p->row_offset;
+  KwsProfScope prof(p->train ? "tail_train" : "tail_infer", 4.0 * p->B * TC * p->T * (p->train ? 2 : 1), 4.0 * p->B * TC * (p->train ? 4 : 1), st);
   if (p->train) {
     static bool attr_set_t = false;
     if (!attr_set_t && lds_floats * 4 > 64 * 1024) {
@@ -345,10 +359,21 @@ int kws_ts_tail_launch(const kws_ts_tail_args* p, hipStream_t st) {
 }
 
 int kws_small_wgrad_launch(const float* X, const float* D, float* out, float* out_bias, int B, int K, int N,
-                           hipStream_t st) {
+                           float* scratch, hipStream_t st) {
   const int64_t n = (int64_t)K * N;
-  hipLaunchKernelGGL(small_wgrad_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, st, X, D, out, B, K, N);
+  KwsProfScope prof("small_wgrad", 2.0 * B * K * N, 4.0 * ((double)B * K + (double)B * N + (double)K * N), st);
+  int S = scratch ? KWS_SMALL_WGRAD_SLICES : 1;
+  if (S > B) S = B;
+  const int rows_per = ceil_div(B, S);
+  S = ceil_div(B, rows_per);
+  float* dst = S > 1 ? scratch : out;
+  hipLaunchKernelGGL(small_wgrad_kernel, dim3((unsigned)ceil_div64(n, 256), (unsigned)S), dim3(256), 0, st, X, D, dst, B,
+                     K, N, rows_per);
   KWS_LAUNCH_CHECK("small_wgrad_kernel");
+  if (S > 1) {
+    hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, st, scratch, out, n, S);
+    KWS_LAUNCH_CHECK("slab_sum_kernel");
+  }
   if (out_bias) {
     KWS_REQUIRE(N <= 64, "small_wgrad: N=%d > 64", N);
     hipLaunchKernelGGL(colsum_kernel, dim3(1), dim3(64), 0, st, D, out_bias, B, N);

@@ -1,0 +1,508 @@
+"""AudioProcessor: dataset index, sampler and batched on-GPU augmentation / feature extraction.
+
+Host-side mirror of the reference's `input_data.py` interface (same names, argument meaning and
+error behaviour; reference input_data.py:49-610) for the accelerated path:
+
+  * index construction (`which_set`, `prepare_data_index`) is host glue, restated here;
+  * every wav of the index is decoded ONCE into an HBM-resident int16 clip bank (DecodeWav
+    semantics: int16/32768, mono, pad/crop to desired_samples; reference input_data.py:335-336);
+  * `get_data` draws the per-clip augmentation parameters on the host in exactly the reference's
+    NumPy-global-RNG order (input_data.py:457-514) and then issues ONE
+    `kws_augment_*` launch (+ ONE `kws_stft_mel_f32` launch for 'mfcc'/'spec') for the whole batch
+    instead of one `sess.run` per clip; the batch stays on the GPU (DeviceArray).
+"""
+from __future__ import absolute_import, division, print_function
+
+import ctypes
+import glob
+import hashlib
+import math
+import os.path
+import random
+import re
+import struct
+import sys
+
+import numpy as np
+import torch
+
+from . import _lib
+from .device_array import DeviceArray, Labels
+
+MAX_NUM_WAVS_PER_CLASS = 2 ** 27 - 1  # ~134M
+SILENCE_LABEL = '_silence_'
+SILENCE_INDEX = 0
+UNKNOWN_WORD_LABEL = '_unknown_'
+UNKNOWN_WORD_INDEX = 1
+BACKGROUND_NOISE_DIR_NAME = '_background_noise_'
+RANDOM_SEED = 59185
+
+
+def prepare_words_list(wanted_words):
+    """reference input_data.py:49-58"""
+    return [SILENCE_LABEL, UNKNOWN_WORD_LABEL] + wanted_words
+
+
+def which_set(filename, validation_percentage, testing_percentage):
+    """Stable SHA-1 partition of a file name (reference input_data.py:61-114): directory
+    `unknown_unknown` -> training; no `_nohash_` in the name -> 'pseudo'; else the hash of the part
+    before `_nohash_` mapped to [0,100] decides validation / testing / training."""
+    if os.path.basename(os.path.dirname(filename)) == 'unknown_unknown':
+        return 'training'
+    base_name = os.path.basename(filename)
+    if base_name.find('_nohash_') == -1:
+        return 'pseudo'
+    hash_name = re.sub(r'_nohash_.*$', '', base_name)
+    digest = hashlib.sha1(hash_name.encode('utf-8')).hexdigest()
+    percentage_hash = ((int(digest, 16) % (MAX_NUM_WAVS_PER_CLASS + 1)) * (100.0 / MAX_NUM_WAVS_PER_CLASS))
+    if percentage_hash < validation_percentage:
+        return 'validation'
+    if percentage_hash < (testing_percentage + validation_percentage):
+        return 'testing'
+    return 'training'
+
+
+# ---- wav I/O (host glue; TF DecodeWav / EncodeWav semantics for 16-bit PCM) ------------------------
+def _read_wav_int16(filename):
+    with open(filename, 'rb') as f:
+        data = f.read()
+    if len(data) < 12 or data[:4] != b'RIFF' or data[8:12] != b'WAVE':
+        raise ValueError('%s is not a RIFF/WAVE file' % filename)
+    pos, fmt, pcm = 12, None, None
+    while pos + 8 <= len(data):
+        cid, size = data[pos:pos + 4], struct.unpack('<I', data[pos + 4:pos + 8])[0]
+        body = data[pos + 8:pos + 8 + size]
+        if cid == b'fmt ':
+            fmt = struct.unpack('<HHIIHH', body[:16])
+        elif cid == b'data':
+            pcm = body
+            break
+        pos += 8 + size + (size & 1)
+    if fmt is None or pcm is None:
+        raise ValueError('%s: missing fmt/data chunk' % filename)
+    audio_format, channels, rate, _, _, bits = fmt
+    if audio_format != 1 or bits != 16:
+        raise ValueError('%s: only 16-bit PCM is supported (DecodeWav)' % filename)
+    a = np.frombuffer(pcm[:len(pcm) // (2 * channels) * 2 * channels], dtype='<i2').reshape(-1, channels)
+    return a[:, 0].copy(), rate
+
+
+def load_wav_file(filename):
+    """float PCM in [-1, 1): int16 / 32768 (reference input_data.py:117-132)."""
+    a, _ = _read_wav_int16(filename)
+    return a.astype(np.float32) / np.float32(32768.0)
+
+
+def save_wav_file(filename, wav_data, sample_rate):
+    """EncodeWav: clamp(x)*32767 -> int16 (reference input_data.py:135-156)."""
+    x = np.clip(np.asarray(wav_data, dtype=np.float32).reshape(-1), -1.0, 1.0)
+    pcm = (x * 32767.0).astype('<i2').tobytes()
+    with open(filename, 'wb') as f:
+        f.write(b'RIFF' + struct.pack('<I', 36 + len(pcm)) + b'WAVE' + b'fmt ' +
+                struct.pack('<IHHIIHH', 16, 1, 1, int(sample_rate), int(sample_rate) * 2, 2, 16) +
+                b'data' + struct.pack('<I', len(pcm)) + pcm)
+
+
+class _Placeholder(object):
+    """Opaque feed key standing in for a tf.placeholder of the reference's processing graph."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __repr__(self):
+        return '<placeholder %s>' % self.name
+
+
+class _Fetch(object):
+    def __init__(self, owner, kind):
+        self.owner, self.kind = owner, kind
+
+
+class ClipBank(object):
+    """HBM-resident clips [n, L] (int16 PCM or f32) + background recordings, plus the metadata the
+    index needs.  `from_arrays` builds the synthetic banks used by bench.py and the tests."""
+
+    def __init__(self, clips, noise_list, device):
+        self.device = device
+        self.clips = clips                      # torch tensor on device, int16 or float32
+        self.noise_host = [np.asarray(n, dtype=np.float32) for n in noise_list]
+        self.noise_starts = np.cumsum([0] + [len(n) for n in self.noise_host])[:-1].astype(np.int64)
+        if self.noise_host:
+            self.noise = torch.from_numpy(np.concatenate(self.noise_host)).to(device)
+        else:
+            self.noise = None
+
+    @property
+    def n_clips(self):
+        return self.clips.shape[0]
+
+    @property
+    def samples(self):
+        return self.clips.shape[1]
+
+
+class AudioProcessor(object):
+    """Handles loading, partitioning, and preparing audio training data (reference
+    input_data.py:159-610); see the module docstring for what runs where."""
+
+    def __init__(self, data_dirs, silence_percentage, unknown_percentage, wanted_words, validation_percentage,
+                 testing_percentage, model_settings, output_representation=False, device=None):
+        if not torch.cuda.is_available():
+            raise _lib.KwsError("AudioProcessor needs an MI355X: augmentation and features run on the GPU "
+                                "(no CPU fallback)")
+        self.lib = _lib.load()
+        self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        self.data_dirs = data_dirs
+        assert output_representation in {'raw', 'spec', 'mfcc', 'mfcc_and_raw'}
+        self.output_representation = output_representation
+        self.model_settings = model_settings
+        self._stream = torch.cuda.Stream(device=self.device)
+        self._plan = None
+        self._synthetic = isinstance(data_dirs, dict)
+        if self._synthetic:
+            self._init_synthetic(data_dirs, wanted_words)
+        else:
+            for data_dir in self.data_dirs:
+                self.maybe_download_and_extract_dataset(data_dir)
+            self.prepare_data_index(silence_percentage, unknown_percentage, wanted_words, validation_percentage,
+                                    testing_percentage)
+            self.prepare_background_data()
+            self._build_bank()
+        self.prepare_processing_graph(model_settings)
+
+    def __del__(self):
+        try:
+            if getattr(self, '_plan', None):
+                self.lib.kws_stft_plan_destroy(self._plan)
+                self._plan = None
+        except Exception:
+            pass
+
+    # -- index ---------------------------------------------------------------------------------------
+    def maybe_download_and_extract_dataset(self, data_dir):
+        if not os.path.exists(data_dir):
+            print("Please download the dataset!")
+            sys.exit(0)
+
+    def prepare_data_index(self, silence_percentage, unknown_percentage, wanted_words, validation_percentage,
+                           testing_percentage):
+        """reference input_data.py:182-272 (same ordering: random.seed(59185), sorted glob, shuffles)."""
+        random.seed(RANDOM_SEED)
+        wanted_words_index = {w: i + 2 for i, w in enumerate(wanted_words)}
+        sets = ['validation', 'testing', 'training', 'pseudo']
+        self.data_index = {s: [] for s in sets}
+        unknown_index = {s: [] for s in sets}
+        all_words = {}
+        for data_dir in self.data_dirs:
+            search_path = os.path.join(data_dir, '*', '*.wav')
+            for wav_path in sorted(glob.glob(search_path)):
+                word = re.search('.*/([^/]+)/.*.wav', wav_path).group(1).lower()
+                if word == BACKGROUND_NOISE_DIR_NAME:
+                    continue
+                all_words[word] = True
+                set_index = which_set(wav_path, validation_percentage, testing_percentage)
+                entry = {'label': word, 'file': wav_path}
+                if word in wanted_words_index:
+                    self.data_index[set_index].append(entry)
+                else:
+                    unknown_index[set_index].append(entry)
+            if not all_words:
+                raise Exception('No .wavs found at ' + search_path)
+            for wanted_word in wanted_words:
+                if wanted_word not in all_words:
+                    raise Exception('Expected to find ' + wanted_word + ' in labels but only found ' +
+                                    ', '.join(all_words.keys()))
+        silence_wav_path = self.data_index['training'][0]['file']
+        for set_index in sets:
+            set_size = len(self.data_index[set_index])
+            silence_size = int(math.ceil(set_size * silence_percentage / 100))
+            for _ in range(silence_size):
+                self.data_index[set_index].append({'label': SILENCE_LABEL, 'file': silence_wav_path})
+            random.shuffle(unknown_index[set_index])
+            unknown_size = int(math.ceil(set_size * unknown_percentage / 100))
+            self.data_index[set_index].extend(unknown_index[set_index][:unknown_size])
+        for set_index in sets:
+            random.shuffle(self.data_index[set_index])
+        self.words_list = prepare_words_list(wanted_words)
+        self.word_to_index = {}
+        for word in all_words:
+            self.word_to_index[word] = wanted_words_index.get(word, UNKNOWN_WORD_INDEX)
+        self.word_to_index[SILENCE_LABEL] = SILENCE_INDEX
+
+    def prepare_background_data(self):
+        """reference input_data.py:274-309"""
+        self.background_data = []
+        background_dir = os.path.join(self.data_dirs[0], BACKGROUND_NOISE_DIR_NAME)
+        if not os.path.exists(background_dir):
+            return self.background_data
+        search_path = os.path.join(background_dir, '*.wav')
+        for wav_path in sorted(glob.glob(search_path)):
+            self.background_data.append(load_wav_file(wav_path))
+        if not self.background_data:
+            raise Exception('No background wav files were found in ' + search_path)
+
+    def _build_bank(self):
+        """Decode every distinct file of the index once into the int16 HBM clip bank."""
+        L = self.model_settings['desired_samples']
+        rows = {}
+        for part in self.data_index.values():
+            for e in part:
+                if e['file'] not in rows:
+                    rows[e['file']] = len(rows)
+        bank = np.zeros((max(len(rows), 1), L), dtype=np.int16)
+        for fn, r in rows.items():
+            a, _ = _read_wav_int16(fn)
+            n = min(len(a), L)
+            bank[r, :n] = a[:n]
+        self._file_row = rows
+        self._finish_index_arrays()
+        self.bank = ClipBank(torch.from_numpy(bank).to(self.device), self.background_data, self.device)
+
+    def _finish_index_arrays(self):
+        self._rows = {s: np.array([self._file_row[e['file']] for e in p], dtype=np.int32)
+                      for s, p in self.data_index.items()}
+        self._labels = {s: np.array([self.word_to_index[e['label']] for e in p], dtype=np.int32)
+                        for s, p in self.data_index.items()}
+        self._silence = {s: np.array([e['label'] == SILENCE_LABEL for e in p], dtype=bool)
+                         for s, p in self.data_index.items()}
+
+    def _init_synthetic(self, spec, wanted_words):
+        """Synthetic source (bench.py / tests): spec = {'bank': ClipBank, 'index': {set: [(row, word)]}}.
+        No files are touched; everything downstream (sampler, kernels) is the production path."""
+        self.bank = spec['bank']
+        self.background_data = self.bank.noise_host
+        self.words_list = prepare_words_list(wanted_words)
+        wanted_words_index = {w: i + 2 for i, w in enumerate(wanted_words)}
+        self.data_index = {s: [] for s in ['validation', 'testing', 'training', 'pseudo']}
+        self.word_to_index = {SILENCE_LABEL: SILENCE_INDEX}
+        self._file_row = {}
+        for s, entries in spec['index'].items():
+            for row, word in entries:
+                fn = 'synthetic://%d' % row
+                self._file_row[fn] = row
+                self.data_index[s].append({'label': word, 'file': fn})
+                if word != SILENCE_LABEL:
+                    self.word_to_index[word] = wanted_words_index.get(word, UNKNOWN_WORD_INDEX)
+        self._finish_index_arrays()
+
+    # -- processing "graph" ----------------------------------------------------------------------
+    def prepare_processing_graph(self, model_settings):
+        """Creates the feed keys / fetch handles of the reference graph (input_data.py:311-381) and
+        the STFT plan (tables follow tf.contrib.signal)."""
+        self.wav_filename_placeholder_ = _Placeholder('filename')
+        self.foreground_volume_placeholder_ = _Placeholder('foreground_volme')
+        self.time_shift_placeholder_ = _Placeholder('timeshift')
+        self.background_data_placeholder_ = _Placeholder('background_data')
+        self.background_volume_placeholder_ = _Placeholder('background_volume')
+        self.background_clamp_ = _Fetch(self, 'raw')
+        self.spectrogram_ = _Fetch(self, 'spec')
+        self.mfcc_ = _Fetch(self, 'mfcc')
+        from .features import path_b_tables
+        t = path_b_tables(model_settings['window_size_samples'], model_settings['dct_coefficient_count'],
+                          model_settings['num_log_mel_features'], model_settings['sample_rate'])
+        self._n_mel = model_settings['dct_coefficient_count']
+        self._n_out = model_settings['num_log_mel_features']
+        plan = ctypes.c_void_p()
+        _lib.check(self.lib.kws_stft_plan_create(
+            model_settings['window_size_samples'], model_settings['window_stride_samples'], t['fft_length'],
+            self._n_mel, self._n_out, t['window'].ctypes.data_as(ctypes.c_void_p),
+            t['mel'].ctypes.data_as(ctypes.c_void_p), t['dct'].ctypes.data_as(ctypes.c_void_p),
+            t['log_offset'], t['log_floor'], ctypes.byref(plan)), "kws_stft_plan_create")
+        self._plan = plan
+        self._n_frames = self.lib.kws_stft_num_frames(plan, model_settings['desired_samples'])
+
+    def set_size(self, mode):
+        """reference input_data.py:383-393"""
+        return len(self.data_index[mode])
+
+    # -- sampler (host, reference RNG order) -----------------------------------------------------------
+    def _draw(self, mode, offset, sample_count, how_many, background_frequency, background_volume_range,
+              foreground_frequency, foreground_volume_range, time_shift_frequency, time_shift_range,
+              pseudo_frequency, flip_frequency, silence_volume_range):
+        """Per-clip parameters in the reference's draw order (input_data.py:457-514)."""
+        rows_m, lab_m, sil_m = self._rows[mode], self._labels[mode], self._silence[mode]
+        rows_p, lab_p, sil_p = self._rows['pseudo'], self._labels['pseudo'], self._silence['pseudo']
+        n_cand, n_pseudo = len(rows_m), len(rows_p)
+        desired = self.model_settings['desired_samples']
+        use_background = bool(self.background_data) and (mode == 'training')
+        pick_deterministically = (mode != 'training')
+        rows = np.empty(sample_count, np.int32)
+        labels = np.empty(sample_count, np.int32)
+        shift = np.zeros(sample_count, np.int32)
+        bg_off = np.zeros(sample_count, np.int64)
+        bg_vol = np.zeros(sample_count, np.float32)
+        fg_vol = np.empty(sample_count, np.float32)
+        uniform, randint = np.random.uniform, np.random.randint
+        bg_lens = [len(b) for b in self.background_data]
+        bg_starts = self.bank.noise_starts if self.background_data else None
+        for k in range(sample_count):
+            i = offset + k
+            if how_many == -1 or pick_deterministically:
+                r, lab, sil = rows_m[i], lab_m[i], sil_m[i]
+            elif uniform(0, 1) < pseudo_frequency:
+                j = randint(n_pseudo)
+                r, lab, sil = rows_p[j], lab_p[j], sil_p[j]
+            else:
+                j = randint(n_cand)
+                r, lab, sil = rows_m[j], lab_m[j], sil_m[j]
+            if uniform(0.0, 1.0) < time_shift_frequency:
+                shift[k] = randint(time_shift_range[0], time_shift_range[1] + 1)
+            if use_background:
+                bi = randint(len(bg_lens))
+                bo = randint(0, bg_lens[bi] - desired)
+                bg_off[k] = bg_starts[bi] + bo
+                if uniform(0, 1) < background_frequency:
+                    bg_vol[k] = uniform(0, background_volume_range)
+                elif sil and uniform(0, 1) < 0.9:
+                    bg_vol[k] = uniform(0, silence_volume_range)
+            if sil:
+                fg = 0.0
+            else:
+                fg = 1.0
+                if uniform(0, 1) < foreground_frequency:
+                    fg = 1.0 + uniform(-foreground_volume_range, foreground_volume_range)
+                if uniform(0, 1) < flip_frequency:
+                    fg *= -1.0
+            fg_vol[k] = fg
+            rows[k], labels[k] = r, lab
+        return rows, labels, shift, bg_off, bg_vol, fg_vol
+
+    # -- device side -----------------------------------------------------------------------------------
+    def _augment(self, rows, shift, bg_off, bg_vol, fg_vol):
+        """One kws_augment launch for the whole batch on the processor's own stream."""
+        B = len(rows)
+        L = self.model_settings['desired_samples']
+        packed_i = np.concatenate([rows.astype(np.int32), shift.astype(np.int32)])
+        packed_f = np.concatenate([fg_vol.astype(np.float32), bg_vol.astype(np.float32)])
+        st = self._stream
+        with torch.cuda.stream(st):
+            di = torch.from_numpy(packed_i).pin_memory().to(self.device, non_blocking=True)
+            df = torch.from_numpy(packed_f).pin_memory().to(self.device, non_blocking=True)
+            do = torch.from_numpy(bg_off.astype(np.int64)).pin_memory().to(self.device, non_blocking=True)
+            out = torch.empty((B, L), dtype=torch.float32, device=self.device)
+            bank = self.bank
+            fn = "kws_augment_i16" if bank.clips.dtype == torch.int16 else "kws_augment_f32"
+            noise = bank.noise if bank.noise is not None else None
+            _lib.call(fn, _lib.ptr(bank.clips), bank.n_clips, L, _lib.ptr(di[:B]), _lib.ptr(df[:B]),
+                      _lib.ptr(di[B:]), _lib.ptr(noise), 0 if noise is None else noise.numel(),
+                      _lib.ptr(do) if noise is not None else None, _lib.ptr(df[B:]), _lib.ptr(out), B,
+                      _lib.stream_ptr(st))
+            self._keep = (di, df, do)     # alive until the next call on this stream
+        return out
+
+    def _features(self, raw, out_kind):
+        B, L = raw.shape
+        width = {0: self._n_out, 1: 257, 2: self._n_mel}[out_kind]
+        st = self._stream
+        with torch.cuda.stream(st):
+            out = torch.empty((B, self._n_frames * width), dtype=torch.float32, device=self.device)
+            _lib.call("kws_stft_mel_f32", self._plan, _lib.ptr(raw), B, L, _lib.ptr(out), out_kind,
+                      _lib.stream_ptr(st))
+        return out
+
+    def get_data(self, how_many, offset, background_frequency, background_volume_range, foreground_frequency,
+                 foreground_volume_range, time_shift_frequency, time_shift_range, mode, sess,
+                 pseudo_frequency=0.0, flip_frequency=0.0, silence_volume_range=0.0):
+        """reference input_data.py:395-541.  Returns (data, labels): data is a DeviceArray
+        [n, D] (or [mfcc, raw] for 'mfcc_and_raw'), labels a float64 one-hot matrix that also
+        carries its device copy.  `sess` is accepted and ignored (there is no TF session)."""
+        candidates = self.data_index[mode]
+        if how_many == -1:
+            sample_count = len(candidates)
+        else:
+            sample_count = max(0, min(how_many, len(candidates) - offset))
+        label_count = self.model_settings['label_count']
+        if sample_count == 0:
+            D = {'raw': self.model_settings['desired_samples'],
+                 'spec': self._n_frames * 257}.get(self.output_representation, self._n_frames * self._n_out)
+            return np.zeros((0, D)), np.zeros((0, label_count))
+        rows, labels, shift, bg_off, bg_vol, fg_vol = self._draw(
+            mode, offset, sample_count, how_many, background_frequency, background_volume_range,
+            foreground_frequency, foreground_volume_range, time_shift_frequency, time_shift_range,
+            pseudo_frequency, flip_frequency, silence_volume_range)
+        raw = self._augment(rows, shift, bg_off, bg_vol, fg_vol)
+        rep = self.output_representation
+        if rep == 'raw':
+            data = raw
+        elif rep == 'spec':
+            data = self._features(raw, 1)
+        else:
+            data = self._features(raw, 0)
+        onehot = np.zeros((sample_count, label_count))
+        onehot[np.arange(sample_count), labels] = 1
+        with torch.cuda.stream(self._stream):
+            dlab = torch.from_numpy(onehot.astype(np.float32)).pin_memory().to(self.device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self._stream)
+        lab = Labels(onehot, dlab, ev)
+        if rep != 'mfcc_and_raw':
+            return DeviceArray(data, ev), lab
+        return [DeviceArray(data, ev), DeviceArray(raw, ev)], lab
+
+    def run_fetch(self, fetch, feed_dict):
+        """Single-clip evaluation of one graph output, for reference-style `sess.run(ap.mfcc_, feed)`
+        call sites (make_submission.py:86-115)."""
+        L = self.model_settings['desired_samples']
+        fn = feed_dict[self.wav_filename_placeholder_]
+        if fn in self._file_row:
+            row = self._file_row[fn]
+            clip = self.bank.clips[row:row + 1]
+        else:
+            a, _ = _read_wav_int16(fn)
+            buf = np.zeros((1, L), np.int16)
+            buf[0, :min(len(a), L)] = a[:L]
+            clip = torch.from_numpy(buf).to(self.device)
+        bg = np.asarray(feed_dict.get(self.background_data_placeholder_, np.zeros(L)), dtype=np.float32).reshape(-1)
+        st = self._stream
+        with torch.cuda.stream(st):
+            one_i = torch.tensor([0, int(feed_dict.get(self.time_shift_placeholder_, 0))], dtype=torch.int32,
+                                 device=self.device)
+            one_f = torch.tensor([float(feed_dict.get(self.foreground_volume_placeholder_, 1.0)),
+                                  float(feed_dict.get(self.background_volume_placeholder_, 0.0))],
+                                 dtype=torch.float32, device=self.device)
+            noise = torch.from_numpy(bg).to(self.device)
+            off = torch.zeros(1, dtype=torch.int64, device=self.device)
+            out = torch.empty((1, L), dtype=torch.float32, device=self.device)
+            name = "kws_augment_i16" if clip.dtype == torch.int16 else "kws_augment_f32"
+            _lib.call(name, _lib.ptr(clip), 1, L, _lib.ptr(one_i[:1]), _lib.ptr(one_f[:1]), _lib.ptr(one_i[1:]),
+                      _lib.ptr(noise), noise.numel(), _lib.ptr(off), _lib.ptr(one_f[1:]), _lib.ptr(out), 1,
+                      _lib.stream_ptr(st))
+        if fetch.kind == 'raw':
+            res = out
+        else:
+            res = self._features(out, 1 if fetch.kind == 'spec' else 0)
+            res = res.reshape(1, self._n_frames, -1)
+        st.synchronize()
+        return res.cpu().numpy()
+
+    def get_unprocessed_data(self, how_many, model_settings, mode):
+        """reference input_data.py:543-589 (no transformations; silence rows are zeroed)."""
+        candidates = self.data_index[mode]
+        sample_count = len(candidates) if how_many == -1 else how_many
+        idx = np.arange(sample_count) if how_many == -1 else \
+            np.array([np.random.randint(len(candidates)) for _ in range(sample_count)])
+        rows = self._rows[mode][idx]
+        fg = np.where(self._silence[mode][idx], 0.0, 1.0).astype(np.float32)
+        z = np.zeros(sample_count)
+        raw = self._augment(rows, z.astype(np.int32), z.astype(np.int64), z.astype(np.float32), fg)
+        self._stream.synchronize()
+        labels = [self.words_list[i] for i in self._labels[mode][idx]]
+        return raw.cpu().numpy().astype(np.float64), labels
+
+    def summary(self):
+        """reference input_data.py:591-610"""
+        set_counts = {}
+        print("There are %d classes." % (len(self.word_to_index)))
+        print("1%% <-> %d samples in 'training'" % int(self.set_size('training') / 100))
+        for set_index in ['training', 'validation', 'testing', 'pseudo']:
+            counts = {k: 0 for k in sorted(self.word_to_index.keys())}
+            num_total = self.set_size(set_index)
+            for data_point in self.data_index[set_index]:
+                counts[data_point['label']] += (1.0 / num_total) * 100.0
+            set_counts[set_index] = counts
+        print("%-13s%-6s%-6s%-6s%-6s" % ('', 'Train', 'Val', 'Test', 'Pseudo'))
+        for label_name in sorted(self.word_to_index.keys(), key=self.word_to_index.get):
+            line = "%02d %-12s: " % (self.word_to_index[label_name], label_name)
+            for set_index in ['training', 'validation', 'testing', 'pseudo']:
+                line += "%.1f%% " % (set_counts[set_index][label_name])
+            print(line)

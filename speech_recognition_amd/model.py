@@ -1,0 +1,85 @@
+"""Host-side mirror of the reference's model.py for the accelerated models: `speech_model`
+dispatch (reference model.py:1729-1781), `prepare_model_settings` (model.py:1785-1829) and the two
+symbols checkpoints name as custom objects (`relu6` model.py:30-31, `overlapping_time_slice_stack`
+model.py:67-76).  The layer graphs themselves are native network programs in csrc/net.hip."""
+from . import _lib
+from .keras_api import Model, RMSprop
+from .net import DeviceNet
+
+ACCELERATED = ('conv_1d_time_sliced_with_attention', 'conv_1d_log_mfcc')
+REFERENCE_MODEL_TYPES = (
+    'simple', 'snn', 'conv_1d_time_stacked', 'conv_1d_multi_time_sliced', 'conv_1d_time_sliced',
+    'conv_1d_time_sliced_group', 'conv_1d_heavy', 'conv_1d_simple', 'conv_1d_gru', 'conv_2d', 'conv_2d_fast',
+    'conv_2d_mobile', 'inception', 'inception_d1', 'conv_1d_learned_spec', 'conv_1d_spec', 'conv_1d_fast',
+    'conv_1d_top_down', 'conv_1d_residual', 'xception_with_attention', 'conv_1d_time_sliced_with_attention',
+    'conv_1d_log_mfcc', 'conv_1d_spectrogram', 'conv_1d_mfcc_and_raw', 'steffeNet')
+
+
+def relu6(x):
+    """K.relu(x, max_value=6).  On the device ReLU6 is fused into the consumer of every BatchNorm
+    (csrc/dwconv.hip, csrc/tail.hip); this callable exists for checkpoint custom_objects."""
+    return x.clamp(0, 6) if hasattr(x, 'clamp') else min(max(x, 0), 6)
+
+
+def overlapping_time_slice_stack(x, ksize, stride, padding='SAME'):
+    """extract_image_patches framing.  On the device it is fused into the first convolution's
+    gathered A-operand (kws_gemm_gather_f32); calling it on host data is not part of the hot path."""
+    raise _lib.KwsError("overlapping_time_slice_stack is fused into kws_gemm_gather_f32 on the device")
+
+
+def conv_1d_time_sliced_with_attention_model(input_size=16000, num_classes=11, filter_mult=1):
+    """reference model.py:775-838: 12-block depthwise/pointwise 1-D CNN on raw waveform, attention-pooled
+    head, RMSprop(1e-3), label-smoothed CE (0.1), categorical accuracy."""
+    net = DeviceNet(_lib.KWS_NET_TS_ATTENTION, num_classes, filter_mult=filter_mult, input_size=input_size)
+    return Model(net, RMSprop(lr=1e-3), name='conv_1d_time_sliced_with_attention')
+
+
+def conv_1d_log_mfcc_model(input_size=16000, num_classes=11, *args, **kwargs):
+    """reference model.py:1400-1479: residual depthwise 1-D CNN on [spectrogram_length, num_log_mel_features]
+    features, softmax-over-time attention, RMSprop(6e-4), categorical CE."""
+    time_size = kwargs.get('spectrogram_length', 65)
+    frequency_size = kwargs.get('num_log_mel_features', 40)
+    net = DeviceNet(_lib.KWS_NET_LOG_MFCC, num_classes, input_size=input_size, spectrogram_length=time_size,
+                    num_features=frequency_size)
+    return Model(net, RMSprop(lr=6e-4), name='conv_1d_log_mfcc')
+
+
+def speech_model(model_type, input_size, num_classes=11, *args, **kwargs):
+    if model_type == 'conv_1d_time_sliced_with_attention':
+        return conv_1d_time_sliced_with_attention_model(input_size, num_classes)
+    if model_type == 'conv_1d_log_mfcc':
+        return conv_1d_log_mfcc_model(input_size, num_classes, *args, **kwargs)
+    if model_type in REFERENCE_MODEL_TYPES:
+        raise NotImplementedError(
+            "model '%s' is outside the accelerated hot path (SURVEY.md 8: only %s are built natively)"
+            % (model_type, ', '.join(ACCELERATED)))
+    raise ValueError("Invalid model: %s" % model_type)
+
+
+def prepare_model_settings(label_count, sample_rate, clip_duration_ms, window_size_ms, window_stride_ms,
+                           dct_coefficient_count, num_log_mel_features, output_representation='raw'):
+    """Settings arithmetic of reference model.py:1785-1829 (truncating int() conversions included)."""
+    desired_samples = int(sample_rate * clip_duration_ms / 1000)
+    window_size_samples = int(sample_rate * window_size_ms / 1000)
+    window_stride_samples = int(sample_rate * window_stride_ms / 1000)
+    length_minus_window = desired_samples - window_size_samples
+    spectrogram_frequencies = 257
+    spectrogram_length = 0 if length_minus_window < 0 else 1 + int(length_minus_window / window_stride_samples)
+    fingerprint_size = {
+        'mfcc': num_log_mel_features * spectrogram_length,
+        'raw': desired_samples,
+        'spec': spectrogram_frequencies * spectrogram_length,
+        'mfcc_and_raw': num_log_mel_features * spectrogram_length,
+    }[output_representation]
+    return {
+        'desired_samples': desired_samples,
+        'window_size_samples': window_size_samples,
+        'window_stride_samples': window_stride_samples,
+        'spectrogram_length': spectrogram_length,
+        'spectrogram_frequencies': spectrogram_frequencies,
+        'dct_coefficient_count': dct_coefficient_count,
+        'fingerprint_size': fingerprint_size,
+        'label_count': label_count,
+        'sample_rate': sample_rate,
+        'num_log_mel_features': num_log_mel_features,
+    }

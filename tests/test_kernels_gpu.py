@@ -164,8 +164,9 @@ def test_dwconv_fwd_bwd(Lin, stride, pad, C, with_bn):
     dgam = torch.empty(C, device="cuda")
     dbet = torch.empty(C, device="cuda")
     coef = torch.empty(2 * C, device="cuda")
-    _lib.call("kws_dw_bwd_finalize", _lib.ptr(part), n_part // (5 * C), B * Lin, C, None, None, _lib.ptr(dwv),
-              _lib.ptr(dgam), _lib.ptr(dbet), _lib.ptr(coef), S())
+    scratch = torch.empty(32 * 5 * C, device="cuda")
+    _lib.call("kws_dw_bwd_finalize", _lib.ptr(part), n_part // (5 * C), B * Lin, C, _lib.ptr(dwv),
+              _lib.ptr(dgam), _lib.ptr(dbet), _lib.ptr(coef), _lib.ptr(scratch), S())
     assert rel_err(dwv.cpu().numpy(), dw_ref) < 2e-5
     np.testing.assert_allclose(dbet.cpu().numpy(), g_ref.sum((0, 1)), rtol=0, atol=2e-5 * np.abs(g_ref).sum((0, 1)).max())
     if with_bn:
@@ -194,7 +195,7 @@ def test_bn_stats_finalize_and_apply():
     bn = torch.empty(4 * N, device="cuda")
     dmm, dmv = dev(mm), dev(mv)
     _lib.call("kws_bn_stats_finalize", _lib.ptr(part), nt, M, N, _lib.ptr(dev(gamma)), _lib.ptr(dev(beta)), 1e-3, 0.99,
-              _lib.ptr(dmm), _lib.ptr(dmv), _lib.ptr(bn), S())
+              _lib.ptr(dmm), _lib.ptr(dmv), _lib.ptr(bn), None, S())
     y64 = y.cpu().numpy().astype(np.float64)[None]
     pre, (mean, var, rstd) = OL.bn_train_fwd(y64, gamma.astype(np.float64), beta.astype(np.float64))
     b = bn.cpu().numpy()
