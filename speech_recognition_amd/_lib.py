@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkws_hip.so")
+LIB_PATH = os.environ.get("KWS_LIB_PATH") or os.path.join(_HERE, "libkws_hip.so")  # override: kernel A/B experiments
 
 KWS_NET_TS_ATTENTION = 1
 KWS_NET_LOG_MFCC = 2

@@ -15,9 +15,23 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifdef KWS_GEMM_STAMP
+__device__ unsigned long long g_stamps[8192][8];
+extern "C" int kws_debug_read_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(g_stamps));
+}
+#define STAMP(i) do { if (tid == 0 && bid < 8192) g_stamps[bid][i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(i)
+#endif
+
 namespace {
 
-constexpr int BK = 32;        // K-tile
+#ifndef KWS_GEMM_BK
+#define KWS_GEMM_BK 16
+#endif
+constexpr int BK = KWS_GEMM_BK;  // K-tile (16: 36 KB LDS per workgroup -> 4 workgroups per CU, out-of-phase overlap)
+constexpr int BK4 = BK / 4;
 constexpr int LDA = BK + 4;   // padded A-tile row (floats); 144 B keeps 16-B alignment
 constexpr int NXCD = 8;
 
@@ -60,7 +74,7 @@ __device__ __forceinline__ float4 gather4(const float* xb, int pos, int x_len) {
 }
 
 template <int BM, int BN, int WM, int WN, bool GATHER, bool STATS>
-__global__ __launch_bounds__(256) void gemm_nn_kernel(NNArgs p) {
+__global__ __launch_bounds__(256, 4) void gemm_nn_kernel(NNArgs p) {
   constexpr int TM = BM / WM / 32;
   constexpr int TN = BN / WN / 32;
   constexpr int A_F4 = BM * BK / 4 / 256;
@@ -79,6 +93,16 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(NNArgs p) {
   const int tile_n = slot % p.n_tiles;
   const int tile_m = (slot / p.n_tiles) * NXCD + xcd;
   if (tile_m >= p.m_tiles) return;  // whole workgroup leaves together
+#ifdef KWS_GEMM_STAGGER
+  // All workgroups of the first residency round start together and, doing identical work, stay in
+  // lockstep: their store-bound epilogues then coincide instead of hiding under another workgroup's MFMA
+  // loop.  A one-off pseudo-random start delay (first round only) de-phases the workgroups that share a
+  // CU; later rounds inherit the spread.  Speed only - never correctness.
+  if (bid < 256 * 4) {
+    const unsigned d = ((unsigned)bid * 2654435761u >> 29) & 3u;
+    for (unsigned q = 0; q < d * KWS_GEMM_STAGGER; ++q) __builtin_amdgcn_s_sleep(127);
+  }
+#endif
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -96,7 +120,7 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(NNArgs p) {
 #pragma unroll
   for (int r = 0; r < A_F4; ++r) {
     const int idx = tid + r * 256;
-    const int row = idx >> 3;
+    const int row = idx / BK4;
     const int64_t gm = m0 + row;
     a_ok[r] = gm < M;
     if (GATHER) {
@@ -114,7 +138,7 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(NNArgs p) {
 #pragma unroll
     for (int r = 0; r < A_F4; ++r) {
       const int idx = tid + r * 256;
-      const int gk = k0 + (idx & 7) * 4;
+      const int gk = k0 + (idx % BK4) * 4;
       if (GATHER) {
         if (a_ok[r] && gk < K) {
           const int j = gk / p.g.cin;
@@ -139,7 +163,7 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(NNArgs p) {
 #pragma unroll
     for (int r = 0; r < A_F4; ++r) {
       const int idx = tid + r * 256;
-      *reinterpret_cast<float4*>(&smem[buf * STAGE + (idx >> 3) * LDA + (idx & 7) * 4]) = ra[r];
+      *reinterpret_cast<float4*>(&smem[buf * STAGE + (idx / BK4) * LDA + (idx % BK4) * 4]) = ra[r];
     }
 #pragma unroll
     for (int r = 0; r < B_F4; ++r) {
@@ -157,9 +181,11 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(NNArgs p) {
       for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
 
   const int nk = (K + BK - 1) / BK;
+  STAMP(0);
   load_global(0);
   store_lds(0);
   __syncthreads();
+  STAMP(1);
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) load_global((kt + 1) * BK);
@@ -188,6 +214,7 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(NNArgs p) {
     __syncthreads();
   }
 
+  STAMP(2);
   // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (v&3) + 8*(v>>2) + 4*(lane>>5)
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -202,6 +229,7 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(NNArgs p) {
     }
   }
 
+  STAMP(3);
   if (STATS) {
     // BatchNorm partial sums of this row tile (rows >= M are exact zeros and add nothing).
     float* red = smem;  // [2][WM][BN]
@@ -236,6 +264,7 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(NNArgs p) {
       p.stats[((int64_t)tile_m * 2 + 1) * N + n0 + tid] = ss;
     }
   }
+  STAMP(4);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -371,19 +400,40 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs p) {
     }
 }
 
+// out[i] = sum_k ws[k][i], k ascending within 4 interleaved groups that are combined in a fixed order
+// (bit-reproducible).  64 float4 columns x 4 slab groups per workgroup so that the S slabs of the small
+// K x N outputs are read by S/4-deep loops on many workgroups instead of S-deep loops on a few.
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* ws, float* out, int64_t n4, int S) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n4) return;
+  __shared__ float4 red[4][64];
+  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + col;
   const float4* w = reinterpret_cast<const float4*>(ws);
-  float4 s = w[i];
-  for (int k = 1; k < S; ++k) {
-    const float4 v = w[(int64_t)k * n4 + i];
-    s.x += v.x;
-    s.y += v.y;
-    s.z += v.z;
-    s.w += v.w;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s;
+  if (i < n4) {
+    int k = grp;
+    for (; k + 4 < S; k += 8) {
+      const float4 v = w[(int64_t)k * n4 + i];
+      const float4 u = w[(int64_t)(k + 4) * n4 + i];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      s2.x += u.x; s2.y += u.y; s2.z += u.z; s2.w += u.w;
+    }
+    if (k < S) {
+      const float4 v = w[(int64_t)k * n4 + i];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    s.x += s2.x; s.y += s2.y; s.z += s2.z; s.w += s2.w;
   }
-  reinterpret_cast<float4*>(out)[i] = s;
+  red[grp][col] = s;
+  __syncthreads();
+  if (grp == 0 && i < n4) {
+    float4 t = red[0][col];
+#pragma unroll
+    for (int g = 1; g < 4; ++g) {
+      const float4 v = red[g][col];
+      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    reinterpret_cast<float4*>(out)[i] = t;
+  }
 }
 
 __global__ __launch_bounds__(256) void transpose_kernel(const float* in, float* out, int rows, int cols) {
@@ -413,7 +463,8 @@ TNPlan tn_plan(int64_t M, int K, int N) {
   pl.k_tiles = ceil_div(K, pl.bko);
   pl.n_tiles = ceil_div(N, pl.bko);
   const int tiles = pl.k_tiles * pl.n_tiles;
-  int64_t S = ceil_div64(1024, tiles);
+  int64_t S = ceil_div64(768, tiles);   // ~3 workgroups per CU in flight
+  if (S > 256) S = 256;                 // bounds the partial-slab traffic (S * K * N floats)
   const int64_t maxS = M / 256 > 1 ? M / 256 : 1;
   if (S > maxS) S = maxS;
   if (S < 1) S = 1;
@@ -461,7 +512,7 @@ int launch_tn(TNArgs a, float* dW, hipStream_t st) {
   else hipLaunchKernelGGL((gemm_tn_kernel<64, 64, GATHER>), g, b, 0, st, a);
   KWS_LAUNCH_CHECK("gemm_tn_kernel");
   const int64_t n4 = (int64_t)a.K * a.N / 4;
-  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)ceil_div64(n4, 256)), dim3(256), 0, st, a.ws, dW, n4, pl.S);
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)ceil_div64(n4, 64)), dim3(256), 0, st, a.ws, dW, n4, pl.S);
   KWS_LAUNCH_CHECK("reduce_slabs_kernel");
   return KWS_OK;
 }

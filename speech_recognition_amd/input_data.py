@@ -29,37 +29,9 @@ import torch
 from . import _lib
 from .device_array import DeviceArray, Labels
 
-MAX_NUM_WAVS_PER_CLASS = 2 ** 27 - 1  # ~134M
-SILENCE_LABEL = '_silence_'
-SILENCE_INDEX = 0
-UNKNOWN_WORD_LABEL = '_unknown_'
-UNKNOWN_WORD_INDEX = 1
-BACKGROUND_NOISE_DIR_NAME = '_background_noise_'
-RANDOM_SEED = 59185
-
-
-def prepare_words_list(wanted_words):
-    """reference input_data.py:49-58"""
-    return [SILENCE_LABEL, UNKNOWN_WORD_LABEL] + wanted_words
-
-
-def which_set(filename, validation_percentage, testing_percentage):
-    """Stable SHA-1 partition of a file name (reference input_data.py:61-114): directory
-    `unknown_unknown` -> training; no `_nohash_` in the name -> 'pseudo'; else the hash of the part
-    before `_nohash_` mapped to [0,100] decides validation / testing / training."""
-    if os.path.basename(os.path.dirname(filename)) == 'unknown_unknown':
-        return 'training'
-    base_name = os.path.basename(filename)
-    if base_name.find('_nohash_') == -1:
-        return 'pseudo'
-    hash_name = re.sub(r'_nohash_.*$', '', base_name)
-    digest = hashlib.sha1(hash_name.encode('utf-8')).hexdigest()
-    percentage_hash = ((int(digest, 16) % (MAX_NUM_WAVS_PER_CLASS + 1)) * (100.0 / MAX_NUM_WAVS_PER_CLASS))
-    if percentage_hash < validation_percentage:
-        return 'validation'
-    if percentage_hash < (testing_percentage + validation_percentage):
-        return 'testing'
-    return 'training'
+from .sampler import (BACKGROUND_NOISE_DIR_NAME, MAX_NUM_WAVS_PER_CLASS, RANDOM_SEED, SILENCE_INDEX,  # noqa: F401
+                      SILENCE_LABEL, UNKNOWN_WORD_INDEX, UNKNOWN_WORD_LABEL, DataIndex, prepare_words_list,
+                      which_set)
 
 
 # ---- wav I/O (host glue; TF DecodeWav / EncodeWav semantics for 16-bit PCM) ------------------------
@@ -186,48 +158,17 @@ class AudioProcessor(object):
 
     def prepare_data_index(self, silence_percentage, unknown_percentage, wanted_words, validation_percentage,
                            testing_percentage):
-        """reference input_data.py:182-272 (same ordering: random.seed(59185), sorted glob, shuffles)."""
-        random.seed(RANDOM_SEED)
-        wanted_words_index = {w: i + 2 for i, w in enumerate(wanted_words)}
-        sets = ['validation', 'testing', 'training', 'pseudo']
-        self.data_index = {s: [] for s in sets}
-        unknown_index = {s: [] for s in sets}
-        all_words = {}
-        for data_dir in self.data_dirs:
-            search_path = os.path.join(data_dir, '*', '*.wav')
-            for wav_path in sorted(glob.glob(search_path)):
-                word = re.search('.*/([^/]+)/.*.wav', wav_path).group(1).lower()
-                if word == BACKGROUND_NOISE_DIR_NAME:
-                    continue
-                all_words[word] = True
-                set_index = which_set(wav_path, validation_percentage, testing_percentage)
-                entry = {'label': word, 'file': wav_path}
-                if word in wanted_words_index:
-                    self.data_index[set_index].append(entry)
-                else:
-                    unknown_index[set_index].append(entry)
-            if not all_words:
-                raise Exception('No .wavs found at ' + search_path)
-            for wanted_word in wanted_words:
-                if wanted_word not in all_words:
-                    raise Exception('Expected to find ' + wanted_word + ' in labels but only found ' +
-                                    ', '.join(all_words.keys()))
-        silence_wav_path = self.data_index['training'][0]['file']
-        for set_index in sets:
-            set_size = len(self.data_index[set_index])
-            silence_size = int(math.ceil(set_size * silence_percentage / 100))
-            for _ in range(silence_size):
-                self.data_index[set_index].append({'label': SILENCE_LABEL, 'file': silence_wav_path})
-            random.shuffle(unknown_index[set_index])
-            unknown_size = int(math.ceil(set_size * unknown_percentage / 100))
-            self.data_index[set_index].extend(unknown_index[set_index][:unknown_size])
-        for set_index in sets:
-            random.shuffle(self.data_index[set_index])
-        self.words_list = prepare_words_list(wanted_words)
-        self.word_to_index = {}
-        for word in all_words:
-            self.word_to_index[word] = wanted_words_index.get(word, UNKNOWN_WORD_INDEX)
-        self.word_to_index[SILENCE_LABEL] = SILENCE_INDEX
+        """reference input_data.py:182-272; the host logic lives in sampler.DataIndex.from_dirs."""
+        self._adopt_index(DataIndex.from_dirs(self.data_dirs, silence_percentage, unknown_percentage, wanted_words,
+                                              validation_percentage, testing_percentage))
+
+    def _adopt_index(self, idx):
+        self._index = idx
+        self.data_index = idx.data_index
+        self.word_to_index = idx.word_to_index
+        self.words_list = idx.words_list
+        self._file_row = idx.file_row
+        self._rows, self._labels, self._silence = idx.rows, idx.labels, idx.silence
 
     def prepare_background_data(self):
         """reference input_data.py:274-309"""
@@ -244,46 +185,20 @@ class AudioProcessor(object):
     def _build_bank(self):
         """Decode every distinct file of the index once into the int16 HBM clip bank."""
         L = self.model_settings['desired_samples']
-        rows = {}
-        for part in self.data_index.values():
-            for e in part:
-                if e['file'] not in rows:
-                    rows[e['file']] = len(rows)
+        rows = self._file_row
         bank = np.zeros((max(len(rows), 1), L), dtype=np.int16)
         for fn, r in rows.items():
             a, _ = _read_wav_int16(fn)
             n = min(len(a), L)
             bank[r, :n] = a[:n]
-        self._file_row = rows
-        self._finish_index_arrays()
         self.bank = ClipBank(torch.from_numpy(bank).to(self.device), self.background_data, self.device)
-
-    def _finish_index_arrays(self):
-        self._rows = {s: np.array([self._file_row[e['file']] for e in p], dtype=np.int32)
-                      for s, p in self.data_index.items()}
-        self._labels = {s: np.array([self.word_to_index[e['label']] for e in p], dtype=np.int32)
-                        for s, p in self.data_index.items()}
-        self._silence = {s: np.array([e['label'] == SILENCE_LABEL for e in p], dtype=bool)
-                         for s, p in self.data_index.items()}
 
     def _init_synthetic(self, spec, wanted_words):
         """Synthetic source (bench.py / tests): spec = {'bank': ClipBank, 'index': {set: [(row, word)]}}.
         No files are touched; everything downstream (sampler, kernels) is the production path."""
         self.bank = spec['bank']
         self.background_data = self.bank.noise_host
-        self.words_list = prepare_words_list(wanted_words)
-        wanted_words_index = {w: i + 2 for i, w in enumerate(wanted_words)}
-        self.data_index = {s: [] for s in ['validation', 'testing', 'training', 'pseudo']}
-        self.word_to_index = {SILENCE_LABEL: SILENCE_INDEX}
-        self._file_row = {}
-        for s, entries in spec['index'].items():
-            for row, word in entries:
-                fn = 'synthetic://%d' % row
-                self._file_row[fn] = row
-                self.data_index[s].append({'label': word, 'file': fn})
-                if word != SILENCE_LABEL:
-                    self.word_to_index[word] = wanted_words_index.get(word, UNKNOWN_WORD_INDEX)
-        self._finish_index_arrays()
+        self._adopt_index(DataIndex.from_entries(spec['index'], wanted_words))
 
     # -- processing "graph" ----------------------------------------------------------------------
     def prepare_processing_graph(self, model_settings):
@@ -316,56 +231,11 @@ class AudioProcessor(object):
         return len(self.data_index[mode])
 
     # -- sampler (host, reference RNG order) -----------------------------------------------------------
-    def _draw(self, mode, offset, sample_count, how_many, background_frequency, background_volume_range,
-              foreground_frequency, foreground_volume_range, time_shift_frequency, time_shift_range,
-              pseudo_frequency, flip_frequency, silence_volume_range):
-        """Per-clip parameters in the reference's draw order (input_data.py:457-514)."""
-        rows_m, lab_m, sil_m = self._rows[mode], self._labels[mode], self._silence[mode]
-        rows_p, lab_p, sil_p = self._rows['pseudo'], self._labels['pseudo'], self._silence['pseudo']
-        n_cand, n_pseudo = len(rows_m), len(rows_p)
-        desired = self.model_settings['desired_samples']
-        use_background = bool(self.background_data) and (mode == 'training')
-        pick_deterministically = (mode != 'training')
-        rows = np.empty(sample_count, np.int32)
-        labels = np.empty(sample_count, np.int32)
-        shift = np.zeros(sample_count, np.int32)
-        bg_off = np.zeros(sample_count, np.int64)
-        bg_vol = np.zeros(sample_count, np.float32)
-        fg_vol = np.empty(sample_count, np.float32)
-        uniform, randint = np.random.uniform, np.random.randint
-        bg_lens = [len(b) for b in self.background_data]
-        bg_starts = self.bank.noise_starts if self.background_data else None
-        for k in range(sample_count):
-            i = offset + k
-            if how_many == -1 or pick_deterministically:
-                r, lab, sil = rows_m[i], lab_m[i], sil_m[i]
-            elif uniform(0, 1) < pseudo_frequency:
-                j = randint(n_pseudo)
-                r, lab, sil = rows_p[j], lab_p[j], sil_p[j]
-            else:
-                j = randint(n_cand)
-                r, lab, sil = rows_m[j], lab_m[j], sil_m[j]
-            if uniform(0.0, 1.0) < time_shift_frequency:
-                shift[k] = randint(time_shift_range[0], time_shift_range[1] + 1)
-            if use_background:
-                bi = randint(len(bg_lens))
-                bo = randint(0, bg_lens[bi] - desired)
-                bg_off[k] = bg_starts[bi] + bo
-                if uniform(0, 1) < background_frequency:
-                    bg_vol[k] = uniform(0, background_volume_range)
-                elif sil and uniform(0, 1) < 0.9:
-                    bg_vol[k] = uniform(0, silence_volume_range)
-            if sil:
-                fg = 0.0
-            else:
-                fg = 1.0
-                if uniform(0, 1) < foreground_frequency:
-                    fg = 1.0 + uniform(-foreground_volume_range, foreground_volume_range)
-                if uniform(0, 1) < flip_frequency:
-                    fg *= -1.0
-            fg_vol[k] = fg
-            rows[k], labels[k] = r, lab
-        return rows, labels, shift, bg_off, bg_vol, fg_vol
+    def _draw(self, mode, offset, sample_count, how_many, *aug):
+        """Per-clip parameters in the reference's draw order (sampler.DataIndex.draw)."""
+        return self._index.draw(mode, offset, sample_count, how_many, self.model_settings['desired_samples'],
+                                [len(b) for b in self.background_data],
+                                self.bank.noise_starts if self.background_data else [], *aug)
 
     # -- device side -----------------------------------------------------------------------------------
     def _augment(self, rows, shift, bg_off, bg_vol, fg_vol):

@@ -20,7 +20,7 @@ from collections import OrderedDict
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, parallel
 from .device_array import DeviceArray, as_device_f32
 from .net import DeviceNet
 
@@ -293,13 +293,6 @@ class GeneratorEnqueuer(object):
 # ------------------------------------------------------------------------------------------------
 # Model
 # ------------------------------------------------------------------------------------------------
-def _dist():
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        return dist
-    return None
-
-
 class Model(object):
     """Keras-shaped model around one DeviceNet replica (data-parallel when torch.distributed is
     initialised: local BN statistics, RCCL all-reduce(sum) of the flat gradient, /world)."""
@@ -367,14 +360,11 @@ class Model(object):
         net = self.net
         xd = as_device_f32(x, self.device)
         yd = as_device_f32(y, self.device)
-        dist = _dist()
-        world = dist.get_world_size() if dist else 1
-        rank = dist.get_rank() if dist else 0
+        world, rank = parallel.world_size(), parallel.rank()
         B = xd.shape[0]
         net.metrics = metrics_row
         net.train_fwd_bwd(xd, yd, seed=self.seed, step=self._step, row_offset=rank * B, loss_batch=B * world)
-        if dist:
-            dist.all_reduce(net.grads)    # RCCL sum over xGMI; grads were scaled by 1/(B*world)
+        parallel.allreduce_grads(net.grads)   # RCCL sum over xGMI; grads are already scaled by 1/(B*world)
         self.optimizer.apply(net, 1.0)
         self._step += 1
 
