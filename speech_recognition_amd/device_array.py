@@ -81,15 +81,16 @@ class Labels(np.ndarray):
 
 def as_device_f32(x, device, stream=None):
     """DeviceArray / torch tensor / numpy -> f32 CUDA tensor usable on `stream`."""
-    if isinstance(x, DeviceArray):
-        t = x.wait(stream)
-        if stream is not None:
-            t.record_stream(stream)
-        return t
-    if isinstance(x, Labels) and x.device_tensor is not None:
+    if isinstance(x, DeviceArray) or (isinstance(x, Labels) and x.device_tensor is not None):
+        # The tensor was allocated and written on the producer's stream.  Make the consumer stream wait
+        # for the producer, and tell the caching allocator about the second stream so the block is not
+        # handed back to the producer while consumer kernels that read it are still queued.
+        s = stream if stream is not None else torch.cuda.current_stream(device)
+        t = x.tensor if isinstance(x, DeviceArray) else x.device_tensor
         if x.ready_event is not None:
-            (stream or torch.cuda.current_stream()).wait_event(x.ready_event)
-        return x.device_tensor
+            s.wait_event(x.ready_event)
+        t.record_stream(s)
+        return t
     if torch.is_tensor(x):
         return x.to(device=device, dtype=torch.float32).contiguous()
     a = np.ascontiguousarray(np.asarray(x), dtype=np.float32)

@@ -336,6 +336,9 @@ class Model(object):
         blob['__optimizer_slots__'] = self.net.slots.cpu().numpy()
         blob['__lr__'] = np.float32(self.optimizer.lr.value)
         blob['__step__'] = np.int64(self._step)
+        blob['__model_name__'] = np.array(self.name)
+        blob['__num_classes__'] = np.int64(self.net.num_classes)
+        blob['__input_size__'] = np.int64(self.net.input_size)
         with open(filepath, 'wb') as f:
             np.savez(f, **blob)
 
