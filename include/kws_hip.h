@@ -63,6 +63,34 @@ int kws_augment_i16(const int16_t* bank, int64_t n_clips, int L, const int32_t* 
                     int64_t noise_len, const int64_t* noise_off, const float* bg_vol,
                     float* out, int B, void* stream);
 
+/* a1  host-side sampler: the per-clip RNG draw loop of AudioProcessor.get_data, reference
+ * input_data.py:457-514 (draw order: SURVEY Appendix C).  Pure host code (no GPU work): consumes the
+ * NumPy legacy MT19937 stream passed in (key[624], pos as in np.random.get_state()) and advances it,
+ * so seeded runs reproduce the reference's choices.  Outputs are the per-clip parameters of
+ * kws_augment_* plus the label indices. */
+typedef struct {
+  const int32_t* rows;    /* clip-bank row of every entry of the partition */
+  const int32_t* labels;  /* label index (word_to_index) */
+  const uint8_t* silence; /* 1 where the entry is a _silence_ clip */
+  int32_t n;
+} kws_sampler_set_t;
+typedef struct {
+  int32_t deterministic;  /* 1: entries offset..offset+count-1 in order (how_many == -1 or mode != training) */
+  int32_t offset, count;
+  int32_t use_background; /* background data present and mode == training */
+  int32_t n_bg;
+  const int64_t* bg_len;   /* samples per background recording */
+  const int64_t* bg_start; /* start of each recording inside the concatenated noise vector */
+  int32_t desired_samples;
+  int32_t shift_lo, shift_hi; /* time_shift_range (inclusive) */
+  double background_frequency, background_volume_range, foreground_frequency, foreground_volume_range;
+  double time_shift_frequency, pseudo_frequency, flip_frequency, silence_volume_range;
+} kws_sampler_args_t;
+int kws_sampler_draw(uint32_t* mt_key, int* mt_pos, const kws_sampler_set_t* cand,
+                     const kws_sampler_set_t* pseudo, const kws_sampler_args_t* args,
+                     int32_t* out_rows, int32_t* out_labels, int32_t* out_shift, int64_t* out_bg_off,
+                     float* out_bg_vol, float* out_fg_vol);
+
 /* a17 TTA transforms, reference make_submission.py:125-134.
  * kind: 0 copy, 1 np.roll(X,-1500,axis=1), 2 1.2*X, 3 clip(1.1*X,-1,1), 4 0.9*X */
 int kws_tta_transform(const float* x, float* out, int B, int L, int kind, void* stream);

@@ -24,6 +24,22 @@ class GatherDesc(ctypes.Structure):
                 ("x_len", ctypes.c_int), ("x_batch_stride", ctypes.c_int64)]
 
 
+class SamplerSet(ctypes.Structure):
+    _fields_ = [("rows", ctypes.c_void_p), ("labels", ctypes.c_void_p), ("silence", ctypes.c_void_p),
+                ("n", ctypes.c_int32)]
+
+
+class SamplerArgs(ctypes.Structure):
+    _fields_ = [("deterministic", ctypes.c_int32), ("offset", ctypes.c_int32), ("count", ctypes.c_int32),
+                ("use_background", ctypes.c_int32), ("n_bg", ctypes.c_int32), ("bg_len", ctypes.c_void_p),
+                ("bg_start", ctypes.c_void_p), ("desired_samples", ctypes.c_int32), ("shift_lo", ctypes.c_int32),
+                ("shift_hi", ctypes.c_int32), ("background_frequency", ctypes.c_double),
+                ("background_volume_range", ctypes.c_double), ("foreground_frequency", ctypes.c_double),
+                ("foreground_volume_range", ctypes.c_double), ("time_shift_frequency", ctypes.c_double),
+                ("pseudo_frequency", ctypes.c_double), ("flip_frequency", ctypes.c_double),
+                ("silence_volume_range", ctypes.c_double)]
+
+
 class NetConfig(ctypes.Structure):
     _fields_ = [("kind", ctypes.c_int), ("num_classes", ctypes.c_int), ("filter_mult", ctypes.c_int),
                 ("input_size", ctypes.c_int), ("spectrogram_length", ctypes.c_int),
@@ -51,6 +67,8 @@ SIGNATURES = {
     "kws_profile_collect": (_I, []),
     "kws_profile_get": (_I, [_I, ctypes.c_char_p, _I, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I64),
                              ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
+    "kws_sampler_draw": (_I, [_P, ctypes.POINTER(_I), ctypes.POINTER(SamplerSet), ctypes.POINTER(SamplerSet),
+                              ctypes.POINTER(SamplerArgs), _P, _P, _P, _P, _P, _P]),
     "kws_augment_f32": (_I, [_P, _I64, _I, _P, _P, _P, _P, _I64, _P, _P, _P, _I, _P]),
     "kws_augment_i16": (_I, [_P, _I64, _I, _P, _P, _P, _P, _I64, _P, _P, _P, _I, _P]),
     "kws_tta_transform": (_I, [_P, _P, _I, _I, _I, _P]),

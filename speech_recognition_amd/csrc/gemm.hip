@@ -46,25 +46,26 @@ struct NNArgs {
   int m_tiles, n_tiles;
 };
 
+// 16 bytes of zeros that masked-out lanes load from instead of branching around their load.
+// hipcc turns `ok ? *p : 0` into a branch per load and waits vmcnt(0) behind each one, which serialises
+// a tile's global loads (measured: 2.3 k cycles to "issue" 8 loads); selecting the ADDRESS keeps every
+// load unconditional and in flight together.
+__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
 __device__ __forceinline__ float4 ld4_or_zero(const float* p, bool ok) {
-  return ok ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+  return *reinterpret_cast<const float4*>(ok ? p : g_zero16);
 }
 
-// gathered load of 4 consecutive elements starting at element index pos of one clip
+// gathered load of 4 consecutive elements starting at element index pos of one clip (0 outside
+// [0, x_len)).  The common case (fully inside, 8-byte aligned: checked on the host) is two unconditional
+// 8-byte loads; only rows that straddle the clip boundary take the element-wise branch.
 __device__ __forceinline__ float4 gather4(const float* xb, int pos, int x_len) {
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (pos >= 0 && pos + 3 < x_len) {
-    const float* p = xb + pos;
-    if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
-      v = *reinterpret_cast<const float4*>(p);
-    } else if ((reinterpret_cast<uintptr_t>(p) & 7) == 0) {
-      float2 lo = *reinterpret_cast<const float2*>(p);
-      float2 hi = *reinterpret_cast<const float2*>(p + 2);
-      v = make_float4(lo.x, lo.y, hi.x, hi.y);
-    } else {
-      v = make_float4(p[0], p[1], p[2], p[3]);
-    }
-  } else {
+  const bool inside = pos >= 0 && pos + 3 < x_len;
+  const float* p = inside ? xb + pos : g_zero16;
+  const float2 lo = *reinterpret_cast<const float2*>(p);
+  const float2 hi = *reinterpret_cast<const float2*>(p + 2);
+  float4 v = make_float4(lo.x, lo.y, hi.x, hi.y);
+  if (!inside && pos + 3 >= 0 && pos < x_len) {
     if (pos >= 0 && pos < x_len) v.x = xb[pos];
     if (pos + 1 >= 0 && pos + 1 < x_len) v.y = xb[pos + 1];
     if (pos + 2 >= 0 && pos + 2 < x_len) v.z = xb[pos + 2];
@@ -265,6 +266,263 @@ __global__ __launch_bounds__(256, 4) void gemm_nn_kernel(NNArgs p) {
     }
   }
   STAMP(4);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Persistent NN kernel (default).  Same tile math as gemm_nn_kernel, restructured around what the
+// in-kernel stamps of the one-tile-per-workgroup version showed (6.1 k cycles exposed first-load
+// latency + 9.4 k cycles of 4-byte-per-lane stores per 16.4 k cycles of MFMA work, and co-resident
+// workgroups in lockstep so none of it overlapped):
+//   * each workgroup walks a list of tiles; while it computes the LAST K-slab of tile t it already has
+//     the first K-slab of tile t+1 in flight (register prefetch), so the load latency hides under MFMA;
+//   * the accumulators leave through LDS: every wave stages its 64 x (TN*32) sub-tile in the (now idle)
+//     pipeline buffers and writes it out as 16-byte row-major stores - 4x fewer store instructions and
+//     256-byte contiguous segments instead of 128-byte ones; the stores drain while the next tile's
+//     main loop runs.
+constexpr int PBK = 32;
+constexpr int PLDA = PBK + 4;
+
+template <int BM, int BN, int WM, int WN, bool GATHER, bool STATS>
+__global__ __launch_bounds__(256, 2) void gemm_nn_persist_kernel(NNArgs p) {
+  constexpr int TM = BM / WM / 32;
+  constexpr int TN = BN / WN / 32;
+  constexpr int A_F4 = BM * PBK / 4 / 256;
+  constexpr int B_F4 = PBK * BN / 4 / 256;
+  constexpr int BN4 = BN / 4;
+  constexpr int PBK4 = PBK / 4;
+  constexpr int STAGE = BM * PLDA + PBK * BN;       // floats per pipeline stage
+  constexpr int WROWS = TM * 32, WCOLS = TN * 32;   // one wave's sub-tile
+  constexpr int C4_PER_ROW = WCOLS / 4;             // float4 per staged row
+  constexpr int RED_OFF = 4 * WROWS * WCOLS;        // stats scratch behind the 4 staging regions
+  static_assert(WM * WN == 4, "4 waves");
+  static_assert(RED_OFF + 2 * WM * BN <= 2 * STAGE, "staging + stats scratch must fit the pipeline LDS");
+  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int li = lane & 31, lh = lane >> 5;
+  const int K = p.K, N = p.N;
+  const int64_t M = p.M;
+  const int nk = (K + PBK - 1) / PBK;
+
+  // XCD-aware persistent tile walk: workgroups b and b+8 share an XCD (round-robin dispatch, speed only);
+  // XCD x owns the row panels tile_m = x (mod 8) and its workgroups take consecutive local tiles, so the
+  // n-tiles of one row panel run at the same time on one L2.
+  const int xcd = blockIdx.x % NXCD;
+  const int wg_in_xcd = blockIdx.x / NXCD;
+  const int wgs_per_xcd = gridDim.x / NXCD;
+  const int panels = (p.m_tiles - xcd + NXCD - 1) / NXCD;   // row panels owned by this XCD
+  const int local_tiles = panels * p.n_tiles;
+  int local = wg_in_xcd;
+  if (local >= local_tiles) return;
+
+  const float* a_row[A_F4];
+  bool a_ok[A_F4];
+  int a_t[A_F4];
+  int64_t m0 = 0;
+  int n0 = 0, tile_m = 0;
+  auto setup = [&](int loc) {
+    tile_m = (loc / p.n_tiles) * NXCD + xcd;
+    m0 = (int64_t)tile_m * BM;
+    n0 = (loc % p.n_tiles) * BN;
+#pragma unroll
+    for (int r = 0; r < A_F4; ++r) {
+      const int idx = tid + r * 256;
+      const int64_t gm = m0 + idx / PBK4;
+      a_ok[r] = gm < M;
+      if (GATHER) {
+        const int64_t b = a_ok[r] ? gm / p.g.L_out : 0;
+        a_t[r] = a_ok[r] ? (int)(gm - b * p.g.L_out) : 0;
+        a_row[r] = p.A + b * p.g.x_batch_stride;
+      } else {
+        a_t[r] = 0;
+        a_row[r] = p.A + (a_ok[r] ? gm : 0) * (int64_t)K;
+      }
+    }
+  };
+  float4 ra[A_F4], rb[B_F4];
+  auto load_global = [&](int k0) {
+#pragma unroll
+    for (int r = 0; r < A_F4; ++r) {
+      const int idx = tid + r * 256;
+      const int gk = k0 + (idx % PBK4) * 4;
+      if (GATHER) {
+        if (a_ok[r] && gk < K) {
+          const int j = gk / p.g.cin;
+          const int c = gk - j * p.g.cin;
+          ra[r] = gather4(a_row[r], a_t[r] * p.g.stride_t + j * p.g.stride_j + c + p.g.base_off, p.g.x_len);
+        } else {
+          ra[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      } else {
+        ra[r] = ld4_or_zero(a_row[r] + gk, a_ok[r] && gk < K);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < B_F4; ++r) {
+      const int idx = tid + r * 256;
+      const int gk = k0 + idx / BN4, gn = n0 + (idx % BN4) * 4;
+      rb[r] = ld4_or_zero(p.W + (int64_t)gk * N + gn, gk < K && gn < N);
+    }
+  };
+  auto store_lds = [&](int buf) {
+#pragma unroll
+    for (int r = 0; r < A_F4; ++r) {
+      const int idx = tid + r * 256;
+      *reinterpret_cast<float4*>(&smem[buf * STAGE + (idx / PBK4) * PLDA + (idx % PBK4) * 4]) = ra[r];
+    }
+#pragma unroll
+    for (int r = 0; r < B_F4; ++r) {
+      const int idx = tid + r * 256;
+      *reinterpret_cast<float4*>(&smem[buf * STAGE + BM * PLDA + (idx / BN4) * BN + (idx % BN4) * 4]) = rb[r];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#ifdef KWS_GEMM_STAMP
+  unsigned long long t_load = 0, t_comp = 0, t_store = 0, t_sync = 0, t_epi = 0, t_mark = 0, n_tiles_done = 0;
+  const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+#define PT0() t_mark = __builtin_amdgcn_s_memtime()
+#define PT(acc_) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc_ += now_ - t_mark; t_mark = now_; } while (0)
+#else
+#define PT0()
+#define PT(acc_)
+#endif
+  setup(local);
+  load_global(0);
+  store_lds(0);
+  __syncthreads();
+  while (true) {
+    const int64_t cm0 = m0;   // the tile being computed (setup() for the prefetch overwrites m0/n0/tile_m)
+    const int cn0 = n0, ctile_m = tile_m;
+    const int next = local + wgs_per_xcd;
+    const bool has_next = next < local_tiles;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      PT0();
+      if (kt + 1 < nk) {
+        load_global((kt + 1) * PBK);
+      } else if (has_next) {
+        setup(next);        // first K-slab of the NEXT tile flies while this tile's last slab is computed
+        load_global(0);
+      }
+      PT(t_load);
+      const float* cA = smem + cur * STAGE + (wm * TM * 32 + li) * PLDA + lh * 4;
+      const float* cB = smem + cur * STAGE + BM * PLDA + (lh * 4) * BN + wn * TN * 32 + li;
+#pragma unroll
+      for (int q = 0; q < PBK / 8; ++q) {
+        float4 a[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const float4*>(cA + i * 32 * PLDA + q * 8);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float b[TN];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) b[j] = cB[(q * 8 + r) * BN + j * 32];
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const float av = r == 0 ? a[i].x : (r == 1 ? a[i].y : (r == 2 ? a[i].z : a[i].w));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[j], acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+      PT(t_comp);
+      if (kt + 1 < nk) store_lds(cur ^ 1);
+      PT(t_store);
+      __syncthreads();   // after the last slab: every wave is done reading the pipeline buffers
+      PT(t_sync);
+    }
+    PT0();
+
+    // ---- epilogue: registers -> this wave's LDS staging region -> 16-byte global stores --------------
+    float* stg = smem + wave * (WROWS * WCOLS);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int v = 0; v < 16; ++v)
+          stg[(i * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh) * WCOLS + j * 32 + li] = acc[i][j][v];
+    if (STATS) {
+      float* red = smem + RED_OFF;  // [2][WM][BN]
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        float s = 0.f, ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int v = 0; v < 16; ++v) {
+            const float x = acc[i][j][v];
+            s += x;
+            ss += x * x;
+          }
+        s += __shfl_xor(s, 32);
+        ss += __shfl_xor(ss, 32);
+        if (lh == 0) {
+          const int c = wn * WCOLS + j * 32 + li;
+          red[(0 * WM + wm) * BN + c] = s;
+          red[(1 * WM + wm) * BN + c] = ss;
+        }
+      }
+    }
+    // same-wave LDS accesses are ordered; only the compiler has to be kept from reordering them
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    {
+      const int64_t row_base = cm0 + wm * WROWS;
+      const int col_base = cn0 + wn * WCOLS;
+      const int c4 = lane % C4_PER_ROW, r_in = lane / C4_PER_ROW;
+      constexpr int ROWS_PER_PASS = 64 / C4_PER_ROW;
+#pragma unroll
+      for (int ps = 0; ps < WROWS / ROWS_PER_PASS; ++ps) {
+        const int r = ps * ROWS_PER_PASS + r_in;
+        const float4 v = *reinterpret_cast<const float4*>(stg + r * WCOLS + c4 * 4);
+        const int64_t row = row_base + r;
+        const int col = col_base + c4 * 4;
+        if (row < M && col < N) *reinterpret_cast<float4*>(p.C + row * N + col) = v;
+      }
+    }
+    if (STATS) {
+      __syncthreads();
+      const float* red = smem + RED_OFF;
+      if (tid < BN && cn0 + tid < N) {
+        float s = 0.f, ss = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) {
+          s += red[(0 * WM + w) * BN + tid];
+          ss += red[(1 * WM + w) * BN + tid];
+        }
+        p.stats[((int64_t)ctile_m * 2 + 0) * N + cn0 + tid] = s;
+        p.stats[((int64_t)ctile_m * 2 + 1) * N + cn0 + tid] = ss;
+      }
+    }
+#ifdef KWS_GEMM_STAMP
+    n_tiles_done++;
+#endif
+    if (!has_next) break;
+    __syncthreads();   // staging / stats scratch fully consumed before the pipeline buffers are refilled
+    store_lds(0);
+    __syncthreads();
+    PT(t_epi);
+    local = next;
+  }
+#ifdef KWS_GEMM_STAMP
+  if (tid == 0 && blockIdx.x < 8192) {
+    g_stamps[blockIdx.x][0] = t_load; g_stamps[blockIdx.x][1] = t_comp; g_stamps[blockIdx.x][2] = t_store;
+    g_stamps[blockIdx.x][3] = t_sync; g_stamps[blockIdx.x][4] = t_epi; g_stamps[blockIdx.x][5] = n_tiles_done;
+    g_stamps[blockIdx.x][6] = __builtin_amdgcn_s_memtime() - t_begin;
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -489,6 +747,22 @@ int launch_nn(const NNArgs& a0, hipStream_t st) {
     return KWS_E_INVALID;
   }
   const bool stats = a.stats != nullptr;
+  static const bool use_v1 = getenv("KWS_GEMM_V1") != nullptr;   // one-tile-per-workgroup kernel, A/B only
+  if (!use_v1) {
+    // persistent: 2 workgroups per CU (69.6 KB LDS each), 32 CUs per XCD
+    int per_xcd = (int)(slots < 64 ? slots : 64);
+    if (const char* e = getenv("KWS_GEMM_WGS_PER_XCD")) per_xcd = atoi(e) > 0 && atoi(e) < slots ? atoi(e) : per_xcd;
+    dim3 gp((unsigned)(per_xcd * NXCD)), bp(256);
+    if (wide) {
+      if (stats) hipLaunchKernelGGL((gemm_nn_persist_kernel<128, 128, 2, 2, GATHER, true>), gp, bp, 0, st, a);
+      else hipLaunchKernelGGL((gemm_nn_persist_kernel<128, 128, 2, 2, GATHER, false>), gp, bp, 0, st, a);
+    } else {
+      if (stats) hipLaunchKernelGGL((gemm_nn_persist_kernel<128, 64, 2, 2, GATHER, true>), gp, bp, 0, st, a);
+      else hipLaunchKernelGGL((gemm_nn_persist_kernel<128, 64, 2, 2, GATHER, false>), gp, bp, 0, st, a);
+    }
+    KWS_LAUNCH_CHECK("gemm_nn_persist_kernel");
+    return KWS_OK;
+  }
   dim3 g((unsigned)grid), b(256);
   if (wide) {
     if (stats) hipLaunchKernelGGL((gemm_nn_kernel<128, 128, 2, 2, GATHER, true>), g, b, 0, st, a);
@@ -522,6 +796,8 @@ int check_gather(const kws_gather_t* g, int B, int N) {
   KWS_REQUIRE(g->L_out > 0 && g->cin > 0 && g->taps > 0 && g->cin % 4 == 0,
               "gather: need L_out>0, taps>0, cin%%4==0 (cin=%d)", g->cin);
   KWS_REQUIRE(g->x_len > 0 && g->x_batch_stride >= g->x_len, "gather: bad x_len/x_batch_stride");
+  KWS_REQUIRE(g->x_batch_stride % 2 == 0 && g->stride_t % 2 == 0 && g->stride_j % 2 == 0 && g->base_off % 2 == 0,
+              "gather: strides/offsets must be even (8-byte aligned 2-float loads)");
   KWS_REQUIRE(B > 0 && N > 0 && N % 4 == 0, "gather: B=%d N=%d (N%%4 must be 0)", B, N);
   return KWS_OK;
 }
