@@ -13,3 +13,21 @@ constexpr int KWS_SMALL_WGRAD_SLICES = 32;  // scratch: KWS_SMALL_WGRAD_SLICES *
 int kws_small_wgrad_launch(const float* X, const float* D, float* out, float* out_bias, int B, int K, int N,
                            float* scratch, hipStream_t st);
 int kws_metrics_launch(const float* per_loss, const float* per_correct, int B, float* metrics, hipStream_t st);
+
+// ---- STFT plan (device tables), shared by stft.hip (v1, generic) and stft2.hip (v2, features) ------
+struct kws_stft_plan {
+  int frame_len, frame_step, fft_len, n_bins, n_mel, n_out;
+  float log_offset, log_floor;
+  int n_w;            // CSR weights
+  float* window;      // [512] zero padded
+  float2* w256;       // [256] e^{-2 pi i j/256}
+  float2* w512;       // [257] e^{-2 pi i k/512}
+  int* band_start;    // [n_mel]
+  int* band_cnt;      // [n_mel]
+  int* band_ofs;      // [n_mel]
+  float* band_w;      // [n_w]
+  float* dct;         // [n_mel * n_out]
+  float2* tw16;       // [16][16] W256^(n2*k1)
+  float* dct64;       // [n_mel][64] zero padded
+};
+int kws_stft2_launch(const kws_stft_plan* pl, const float* x, int B, int L, int F, float* out, hipStream_t st);

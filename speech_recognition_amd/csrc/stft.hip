@@ -10,25 +10,11 @@
 // butterfly per lane per stage, ping-pong in LDS) plus the real-input split step; magnitudes, the
 // sparse (CSR) triangular mel bands, log and the small dense DCT all stay in LDS - only the
 // [F, n_out] features go back to HBM.
-#include "common.h"
+#include "internal.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <vector>
-
-struct kws_stft_plan {
-  int frame_len, frame_step, fft_len, n_bins, n_mel, n_out;
-  float log_offset, log_floor;
-  int n_w;            // CSR weights
-  // device tables
-  float* window;      // [512] zero padded
-  float2* w256;       // [256] e^{-2 pi i j/256}
-  float2* w512;       // [257] e^{-2 pi i k/512}
-  int* band_start;    // [n_mel]
-  int* band_cnt;      // [n_mel]
-  int* band_ofs;      // [n_mel]
-  float* band_w;      // [n_w]
-  float* dct;         // [n_mel * n_out]
-};
 
 namespace {
 
@@ -262,6 +248,16 @@ int kws_stft_plan_create(int frame_len, int frame_step, int fft_len, int n_mel, 
   if (bw.empty()) bw.push_back(0.f);
   p->n_w = (int)bw.size();
   std::vector<float> d(dct, dct + (size_t)n_mel * n_out);
+  // v2 kernel tables: inter-stage twiddles W256^(n2*k1) as [n2][k1], DCT matrix padded to 64 columns
+  std::vector<float2> tw16(256);
+  for (int n2 = 0; n2 < 16; ++n2)
+    for (int k1 = 0; k1 < 16; ++k1) {
+      const double ang = -2.0 * M_PI * (n2 * k1) / 256.0;
+      tw16[n2 * 16 + k1] = make_float2((float)cos(ang), (float)sin(ang));
+    }
+  std::vector<float> d64((size_t)n_mel * 64, 0.f);
+  for (int m = 0; m < n_mel; ++m)
+    for (int q = 0; q < n_out && q < 64; ++q) d64[(size_t)m * 64 + q] = dct[(size_t)m * n_out + q];
   int rc = upload(&p->window, win);
   if (rc == KWS_OK) rc = upload(&p->w256, w256);
   if (rc == KWS_OK) rc = upload(&p->w512, w512);
@@ -270,6 +266,8 @@ int kws_stft_plan_create(int frame_len, int frame_step, int fft_len, int n_mel, 
   if (rc == KWS_OK) rc = upload(&p->band_ofs, bo);
   if (rc == KWS_OK) rc = upload(&p->band_w, bw);
   if (rc == KWS_OK) rc = upload(&p->dct, d);
+  if (rc == KWS_OK) rc = upload(&p->tw16, tw16);
+  if (rc == KWS_OK) rc = upload(&p->dct64, d64);
   if (rc != KWS_OK) {
     kws_stft_plan_destroy(p);
     return rc;
@@ -280,7 +278,8 @@ int kws_stft_plan_create(int frame_len, int frame_step, int fft_len, int n_mel, 
 
 int kws_stft_plan_destroy(kws_stft_plan_t* p) {
   if (!p) return KWS_OK;
-  void* bufs[8] = {p->window, p->w256, p->w512, p->band_start, p->band_cnt, p->band_ofs, p->band_w, p->dct};
+  void* bufs[10] = {p->window, p->w256, p->w512, p->band_start, p->band_cnt, p->band_ofs, p->band_w, p->dct,
+                    p->tw16, p->dct64};
   for (void* q : bufs)
     if (q) (void)hipFree(q);
   delete p;
@@ -306,6 +305,9 @@ int kws_stft_mel_f32(const kws_stft_plan_t* plan, const float* x, int B, int L, 
   // ~5 N log2 N for the 256-point complex FFT + split + sparse mel + dense DCT, per frame
   const double fl = (double)B * a.F * (5.0 * 256 * 8 + 12.0 * 257 + 2.0 * plan->n_w + 2.0 * plan->n_mel * plan->n_out);
   KwsProfScope prof("stft_mel", fl, 4.0 * ((double)B * L + (double)B * a.F * width), st);
+  static const bool force_v1 = getenv("KWS_STFT_V1") != nullptr;
+  if (out_kind == 0 && plan->n_out <= 64 && plan->n_mel <= 128 && plan->frame_len % 2 == 0 && !force_v1)
+    return kws_stft2_launch(plan, x, B, L, a.F, out, st);
   if (a.F % 14 == 0) {
     a.run_samples = (7 * 2 - 1) * plan->frame_step + plan->frame_len;
     return launch_stft<7, 2>(a, B, st);

@@ -1,0 +1,267 @@
+// STFT -> |X| -> mel -> log -> DCT feature kernel, second generation.
+//
+// What the first kernel (stft.hip) got wrong for this chip, from its profile (0.46 ms / 1024 clips =
+// 2.4 % of the HBM roof): one radix-4 butterfly per lane per stage means four LDS round trips per frame
+// with a dependent wait each, one wave = one frame means 64 lanes share a 256-point transform, and every
+// workgroup re-staged 25 KB of tables for 14 frames of work.
+//
+// Here a frame is owned by 16 lanes (one DPP row, four frames per wave) and the 256-point complex FFT of
+// the even/odd-packed 512-sample frame is the 16 x 16 Cooley-Tukey split done in REGISTERS:
+//     n = 16 n1 + n2,  k = k1 + 16 k2
+//     lane n2: 16-point FFT over n1  ->  x W256^(n2 k1)  ->  [one 16x16 transpose through LDS]
+//     lane k1: 16-point FFT over n2  ->  Z[k1 + 16 k2] in register k2
+// so a frame crosses LDS once instead of four times.  The real-input split needs Z[256-k], which lives in
+// lane 16-k1, register 15-k2: one row-local shuffle per register.  Magnitudes go to LDS once; every lane
+// then gathers 5-6 triangular mel bands (CSR), takes the log, and produces 4 DCT outputs per lane from a
+// 16-byte-wide read of the zero-padded [n_mel][64] DCT table, so one frame's feature row leaves as one
+// contiguous 16-lane x 16-byte store.  Waves take frame quads grid-stride over the WHOLE batch and read
+// their PCM straight from global memory (128-byte coalesced per 16-lane row; the 3x frame overlap is
+// served by L2), so there is no per-clip staging, no workgroup barrier after the table load, and the
+// tables are loaded once per persistent workgroup.
+#include "internal.h"
+
+namespace {
+
+constexpr int NW2 = 12;            // waves per workgroup (3 per SIMD; 134 KB LDS incl. tables)
+constexpr int TP = 17;             // padded row (complex) of the per-frame 16x16 transpose tile
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }   // a * (-i)
+
+// forward 4-point DFT (W4 = -i)
+__device__ __forceinline__ void dft4(float2& x0, float2& x1, float2& x2, float2& x3) {
+  const float2 s02 = cadd(x0, x2), d02 = csub(x0, x2), s13 = cadd(x1, x3), d13 = mul_mi(csub(x1, x3));
+  x0 = cadd(s02, s13);
+  x1 = cadd(d02, d13);
+  x2 = csub(s02, s13);
+  x3 = csub(d02, d13);
+}
+
+// in-place forward 16-point FFT, natural order in and out (radix-4 x radix-4, all indices static)
+__device__ __forceinline__ void fft16(float2 (&a)[16]) {
+  constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R2 = 0.70710678118654752f;
+  // stage 1: DFT4 over s for each r (elements r, r+4, r+8, r+12) -> b[r][q] stored at a[r + 4q]
+#pragma unroll
+  for (int r = 0; r < 4; ++r) dft4(a[r], a[r + 4], a[r + 8], a[r + 12]);
+  // twiddle W16^(r q)
+  a[1 + 4] = cmul(a[1 + 4], make_float2(C1, -S1));     // r=1,q=1: W^1
+  a[1 + 8] = cmul(a[1 + 8], make_float2(R2, -R2));     // r=1,q=2: W^2
+  a[1 + 12] = cmul(a[1 + 12], make_float2(S1, -C1));   // r=1,q=3: W^3
+  a[2 + 4] = cmul(a[2 + 4], make_float2(R2, -R2));     // r=2,q=1: W^2
+  a[2 + 8] = mul_mi(a[2 + 8]);                         // r=2,q=2: W^4 = -i
+  a[2 + 12] = cmul(a[2 + 12], make_float2(-R2, -R2));  // r=2,q=3: W^6
+  a[3 + 4] = cmul(a[3 + 4], make_float2(S1, -C1));     // r=3,q=1: W^3
+  a[3 + 8] = cmul(a[3 + 8], make_float2(-R2, -R2));    // r=3,q=2: W^6
+  a[3 + 12] = cmul(a[3 + 12], make_float2(-C1, S1));   // r=3,q=3: W^9
+  // stage 2: for each q, DFT4 over r of c[r][q] (at a[r + 4q]) -> A[q + 4p] ; write back in natural order
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dft4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
+  // now a[4q + p] holds A[q + 4p]: transpose the 4x4 index grid to natural order
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int p = q + 1; p < 4; ++p) {
+      const float2 t = a[4 * q + p];
+      a[4 * q + p] = a[4 * p + q];
+      a[4 * p + q] = t;
+    }
+}
+
+struct Stft2Args {
+  kws_stft_plan pl;
+  const float* x;
+  float* out;
+  int B, L, F;
+  int quads_per_clip;
+  int64_t total_quads;
+};
+
+__global__ __launch_bounds__(NW2 * 64, 1) void stft2_kernel(Stft2Args a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const kws_stft_plan& pl = a.pl;
+  const int n_mel = pl.n_mel, n_out = pl.n_out;
+  // ---- LDS carve (floats) --------------------------------------------------------------------------
+  float* s_win = lds;                                              // [512]
+  float2* s_tw = reinterpret_cast<float2*>(s_win + 512);           // [256]  W256^(n2 k1), index n2*16+k1
+  float2* s_w512 = s_tw + 256;                                     // [258]
+  float* s_dct = reinterpret_cast<float*>(s_w512 + 258);           // [n_mel][64]
+  float* s_bw = s_dct + n_mel * 64;                                // [n_w]
+  int* s_csr = reinterpret_cast<int*>(s_bw + ((pl.n_w + 3) & ~3)); // [3][128] start | cnt | ofs
+  float* s_wave = reinterpret_cast<float*>(s_csr + 3 * 128);       // per-wave scratch
+  constexpr int FR_FLOATS = 16 * TP * 2;                           // one frame's transpose tile (544 floats)
+  constexpr int WAVE_FLOATS = 4 * FR_FLOATS;                       // also reused for mag[260] + logmel[128]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l16 = lane & 15, fq = lane >> 4;                       // lane in frame, frame in quad
+  float* s_fr = s_wave + wave * WAVE_FLOATS + fq * FR_FLOATS;      // this frame's scratch
+
+  for (int i = tid; i < 512; i += NW2 * 64) s_win[i] = pl.window[i];
+  for (int i = tid; i < 256; i += NW2 * 64) s_tw[i] = pl.tw16[i];
+  for (int i = tid; i < 257; i += NW2 * 64) s_w512[i] = pl.w512[i];
+  for (int i = tid; i < n_mel * 64; i += NW2 * 64) s_dct[i] = pl.dct64[i];
+  for (int i = tid; i < pl.n_w; i += NW2 * 64) s_bw[i] = pl.band_w[i];
+  for (int i = tid; i < 128; i += NW2 * 64) {
+    s_csr[i] = i < n_mel ? pl.band_start[i] : 0;
+    s_csr[128 + i] = i < n_mel ? pl.band_cnt[i] : 0;
+    s_csr[256 + i] = i < n_mel ? pl.band_ofs[i] : 0;
+  }
+  __syncthreads();
+
+  const int64_t wave_global = (int64_t)blockIdx.x * NW2 + wave;
+  const int64_t wave_stride = (int64_t)gridDim.x * NW2;
+  const int nb = (n_mel + 15) >> 4;   // mel bands per lane
+  for (int64_t quad = wave_global; quad < a.total_quads; quad += wave_stride) {
+    const int64_t b = quad / a.quads_per_clip;
+    const int f = (int)(quad - b * a.quads_per_clip) * 4 + fq;
+    const bool live = f < a.F;                      // 16-lane uniform
+    const float* fx = a.x + b * (int64_t)a.L + (int64_t)(live ? f : 0) * pl.frame_step;
+    // ---- load: lane n2 = l16 takes z[16 n1 + n2] = w x[2n] + i w x[2n+1], n1 = 0..15 ----------------
+    float2 z[16];
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) {
+      // Unconditional loads (a branch per load would serialise them behind vmcnt(0) waits): positions
+      // past the frame read a clamped in-frame address and are zeroed by the zero-padded window.
+      const int s = 2 * (16 * n1 + l16);
+      const int sc = s < pl.frame_len ? s : pl.frame_len - 2;   // frame_len is even (checked on the host)
+      const float2 xv = *reinterpret_cast<const float2*>(fx + sc);
+      const float2 wv = *reinterpret_cast<const float2*>(s_win + s);
+      z[n1] = make_float2(xv.x * wv.x, xv.y * wv.y);
+    }
+    fft16(z);                                       // over n1: z[k1] = Y[n2][k1]
+#pragma unroll
+    for (int k1 = 1; k1 < 16; ++k1) z[k1] = cmul(z[k1], s_tw[l16 * 16 + k1]);
+    // ---- 16x16 transpose through LDS: write [k1][n2], read row k1 = l16 ------------------------------
+    float2* tile = reinterpret_cast<float2*>(s_fr);
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) tile[k1 * TP + l16] = z[k1];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int n2 = 0; n2 < 16; ++n2) z[n2] = tile[l16 * TP + n2];
+    fft16(z);                                       // over n2: z[k2] = Z[k1 + 16 k2], k1 = l16
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();                // tile reads done before the scratch is reused
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- real-input split + magnitude: X[k] = E + W512^k O, partner = Z[256-k] ----------------------
+    float* s_mag = s_fr;                            // [260]
+    const int partner = (16 - l16) & 15;            // lane holding bins 256-k (k1 > 0); lane 0 pairs with itself
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) {
+      // partner register: 15-k2 for k1 > 0, (16-k2)&15 for k1 = 0 (static indices, selected per lane)
+      const float2 pa = z[15 - k2], pb = z[(16 - k2) & 15];
+      const float px = __shfl(pa.x, partner, 16), py = __shfl(pa.y, partner, 16);
+      const float2 zn0 = (l16 == 0) ? pb : make_float2(px, py);
+      const float2 zk = z[k2];
+      const float2 zn = make_float2(zn0.x, -zn0.y);
+      const float2 E = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y + zn.y));
+      const float2 dd = csub(zk, zn);
+      const float2 O = make_float2(0.5f * dd.y, -0.5f * dd.x);
+      const int k = l16 + 16 * k2;
+      const float2 X = cadd(E, cmul(s_w512[k], O));
+      s_mag[k] = __builtin_amdgcn_sqrtf(X.x * X.x + X.y * X.y);
+    }
+    if (l16 == 0) s_mag[256] = fabsf(z[0].x - z[0].y);   // Nyquist bin: Re Z0 - Im Z0
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- sparse mel bands + log: lane takes bands l16, l16+16, ... -----------------------------------
+    float* s_lm = s_fr + 264;                       // [128]
+    for (int i = 0; i < nb; ++i) {
+      const int m = l16 + 16 * i;
+      if (m < n_mel) {
+        const int st0 = s_csr[m], cnt = s_csr[128 + m], ofs = s_csr[256 + m];
+        // 4 independent (magnitude, weight) pairs per trip: the LDS latency is paid once per 4 taps
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        for (int j = 0; j < cnt; j += 4) {
+          const int j1 = j + 1 < cnt ? j + 1 : j, j2 = j + 2 < cnt ? j + 2 : j, j3 = j + 3 < cnt ? j + 3 : j;
+          const float m0 = s_mag[st0 + j], m1 = s_mag[st0 + j1], m2 = s_mag[st0 + j2], m3 = s_mag[st0 + j3];
+          const float w0 = s_bw[ofs + j];
+          const float w1 = j + 1 < cnt ? s_bw[ofs + j1] : 0.f;
+          const float w2 = j + 2 < cnt ? s_bw[ofs + j2] : 0.f;
+          const float w3 = j + 3 < cnt ? s_bw[ofs + j3] : 0.f;
+          s0 = fmaf(m0, w0, s0);
+          s1 = fmaf(m1, w1, s1);
+          s2 = fmaf(m2, w2, s2);
+          s3 = fmaf(m3, w3, s3);
+        }
+        float sm = ((s0 + s1) + (s2 + s3)) + pl.log_offset;
+        if (pl.log_floor > 0.f) sm = fmaxf(sm, pl.log_floor);
+        s_lm[m] = __logf(sm);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- DCT: 4 outputs per lane (q = 4 l16 .. +3) ----------------------------------------------------
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f), o2 = o;
+    {
+      // two independent accumulator sets, 4 mel bins per LDS read of the log-mel row
+      const float* dcol = s_dct + 4 * l16;
+      int m = 0;
+#pragma unroll 2
+      for (; m + 3 < n_mel; m += 4) {
+        const float4 lv = *reinterpret_cast<const float4*>(s_lm + m);
+        const float4 d0 = *reinterpret_cast<const float4*>(dcol + (m + 0) * 64);
+        const float4 d1 = *reinterpret_cast<const float4*>(dcol + (m + 1) * 64);
+        const float4 d2 = *reinterpret_cast<const float4*>(dcol + (m + 2) * 64);
+        const float4 d3 = *reinterpret_cast<const float4*>(dcol + (m + 3) * 64);
+        o.x = fmaf(lv.x, d0.x, o.x); o.y = fmaf(lv.x, d0.y, o.y); o.z = fmaf(lv.x, d0.z, o.z); o.w = fmaf(lv.x, d0.w, o.w);
+        o2.x = fmaf(lv.y, d1.x, o2.x); o2.y = fmaf(lv.y, d1.y, o2.y); o2.z = fmaf(lv.y, d1.z, o2.z); o2.w = fmaf(lv.y, d1.w, o2.w);
+        o.x = fmaf(lv.z, d2.x, o.x); o.y = fmaf(lv.z, d2.y, o.y); o.z = fmaf(lv.z, d2.z, o.z); o.w = fmaf(lv.z, d2.w, o.w);
+        o2.x = fmaf(lv.w, d3.x, o2.x); o2.y = fmaf(lv.w, d3.y, o2.y); o2.z = fmaf(lv.w, d3.z, o2.z); o2.w = fmaf(lv.w, d3.w, o2.w);
+      }
+      for (; m < n_mel; ++m) {
+        const float lv = s_lm[m];
+        const float4 d = *reinterpret_cast<const float4*>(dcol + m * 64);
+        o.x = fmaf(lv, d.x, o.x); o.y = fmaf(lv, d.y, o.y); o.z = fmaf(lv, d.z, o.z); o.w = fmaf(lv, d.w, o.w);
+      }
+      o.x += o2.x; o.y += o2.y; o.z += o2.z; o.w += o2.w;
+    }
+    if (live) {
+      float* orow = a.out + (b * a.F + f) * (int64_t)n_out;
+      const int q0 = 4 * l16;
+      if ((n_out & 3) == 0 && q0 + 3 < n_out) {
+        *reinterpret_cast<float4*>(orow + q0) = o;
+      } else {
+        if (q0 < n_out) orow[q0] = o.x;
+        if (q0 + 1 < n_out) orow[q0 + 1] = o.y;
+        if (q0 + 2 < n_out) orow[q0 + 2] = o.z;
+        if (q0 + 3 < n_out) orow[q0 + 3] = o.w;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();                // scratch reads done before the next quad's writes
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
+}  // namespace
+
+int kws_stft2_launch(const kws_stft_plan* pl, const float* x, int B, int L, int F, float* out, hipStream_t st) {
+  KWS_REQUIRE(pl->n_out <= 64 && pl->n_mel <= 128, "stft2: n_mel=%d n_out=%d unsupported", pl->n_mel, pl->n_out);
+  KWS_REQUIRE(F > 0 && (pl->frame_step % 2) == 0 && (L % 2) == 0, "stft2: bad geometry");
+  Stft2Args a;
+  a.pl = *pl;
+  a.x = x; a.out = out; a.B = B; a.L = L; a.F = F;
+  a.quads_per_clip = (F + 3) / 4;
+  a.total_quads = (int64_t)B * a.quads_per_clip;
+  const size_t floats = 512 + 2 * 256 + 2 * 258 + (size_t)pl->n_mel * 64 + ((pl->n_w + 3) & ~3) + 3 * 128 +
+                        (size_t)NW2 * 4 * (16 * TP * 2);
+  const size_t bytes = floats * 4;
+  KWS_REQUIRE(bytes <= 160 * 1024, "stft2: LDS need %zu B exceeds 160 KiB", bytes);
+  static bool attr_done = false;
+  if (!attr_done) {
+    KWS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&stft2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024));
+    attr_done = true;
+  }
+  int64_t wgs = (a.total_quads + NW2 - 1) / NW2;
+  if (wgs > 256) wgs = 256;   // persistent: one workgroup (8 waves) per CU, tables staged once
+  hipLaunchKernelGGL(stft2_kernel, dim3((unsigned)wgs), dim3(NW2 * 64), bytes, st, a);
+  KWS_LAUNCH_CHECK("stft2_kernel");
+  return KWS_OK;
+}
