@@ -238,3 +238,224 @@ class TimeSlicedAttentionNet(object):
                 self.state[key] = L.bn_moving_update(self.state[key].astype(self.dtype), val)
         acc = float((p.argmax(axis=1) == np.asarray(y_onehot).argmax(axis=1)).mean())
         return float(total), acc
+
+
+# ================================================================================================
+# a19: conv_1d_log_mfcc_model (reference model.py:1400-1479), SURVEY Appendix B.2
+# ================================================================================================
+LM_BLOCKS = [(64, 1), (64, 1), (128, 2), (128, 1), (192, 2), (192, 1), (192, 1), (256, 2), (256, 1), (256, 1)]
+
+
+def maxpool_same_fwd(a, pool):
+    """MaxPool1D(pool_size=pool, strides=pool, padding='same') (model.py:1440).  Lengths here are
+    multiples of the pool, so 'same' adds no padding."""
+    if pool == 1:
+        return a, None
+    B, L, C = a.shape
+    assert L % pool == 0
+    w = a.reshape(B, L // pool, pool, C)
+    return w.max(axis=2), w.argmax(axis=2)     # first maximum wins (MaxPoolGrad semantics)
+
+
+def maxpool_same_bwd(do, arg, pool, L):
+    if pool == 1:
+        return do
+    B, Lo, C = do.shape
+    d = np.zeros((B, Lo, pool, C), dtype=do.dtype)
+    for j in range(pool):
+        d[:, :, j, :] = do * (arg == j)
+    return d.reshape(B, L, C)
+
+
+class LogMfccNet(object):
+    """Residual depthwise/pointwise 1-D CNN on [spectrogram_length, num_log_mel_features] features with a
+    softmax-over-time attention and global average pooling.  Parameter names follow Keras' per-class
+    auto-numbering in layer CREATION order (shortcut Conv1D + BN of a strided block are created before
+    the block's depthwise layers, model.py:1429-1441)."""
+
+    def __init__(self, num_classes=32, spectrogram_length=98, num_features=40, seed=87654321, dtype=np.float64):
+        self.dtype = dtype
+        self.num_classes = num_classes
+        self.T0, self.F = spectrogram_length, num_features
+        rng = np.random.RandomState(seed)
+        P, S = OrderedDict(), OrderedDict()
+        self.cnt = dict(conv=0, bn=0, dw=0)
+        self.l2_names = []
+
+        def conv(k, cin, cout, l2):
+            self.cnt['conv'] += 1
+            name = 'conv1d_%d/kernel' % self.cnt['conv']
+            P[name] = glorot_uniform(rng, (k, cin, cout), k * cin, k * cout)
+            if l2:
+                self.l2_names.append(name)
+            return name
+
+        def bn(c):
+            self.cnt['bn'] += 1
+            TimeSlicedAttentionNet._add_bn(P, S, self.cnt['bn'], c)
+            return self.cnt['bn']
+
+        def dw(c):
+            self.cnt['dw'] += 1
+            name = 'depthwise_conv2d_%d/depthwise_kernel' % self.cnt['dw']
+            P[name] = glorot_uniform(rng, (1, 3, c, 1), 3 * c, 3)
+            self.l2_names.append(name)
+            return name
+
+        self.first = (conv(3, num_features, 64, True), bn(64))
+        self.blocks = []
+        cin, L = 64, spectrogram_length - 2
+        for nf, stride in LM_BLOCKS:
+            blk = dict(nf=nf, stride=stride, cin=cin, Lin=L, Lout=L // stride)
+            if stride != 1:
+                blk['short'] = (conv(1, cin, nf, False), bn(nf))   # no kernel_regularizer (model.py:1431-1432)
+            blk['dw1'], blk['pw1'], blk['bn1'] = dw(cin), conv(1, cin, nf, True), bn(nf)
+            blk['dw2'], blk['pw2'], blk['bn2'] = dw(nf), conv(1, nf, nf, True), bn(nf)
+            self.blocks.append(blk)
+            cin, L = nf, L // stride
+        self.T, self.C = L, cin
+        self.att = (dw(cin), conv(1, cin, 1, True), bn(1))         # _context_conv(x, 1, 3, 'same'), model.py:1464
+        P['dense_1/kernel'] = glorot_uniform(rng, (cin, num_classes), cin, num_classes)
+        P['dense_1/bias'] = np.zeros((num_classes,), np.float32)
+        self.l2_names.append('dense_1/kernel')
+        self.params, self.state = P, S
+        self.drop_keep = 0.8                                       # Dropout(0.2), model.py:1471
+
+    def count_params(self):
+        return sum(v.size for v in self.params.values()) + sum(v.size for v in self.state.values())
+
+    def _p(self, name):
+        return self.params[name].astype(self.dtype)
+
+    def _bn(self, idx, y, training, cache, relu=True):
+        g = self._p('batch_normalization_%d/gamma' % idx)
+        b = self._p('batch_normalization_%d/beta' % idx)
+        if training:
+            pre, stats = L.bn_train_fwd(y, g, b)
+            cache['bn%d' % idx] = (y, g, stats, pre)
+            cache.setdefault('batch_stats', OrderedDict())[idx] = (stats[0], stats[1])
+        else:
+            pre = L.bn_infer_fwd(y, g, b,
+                                 self.state['batch_normalization_%d/moving_mean' % idx].astype(self.dtype),
+                                 self.state['batch_normalization_%d/moving_variance' % idx].astype(self.dtype))
+        return L.relu6(pre) if relu else pre
+
+    def _bn_bwd(self, idx, dout, cache, grads, relu=True):
+        y, g, stats, pre = cache['bn%d' % idx]
+        if relu:
+            mask = L.relu6_mask(pre)
+            ov = cache.get('relu_masks')
+            if ov is not None and idx in ov:
+                mask = np.asarray(ov[idx], dtype=self.dtype).reshape(pre.shape)
+            dout = dout * mask
+        dy, dg, db = L.bn_train_bwd(dout, y, g, stats)
+        grads['batch_normalization_%d/gamma' % idx] = dg
+        grads['batch_normalization_%d/beta' % idx] = db
+        return dy
+
+    def forward(self, x, training=False, seed=0, step=0, cache=None, drop_offset=0):
+        dt = self.dtype
+        cache = {} if cache is None else cache
+        B = x.shape[0]
+        h = np.asarray(x, dtype=dt).reshape(B, self.T0, self.F)                       # Reshape, model.py:1446
+        y, cols = L.conv1d_fwd(h, self._p(self.first[0]), stride=1)                   # Conv1D(64,3) valid
+        cache['conv1_cols'] = cols
+        h = self._bn(self.first[1], y, training, cache)
+        for i, blk in enumerate(self.blocks):                                         # model.py:1453-1462
+            c = {}
+            c['x'] = h
+            if 'short' in blk:
+                xs = h[:, ::blk['stride'], :]                                         # Conv1D(nf,1,strides,same)
+                Ws = self._p(blk['short'][0]).reshape(blk['cin'], blk['nf'])
+                c['xs'], c['Ws'] = xs, Ws
+                res = self._bn(blk['short'][1], L.pw_fwd(xs, Ws), training, cache, relu=False)
+            else:
+                res = h
+            w1 = self._p(blk['dw1']).reshape(3, blk['cin'])
+            z1 = L.dwconv_fwd(h, w1, 1, (1, 1))
+            W1 = self._p(blk['pw1']).reshape(blk['cin'], blk['nf'])
+            a1 = self._bn(blk['bn1'], L.pw_fwd(z1, W1), training, cache)
+            w2 = self._p(blk['dw2']).reshape(3, blk['nf'])
+            z2 = L.dwconv_fwd(a1, w2, 1, (1, 1))
+            W2 = self._p(blk['pw2']).reshape(blk['nf'], blk['nf'])
+            a2 = self._bn(blk['bn2'], L.pw_fwd(z2, W2), training, cache)
+            pooled, arg = maxpool_same_fwd(a2, blk['stride'])
+            c.update(w1=w1, z1=z1, W1=W1, a1=a1, w2=w2, z2=z2, W2=W2, arg=arg)
+            cache['blk%d' % i] = c
+            h = pooled + res                                                          # Add
+        wa = self._p(self.att[0]).reshape(3, self.C)
+        za = L.dwconv_fwd(h, wa, 1, (1, 1))
+        Wa = self._p(self.att[1]).reshape(self.C, 1)
+        u = self._bn(self.att[2], L.pw_fwd(za, Wa), training, cache)                  # [B, T, 1]
+        att = L.softmax(u, axis=1)                                                    # softmax over time
+        feat = (h * att).mean(axis=1)                                                 # Multiply + GAP
+        if training:
+            m = L.dropout_mask(L.dropout_key(seed, step, 1), B * self.C, self.drop_keep,
+                               drop_offset * self.C).reshape(B, self.C)
+            fd = feat * m / dt(self.drop_keep)
+        else:
+            m, fd = None, feat
+        Wd, bd = self._p('dense_1/kernel'), self._p('dense_1/bias')
+        p = L.softmax(fd @ Wd + bd, axis=1)
+        cache['tail'] = (h, wa, za, Wa, u, att, m, fd, Wd, p)
+        return p
+
+    def reg_loss(self):
+        return sum(L.L2_COEF * float((self._p(k) ** 2).sum()) for k in self.l2_names)
+
+    def loss_and_grads(self, x, y_onehot, seed=0, step=0, drop_offset=0, loss_scale_B=None, relu_masks=None,
+                       pool_args=None):
+        dt = self.dtype
+        cache = {'relu_masks': relu_masks}
+        p = self.forward(x, training=True, seed=seed, step=step, cache=cache, drop_offset=drop_offset)
+        y_onehot = np.asarray(y_onehot, dtype=dt)
+        loss, per, dp = L.cce_fwd_bwd(p, y_onehot)                                    # model.py:1477
+        B = x.shape[0]
+        if loss_scale_B is not None:
+            dp = dp * dt(B) / dt(loss_scale_B)
+        grads = OrderedDict()
+        h, wa, za, Wa, u, att, m, fd, Wd, p = cache['tail']
+        dl = L.softmax_bwd(dp, p, axis=1)
+        grads['dense_1/kernel'] = fd.T @ dl
+        grads['dense_1/bias'] = dl.sum(axis=0)
+        dfeat = (dl @ Wd.T) * m / dt(self.drop_keep)
+        dprod = np.repeat(dfeat[:, None, :], self.T, axis=1) / dt(self.T)             # GAP backward
+        dh = dprod * att
+        datt = (dprod * h).sum(axis=2, keepdims=True)
+        du = L.softmax_bwd(datt, att, axis=1)
+        dyu = self._bn_bwd(self.att[2], du, cache, grads)
+        dza, dWa = L.pw_bwd(dyu, za, Wa)
+        grads[self.att[1]] = dWa.reshape(1, self.C, 1)
+        dh2, dwa = L.dwconv_bwd(dza, h, wa, 1, (1, 1))
+        grads[self.att[0]] = dwa.reshape(1, 3, self.C, 1)
+        dh = dh + dh2
+        for i in reversed(range(len(self.blocks))):
+            blk, c = self.blocks[i], cache['blk%d' % i]
+            arg = c['arg'] if pool_args is None or i not in pool_args else pool_args[i]
+            da2 = maxpool_same_bwd(dh, arg, blk['stride'], blk['Lin'])
+            dy2 = self._bn_bwd(blk['bn2'], da2, cache, grads)
+            dz2, dW2 = L.pw_bwd(dy2, c['z2'], c['W2'])
+            grads[blk['pw2']] = dW2.reshape(1, blk['nf'], blk['nf'])
+            da1, dw2 = L.dwconv_bwd(dz2, c['a1'], c['w2'], 1, (1, 1))
+            grads[blk['dw2']] = dw2.reshape(1, 3, blk['nf'], 1)
+            dy1 = self._bn_bwd(blk['bn1'], da1, cache, grads)
+            dz1, dW1 = L.pw_bwd(dy1, c['z1'], c['W1'])
+            grads[blk['pw1']] = dW1.reshape(1, blk['cin'], blk['nf'])
+            dx, dw1 = L.dwconv_bwd(dz1, c['x'], c['w1'], 1, (1, 1))
+            grads[blk['dw1']] = dw1.reshape(1, 3, blk['cin'], 1)
+            if 'short' in blk:
+                dys = self._bn_bwd(blk['short'][1], dh, cache, grads, relu=False)
+                dxs, dWs = L.pw_bwd(dys, c['xs'], c['Ws'])
+                grads[blk['short'][0]] = dWs.reshape(1, blk['cin'], blk['nf'])
+                dx = dx.copy()
+                dx[:, ::blk['stride'], :] += dxs
+            else:
+                dx = dx + dh
+            dh = dx
+        dy = self._bn_bwd(self.first[1], dh, cache, grads)
+        Wc = self._p(self.first[0])
+        B2, Lo, Co = dy.shape
+        grads[self.first[0]] = (cache['conv1_cols'].T @ dy.reshape(B2 * Lo, Co)).reshape(Wc.shape)
+        for k in self.l2_names:
+            grads[k] = grads[k] + dt(2.0 * L.L2_COEF) * self._p(k)
+        return loss, p, OrderedDict((k, grads[k]) for k in self.params), cache

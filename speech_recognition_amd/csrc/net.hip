@@ -9,54 +9,10 @@
 //   y_l = z_l W_l                                f32 MFMA GEMM, BN statistics in the epilogue
 // Backward keeps two scratch tensors (G: gradient wrt a BN output / pre-BN tensor, DZ: gradient wrt
 // a depthwise output) and walks the blocks in reverse.
-#include <string.h>
+#include "net_internal.h"
 
-#include <algorithm>
-#include <string>
-#include <vector>
-
-#include "internal.h"
-
-namespace {
-
-constexpr float BN_EPS = 1e-3f;
-constexpr float BN_MOMENTUM = 0.99f;
-constexpr float L2_COEF = 1e-5f;
-constexpr float DROP_KEEP = 0.6f;     // Dropout(0.4), model.py:819,828
-constexpr float LABEL_SMOOTH = 0.1f;  // model.py:835-836
-
-struct BnRef {
-  int64_t gamma, beta;  // param offsets
-  int64_t mm, mv;       // state offsets
-  int C;
-};
-struct Block {
-  int stride, pad_l, cin, cout, Lin, Lout;
-  int64_t dw, pw;  // param offsets
-  BnRef bn;        // BN after the pointwise conv
-};
-
-}  // namespace
-
-struct kws_net {
-  kws_net_config_t cfg;
-  std::vector<kws_tensor_info_t> tensors;
-  int64_t n_params = 0, n_state = 0;
-  // TS_ATTENTION
-  int L_in = 0;      // samples per clip
-  int L1 = 0, C1 = 0;  // conv1 output
-  int64_t conv1 = 0;
-  BnRef bn1;
-  std::vector<Block> blocks;
-  int T = 0, C = 0, NC = 0;
-  int64_t d1k = 0, d1b = 0, d2k = 0;
-  kws_gather_t gather1;
-};
-
-namespace {
-
-int64_t add_tensor(kws_net* n, const std::string& name, std::vector<int64_t> shape, bool is_state, float l2,
-                   int fan_in, int fan_out, float init) {
+int64_t kws_net_add_tensor(kws_net* n, const std::string& name, std::vector<int64_t> shape, bool is_state, float l2,
+                           int fan_in, int fan_out, float init) {
   kws_tensor_info_t t;
   memset(&t, 0, sizeof(t));
   snprintf(t.name, sizeof(t.name), "%s", name.c_str());
@@ -79,16 +35,30 @@ int64_t add_tensor(kws_net* n, const std::string& name, std::vector<int64_t> sha
   return t.offset;
 }
 
-BnRef add_bn(kws_net* n, int idx, int C) {
+BnRef kws_net_add_bn(kws_net* n, int idx, int C) {
   BnRef r;
   const std::string base = "batch_normalization_" + std::to_string(idx) + "/";
-  r.gamma = add_tensor(n, base + "gamma", {C}, false, 0.f, 0, 0, 1.f);
-  r.beta = add_tensor(n, base + "beta", {C}, false, 0.f, 0, 0, 0.f);
-  r.mm = add_tensor(n, base + "moving_mean", {C}, true, 0.f, 0, 0, 0.f);
-  r.mv = add_tensor(n, base + "moving_variance", {C}, true, 0.f, 0, 0, 1.f);
+  r.gamma = kws_net_add_tensor(n, base + "gamma", {C}, false, 0.f, 0, 0, 1.f);
+  r.beta = kws_net_add_tensor(n, base + "beta", {C}, false, 0.f, 0, 0, 0.f);
+  r.mm = kws_net_add_tensor(n, base + "moving_mean", {C}, true, 0.f, 0, 0, 0.f);
+  r.mv = kws_net_add_tensor(n, base + "moving_variance", {C}, true, 0.f, 0, 0, 1.f);
   r.C = C;
   return r;
 }
+
+namespace {
+
+constexpr float BN_EPS = KWS_BN_EPS;
+constexpr float BN_MOMENTUM = KWS_BN_MOMENTUM;
+constexpr float L2_COEF = KWS_L2_COEF;
+constexpr float DROP_KEEP = 0.6f;     // Dropout(0.4), model.py:819,828
+constexpr float LABEL_SMOOTH = 0.1f;  // model.py:835-836
+
+inline int64_t add_tensor(kws_net* n, const std::string& name, std::vector<int64_t> shape, bool is_state, float l2,
+                          int fan_in, int fan_out, float init) {
+  return kws_net_add_tensor(n, name, shape, is_state, l2, fan_in, fan_out, init);
+}
+inline BnRef add_bn(kws_net* n, int idx, int C) { return kws_net_add_bn(n, idx, C); }
 
 void same_pad(int L, int k, int s, int* Lout, int* pl) {
   *Lout = (L + s - 1) / s;
@@ -158,15 +128,6 @@ struct Layout {
   int64_t G = 0, DZ = 0, bn = 0, part = 0, coef = 0, WT = 0, tn = 0, red = 0, swg = 0;
   int64_t xd = 0, fd = 0, dl1 = 0, dl2 = 0, per_loss = 0, per_correct = 0, att = 0;
   int64_t bn_stride = 0;
-};
-
-struct Bump {
-  int64_t cur = 0;  // in floats
-  int64_t take(int64_t floats) {
-    const int64_t o = cur;
-    cur += (floats + 63) / 64 * 64;  // 256-B granules
-    return o;
-  }
 };
 
 void make_layout(const kws_net* n, int B, bool training, Layout* lo) {
@@ -242,6 +203,8 @@ int kws_net_create(const kws_net_config_t* cfg, kws_net_t** out) {
   int rc;
   if (cfg->kind == KWS_NET_TS_ATTENTION) {
     rc = build_ts_attention(n);
+  } else if (cfg->kind == KWS_NET_LOG_MFCC) {
+    rc = lm_build(n);
   } else {
     kws_set_error("net_create: kind %d not supported", cfg->kind);
     rc = KWS_E_INVALID;
@@ -255,6 +218,7 @@ int kws_net_create(const kws_net_config_t* cfg, kws_net_t** out) {
 }
 
 int kws_net_destroy(kws_net_t* net) {
+  if (net) lm_free(net);
   delete net;
   return KWS_OK;
 }
@@ -271,6 +235,7 @@ int kws_net_tensor_info(const kws_net_t* net, int idx, kws_tensor_info_t* info) 
 
 int64_t kws_net_workspace_bytes(const kws_net_t* net, int max_batch, int training) {
   if (!net || max_batch <= 0) return 0;
+  if (net->cfg.kind == KWS_NET_LOG_MFCC) return lm_workspace_bytes(net, max_batch, training);
   Layout lo;
   make_layout(net, max_batch, training != 0, &lo);
   return lo.total;
@@ -279,6 +244,7 @@ int64_t kws_net_workspace_bytes(const kws_net_t* net, int max_batch, int trainin
 int kws_net_debug_view(const kws_net_t* net, int batch, int training, int what, int index, int64_t* offset_floats,
                        int64_t* count) {
   KWS_REQUIRE(net && offset_floats && count && batch > 0, "net_debug_view: bad arguments");
+  if (net->cfg.kind == KWS_NET_LOG_MFCC) return lm_debug_view(net, batch, training, what, index, offset_floats, count);
   Layout lo;
   make_layout(net, batch, training != 0, &lo);
   const int nb = (int)net->blocks.size();
@@ -309,6 +275,8 @@ int kws_net_debug_view(const kws_net_t* net, int batch, int training, int what, 
 int kws_net_predict(const kws_net_t* net, const float* params, const float* state, const float* x, int B,
                     float* probs, void* workspace, int64_t workspace_bytes, void* stream) {
   KWS_REQUIRE(net && params && state && x && probs && workspace && B > 0, "net_predict: bad arguments");
+  if (net->cfg.kind == KWS_NET_LOG_MFCC)
+    return lm_predict(net, params, state, x, B, probs, (float*)workspace, workspace_bytes, (hipStream_t)stream);
   Layout lo;
   make_layout(net, B, false, &lo);
   if (lo.total > workspace_bytes) {
@@ -349,6 +317,9 @@ int kws_net_train_fwd_bwd(const kws_net_t* net, const float* params, float* stat
   KWS_REQUIRE(net && params && state && x && y_onehot && grads && probs && metrics && workspace && B > 0,
               "net_train_fwd_bwd: bad arguments");
   KWS_REQUIRE(loss_batch >= B, "net_train_fwd_bwd: loss_batch %d < B %d", loss_batch, B);
+  if (net->cfg.kind == KWS_NET_LOG_MFCC)
+    return lm_train(net, params, state, x, y_onehot, B, grads, probs, metrics, seed, step, row_offset, loss_batch,
+                    (float*)workspace, workspace_bytes, (hipStream_t)stream);
   Layout lo;
   make_layout(net, B, true, &lo);
   if (lo.total > workspace_bytes) {

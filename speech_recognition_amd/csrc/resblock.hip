@@ -1,0 +1,533 @@
+// Kernels specific to conv_1d_log_mfcc_model (reference model.py:1400-1479):
+// the residual-block join (BN + ReLU6 + MaxPool1D(pool=stride) + Add, model.py:1429-1441) forward and
+// backward, and the softmax-over-time attention tail (model.py:1464-1473) with its loss
+// (keras categorical_crossentropy, model.py:1477).  All HBM/latency-bound; same conventions as
+// dwconv.hip: a thread owns a float4 of channels and walks a short run of time steps, cross-workgroup
+// sums are written as partial slabs and folded in a fixed order by the bn.hip finalisers.
+#include "net_internal.h"
+
+namespace {
+
+constexpr int TT = 8;
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 bn4(float4 v, float4 sc, float4 sh) {
+  return make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
+}
+__device__ __forceinline__ float4 relu6_4(float4 v) {
+  return make_float4(relu6f(v.x), relu6f(v.y), relu6f(v.z), relu6f(v.w));
+}
+__device__ __forceinline__ float mk(float pre) { return (pre > 0.f && pre <= 6.f) ? 1.f : 0.f; }
+
+// o[b,t,c] = max_{j<P} relu6(bn(y[b,P t+j,c])) + res
+template <int P, bool RES_BN>
+__global__ __launch_bounds__(256) void block_out_fwd_kernel(const float* __restrict__ y, const float* __restrict__ bn,
+                                                            const float* __restrict__ res,
+                                                            const float* __restrict__ res_bn, float* __restrict__ o,
+                                                            int64_t n4, int Lo, int C) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const int C4 = C >> 2;
+  const int c = (int)(i % C4) * 4;
+  const int64_t bt = i / C4;  // b*Lo + t
+  const float4 sc = ld4(bn + c), sh = ld4(bn + C + c);
+  float4 v = relu6_4(bn4(ld4(y + (bt * P) * C + c), sc, sh));
+  if (P == 2) {
+    const float4 w = relu6_4(bn4(ld4(y + (bt * P + 1) * C + c), sc, sh));
+    v = make_float4(fmaxf(v.x, w.x), fmaxf(v.y, w.y), fmaxf(v.z, w.z), fmaxf(v.w, w.w));
+  }
+  float4 r = ld4(res + bt * C + c);
+  if (RES_BN) r = bn4(r, ld4(res_bn + c), ld4(res_bn + C + c));
+  *reinterpret_cast<float4*>(o + bt * C + c) = make_float4(v.x + r.x, v.y + r.y, v.z + r.z, v.w + r.w);
+}
+
+// Backward of the join's main branch.  One thread: float4 of channels x TT output steps.
+// part[block][5][C]: sums of (g, g*xhat, 0, 0, 0).
+template <int P, bool RELU>
+__global__ __launch_bounds__(256) void block_out_bwd_kernel(const float* __restrict__ dO, const float* __restrict__ y,
+                                                            const float* __restrict__ bn, float* __restrict__ g,
+                                                            float* __restrict__ part, int B, int Lo, int C,
+                                                            int nchunks, int R) {
+  __shared__ float red[2][256 * 4];
+  const int C4 = C >> 2;
+  const int tid = threadIdx.x;
+  const int r = tid / C4, c4 = tid - r * C4;
+  const int c = c4 * 4;
+  const int64_t unit = (int64_t)blockIdx.x * R + r;
+  const int64_t b = unit / nchunks;
+  const int chunk = (int)(unit - b * nchunks);
+  float4 sg = make_float4(0.f, 0.f, 0.f, 0.f), sgx = sg;
+  if (b < B) {
+    const float4 sc = ld4(bn + c), sh = ld4(bn + C + c), mean = ld4(bn + 2 * C + c), rstd = ld4(bn + 3 * C + c);
+#pragma unroll
+    for (int i = 0; i < TT; ++i) {
+      const int t = chunk * TT + i;
+      if (t >= Lo) break;
+      const float4 d = ld4(dO + (b * Lo + t) * (int64_t)C + c);
+      const int64_t u0 = (b * Lo + t) * (int64_t)P;
+      const float4 y0 = ld4(y + u0 * C + c);
+      const float4 p0 = bn4(y0, sc, sh);
+      float4 g0, g1 = make_float4(0.f, 0.f, 0.f, 0.f), y1 = g1;
+      if (P == 1) {
+        g0 = RELU ? make_float4(d.x * mk(p0.x), d.y * mk(p0.y), d.z * mk(p0.z), d.w * mk(p0.w)) : d;
+      } else {
+        y1 = ld4(y + (u0 + 1) * C + c);
+        const float4 p1 = bn4(y1, sc, sh);
+        // the FIRST maximum of the pool window receives the gradient (MaxPoolGrad)
+        const bool w1x = relu6f(p1.x) > relu6f(p0.x), w1y = relu6f(p1.y) > relu6f(p0.y);
+        const bool w1z = relu6f(p1.z) > relu6f(p0.z), w1w = relu6f(p1.w) > relu6f(p0.w);
+        g0 = make_float4(w1x ? 0.f : d.x * mk(p0.x), w1y ? 0.f : d.y * mk(p0.y), w1z ? 0.f : d.z * mk(p0.z),
+                         w1w ? 0.f : d.w * mk(p0.w));
+        g1 = make_float4(w1x ? d.x * mk(p1.x) : 0.f, w1y ? d.y * mk(p1.y) : 0.f, w1z ? d.z * mk(p1.z) : 0.f,
+                         w1w ? d.w * mk(p1.w) : 0.f);
+      }
+      *reinterpret_cast<float4*>(g + u0 * C + c) = g0;
+      sg.x += g0.x; sg.y += g0.y; sg.z += g0.z; sg.w += g0.w;
+      sgx.x = fmaf(g0.x, (y0.x - mean.x) * rstd.x, sgx.x);
+      sgx.y = fmaf(g0.y, (y0.y - mean.y) * rstd.y, sgx.y);
+      sgx.z = fmaf(g0.z, (y0.z - mean.z) * rstd.z, sgx.z);
+      sgx.w = fmaf(g0.w, (y0.w - mean.w) * rstd.w, sgx.w);
+      if (P == 2) {
+        *reinterpret_cast<float4*>(g + (u0 + 1) * C + c) = g1;
+        sg.x += g1.x; sg.y += g1.y; sg.z += g1.z; sg.w += g1.w;
+        sgx.x = fmaf(g1.x, (y1.x - mean.x) * rstd.x, sgx.x);
+        sgx.y = fmaf(g1.y, (y1.y - mean.y) * rstd.y, sgx.y);
+        sgx.z = fmaf(g1.z, (y1.z - mean.z) * rstd.z, sgx.z);
+        sgx.w = fmaf(g1.w, (y1.w - mean.w) * rstd.w, sgx.w);
+      }
+    }
+  }
+  *reinterpret_cast<float4*>(&red[0][tid * 4]) = sg;
+  *reinterpret_cast<float4*>(&red[1][tid * 4]) = sgx;
+  __syncthreads();
+  for (int o = tid; o < 5 * C; o += blockDim.x) {
+    const int q = o / C, ch = o - q * C;
+    float s = 0.f;
+    if (q < 2)
+      for (int rr = 0; rr < R; ++rr) s += red[q][rr * C + ch];
+    part[((int64_t)blockIdx.x * 5 + q) * C + ch] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                  float* __restrict__ out, int64_t n4) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const float4 x = reinterpret_cast<const float4*>(a)[i], y = reinterpret_cast<const float4*>(b)[i];
+  reinterpret_cast<float4*>(out)[i] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+}
+
+__global__ __launch_bounds__(256) void add_strided_kernel(float* __restrict__ out, const float* __restrict__ in,
+                                                          int64_t n4, int L_out, int L_in, int C, int stride) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const int C4 = C >> 2;
+  const int c = (int)(i % C4) * 4;
+  const int64_t bt = i / C4;
+  const int64_t b = bt / L_in;
+  const int t = (int)(bt - b * L_in);
+  float* o = out + ((b * L_out + (int64_t)t * stride) * C + c);
+  const float4 x = *reinterpret_cast<const float4*>(o), y = ld4(in + bt * C + c);
+  *reinterpret_cast<float4*>(o) = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// attention tail
+// ------------------------------------------------------------------------------------------------------
+constexpr int LM_MAXT = 16;
+constexpr int LM_MAXNC = 64;
+
+struct LmArgs {
+  kws_lm_tail_args a;
+  uint32_t key, thresh;
+  float inv_keep, inv_loss_batch;
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+  return v;
+}
+
+// u[b,t] = sum_c Wa[c] * sum_j wa[j,c] x[b, t+j-1, c]      (dw k3 SAME, then pointwise C -> 1)
+__global__ __launch_bounds__(256) void lm_att_logits_kernel(LmArgs p) {
+  __shared__ float red[4][LM_MAXT];
+  const kws_lm_tail_args& a = p.a;
+  const int T = a.T, C = a.C, b = blockIdx.x, tid = threadIdx.x;
+  const float* xb = a.x + (int64_t)b * T * C;
+  float acc[LM_MAXT];
+#pragma unroll
+  for (int t = 0; t < LM_MAXT; ++t) acc[t] = 0.f;
+  for (int c = tid; c < C; c += 256) {
+    const float w0 = a.wa[c], w1 = a.wa[C + c], w2 = a.wa[2 * C + c], wp = a.Wa[c];
+    float xm = 0.f, x0 = xb[c];
+#pragma unroll
+    for (int t = 0; t < LM_MAXT; ++t) {
+      if (t < T) {
+        const float xp = (t + 1 < T) ? xb[(t + 1) * C + c] : 0.f;
+        acc[t] = fmaf(wp, fmaf(w2, xp, fmaf(w1, x0, w0 * xm)), acc[t]);
+        xm = x0;
+        x0 = xp;
+      }
+    }
+  }
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int t = 0; t < LM_MAXT; ++t) {
+    if (t < T) {
+      const float s = wave_sum(acc[t]);
+      if (lane == 0) red[wave][t] = s;
+    }
+  }
+  __syncthreads();
+  if (tid < T) a.u[(int64_t)b * T + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+}
+
+// BatchNorm statistics of the 1-channel attention logits over all B*T values (fixed-order, one workgroup)
+__global__ __launch_bounds__(256) void lm_att_bn_kernel(LmArgs p, int training) {
+  __shared__ double red[2][256];
+  const kws_lm_tail_args& a = p.a;
+  const int n = a.B * a.T, tid = threadIdx.x;
+  float gamma = a.bn_gamma[0], beta = a.bn_beta[0];
+  if (!training) {
+    if (tid == 0) {
+      const float rstd = 1.0f / sqrtf(a.mv[0] + KWS_BN_EPS);
+      a.bn[0] = gamma * rstd; a.bn[1] = beta - a.mm[0] * gamma * rstd; a.bn[2] = a.mm[0]; a.bn[3] = rstd;
+    }
+    return;
+  }
+  double s = 0.0, ss = 0.0;
+  for (int i = tid; i < n; i += 256) {
+    const double v = a.u[i];
+    s += v;
+    ss += v * v;
+  }
+  red[0][tid] = s;
+  red[1][tid] = ss;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) {
+      red[0][tid] += red[0][tid + o];
+      red[1][tid] += red[1][tid + o];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const double mean = red[0][0] / n;
+    double var = red[1][0] / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)KWS_BN_EPS));
+    const float meanf = (float)mean, varf = (float)var;
+    a.bn[0] = gamma * rstd; a.bn[1] = beta - meanf * gamma * rstd; a.bn[2] = meanf; a.bn[3] = rstd;
+    const float omm = (float)(1.0 - (double)KWS_BN_MOMENTUM);
+    a.mm[0] = a.mm[0] - (a.mm[0] - meanf) * omm;
+    a.mv[0] = a.mv[0] - (a.mv[0] - varf) * omm;
+  }
+}
+
+// per clip: att = softmax_t(relu6(bn(u))), feat = mean_t(x * att), dropout, dense + softmax, CCE loss and the
+// backward down to (dX partial, masked gradient of the attention logits)
+template <bool TRAIN>
+__global__ __launch_bounds__(256) void lm_tail_kernel(LmArgs p) {
+  __shared__ float s_att[LM_MAXT], s_pre[LM_MAXT], s_datt[LM_MAXT], s_p[LM_MAXNC], s_dl[LM_MAXNC];
+  __shared__ float s_feat[1024], s_red[4][LM_MAXNC];
+  const kws_lm_tail_args& a = p.a;
+  const int T = a.T, C = a.C, NC = a.NC, b = blockIdx.x, tid = threadIdx.x;
+  const float* xb = a.x + (int64_t)b * T * C;
+  const uint32_t row = (uint32_t)(a.row_offset + b);
+  if (tid == 0) {
+    float m = -INFINITY;
+    for (int t = 0; t < T; ++t) {
+      const float pre = fmaf(a.u[(int64_t)b * T + t], a.bn[0], a.bn[1]);
+      s_pre[t] = pre;
+      s_att[t] = relu6f(pre);
+      m = fmaxf(m, s_att[t]);
+    }
+    float den = 0.f;
+    for (int t = 0; t < T; ++t) {
+      s_att[t] = expf(s_att[t] - m);
+      den += s_att[t];
+    }
+    for (int t = 0; t < T; ++t) s_att[t] /= den;
+  }
+  __syncthreads();
+  if (TRAIN && a.att != nullptr && tid < T) a.att[(int64_t)b * T + tid] = s_att[tid];
+  for (int c = tid; c < C; c += 256) {
+    float f = 0.f;
+    for (int t = 0; t < T; ++t) f = fmaf(xb[t * C + c], s_att[t], f);
+    f = f / (float)T;
+    if (TRAIN) {
+      f = kws_keep(row * (uint32_t)C + (uint32_t)c, p.key, p.thresh) ? f * p.inv_keep : 0.f;
+      a.fd[(int64_t)b * C + c] = f;
+    }
+    s_feat[c] = f;
+  }
+  __syncthreads();
+  {
+    const int k = tid & 63, sl = tid >> 6;
+    float s = 0.f;
+    if (k < NC)
+      for (int c = sl; c < C; c += 4) s = fmaf(s_feat[c], a.Wd[(int64_t)c * NC + k], s);
+    s_red[sl][k] = s;
+    __syncthreads();
+    if (tid < NC) s_p[tid] = (((s_red[0][tid] + s_red[1][tid]) + s_red[2][tid]) + s_red[3][tid]) + a.bd[tid];
+    __syncthreads();
+    if (tid == 0) {
+      float m = s_p[0];
+      for (int q = 1; q < NC; ++q) m = fmaxf(m, s_p[q]);
+      float den = 0.f;
+      for (int q = 0; q < NC; ++q) {
+        s_p[q] = expf(s_p[q] - m);
+        den += s_p[q];
+      }
+      for (int q = 0; q < NC; ++q) s_p[q] /= den;
+    }
+    __syncthreads();
+    if (tid < NC) a.probs[(int64_t)b * NC + tid] = s_p[tid];
+  }
+  if (!TRAIN) return;
+  if (tid == 0) {
+    // keras categorical_crossentropy: p /= sum(p); clip(eps, 1-eps); -sum(y log p)
+    const float eps = 1e-7f;
+    const float* yl = a.labels + (int64_t)b * NC;
+    float S = 0.f;
+    for (int q = 0; q < NC; ++q) S += s_p[q];
+    float loss = 0.f, dotp = 0.f;
+    int am_p = 0, am_y = 0;
+    for (int q = 0; q < NC; ++q) {
+      const float pn = s_p[q] / S;
+      const float pc = fminf(fmaxf(pn, eps), 1.f - eps);
+      loss -= yl[q] * logf(pc);
+      const float inside = (pn >= eps && pn <= 1.f - eps) ? 1.f : 0.f;
+      const float dpn = (-yl[q] / pc) * inside * p.inv_loss_batch;
+      s_dl[q] = dpn;   // dL/dpn for now
+      dotp += dpn * s_p[q];
+      if (s_p[q] > s_p[am_p]) am_p = q;
+      if (yl[q] > yl[am_y]) am_y = q;
+    }
+    a.per_loss[b] = loss;
+    a.per_correct[b] = (am_p == am_y) ? 1.f : 0.f;
+    float dot2 = 0.f;
+    for (int q = 0; q < NC; ++q) {
+      const float dp = s_dl[q] / S - dotp / (S * S);   // through the renormalisation
+      s_dl[q] = dp;
+      dot2 += dp * s_p[q];
+    }
+    for (int q = 0; q < NC; ++q) s_dl[q] = s_p[q] * (s_dl[q] - dot2);   // softmax backward
+  }
+  __syncthreads();
+  if (tid < NC) a.dl[(int64_t)b * NC + tid] = s_dl[tid];
+  // dfeat -> dX (through Multiply + GAP) and datt
+  float dattl[LM_MAXT];
+#pragma unroll
+  for (int t = 0; t < LM_MAXT; ++t) dattl[t] = 0.f;
+  float* dxb = a.dX + (int64_t)b * T * C;
+  for (int c = tid; c < C; c += 256) {
+    float s = 0.f;
+    for (int q = 0; q < NC; ++q) s = fmaf(a.Wd[(int64_t)c * NC + q], s_dl[q], s);
+    const bool keep = kws_keep(row * (uint32_t)C + (uint32_t)c, p.key, p.thresh);
+    const float dprod = (keep ? s * p.inv_keep : 0.f) / (float)T;
+#pragma unroll
+    for (int t = 0; t < LM_MAXT; ++t) {
+      if (t < T) {
+        dxb[t * C + c] = dprod * s_att[t];
+        dattl[t] = fmaf(dprod, xb[t * C + c], dattl[t]);
+      }
+    }
+  }
+  {
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int t = 0; t < LM_MAXT; ++t) {
+      if (t < T) {
+        const float s = wave_sum(dattl[t]);
+        if (lane == 0) s_red[wave][t] = s;
+      }
+    }
+    __syncthreads();
+    if (tid < T) s_datt[tid] = ((s_red[0][tid] + s_red[1][tid]) + s_red[2][tid]) + s_red[3][tid];
+    __syncthreads();
+    if (tid == 0) {
+      float dot = 0.f;
+      for (int t = 0; t < T; ++t) dot += s_att[t] * s_datt[t];
+      for (int t = 0; t < T; ++t) {
+        const float du = s_att[t] * (s_datt[t] - dot);
+        a.gu[(int64_t)b * T + t] = du * mk(s_pre[t]);
+      }
+    }
+  }
+}
+
+// BN backward of the attention logits (1 channel): sums over all B*T, then coef / dgamma / dbeta
+__global__ __launch_bounds__(256) void lm_att_bn_bwd_kernel(LmArgs p) {
+  __shared__ double red[2][256];
+  const kws_lm_tail_args& a = p.a;
+  const int n = a.B * a.T, tid = threadIdx.x;
+  const float mean = a.bn[2], rstd = a.bn[3];
+  double s = 0.0, sx = 0.0;
+  for (int i = tid; i < n; i += 256) {
+    const double g = a.gu[i];
+    s += g;
+    sx += g * (double)((a.u[i] - mean) * rstd);
+  }
+  red[0][tid] = s;
+  red[1][tid] = sx;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) {
+      red[0][tid] += red[0][tid + o];
+      red[1][tid] += red[1][tid + o];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    a.d_beta[0] = (float)red[0][0];
+    a.d_gamma[0] = (float)red[1][0];
+    a.coef[0] = (float)(red[0][0] / n);
+    a.coef[1] = (float)(red[1][0] / n);
+  }
+}
+
+// per clip: dyu -> dza -> (dWa, dwa partials) and dX += dw^T dza
+__global__ __launch_bounds__(256) void lm_att_bwd_kernel(LmArgs p) {
+  __shared__ float s_dyu[LM_MAXT];
+  const kws_lm_tail_args& a = p.a;
+  const int T = a.T, C = a.C, b = blockIdx.x, tid = threadIdx.x;
+  if (tid < T) {
+    const float uu = a.u[(int64_t)b * T + tid];
+    const float xh = (uu - a.bn[2]) * a.bn[3];
+    s_dyu[tid] = a.bn_gamma[0] * a.bn[3] * (a.gu[(int64_t)b * T + tid] - a.coef[0] - xh * a.coef[1]);
+  }
+  __syncthreads();
+  const float* xb = a.x + (int64_t)b * T * C;
+  float* dxb = a.dX + (int64_t)b * T * C;
+  float* pb = a.part + (int64_t)b * 5 * C;
+  for (int c = tid; c < C; c += 256) {
+    const float w0 = a.wa[c], w1 = a.wa[C + c], w2 = a.wa[2 * C + c], wp = a.Wa[c];
+    float sWa = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int t = 0; t < T; ++t) {
+      const float xm = t > 0 ? xb[(t - 1) * C + c] : 0.f, x0 = xb[t * C + c];
+      const float xp = t + 1 < T ? xb[(t + 1) * C + c] : 0.f;
+      const float za = fmaf(w2, xp, fmaf(w1, x0, w0 * xm));
+      const float dy = s_dyu[t];
+      sWa = fmaf(za, dy, sWa);
+      const float dza = dy * wp;
+      s0 = fmaf(dza, xm, s0);
+      s1 = fmaf(dza, x0, s1);
+      s2 = fmaf(dza, xp, s2);
+      // dX[t'] += sum_j wa[j] dza[t' - j + 1]
+      const float dzm = t > 0 ? s_dyu[t - 1] * wp : 0.f, dzp = t + 1 < T ? s_dyu[t + 1] * wp : 0.f;
+      dxb[t * C + c] += fmaf(w0, dzp, fmaf(w1, dza, w2 * dzm));
+    }
+    pb[c] = sWa; pb[C + c] = 0.f; pb[2 * C + c] = s0; pb[3 * C + c] = s1; pb[4 * C + c] = s2;
+  }
+}
+
+struct Geom {
+  int nchunks, R, block;
+  int64_t grid;
+};
+Geom geom(int B, int Lo, int C) {
+  Geom g;
+  const int C4 = C / 4;
+  g.nchunks = ceil_div(Lo, TT);
+  g.R = 256 / C4 < 1 ? 1 : 256 / C4;
+  g.block = g.R * C4;
+  g.grid = ceil_div64((int64_t)B * g.nchunks, g.R);
+  return g;
+}
+
+LmArgs make_args(const kws_lm_tail_args* a) {
+  LmArgs p;
+  p.a = *a;
+  p.key = kws_dropout_key(a->seed, a->step, 1);
+  p.thresh = kws_dropout_threshold(a->keep_prob);
+  p.inv_keep = (float)(1.0 / (double)a->keep_prob);
+  p.inv_loss_batch = 1.0f / (float)(a->loss_batch > 0 ? a->loss_batch : 1);
+  return p;
+}
+
+}  // namespace
+
+int kws_block_out_fwd(const float* y, const float* bn, const float* res, const float* res_bn, float* o, int B, int L,
+                      int C, int pool, hipStream_t st) {
+  KWS_REQUIRE(y && bn && res && o && B > 0 && L > 0 && C % 4 == 0 && (pool == 1 || pool == 2) && L % pool == 0,
+              "block_out_fwd: bad arguments (L=%d C=%d pool=%d)", L, C, pool);
+  const int Lo = L / pool;
+  const int64_t n4 = (int64_t)B * Lo * C / 4;
+  KwsProfScope prof("block_join", 4.0 * B * L * C, 4.0 * ((double)B * L * C + 2.0 * B * Lo * C), st);
+  dim3 g((unsigned)ceil_div64(n4, 256)), b(256);
+  if (pool == 1) {
+    if (res_bn) hipLaunchKernelGGL((block_out_fwd_kernel<1, true>), g, b, 0, st, y, bn, res, res_bn, o, n4, Lo, C);
+    else hipLaunchKernelGGL((block_out_fwd_kernel<1, false>), g, b, 0, st, y, bn, res, res_bn, o, n4, Lo, C);
+  } else {
+    if (res_bn) hipLaunchKernelGGL((block_out_fwd_kernel<2, true>), g, b, 0, st, y, bn, res, res_bn, o, n4, Lo, C);
+    else hipLaunchKernelGGL((block_out_fwd_kernel<2, false>), g, b, 0, st, y, bn, res, res_bn, o, n4, Lo, C);
+  }
+  KWS_LAUNCH_CHECK("block_out_fwd_kernel");
+  return KWS_OK;
+}
+
+int64_t kws_block_out_bwd_part_floats(int B, int L, int C, int pool) {
+  if (B <= 0 || L <= 0 || C <= 0 || C % 4 || C > 1024 || pool < 1) return 0;
+  return geom(B, L / pool, C).grid * 5 * C;
+}
+
+int kws_block_out_bwd(const float* dO, const float* y, const float* bn, float* g, float* part, int B, int L, int C,
+                      int pool, int relu, hipStream_t st) {
+  KWS_REQUIRE(dO && y && bn && g && part && B > 0 && L > 0 && C % 4 == 0 && C <= 1024 && (pool == 1 || pool == 2) &&
+                  L % pool == 0 && (relu || pool == 1),
+              "block_out_bwd: bad arguments (L=%d C=%d pool=%d relu=%d)", L, C, pool, relu);
+  const int Lo = L / pool;
+  const Geom ge = geom(B, Lo, C);
+  KwsProfScope prof("block_join", 6.0 * B * L * C, 4.0 * (2.0 * B * L * C + (double)B * Lo * C), st);
+  dim3 gr((unsigned)ge.grid), b((unsigned)ge.block);
+  if (pool == 2) hipLaunchKernelGGL((block_out_bwd_kernel<2, true>), gr, b, 0, st, dO, y, bn, g, part, B, Lo, C, ge.nchunks, ge.R);
+  else if (relu) hipLaunchKernelGGL((block_out_bwd_kernel<1, true>), gr, b, 0, st, dO, y, bn, g, part, B, Lo, C, ge.nchunks, ge.R);
+  else hipLaunchKernelGGL((block_out_bwd_kernel<1, false>), gr, b, 0, st, dO, y, bn, g, part, B, Lo, C, ge.nchunks, ge.R);
+  KWS_LAUNCH_CHECK("block_out_bwd_kernel");
+  return KWS_OK;
+}
+
+int kws_add_f32(const float* a, const float* b, float* out, int64_t n, hipStream_t st) {
+  KWS_REQUIRE(a && b && out && n > 0 && n % 4 == 0, "add: bad arguments");
+  KwsProfScope prof("add", (double)n, 12.0 * n, st);
+  hipLaunchKernelGGL(add_kernel, dim3((unsigned)ceil_div64(n / 4, 256)), dim3(256), 0, st, a, b, out, n / 4);
+  KWS_LAUNCH_CHECK("add_kernel");
+  return KWS_OK;
+}
+
+int kws_add_strided_f32(float* out, const float* in, int B, int L_out, int L_in, int C, int stride, hipStream_t st) {
+  KWS_REQUIRE(out && in && B > 0 && C % 4 == 0 && (L_in - 1) * stride < L_out, "add_strided: bad arguments");
+  const int64_t n4 = (int64_t)B * L_in * C / 4;
+  KwsProfScope prof("add", (double)n4 * 4, 48.0 * n4, st);
+  hipLaunchKernelGGL(add_strided_kernel, dim3((unsigned)ceil_div64(n4, 256)), dim3(256), 0, st, out, in, n4, L_out, L_in,
+                     C, stride);
+  KWS_LAUNCH_CHECK("add_strided_kernel");
+  return KWS_OK;
+}
+
+int kws_lm_tail_fwd(const kws_lm_tail_args* a, int training, hipStream_t st) {
+  KWS_REQUIRE(a->T > 0 && a->T <= LM_MAXT && a->NC > 0 && a->NC <= LM_MAXNC && a->C > 0 && a->C <= 1024,
+              "lm_tail: bad shape T=%d C=%d NC=%d", a->T, a->C, a->NC);
+  const LmArgs p = make_args(a);
+  KwsProfScope prof(training ? "tail_train" : "tail_infer", 8.0 * a->B * a->T * a->C, 8.0 * a->B * a->T * a->C, st);
+  hipLaunchKernelGGL(lm_att_logits_kernel, dim3((unsigned)a->B), dim3(256), 0, st, p);
+  KWS_LAUNCH_CHECK("lm_att_logits_kernel");
+  hipLaunchKernelGGL(lm_att_bn_kernel, dim3(1), dim3(256), 0, st, p, training);
+  KWS_LAUNCH_CHECK("lm_att_bn_kernel");
+  if (training) hipLaunchKernelGGL((lm_tail_kernel<true>), dim3((unsigned)a->B), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((lm_tail_kernel<false>), dim3((unsigned)a->B), dim3(256), 0, st, p);
+  KWS_LAUNCH_CHECK("lm_tail_kernel");
+  return KWS_OK;
+}
+
+int kws_lm_tail_bwd(const kws_lm_tail_args* a, hipStream_t st) {
+  const LmArgs p = make_args(a);
+  KwsProfScope prof("tail_train", 12.0 * a->B * a->T * a->C, 12.0 * a->B * a->T * a->C, st);
+  hipLaunchKernelGGL(lm_att_bn_bwd_kernel, dim3(1), dim3(256), 0, st, p);
+  KWS_LAUNCH_CHECK("lm_att_bn_bwd_kernel");
+  hipLaunchKernelGGL(lm_att_bwd_kernel, dim3((unsigned)a->B), dim3(256), 0, st, p);
+  KWS_LAUNCH_CHECK("lm_att_bwd_kernel");
+  return KWS_OK;
+}

@@ -1,0 +1,163 @@
+"""GPU parity of the conv_1d_log_mfcc network program (BASELINE config C3: 32-class
+head on 98x40 features) against the CPU oracle, plus the composed config-C3 inference path
+(features -> net -> 32->12 head).  Same method as tests/test_net_gpu.py: the device's discrete decisions
+(ReLU6 masks, max-pool winners) are read back and handed to the oracle's backward pass."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import features as OF
+from oracle import layers as OL
+from oracle.net import LogMfccNet
+from speech_recognition_amd import _lib
+from speech_recognition_amd.net import DeviceNet
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(num_classes=32, seed=11):
+    ora = LogMfccNet(num_classes=num_classes, dtype=np.float64)
+    rng = np.random.RandomState(seed)
+    for k in ora.params:
+        if k.endswith('gamma'):
+            ora.params[k] = (1.0 + 0.1 * rng.randn(*ora.params[k].shape)).astype(np.float32)
+        if k.endswith('beta') or k.endswith('bias'):
+            ora.params[k] = (0.1 * rng.randn(*ora.params[k].shape)).astype(np.float32)
+    for k in ora.state:
+        if k.endswith('moving_mean'):
+            ora.state[k] = (0.05 * rng.randn(*ora.state[k].shape)).astype(np.float32)
+        else:
+            ora.state[k] = (1.0 + 0.2 * rng.rand(*ora.state[k].shape)).astype(np.float32)
+    net = DeviceNet(_lib.KWS_NET_LOG_MFCC, num_classes, input_size=98 * 40, spectrogram_length=98, num_features=40)
+    net.set_weights(dict(ora.params, **ora.state))
+    return ora, net
+
+
+def _batch(B, nc, seed):
+    rng = np.random.RandomState(seed)
+    lab = rng.randint(0, nc, B)
+    x = rng.randn(B, 98, 40) * 2.0 - 0.7 + 0.5 * np.sin(np.arange(40)[None, None, :] * (1 + lab)[:, None, None] * 0.1)
+    return x.reshape(B, -1).astype(np.float32), np.eye(nc, dtype=np.float32)[lab]
+
+
+def _decisions(net, ora, B):
+    """ReLU6 masks per BN index and max-pool winners per strided block from the device tensors (f32 math
+    of the kernels: pre = fmaf(y, scale, shift))."""
+    shapes = {ora.first[1]: (B, 96, 64), ora.att[2]: (B, ora.T, 1)}
+    pools = {}
+    for i, blk in enumerate(ora.blocks):
+        if 'short' in blk:
+            shapes[blk['short'][1]] = None                       # linear BN: no mask
+        shapes[blk['bn1']] = (B, blk['Lin'], blk['nf'])
+        shapes[blk['bn2']] = (B, blk['Lin'], blk['nf'])
+        if blk['stride'] != 1:
+            pools[i] = blk['bn2']
+    masks, pre_of = {}, {}
+    for idx, shp in shapes.items():
+        if shp is None:
+            continue
+        C = shp[2]
+        bn = net.debug_view(B, 2, idx)
+        if idx == ora.att[2]:
+            y = net.debug_view(B, 4, 0).reshape(shp)
+        else:
+            y = net.debug_view(B, 0, idx).reshape(shp)
+        pre = (y.astype(np.float64) * bn[:C].astype(np.float64) + bn[C:2 * C].astype(np.float64)).astype(np.float32)
+        masks[idx] = ((pre > 0) & (pre <= 6)).astype(np.float64)
+        pre_of[idx] = pre
+    args = {}
+    for i, idx in pools.items():
+        a = np.minimum(np.maximum(pre_of[idx], np.float32(0)), np.float32(6))
+        Bc, L, C = a.shape
+        w = a.reshape(Bc, L // 2, 2, C)
+        args[i] = (w[:, :, 1, :] > w[:, :, 0, :]).astype(np.int64)      # first maximum wins
+    return masks, args
+
+
+def test_tensor_table_matches_oracle():
+    ora, net = _pair()
+    assert net.count_params() == 784484
+    assert [s.name for s in net.tensors.values() if not s.is_state] == list(ora.params.keys())
+    for k, v in list(ora.params.items()) + list(ora.state.items()):
+        assert net.tensors[k].shape == v.shape, k
+
+
+def test_predict_matches_oracle():
+    ora, net = _pair()
+    x, _ = _batch(7, 32, 1)
+    p = net.predict(torch.from_numpy(x).cuda()).cpu().numpy()
+    ref = ora.forward(x.astype(np.float64), training=False)
+    assert np.abs(p - ref).max() < 1e-5
+    assert np.array_equal(p.argmax(1), ref.argmax(1))
+
+
+@pytest.mark.parametrize("B", [4, 19])
+def test_train_fwd_bwd_matches_oracle(B):
+    ora, net = _pair()
+    x, y = _batch(B, 32, B)
+    probs = net.train_fwd_bwd(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(), seed=77, step=2)
+    torch.cuda.synchronize()
+    masks, args = _decisions(net, ora, B)
+    loss, p, grads, cache = ora.loss_and_grads(x.astype(np.float64), y.astype(np.float64), seed=77, step=2,
+                                               relu_masks=masks, pool_args=args)
+    got = probs.cpu().numpy()
+    assert np.abs(got - p).max() < 2e-5
+    assert np.array_equal(got.argmax(1), p.argmax(1))
+    m = net.metrics.cpu().numpy()
+    assert abs(m[0] / B - loss) < 5e-5
+    assert m[1] == (p.argmax(1) == y.argmax(1)).sum()
+    g = net.grads_dict()
+    for k, ref in grads.items():
+        if k in ora.l2_names:
+            ref = ref - 2e-5 * ora.params[k].astype(np.float64)
+        ref = ref.reshape(g[k].shape)
+        err = np.abs(g[k] - ref).max() / max(np.abs(ref).max(), 1e-7)
+        assert err < 1e-4, (k, err)
+    w = net.get_weights()
+    for idx, (mean, var) in cache['batch_stats'].items():
+        mm = ora.state['batch_normalization_%d/moving_mean' % idx].astype(np.float64)
+        np.testing.assert_allclose(w['batch_normalization_%d/moving_mean' % idx], mm - (mm - mean) * 0.01, atol=5e-6)
+
+
+def test_config_c3_features_net_head32to12():
+    """BASELINE config C3 end to end on the device: raw clips -> STFT/mel/DCT (M=40, K=40) -> 32-class
+    log-mfcc net -> 32->12 head (freeze_graph_32_classes.py:55-69); checked against the oracle chain."""
+    ora, net = _pair()
+    rng = np.random.RandomState(3)
+    B = 6
+    t = np.arange(16000) / 16000.0
+    clips = (rng.randn(B, 16000) * 0.0774 + 0.05 * np.sin(2 * np.pi * 300 * t)[None]).astype(np.float32)
+    tables = OF.tables_path_b(480, 40, 40)
+    lib = _lib.load()
+    plan = ctypes.c_void_p()
+    win, mel, dct = (np.ascontiguousarray(tables[k], dtype=np.float32) for k in ('window', 'mel', 'dct'))
+    _lib.check(lib.kws_stft_plan_create(480, 160, 512, 40, 40, win.ctypes.data_as(ctypes.c_void_p),
+                                        mel.ctypes.data_as(ctypes.c_void_p), dct.ctypes.data_as(ctypes.c_void_p),
+                                        1e-6, 0.0, ctypes.byref(plan)), "plan")
+    dclips = torch.from_numpy(clips).cuda()
+    feats = torch.empty((B, 98 * 40), device="cuda")
+    _lib.call("kws_stft_mel_f32", plan, _lib.ptr(dclips), B, 16000, _lib.ptr(feats), 0, _lib.stream_ptr())
+    p32 = net.predict(feats)
+    all_classes = ('sheila nine stop bed four six down bird marvin cat off right seven eight up three happy go zero '
+                   'on wow dog yes five one tree house two left no').split()
+    wanted = 'stop down off right up go on yes left no'.split()
+    mp = np.zeros(32, np.int32)
+    mp[1], slot = 1, 2
+    for i, c in enumerate(all_classes):
+        if c in wanted:
+            mp[i + 2] = slot
+            slot += 1
+        else:
+            mp[i + 2] = 1
+    dmap = torch.from_numpy(mp).cuda()
+    p12 = torch.empty((B, 12), device="cuda")
+    _lib.call("kws_head32to12", _lib.ptr(p32), 32, _lib.ptr(dmap), 12, _lib.ptr(p12), B, _lib.stream_ptr())
+    ref_feat = OF.features(clips, tables, 160, dtype=np.float64).reshape(B, -1)
+    ref32 = ora.forward(ref_feat, training=False)
+    ref12 = OL.head32to12(ref32, all_classes, wanted)
+    assert np.abs(feats.cpu().numpy() - ref_feat).max() < 2e-3
+    assert np.abs(p12.cpu().numpy() - ref12).max() < 1e-3          # north_star tolerance on softmax
+    assert np.array_equal(p12.cpu().numpy().argmax(1), ref12.argmax(1))
+    lib.kws_stft_plan_destroy(plan)

@@ -90,3 +90,75 @@ def test_inference_uses_moving_stats():
     p2 = net.forward(x[:1], training=False)
     np.testing.assert_allclose(p1[:1], p2, rtol=1e-10)
     np.testing.assert_allclose(p1.sum(axis=1), 1.0, rtol=1e-12)
+
+
+# ---- a19: conv_1d_log_mfcc_model -------------------------------------------------------------------------
+def _torch_logmfcc(net, params, x, y, seed, step):
+    from oracle.net import LM_BLOCKS
+    B = x.shape[0]
+    dt = torch.float64
+
+    def bn(h, idx, relu=True):
+        g = params['batch_normalization_%d/gamma' % idx]
+        b = params['batch_normalization_%d/beta' % idx]
+        h = F.batch_norm(h, None, None, g, b, training=True, eps=1e-3)
+        return torch.clamp(h, 0, 6) if relu else h
+
+    def dwpw(h, dwn, pwn, cin, cout):
+        w = params[dwn].reshape(3, cin)
+        h = F.conv1d(F.pad(h, (1, 1)), w.t().unsqueeze(1), groups=cin)
+        return F.conv1d(h, params[pwn].reshape(cin, cout).t().unsqueeze(2))
+    h = torch.from_numpy(x).to(dt).reshape(B, net.T0, net.F).permute(0, 2, 1)
+    h = bn(F.conv1d(h, params[net.first[0]].permute(2, 1, 0)), net.first[1])
+    for blk in net.blocks:
+        if 'short' in blk:
+            res = bn(F.conv1d(h, params[blk['short'][0]].reshape(blk['cin'], blk['nf']).t().unsqueeze(2), stride=blk['stride']),
+                     blk['short'][1], relu=False)
+        else:
+            res = h
+        a = bn(dwpw(h, blk['dw1'], blk['pw1'], blk['cin'], blk['nf']), blk['bn1'])
+        a = bn(dwpw(a, blk['dw2'], blk['pw2'], blk['nf'], blk['nf']), blk['bn2'])
+        if blk['stride'] != 1:
+            a = F.max_pool1d(a, blk['stride'], blk['stride'])
+        h = a + res
+    u = bn(dwpw(h, net.att[0], net.att[1], net.C, 1), net.att[2])        # [B, 1, T]
+    att = torch.softmax(u, dim=2)
+    feat = (h * att).mean(dim=2)
+    m = torch.from_numpy(L.dropout_mask(L.dropout_key(seed, step, 1), B * net.C, 0.8).reshape(B, net.C)).to(dt)
+    p = torch.softmax((feat * m / 0.8) @ params['dense_1/kernel'] + params['dense_1/bias'], dim=1)
+    yt = torch.from_numpy(y).to(dt)
+    pn = p / p.sum(dim=1, keepdim=True)
+    loss = -(yt * torch.log(torch.clamp(pn, 1e-7, 1 - 1e-7))).sum(dim=1).mean()
+    reg = sum(1e-5 * (params[k] ** 2).sum() for k in net.l2_names)
+    return p, loss, reg
+
+
+def test_logmfcc_param_count_and_shapes():
+    from oracle.net import LogMfccNet
+    net = LogMfccNet(num_classes=32)
+    assert net.count_params() == 784484
+    assert (net.T, net.C) == (12, 256)
+    assert [b['Lout'] for b in net.blocks] == [96, 96, 48, 48, 24, 24, 24, 12, 12, 12]
+
+
+def test_logmfcc_grads_match_torch_autograd():
+    from oracle.net import LogMfccNet
+    net = LogMfccNet(num_classes=32, dtype=np.float64)
+    rng = np.random.RandomState(4)
+    for k in net.params:
+        if k.endswith('gamma'):
+            net.params[k] = (1.0 + 0.1 * rng.randn(*net.params[k].shape)).astype(np.float32)
+        if k.endswith('beta') or k.endswith('bias'):
+            net.params[k] = (0.1 * rng.randn(*net.params[k].shape)).astype(np.float32)
+    B = 4
+    x = (rng.randn(B, 98 * 40) * 3.0).astype(np.float64)
+    y = np.eye(32)[[3, 0, 17, 31]]
+    loss, p, grads, _ = net.loss_and_grads(x, y, seed=9, step=2)
+    tparams = {k: torch.tensor(v.astype(np.float64), requires_grad=True) for k, v in net.params.items()}
+    pt, tloss, treg = _torch_logmfcc(net, tparams, x, y, 9, 2)
+    (tloss + treg).backward()
+    np.testing.assert_allclose(p, pt.detach().numpy(), rtol=1e-9, atol=1e-12)
+    assert abs(loss - tloss.item()) < 1e-10
+    for k, g in grads.items():
+        tg = tparams[k].grad.numpy().reshape(g.shape)
+        assert np.abs(g - tg).max() / max(np.abs(tg).max(), 1e-12) < 1e-8, k
