@@ -8,7 +8,10 @@ def load_model(filepath, custom_objects=None, compile=True):
         name = str(z['__model_name__']) if '__model_name__' in z.files else 'conv_1d_time_sliced_with_attention'
         num_classes = int(z['__num_classes__']) if '__num_classes__' in z.files else 12
         input_size = int(z['__input_size__']) if '__input_size__' in z.files else 16000
-    model = speech_model(name, input_size, num_classes=num_classes)
+        kw = {}
+        if '__spectrogram_length__' in z.files and int(z['__spectrogram_length__']) > 0:
+            kw = dict(spectrogram_length=int(z['__spectrogram_length__']), num_log_mel_features=int(z['__num_features__']))
+    model = speech_model(name, input_size, num_classes=num_classes, **kw)
     model.load_weights(filepath)
     return model
 

@@ -299,8 +299,9 @@ class Model(object):
 
     metrics_names = ['loss', 'categorical_accuracy']
 
-    def __init__(self, net, optimizer, name='model', seed=87654321):
+    def __init__(self, net, optimizer, name='model', seed=87654321, loss='smooth_cce'):
         self.net = net
+        self.loss = loss      # 'smooth_cce' (utils.py:87-108, model.py:835) or 'cce' (model.py:1477)
         self.optimizer = optimizer
         self.name = name
         self.stop_training = False
@@ -339,6 +340,8 @@ class Model(object):
         blob['__model_name__'] = np.array(self.name)
         blob['__num_classes__'] = np.int64(self.net.num_classes)
         blob['__input_size__'] = np.int64(self.net.input_size)
+        blob['__spectrogram_length__'] = np.int64(self.net.spectrogram_length)
+        blob['__num_features__'] = np.int64(self.net.num_features)
         with open(filepath, 'wb') as f:
             np.savez(f, **blob)
 
@@ -382,11 +385,16 @@ class Model(object):
     def test_on_batch(self, x, y):
         p = self.predict_on_batch(x)
         yt = np.asarray(y, dtype=np.float64)
-        pc = np.clip(p.astype(np.float64), 1e-7, 1 - 1e-7)
-        C = yt.shape[1]
-        ysm = yt * 0.9 + 0.1 / C
-        S = pc.sum(axis=1, keepdims=True)
-        loss = float((-(ysm * (np.log(pc) - np.log(S))).sum(axis=1)).mean()) + float(self.net.l2_loss().item())
+        if self.loss == 'cce':
+            pn = p.astype(np.float64) / p.astype(np.float64).sum(axis=1, keepdims=True)
+            data_loss = float((-(yt * np.log(np.clip(pn, 1e-7, 1 - 1e-7))).sum(axis=1)).mean())
+        else:
+            pc = np.clip(p.astype(np.float64), 1e-7, 1 - 1e-7)
+            C = yt.shape[1]
+            ysm = yt * 0.9 + 0.1 / C
+            S = pc.sum(axis=1, keepdims=True)
+            data_loss = float((-(ysm * (np.log(pc) - np.log(S))).sum(axis=1)).mean())
+        loss = data_loss + float(self.net.l2_loss().item())
         acc = float((p.argmax(1) == yt.argmax(1)).mean())
         return [loss, acc]
 

@@ -41,7 +41,7 @@ def conv_1d_log_mfcc_model(input_size=16000, num_classes=11, *args, **kwargs):
     frequency_size = kwargs.get('num_log_mel_features', 40)
     net = DeviceNet(_lib.KWS_NET_LOG_MFCC, num_classes, input_size=input_size, spectrogram_length=time_size,
                     num_features=frequency_size)
-    return Model(net, RMSprop(lr=6e-4), name='conv_1d_log_mfcc')
+    return Model(net, RMSprop(lr=6e-4), name='conv_1d_log_mfcc', loss='cce')
 
 
 def speech_model(model_type, input_size, num_classes=11, *args, **kwargs):

@@ -38,6 +38,7 @@ class DeviceNet(object):
         self.kind = kind
         self.num_classes = num_classes
         self.input_size = input_size
+        self.spectrogram_length, self.num_features = spectrogram_length, num_features
         self.n_params = int(self.lib.kws_net_num_params(h))
         self.n_state = int(self.lib.kws_net_num_state(h))
         self.tensors = OrderedDict()
