@@ -204,9 +204,16 @@ def main():
             k = prof.get("gemm_nn")
             if k and k["ms"] > 0:
                 ach = k["flops"] / (k["ms"] * 1e-3) / 1e12
-                roof = {"kernel": "gemm_nn_kernel (f32 MFMA: pointwise fwd + dgrad + first conv)",
+                traffic = None   # HBM bytes per launch from the separate rocprofv3 --pmc passes (profiles/)
+                try:
+                    with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                        traffic = json.load(f)["kernels"]["gemm_nn_persist_kernel"]["hbm_bytes_per_launch"]
+                except Exception:
+                    pass
+                roof = {"kernel": "gemm_nn_persist_kernel (f32 MFMA: pointwise fwd + dgrad + first conv)",
                         "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                        "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                        "algorithmic_bytes_per_launch": k["bytes"] / max(k["count"], 1),
                         "launches": k["count"], "avg_launch_us": 1e3 * k["ms"] / max(k["count"], 1)}
     enq.stop()
 

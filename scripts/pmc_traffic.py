@@ -1,0 +1,30 @@
+"""Summarises rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs) into per-kernel HBM traffic.
+usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
+Units/corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE/WRITE_SIZE are in
+KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request for wide coalesced streaming reads -> doubled."""
+import collections, csv, json, re, sys
+
+
+def load(path, counter):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            name = r["Kernel_Name"]
+            m = re.search(r"(?:\(anonymous namespace\)::)?(\w+)(?:<[^(]*>)?\(", name.replace("void ", ""))
+            agg[m.group(1) if m else name[:60]].append(float(r["Counter_Value"]))
+    return agg
+
+
+f = load(sys.argv[1], "FETCH_SIZE")
+w = load(sys.argv[2], "WRITE_SIZE")
+out = {}
+for k in sorted(set(f) | set(w)):
+    fk = sum(f.get(k, [0])) / max(len(f.get(k, [])), 1)
+    wk = sum(w.get(k, [0])) / max(len(w.get(k, [])), 1)
+    out[k] = {"launches_seen": len(f.get(k, [])), "fetch_kib_avg_raw": fk, "write_kib_avg": wk,
+              "hbm_bytes_per_launch": (2.0 * fk + wk) * 1024.0}
+json.dump({"note": "FETCH_SIZE doubled (gfx950 correction), separate --pmc passes, bench.py --batch 1024",
+           "kernels": out}, open(sys.argv[3], "w"), indent=1, sort_keys=True)
+for k, v in out.items():
+    if v["hbm_bytes_per_launch"] > 1e6:
+        print("%-60s n=%4d  %.1f MB/launch" % (k[:60], v["launches_seen"], v["hbm_bytes_per_launch"] / 1e6))

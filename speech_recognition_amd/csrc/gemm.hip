@@ -533,7 +533,7 @@ struct TNArgs {
   int64_t M;
   int K, N;
   int64_t chunk;    // rows per split (multiple of 32)
-  int k_tiles, n_tiles;
+  int k_tiles, n_tiles, S;
   kws_gather_t g;
 };
 
@@ -549,9 +549,15 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs p) {
   __shared__ __attribute__((aligned(16))) float smem[2 * MS * (BKO + BNO)];
   constexpr int STAGE = MS * (BKO + BNO);  // floats per pipeline stage: Z tile then G tile
 
-  const int tile = blockIdx.x;
+  // XCD-aware order (PMC: 2.7x the algorithmic bytes left L2 with tile-major order): all output tiles of
+  // ONE M-split re-read the same [chunk, K] and [chunk, N] row panels, so they are given to consecutive
+  // slots of one XCD (workgroups b, b+8, ... share an L2) and run back to back there.
+  const int n_out_tiles = p.k_tiles * p.n_tiles;
+  const int xcd = blockIdx.x % NXCD, slot = blockIdx.x / NXCD;
+  const int tile = slot % n_out_tiles;
+  const int split = (slot / n_out_tiles) * NXCD + xcd;
+  if (split >= p.S) return;   // whole workgroup leaves together (before any barrier)
   const int tile_k = tile / p.n_tiles, tile_n = tile % p.n_tiles;
-  const int split = blockIdx.y;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wk = wave >> 1, wn = wave & 1;
@@ -781,7 +787,8 @@ int launch_tn(TNArgs a, float* dW, hipStream_t st) {
   a.chunk = pl.chunk;
   a.k_tiles = pl.k_tiles;
   a.n_tiles = pl.n_tiles;
-  dim3 g((unsigned)(pl.k_tiles * pl.n_tiles), (unsigned)pl.S), b(256);
+  a.S = pl.S;
+  dim3 g((unsigned)(pl.k_tiles * pl.n_tiles * ceil_div(pl.S, NXCD) * NXCD)), b(256);
   if (pl.bko == 128) hipLaunchKernelGGL((gemm_tn_kernel<128, 128, GATHER>), g, b, 0, st, a);
   else hipLaunchKernelGGL((gemm_tn_kernel<64, 64, GATHER>), g, b, 0, st, a);
   KWS_LAUNCH_CHECK("gemm_tn_kernel");
