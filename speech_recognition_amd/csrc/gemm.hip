@@ -280,6 +280,9 @@ __global__ __launch_bounds__(256, 4) void gemm_nn_kernel(NNArgs p) {
 //     256-byte contiguous segments instead of 128-byte ones; the stores drain while the next tile's
 //     main loop runs.
 constexpr int PBK = 32;
+#ifndef KWS_WS_DBG
+#define KWS_WS_DBG 0   // role-isolation experiments: 1 no global loads, 2 no global stores, 4 1/8 of the MFMAs
+#endif
 constexpr int PLDA = PBK + 4;
 
 template <int BM, int BN, int WM, int WN, bool GATHER, bool STATS>
@@ -526,6 +529,405 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_persist_kernel(NNArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Wave-specialised NN kernel.  The stamps of the persistent kernel show that one wave cannot overlap its
+// own memory phases with MFMA issue (per 128x128 tile: 15.8 k cycles MFMA, 3.7 k issuing loads, 2.4 k
+// waiting for them, 5.5 k moving C out), and co-resident workgroups drift into lockstep.  Here the roles
+// are split inside ONE workgroup per CU:
+//   4 compute waves: MFMA only - read the A/B slab of iteration g from LDS slot g&1 with the fragments
+//              of the next k-group prefetched under the current MFMAs.  The matrix pipe queues ~48 MFMAs,
+//              so a wave finishes ISSUING an iteration ~1.5 k cycles before the pipe finishes executing
+//              it; that slack pays for the epilogue: tiles alternate between two accumulator sets and the
+//              finished set is written to the LDS staging tile after the FIRST iteration of the next tile
+//              has been issued, so the pipe never drains.  The MFMA operands are swapped
+//              (D = W^T-fragment x A-fragment) so that a lane's 4 consecutive accumulator registers are 4
+//              consecutive COLUMNS of one C row: 16 ds_write_b128 per lane instead of 64 ds_write_b32;
+//   NLW loader waves: wave w owns the K-slabs s = w (mod NLW); it writes slab s into slot s&1 during
+//              iteration s-1 and immediately re-issues its loads for slab s+NLW, so the loads have almost
+//              NLW full iterations to land and every wait is a plain vmcnt(0) on the wave's own register
+//              set.  Loads are buffer loads: the tile base and K offset live in SGPRs (no per-load VALU
+//              address math) and rows past M read as zeros through the descriptor's range check;
+//   NSW storer waves: move the staging tile to global memory as 16-byte row stores (buffer stores, rows
+//              past M dropped by the range check) in nk-1 equal chunks spread over the next tile's
+//              iterations (a VALU instruction on a SIMD whose matrix pipe is saturated costs ~60 cycles,
+//              and all CUs finish tiles together, so one burst per tile stalls the barrier), and
+//              accumulate the BN column sums on the way (fixed order).
+// One __syncthreads per iteration orders everything: slot (g+1)&1 was last read in iteration g-1; the
+// staging tile is written at the end of iteration kt=0 of a tile, read during kt=1..nk-1, and its column
+// sums are finished at kt=0 of the following tile.
+// Host-checked preconditions: K % 32 == 0, K >= 64, N % BN == 0, 32-bit byte offsets inside a tile view.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int KWS_BUFFER_RSRC_FLAGS = 0x00020000;   // raw buffer, 32-bit data format (gfx9 family)
+
+__device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+template <int BN, int NLW, int NSW, bool STATS>
+__global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNArgs p) {
+  constexpr int BM = 128, WM = 2, WN = 2;
+  constexpr int NCT = WM * WN * 64;                 // compute threads
+  constexpr int NLT = NLW * 64;                     // loader threads
+  constexpr int NST = NSW * 64;                     // storer threads
+  constexpr int TM = BM / WM / 32;
+  constexpr int TN = BN / WN / 32;
+  constexpr int A_F4 = BM * PBK / 4 / 64;           // 16 per loader lane
+  constexpr int B_F4 = PBK * BN / 4 / 64;           // 16 or 8
+  constexpr int BN4 = BN / 4;
+  constexpr int PBK4 = PBK / 4;
+  constexpr int STAGE = BM * PLDA + PBK * BN;
+  constexpr int SLD = BN + 4;                       // staging row stride (floats): conflict-free b128 writes
+  constexpr int STG_OFF = 2 * STAGE;
+  constexpr int RGROUPS = NST / BN4;                // storer row groups
+  constexpr int NPASS = BM / RGROUPS;               // row passes per tile and storer thread
+  constexpr int RED_OFF = STG_OFF + BM * SLD;
+  constexpr int SMEM = RED_OFF + (NCT / BN4) * 2 * BN;
+  static_assert(SMEM * 4 <= 160 * 1024, "LDS budget");
+  __shared__ __attribute__((aligned(16))) float smem[SMEM];
+
+  const int tid = threadIdx.x;
+  const int K = p.K, N = p.N;
+  const int64_t M = p.M;
+  const int nk = K / PBK;                           // >= 2
+
+  const int xcd = blockIdx.x % NXCD;
+  const int wg_in_xcd = blockIdx.x / NXCD;
+  const int wgs_per_xcd = gridDim.x / NXCD;
+  const int panels = (p.m_tiles - xcd + NXCD - 1) / NXCD;
+  const int local_tiles = panels * p.n_tiles;
+  if (wg_in_xcd >= local_tiles) return;
+  const int n_my = (local_tiles - wg_in_xcd + wgs_per_xcd - 1) / wgs_per_xcd;
+  const int G = n_my * nk;
+  // barriers executed by every wave: 1 (prologue) + G (iterations) + 2 (last tile staged / moved out)
+
+  if (tid < NCT) {
+    // ------------------------------------------------------------------ MFMA waves
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+    struct Frag {
+      float4 a[TM];
+      float b[4][TN];
+    };
+    struct Acc {
+      f32x16 t[TM][TN];
+    };
+    Acc accA, accB;
+    // C[m][n]: m = wm*TM*32 + i*32 + li, n = wn*TN*32 + j*32 + 8*(v>>2) + 4*lh + (v&3)
+    float* const stg = smem + STG_OFF + (wm * TM * 32 + li) * SLD + wn * TN * 32 + 4 * lh;
+    auto stage = [&](const Acc& c) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int v4 = 0; v4 < 4; ++v4)
+            *reinterpret_cast<float4*>(stg + i * 32 * SLD + j * 32 + 8 * v4) =
+                make_float4(c.t[i][j][4 * v4], c.t[i][j][4 * v4 + 1], c.t[i][j][4 * v4 + 2], c.t[i][j][4 * v4 + 3]);
+    };
+    // BN column sums of a staged tile: VALU work is only cheap inside the MFMA waves' own instruction
+    // stream (a VALU instruction of another wave waits ~60 cycles for an issue slot while the matrix pipe
+    // is saturated), so it lives here, in the slack after an iteration's MFMAs have been issued.
+    constexpr int CRG = NCT / BN4;                  // row groups of the column-sum pass
+    const int sc4 = tid % BN4, srg = tid / BN4;
+    int st_tile_m = 0, st_n0 = 0;                   // coordinates of the staged tile
+    constexpr int SPASS = BM / CRG, SHALF = SPASS / 2;
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), css = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* const sp = smem + STG_OFF + srg * SLD + sc4 * 4;
+    // the LDS reads of half a tile are issued BEFORE an iteration's MFMAs and consumed after them, so their
+    // latency never shows; rows >= M hold exact zeros (their A rows were loaded as zeros)
+    auto stats_read = [&](float4 (&sv)[SHALF], int half) {
+#pragma unroll
+      for (int ps = 0; ps < SHALF; ++ps) sv[ps] = *reinterpret_cast<const float4*>(sp + (half * SHALF + ps) * CRG * SLD);
+    };
+    auto stats_add = [&](const float4 (&sv)[SHALF], int half) {
+      if (half == 0) {
+        cs = make_float4(0.f, 0.f, 0.f, 0.f);
+        css = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int ps = 0; ps < SHALF; ++ps) {
+        const float4 v = sv[ps];
+        cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
+        css.x += v.x * v.x; css.y += v.y * v.y; css.z += v.z * v.z; css.w += v.w * v.w;
+      }
+      if (half == 1) {
+        float* red = smem + RED_OFF + (srg * 2) * BN + sc4 * 4;   // [CRG][2][BN]
+        *reinterpret_cast<float4*>(red) = cs;
+        *reinterpret_cast<float4*>(red + BN) = css;
+      }
+    };
+    auto stats_partial = [&]() {
+      float4 sv[SHALF];
+      stats_read(sv, 0);
+      stats_add(sv, 0);
+      stats_read(sv, 1);
+      stats_add(sv, 1);
+    };
+    auto stats_finish = [&]() {                     // >= one barrier after stats_partial: fixed-order sum
+      if (tid < BN) {
+        const float* red = smem + RED_OFF + tid;
+        float cs = 0.f, css = 0.f;
+#pragma unroll
+        for (int w = 0; w < CRG; ++w) {
+          cs += red[(w * 2 + 0) * BN];
+          css += red[(w * 2 + 1) * BN];
+        }
+        p.stats[((int64_t)st_tile_m * 2 + 0) * N + st_n0 + tid] = cs;
+        p.stats[((int64_t)st_tile_m * 2 + 1) * N + st_n0 + tid] = css;
+      }
+    };
+    auto set_staged_tile = [&](int ordinal) {
+      const int loc = wg_in_xcd + ordinal * wgs_per_xcd;
+      st_tile_m = (loc / p.n_tiles) * NXCD + xcd;
+      st_n0 = (loc % p.n_tiles) * BN;
+    };
+    __syncthreads();
+#ifdef KWS_GEMM_STAMP
+    unsigned long long t_mma = 0, t_bar = 0, t_stage = 0, t_mark = __builtin_amdgcn_s_memtime();
+    const unsigned long long t_begin = t_mark, r_begin = __builtin_amdgcn_s_memrealtime();
+#define WT(acc_) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc_ += now_ - t_mark; t_mark = now_; } while (0)
+#else
+#define WT(acc_)
+#endif
+    int g = 0, tile_ord = 0;
+    auto run_tile = [&](Acc& acc, const Acc& prev, bool have_prev) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int v = 0; v < 16; ++v) acc.t[i][j][v] = 0.f;
+      for (int kt = 0; kt < nk; ++kt, ++g) {
+        const int cur = g & 1;
+        const float* cA = smem + cur * STAGE + (wm * TM * 32 + li) * PLDA + lh * 4;
+        const float* cB = smem + cur * STAGE + BM * PLDA + (lh * 4) * BN + wn * TN * 32 + li;
+        auto load_frag = [&](Frag& f, int q) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) f.a[i] = *reinterpret_cast<const float4*>(cA + i * 32 * PLDA + q * 8);
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) f.b[r][j] = cB[(q * 8 + r) * BN + j * 32];
+        };
+        auto mma = [&](const Frag& f) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+              const float av = r == 0 ? f.a[i].x : (r == 1 ? f.a[i].y : (r == 2 ? f.a[i].z : f.a[i].w));
+#pragma unroll
+              for (int j = 0; j < TN; ++j)   // swapped operands: lane <-> C row, register <-> C column
+                if (!(KWS_WS_DBG & 4) || (r == 0 && i == 0))
+                  acc.t[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.b[r][j], av, acc.t[i][j], 0, 0, 0);
+            }
+        };
+        // column sums of the staged tile: first half at kt = 1, second half at kt = 2 (both at kt = 1 when nk = 2)
+        const bool st_a = STATS && have_prev && kt == 1, st_b = STATS && have_prev && kt == 2;
+        float4 sv[SHALF];
+        if (st_a) stats_read(sv, 0);
+        if (st_b) stats_read(sv, 1);
+        Frag f0, f1;
+        load_frag(f0, 0);
+        load_frag(f1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(f0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_frag(f0, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(f1);
+        __builtin_amdgcn_sched_barrier(0);
+        load_frag(f1, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(f0);
+        mma(f1);
+        __builtin_amdgcn_sched_barrier(0);
+        WT(t_mma);
+        if (have_prev) {
+          if (kt == 0) {
+            if (STATS && tile_ord >= 2) stats_finish();   // tile tile_ord-2: partial sums written one tile ago
+            stage(prev);        // previous tile's accumulators: finished long ago, pipe stays fed by this tile
+            set_staged_tile(tile_ord - 1);
+            WT(t_stage);
+          } else if (st_a) {
+            stats_add(sv, 0);
+            if (nk == 2) {
+              stats_read(sv, 1);
+              stats_add(sv, 1);
+            }
+            WT(t_stage);
+          } else if (st_b) {
+            stats_add(sv, 1);
+            WT(t_stage);
+          }
+        }
+        __syncthreads();
+        WT(t_bar);
+      }
+      ++tile_ord;
+    };
+    for (int t = 0; t < n_my; t += 2) {
+      run_tile(accA, accB, t > 0);
+      if (t + 1 < n_my) run_tile(accB, accA, true);
+    }
+    if (STATS && n_my >= 2) stats_finish();         // tile n_my-2
+    if (n_my & 1) stage(accA); else stage(accB);
+    set_staged_tile(n_my - 1);
+#ifdef KWS_GEMM_STAMP
+    if (tid == 0 && blockIdx.x < 8192) {
+      g_stamps[blockIdx.x][0] = t_mma; g_stamps[blockIdx.x][1] = t_bar; g_stamps[blockIdx.x][2] = t_stage;
+      g_stamps[blockIdx.x][3] = (unsigned long long)G;
+      g_stamps[blockIdx.x][4] = __builtin_amdgcn_s_memtime() - t_begin;
+      g_stamps[blockIdx.x][5] = __builtin_amdgcn_s_memrealtime() - r_begin;
+    }
+#endif
+    __syncthreads();   // last tile staged
+    if (STATS) stats_partial();
+    __syncthreads();   // last tile moved out, its partial sums in LDS
+    if (STATS) stats_finish();
+  } else if (tid < NCT + NLT) {
+    // ------------------------------------------------------------------ loader waves
+    const int lane = tid & 63;
+    const int lw = __builtin_amdgcn_readfirstlane((tid - NCT) >> 6);   // my slabs: s = lw (mod NLW)
+    const int arow = lane / PBK4;                   // + 8 r
+    const int acol = (lane % PBK4) * 4;
+    const int brow = lane / BN4;                    // + BROWS r
+    const int bcol = (lane % BN4) * 4;
+    constexpr int BROWS = 64 / BN4;                 // B rows covered by one wave instruction
+    const int a_voff = (arow * K + acol) * 4;       // byte offsets inside the tile's buffer views
+    const int b_voff = (brow * N + bcol) * 4;
+    int ld_i = lw / nk, ld_kt = lw % nk;            // my next slab: tile ordinal, K-slab
+    float4 ra[A_F4], rb[B_F4];
+    auto issue = [&]() {
+      const int loc = wg_in_xcd + ld_i * wgs_per_xcd;
+      const bool tile_ok = !(KWS_WS_DBG & 1) && ld_i < n_my;
+      const int tile_m = (loc / p.n_tiles) * NXCD + xcd;
+      const int64_t m0 = (int64_t)tile_m * BM;
+      const int n0 = (loc % p.n_tiles) * BN;
+      const int64_t rows_left = M - m0;
+      const int rows = tile_ok ? (int)(rows_left < BM ? rows_left : BM) : 0;
+      const __amdgpu_buffer_rsrc_t ares = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float*>(p.A + m0 * K), 0, rows * K * 4, KWS_BUFFER_RSRC_FLAGS);
+      const __amdgpu_buffer_rsrc_t bres = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float*>(p.W + n0), 0, tile_ok ? (K * N - n0) * 4 : 0, KWS_BUFFER_RSRC_FLAGS);
+      const int k0 = ld_kt * PBK;
+#pragma unroll
+      for (int r = 0; r < A_F4; ++r) ra[r] = buf_ld4(ares, a_voff, (k0 + 8 * r * K) * 4);
+#pragma unroll
+      for (int r = 0; r < B_F4; ++r) rb[r] = buf_ld4(bres, b_voff, (k0 + BROWS * r) * N * 4);
+      ld_kt += NLW;
+      while (ld_kt >= nk) {
+        ld_kt -= nk;
+        ++ld_i;
+      }
+    };
+    auto write_lds = [&](int slot) {
+      float* sA = smem + slot * STAGE + arow * PLDA + acol;
+#pragma unroll
+      for (int r = 0; r < A_F4; ++r) *reinterpret_cast<float4*>(sA + 8 * r * PLDA) = ra[r];
+      float* sB = smem + slot * STAGE + BM * PLDA + brow * BN + bcol;
+#pragma unroll
+      for (int r = 0; r < B_F4; ++r) *reinterpret_cast<float4*>(sB + BROWS * r * BN) = rb[r];
+    };
+    issue();                     // slab lw
+    if (lw == 0) {
+      write_lds(0);
+      issue();                   // slab NLW
+    }
+    __syncthreads();
+#ifdef KWS_GEMM_STAMP
+    unsigned long long t_write = 0, t_issue = 0, t_mark = 0;
+#endif
+    for (int g = 0; g < G; ++g) {
+      if ((g + 1) % NLW == lw) {
+#ifdef KWS_GEMM_STAMP
+        t_mark = __builtin_amdgcn_s_memtime();
+#endif
+        write_lds((g + 1) & 1);  // slab g+1 (zeros past the end)
+        WT(t_write);
+        issue();                 // slab g+1+NLW
+        WT(t_issue);
+      }
+      __syncthreads();
+    }
+#ifdef KWS_GEMM_STAMP
+    if (tid == NCT && blockIdx.x < 8192) {
+      g_stamps[blockIdx.x][6] = t_write; g_stamps[blockIdx.x][7] = t_issue;
+    }
+#endif
+    __syncthreads();
+    __syncthreads();
+  } else {
+    // ------------------------------------------------------------------ storer waves
+    // pure data movers (LDS read + buffer store, one address add per pass): the tile staged at kt = 0 is
+    // moved out in nk-1 equal chunks at kt = 1..nk-1
+    const int stt = tid - NCT - NLT;
+    const int c4 = stt % BN4, r_in = stt / BN4;
+    const int c_voff = (r_in * N + c4 * 4) * 4;
+    const int ppi = (NPASS + nk - 2) / (nk - 1);    // passes per iteration
+    int st_i = 0;                                   // ordinal of the next tile to move out
+    __amdgpu_buffer_rsrc_t cres = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, 0, KWS_BUFFER_RSRC_FLAGS);
+    auto begin_tile = [&]() {
+      const int loc = wg_in_xcd + st_i * wgs_per_xcd;
+      const int tile_m = (loc / p.n_tiles) * NXCD + xcd;
+      const int n0 = (loc % p.n_tiles) * BN;
+      const int64_t m0 = (int64_t)tile_m * BM;
+      const int64_t rows_left = M - m0;
+      const int rows = (KWS_WS_DBG & 2) ? 0 : (int)(rows_left < BM ? rows_left : BM);
+      // view of C starting at (m0, n0): rows past M fall outside rows*N floats and are dropped
+      cres = __builtin_amdgcn_make_buffer_rsrc(p.C + m0 * N + n0, 0, rows > 0 ? (rows * N - n0) * 4 : 0,
+                                               KWS_BUFFER_RSRC_FLAGS);
+      ++st_i;
+    };
+    auto move_rows = [&](int lo, int hi) {          // passes [lo, hi) of the staged tile
+      const float* stg = smem + STG_OFF + c4 * 4 + r_in * SLD;
+      constexpr int GRP = 8;                        // all LDS reads of a group are in flight before its first store
+      for (int p0 = lo; p0 < hi; p0 += GRP) {
+        float4 v[GRP];
+#pragma unroll
+        for (int i = 0; i < GRP; ++i)
+          if (p0 + i < hi) v[i] = *reinterpret_cast<const float4*>(stg + (p0 + i) * RGROUPS * SLD);
+#pragma unroll
+        for (int i = 0; i < GRP; ++i)
+          if (p0 + i < hi) {
+            u32x4 u;
+            u.x = __float_as_uint(v[i].x); u.y = __float_as_uint(v[i].y); u.z = __float_as_uint(v[i].z); u.w = __float_as_uint(v[i].w);
+            __builtin_amdgcn_raw_buffer_store_b128(u, cres, c_voff, (p0 + i) * RGROUPS * N * 4, 0);
+          }
+      }
+    };
+    __syncthreads();
+#ifdef KWS_GEMM_STAMP
+    unsigned long long t_store = 0, t_mark = 0;
+#endif
+    int kt = 0;
+    for (int g = 0; g < G; ++g) {
+      if (g >= nk) {                                // a previous tile exists
+        if (kt == 0) {
+          begin_tile();       // descriptors only: the compute waves stage this tile during this iteration
+        } else {
+#ifdef KWS_GEMM_STAMP
+          t_mark = __builtin_amdgcn_s_memtime();
+#endif
+          const int lo = (kt - 1) * ppi, hi = lo + ppi < NPASS ? lo + ppi : NPASS;
+          if (lo < NPASS && !(KWS_WS_DBG & 32)) move_rows(lo, hi);
+          WT(t_store);
+        }
+      }
+      if (++kt == nk) kt = 0;
+      __syncthreads();
+    }
+#ifdef KWS_GEMM_STAMP
+    if (stt == 0 && blockIdx.x < 8192) g_stamps[blockIdx.x + 256][0] = t_store;
+#endif
+    begin_tile();
+    __syncthreads();   // last tile staged
+    move_rows(0, NPASS);
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 struct TNArgs {
   const float* A;   // [M,K] or gathered X
   const float* G;   // [M,N]
@@ -753,7 +1155,28 @@ int launch_nn(const NNArgs& a0, hipStream_t st) {
     return KWS_E_INVALID;
   }
   const bool stats = a.stats != nullptr;
-  static const bool use_v1 = getenv("KWS_GEMM_V1") != nullptr;   // one-tile-per-workgroup kernel, A/B only
+  static const bool use_v1 = getenv("KWS_GEMM_V1") != nullptr;            // one-tile-per-workgroup kernel, A/B only
+  static const bool use_persist = getenv("KWS_GEMM_PERSIST") != nullptr;  // 4-wave persistent kernel, A/B only
+  // wave-specialised kernel (default): needs whole K-slabs and column tiles, and 32-bit byte offsets
+  // inside one tile's buffer views (128 rows of A / C, all of W); everything else (the gathered first
+  // convolution, ragged K or N) takes the persistent kernel
+  const bool ws_ok = !GATHER && a.K % PBK == 0 && a.K >= 2 * PBK && a.N % BN == 0 &&
+                     (int64_t)a.K * a.N * 4 < (1ll << 31) && 128ll * a.K * 4 < (1ll << 31) && 128ll * a.N * 4 < (1ll << 31);
+  if (ws_ok && !use_v1 && !use_persist) {
+    // one 8-wave workgroup per CU (145 KB LDS), 32 CUs per XCD
+    int per_xcd = (int)(slots < 32 ? slots : 32);
+    if (const char* e = getenv("KWS_GEMM_WGS_PER_XCD")) per_xcd = atoi(e) > 0 && atoi(e) < slots ? atoi(e) : per_xcd;
+    dim3 gp((unsigned)(per_xcd * NXCD)), bp(8 * 64);
+    if (wide) {
+      if (stats) hipLaunchKernelGGL((gemm_nn_ws_kernel<128, 2, 2, true>), gp, bp, 0, st, a);
+      else hipLaunchKernelGGL((gemm_nn_ws_kernel<128, 2, 2, false>), gp, bp, 0, st, a);
+    } else {
+      if (stats) hipLaunchKernelGGL((gemm_nn_ws_kernel<64, 2, 2, true>), gp, bp, 0, st, a);
+      else hipLaunchKernelGGL((gemm_nn_ws_kernel<64, 2, 2, false>), gp, bp, 0, st, a);
+    }
+    KWS_LAUNCH_CHECK("gemm_nn_ws_kernel");
+    return KWS_OK;
+  }
   if (!use_v1) {
     // persistent: 2 workgroups per CU (69.6 KB LDS each), 32 CUs per XCD
     int per_xcd = (int)(slots < 64 ? slots : 64);
