@@ -68,7 +68,12 @@ __device__ void block_sum(const float (&vals)[NV], int nv, float* scratch /*[4*M
   __syncthreads();
 }
 
-template <bool TRAIN>
+// TT > 0: the attention width T is known at compile time (9 for the 16000-sample model), which lets both
+// passes over the [T*C, T] attention kernel W1 read it as whole 16-byte vectors, 4 rows (= T float4) per
+// thread and step, consecutive threads on consecutive 16*T-byte chunks.  The generic path (TT = 0) walks W1
+// with 4-byte strided loads: at T = 9 every wave-load touched 18 cache lines and the 1024 workgroups pulled
+// ~1.8 GB through L1 per step (0.35 ms; this kernel's HBM-side traffic is only ~60 MB).
+template <bool TRAIN, int TT>
 __global__ __launch_bounds__(256) void ts_tail_kernel(TailArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int T = a.T, C = a.C, NC = a.NC, TC = T * C;
@@ -102,20 +107,47 @@ __global__ __launch_bounds__(256) void ts_tail_kernel(TailArgs a) {
     if (TRAIN) a.xd[(int64_t)b * TC + e] = d;
   }
   __syncthreads();
-  // ---- logits1 = xd . W1 + b1 : thread (t = tid%16, slice = tid/16) --------------------------
+  // ---- logits1 = xd . W1 + b1 ------------------------------------------------------------------
   {
-    const int t = tid & 15, sl = tid >> 4;
-    float s = 0.f;
-    if (t < T)
-      for (int e = sl; e < TC; e += 16) s = fmaf(xd[e], a.W1[(int64_t)e * T + t], s);
-    part16[sl * 16 + t] = s;
-    __syncthreads();
-    if (tid < T) {
-      float acc = a.b1[tid];
-      for (int k = 0; k < 16; ++k) acc += part16[k * 16 + tid];
-      l1[tid] = acc;
+    if (TT > 0) {
+      // thread <- row groups rg, rg+256, ...: 4 rows of W1 = TT float4, 4 x values = one LDS float4
+      constexpr int TV = TT > 0 ? TT : 1;
+      float pl[TV];
+#pragma unroll
+      for (int t = 0; t < TV; ++t) pl[t] = 0.f;
+      for (int rg = tid; rg < TC / 4; rg += 256) {
+        const float4* wp = reinterpret_cast<const float4*>(a.W1 + (int64_t)rg * 4 * TV);
+        float wv[4 * TV];
+#pragma unroll
+        for (int i = 0; i < TV; ++i) {
+          const float4 w4 = wp[i];
+          wv[4 * i] = w4.x; wv[4 * i + 1] = w4.y; wv[4 * i + 2] = w4.z; wv[4 * i + 3] = w4.w;
+        }
+        const float4 x4 = *reinterpret_cast<const float4*>(xd + rg * 4);
+        const float xr[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int t = 0; t < TV; ++t) pl[t] = fmaf(xr[r], wv[r * TV + t], pl[t]);
+      }
+      block_sum(pl, TV, scratch, l1);
+      if (tid < T) l1[tid] += a.b1[tid];
+      __syncthreads();
+    } else {
+      // generic T: thread (t = tid%16, slice = tid/16)
+      const int t = tid & 15, sl = tid >> 4;
+      float s = 0.f;
+      if (t < T)
+        for (int e = sl; e < TC; e += 16) s = fmaf(xd[e], a.W1[(int64_t)e * T + t], s);
+      part16[sl * 16 + t] = s;
+      __syncthreads();
+      if (tid < T) {
+        float acc = a.b1[tid];
+        for (int k = 0; k < 16; ++k) acc += part16[k * 16 + tid];
+        l1[tid] = acc;
+      }
+      __syncthreads();
     }
-    __syncthreads();
     if (tid == 0) {
       float m = l1[0];
       for (int k = 1; k < T; ++k) m = fmaxf(m, l1[k]);
@@ -244,16 +276,48 @@ __global__ __launch_bounds__(256) void ts_tail_kernel(TailArgs a) {
   __syncthreads();
   if (tid < T) a.dl1[(int64_t)b * T + tid] = dl1[tid];
   // ---- dx += (W1 . dl1) * mask1 / keep ; g = dx * relu6'(pre) ; BN-backward partial sums ------
+  if (TT > 0) {
+    // coalesced pass over W1 (same 4-row groups as the forward): xd (= dx) += dropout-masked W1 . dl1
+    constexpr int TV = TT > 0 ? TT : 1;
+    float dv[TV];
+#pragma unroll
+    for (int t = 0; t < TV; ++t) dv[t] = dl1[t];
+    for (int rg = tid; rg < TC / 4; rg += 256) {
+      const float4* wp = reinterpret_cast<const float4*>(a.W1 + (int64_t)rg * 4 * TV);
+      float wv[4 * TV];
+#pragma unroll
+      for (int i = 0; i < TV; ++i) {
+        const float4 w4 = wp[i];
+        wv[4 * i] = w4.x; wv[4 * i + 1] = w4.y; wv[4 * i + 2] = w4.z; wv[4 * i + 3] = w4.w;
+      }
+      float sr[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < TV; ++q) s = fmaf(wv[r * TV + q], dv[q], s);
+        const bool keep = kws_keep(row * (uint32_t)TC + (uint32_t)(rg * 4 + r), a.key1, a.thresh);
+        sr[r] = keep ? s * a.inv_keep : 0.f;
+      }
+      float4 d4 = *reinterpret_cast<float4*>(xd + rg * 4);
+      d4.x += sr[0]; d4.y += sr[1]; d4.z += sr[2]; d4.w += sr[3];
+      *reinterpret_cast<float4*>(xd + rg * 4) = d4;
+    }
+    __syncthreads();
+  }
   float* gb = a.g + (int64_t)b * TC;
   for (int c = tid; c < C; c += 256) {
     const float sc = a.bn[c], sh = a.bn[C + c], mean = a.bn[2 * C + c], rstd = a.bn[3 * C + c];
     float sg = 0.f, sgx = 0.f;
     for (int t = 0; t < T; ++t) {
       const int e = t * C + c;
-      float s = 0.f;
-      for (int q = 0; q < T; ++q) s = fmaf(a.W1[(int64_t)e * T + q], dl1[q], s);
-      const bool keep = kws_keep(row * (uint32_t)TC + (uint32_t)e, a.key1, a.thresh);
-      const float dx = xd[e] + (keep ? s * a.inv_keep : 0.f);
+      float dx = xd[e];
+      if (TT == 0) {
+        float s = 0.f;
+        for (int q = 0; q < T; ++q) s = fmaf(a.W1[(int64_t)e * T + q], dl1[q], s);
+        const bool keep = kws_keep(row * (uint32_t)TC + (uint32_t)e, a.key1, a.thresh);
+        dx += keep ? s * a.inv_keep : 0.f;
+      }
       const float yv = yb[e];
       const float pre = fmaf(yv, sc, sh);
       const float gv = (pre > 0.f && pre <= 6.f) ? dx : 0.f;
@@ -337,22 +401,22 @@ int kws_ts_tail_launch(const kws_ts_tail_args* p, hipStream_t st) {
   a.inv_loss_batch = 1.0f / (float)p->loss_batch;
   a.row_offset = p->row_offset;
   KwsProfScope prof(p->train ? "tail_train" : "tail_infer", 4.0 * p->B * TC * p->T * (p->train ? 2 : 1), 4.0 * p->B * TC * (p->train ? 4 : 1), st);
+  // T = 9 (16000-sample input) takes the vectorised W1 passes; W1 rows must then be 16-byte aligned in
+  // groups of 4 (T*C % 4 == 0 and an aligned base, both true for the flat parameter buffer)
+  const bool fast9 = p->T == 9 && TC % 4 == 0 && (reinterpret_cast<uintptr_t>(p->W1) & 15) == 0 &&
+                     getenv("KWS_TAIL_GENERIC") == nullptr;
+  const void* fn = p->train ? (fast9 ? reinterpret_cast<const void*>(&ts_tail_kernel<true, 9>)
+                                     : reinterpret_cast<const void*>(&ts_tail_kernel<true, 0>))
+                            : (fast9 ? reinterpret_cast<const void*>(&ts_tail_kernel<false, 9>)
+                                     : reinterpret_cast<const void*>(&ts_tail_kernel<false, 0>));
+  if (lds_floats * 4 > 64 * 1024)
+    KWS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_floats * 4)));
   if (p->train) {
-    static bool attr_set_t = false;
-    if (!attr_set_t && lds_floats * 4 > 64 * 1024) {
-      KWS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ts_tail_kernel<true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_floats * 4)));
-      attr_set_t = true;
-    }
-    hipLaunchKernelGGL((ts_tail_kernel<true>), dim3((unsigned)p->B), dim3(256), lds_floats * 4, st, a);
+    if (fast9) hipLaunchKernelGGL((ts_tail_kernel<true, 9>), dim3((unsigned)p->B), dim3(256), lds_floats * 4, st, a);
+    else hipLaunchKernelGGL((ts_tail_kernel<true, 0>), dim3((unsigned)p->B), dim3(256), lds_floats * 4, st, a);
   } else {
-    static bool attr_set_i = false;
-    if (!attr_set_i && lds_floats * 4 > 64 * 1024) {
-      KWS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ts_tail_kernel<false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_floats * 4)));
-      attr_set_i = true;
-    }
-    hipLaunchKernelGGL((ts_tail_kernel<false>), dim3((unsigned)p->B), dim3(256), lds_floats * 4, st, a);
+    if (fast9) hipLaunchKernelGGL((ts_tail_kernel<false, 9>), dim3((unsigned)p->B), dim3(256), lds_floats * 4, st, a);
+    else hipLaunchKernelGGL((ts_tail_kernel<false, 0>), dim3((unsigned)p->B), dim3(256), lds_floats * 4, st, a);
   }
   KWS_LAUNCH_CHECK("ts_tail_kernel");
   return KWS_OK;
