@@ -129,10 +129,15 @@ int kws_stft_mel_f32(const kws_stft_plan_t* plan, const float* x, int B, int L, 
  *   / the stride-2 1x1 shortcut (model.py:1431-1432):
  *   A[(b,t), j*cin + c] = X[b*x_batch_stride + t*stride_t + j*stride_j + c + base_off], 0 outside
  *   [0, x_len) of clip b.
- * stats (optional, may be NULL): per-row-tile partial sums for BatchNorm, finalised by
- * kws_bn_stats_finalize (a11).  part must hold 2 * kws_gemm_num_row_tiles(M) * N floats.
+ * stats (optional, may be NULL): partial column sums [rows][2][N] (sum x, sum x^2) for BatchNorm, finalised
+ * by kws_bn_stats_finalize (a11).  The buffer must hold 2 * kws_gemm_num_row_tiles(M) * N floats (an upper
+ * bound); the number of rows a call actually writes is kws_gemm_nn_stats_rows(M, K, N) for kws_gemm_nn_f32
+ * (one row per workgroup of the persistent kernel, <= 256) and kws_gemm_gather_stats_rows(M) for
+ * kws_gemm_gather_f32 (one row per 128-row tile) - pass that count to kws_bn_stats_finalize.
  * ---------------------------------------------------------------------------------------- */
 int kws_gemm_num_row_tiles(int64_t M);
+int kws_gemm_nn_stats_rows(int64_t M, int K, int N);
+int kws_gemm_gather_stats_rows(int64_t M);
 int kws_gemm_nn_f32(const float* A, const float* W, float* C, int64_t M, int K, int N,
                     float* stats_part, void* stream);
 typedef struct {

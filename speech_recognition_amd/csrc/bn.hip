@@ -6,6 +6,10 @@
 
 namespace {
 
+// finalise kernels: 256 threads = FIN_CG channels x FIN_RG row groups; up to 256 partial rows are summed
+// directly (<= 16 per thread), row group r takes rows r, r+FIN_RG, ... and the groups are combined in order
+constexpr int FIN_CG = 16, FIN_RG = 16;
+
 // part[n_tiles][2][C] -> bn[4C] = scale | shift | mean | rstd ; moving stats update in place.
 __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ part, int n_tiles,
                                                                 double inv_count, int C,
@@ -13,12 +17,12 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __r
                                                                 const float* __restrict__ beta, float eps,
                                                                 float one_minus_momentum, float* moving_mean,
                                                                 float* moving_var, float* __restrict__ bn) {
-  __shared__ double red[2][8][32];
-  const int cg = threadIdx.x & 31, rg = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cg;
+  __shared__ double red[2][FIN_RG][FIN_CG];
+  const int cg = threadIdx.x % FIN_CG, rg = threadIdx.x / FIN_CG;
+  const int c = blockIdx.x * FIN_CG + cg;
   double s = 0.0, ss = 0.0;
   if (c < C) {
-    for (int t = rg; t < n_tiles; t += 8) {
+    for (int t = rg; t < n_tiles; t += FIN_RG) {
       s += (double)part[((int64_t)t * 2 + 0) * C + c];
       ss += (double)part[((int64_t)t * 2 + 1) * C + c];
     }
@@ -29,7 +33,7 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __r
   if (rg == 0 && c < C) {
     s = 0.0;
     ss = 0.0;
-    for (int r = 0; r < 8; ++r) {
+    for (int r = 0; r < FIN_RG; ++r) {
       s += red[0][r][cg];
       ss += red[1][r][cg];
     }
@@ -105,12 +109,12 @@ __global__ __launch_bounds__(256) void bn_relu6_apply_kernel(const float* __rest
 __global__ __launch_bounds__(256) void dw_bwd_finalize_kernel(const float* __restrict__ part, int n_parts,
                                                               double inv_count, int C, float* dw, float* dgamma,
                                                               float* dbeta, float* coef) {
-  __shared__ double red[5][8][32];
-  const int cg = threadIdx.x & 31, rg = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cg;
+  __shared__ double red[5][FIN_RG][FIN_CG];
+  const int cg = threadIdx.x % FIN_CG, rg = threadIdx.x / FIN_CG;
+  const int c = blockIdx.x * FIN_CG + cg;
   double s[5] = {0, 0, 0, 0, 0};
   if (c < C) {
-    for (int t = rg; t < n_parts; t += 8) {
+    for (int t = rg; t < n_parts; t += FIN_RG) {
 #pragma unroll
       for (int q = 0; q < 5; ++q) s[q] += (double)part[((int64_t)t * 5 + q) * C + c];
     }
@@ -122,7 +126,7 @@ __global__ __launch_bounds__(256) void dw_bwd_finalize_kernel(const float* __res
 #pragma unroll
     for (int q = 0; q < 5; ++q) {
       double a = 0.0;
-      for (int r = 0; r < 8; ++r) a += red[q][r][cg];
+      for (int r = 0; r < FIN_RG; ++r) a += red[q][r][cg];
       s[q] = a;
     }
     if (dbeta) dbeta[c] = (float)s[0];
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ g
 
 // Folds n partial rows of width W into at most KWS_REDUCE_SLICES rows in `scratch` when that pays.
 int pre_reduce(const float* part, int n, int W, float* scratch, hipStream_t st, const float** out_part, int* out_n) {
-  if (scratch == nullptr || n <= 2 * KWS_REDUCE_SLICES) {
+  if (scratch == nullptr || n <= 8 * KWS_REDUCE_SLICES) {   // up to 256 rows: the finalise kernels sum them directly
     *out_part = part;
     *out_n = n;
     return KWS_OK;
@@ -190,7 +194,7 @@ int kws_bn_stats_finalize(const float* stats_part, int n_tiles, int64_t count, i
   const float omm = (float)(1.0 - (double)momentum);
   KwsProfScope prof("bn_finalize", 0.0, 8.0 * n_tiles * C, (hipStream_t)stream);
   KWS_TRY(pre_reduce(stats_part, n_tiles, 2 * C, scratch, (hipStream_t)stream, &stats_part, &n_tiles));
-  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((unsigned)ceil_div(C, 32)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((unsigned)ceil_div(C, FIN_CG)), dim3(256), 0, (hipStream_t)stream,
                      stats_part, n_tiles, 1.0 / (double)count, C, gamma, beta, eps, omm, moving_mean, moving_var, bn);
   KWS_LAUNCH_CHECK("bn_stats_finalize_kernel");
   return KWS_OK;
@@ -219,7 +223,7 @@ int kws_dw_bwd_finalize(const float* part, int n_parts, int64_t count, int C, fl
   KWS_REQUIRE(part && n_parts > 0 && count > 0 && C > 0, "dw_bwd_finalize: bad arguments");
   KwsProfScope prof("bn_finalize", 0.0, 20.0 * n_parts * C, (hipStream_t)stream);
   KWS_TRY(pre_reduce(part, n_parts, 5 * C, scratch, (hipStream_t)stream, &part, &n_parts));
-  hipLaunchKernelGGL(dw_bwd_finalize_kernel, dim3((unsigned)ceil_div(C, 32)), dim3(256), 0, (hipStream_t)stream, part,
+  hipLaunchKernelGGL(dw_bwd_finalize_kernel, dim3((unsigned)ceil_div(C, FIN_CG)), dim3(256), 0, (hipStream_t)stream, part,
                      n_parts, 1.0 / (double)count, C, dw, dgamma, dbeta, coef);
   KWS_LAUNCH_CHECK("dw_bwd_finalize_kernel");
   return KWS_OK;

@@ -556,6 +556,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_persist_kernel(NNArgs p) {
 // sums are finished at kt=0 of the following tile.
 // Host-checked preconditions: K % 32 == 0, K >= 64, N % BN == 0, 32-bit byte offsets inside a tile view.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int KWS_WS_MAX_N = 1024;                  // widest N the per-workgroup statistics row supports
 constexpr int KWS_BUFFER_RSRC_FLAGS = 0x00020000;   // raw buffer, 32-bit data format (gfx9 family)
 
 __device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
@@ -581,7 +582,8 @@ __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNA
   constexpr int RGROUPS = NST / BN4;                // storer row groups
   constexpr int NPASS = BM / RGROUPS;               // row passes per tile and storer thread
   constexpr int RED_OFF = STG_OFF + BM * SLD;
-  constexpr int SMEM = RED_OFF + (NCT / BN4) * 2 * BN;
+  constexpr int WACC_OFF = RED_OFF + (NCT / BN4) * 2 * BN;   // [2][KWS_WS_MAX_N] column sums of ALL my tiles
+  constexpr int SMEM = WACC_OFF + (STATS ? 2 * KWS_WS_MAX_N : 0);
   static_assert(SMEM * 4 <= 160 * 1024, "LDS budget");
   __shared__ __attribute__((aligned(16))) float smem[SMEM];
 
@@ -595,10 +597,15 @@ __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNA
   const int wgs_per_xcd = gridDim.x / NXCD;
   const int panels = (p.m_tiles - xcd + NXCD - 1) / NXCD;
   const int local_tiles = panels * p.n_tiles;
-  if (wg_in_xcd >= local_tiles) return;
+  if (wg_in_xcd >= local_tiles) {                   // no tile for this workgroup: its statistics row is zero
+    if (STATS)
+      for (int c = tid; c < 2 * N; c += blockDim.x) p.stats[(int64_t)blockIdx.x * 2 * N + c] = 0.f;
+    return;
+  }
   const int n_my = (local_tiles - wg_in_xcd + wgs_per_xcd - 1) / wgs_per_xcd;
   const int G = n_my * nk;
   // barriers executed by every wave: 1 (prologue) + G (iterations) + 2 (last tile staged / moved out)
+  // + 1 when STATS (column sums complete)
 
   if (tid < NCT) {
     // ------------------------------------------------------------------ MFMA waves
@@ -630,7 +637,7 @@ __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNA
     // is saturated), so it lives here, in the slack after an iteration's MFMAs have been issued.
     constexpr int CRG = NCT / BN4;                  // row groups of the column-sum pass
     const int sc4 = tid % BN4, srg = tid / BN4;
-    int st_tile_m = 0, st_n0 = 0;                   // coordinates of the staged tile
+    int st_n0 = 0;                                  // first column of the staged tile
     constexpr int SPASS = BM / CRG, SHALF = SPASS / 2;
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), css = make_float4(0.f, 0.f, 0.f, 0.f);
     const float* const sp = smem + STG_OFF + srg * SLD + sc4 * 4;
@@ -673,15 +680,19 @@ __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNA
           cs += red[(w * 2 + 0) * BN];
           css += red[(w * 2 + 1) * BN];
         }
-        p.stats[((int64_t)st_tile_m * 2 + 0) * N + st_n0 + tid] = cs;
-        p.stats[((int64_t)st_tile_m * 2 + 1) * N + st_n0 + tid] = css;
+        // the workgroup's tiles are folded in tile order into ONE statistics row per workgroup (<= 256
+        // rows for kws_bn_stats_finalize instead of one per 128-row tile); column st_n0 + tid is always
+        // updated by this same thread
+        smem[WACC_OFF + st_n0 + tid] += cs;
+        smem[WACC_OFF + KWS_WS_MAX_N + st_n0 + tid] += css;
       }
     };
     auto set_staged_tile = [&](int ordinal) {
       const int loc = wg_in_xcd + ordinal * wgs_per_xcd;
-      st_tile_m = (loc / p.n_tiles) * NXCD + xcd;
       st_n0 = (loc % p.n_tiles) * BN;
     };
+    if (STATS)
+      for (int c = tid; c < 2 * KWS_WS_MAX_N; c += NCT) smem[WACC_OFF + c] = 0.f;
     __syncthreads();
 #ifdef KWS_GEMM_STAMP
     unsigned long long t_mma = 0, t_bar = 0, t_stage = 0, t_mark = __builtin_amdgcn_s_memtime();
@@ -784,7 +795,14 @@ __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNA
     __syncthreads();   // last tile staged
     if (STATS) stats_partial();
     __syncthreads();   // last tile moved out, its partial sums in LDS
-    if (STATS) stats_finish();
+    if (STATS) {
+      stats_finish();
+      __syncthreads();
+      for (int c = tid; c < N; c += NCT) {
+        p.stats[((int64_t)blockIdx.x * 2 + 0) * N + c] = smem[WACC_OFF + c];
+        p.stats[((int64_t)blockIdx.x * 2 + 1) * N + c] = smem[WACC_OFF + KWS_WS_MAX_N + c];
+      }
+    }
   } else if (tid < NCT + NLT) {
     // ------------------------------------------------------------------ loader waves
     const int lane = tid & 63;
@@ -857,6 +875,7 @@ __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNA
 #endif
     __syncthreads();
     __syncthreads();
+    if (STATS) __syncthreads();
   } else {
     // ------------------------------------------------------------------ storer waves
     // pure data movers (LDS read + buffer store, one address add per pass): the tile staged at kt = 0 is
@@ -924,6 +943,7 @@ __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNA
     __syncthreads();   // last tile staged
     move_rows(0, NPASS);
     __syncthreads();
+    if (STATS) __syncthreads();
   }
 }
 
@@ -1141,6 +1161,30 @@ TNPlan tn_plan(int64_t M, int K, int N) {
   return pl;
 }
 
+// which kernel kws_gemm_nn_f32 runs for a shape, and how many statistics rows it writes
+struct NNPlan {
+  bool ws;          // wave-specialised kernel
+  int wgs;          // its grid (= statistics rows: one per workgroup)
+  int m_tiles;      // statistics rows of the tile-per-row kernels
+};
+NNPlan nn_plan(int64_t M, int K, int N, bool gather) {
+  static const bool use_v1 = getenv("KWS_GEMM_V1") != nullptr;            // one-tile-per-workgroup kernel, A/B only
+  static const bool use_persist = getenv("KWS_GEMM_PERSIST") != nullptr;  // 4-wave persistent kernel, A/B only
+  NNPlan pl;
+  const int BN = (N % 128 == 0) ? 128 : 64;
+  pl.m_tiles = (int)ceil_div64(M, 128);
+  const int64_t slots = ceil_div64(pl.m_tiles, NXCD) * ceil_div(N, BN);
+  // wave-specialised kernel (default): needs whole K-slabs and column tiles, and 32-bit byte offsets
+  // inside one tile's buffer views (128 rows of A / C, all of W); everything else (the gathered first
+  // convolution, ragged K or N) takes the persistent kernel
+  pl.ws = !gather && !use_v1 && !use_persist && K % PBK == 0 && K >= 2 * PBK && N % BN == 0 && N <= KWS_WS_MAX_N &&
+          (int64_t)K * N * 4 < (1ll << 31) && 128ll * K * 4 < (1ll << 31) && 128ll * N * 4 < (1ll << 31);
+  int per_xcd = (int)(slots < 32 ? slots : 32);    // one 8-wave workgroup per CU (153 KB LDS), 32 CUs per XCD
+  if (const char* e = getenv("KWS_GEMM_WGS_PER_XCD")) per_xcd = atoi(e) > 0 && atoi(e) < slots ? atoi(e) : per_xcd;
+  pl.wgs = per_xcd * NXCD;
+  return pl;
+}
+
 template <bool GATHER>
 int launch_nn(const NNArgs& a0, hipStream_t st) {
   NNArgs a = a0;
@@ -1155,18 +1199,10 @@ int launch_nn(const NNArgs& a0, hipStream_t st) {
     return KWS_E_INVALID;
   }
   const bool stats = a.stats != nullptr;
-  static const bool use_v1 = getenv("KWS_GEMM_V1") != nullptr;            // one-tile-per-workgroup kernel, A/B only
-  static const bool use_persist = getenv("KWS_GEMM_PERSIST") != nullptr;  // 4-wave persistent kernel, A/B only
-  // wave-specialised kernel (default): needs whole K-slabs and column tiles, and 32-bit byte offsets
-  // inside one tile's buffer views (128 rows of A / C, all of W); everything else (the gathered first
-  // convolution, ragged K or N) takes the persistent kernel
-  const bool ws_ok = !GATHER && a.K % PBK == 0 && a.K >= 2 * PBK && a.N % BN == 0 &&
-                     (int64_t)a.K * a.N * 4 < (1ll << 31) && 128ll * a.K * 4 < (1ll << 31) && 128ll * a.N * 4 < (1ll << 31);
-  if (ws_ok && !use_v1 && !use_persist) {
-    // one 8-wave workgroup per CU (145 KB LDS), 32 CUs per XCD
-    int per_xcd = (int)(slots < 32 ? slots : 32);
-    if (const char* e = getenv("KWS_GEMM_WGS_PER_XCD")) per_xcd = atoi(e) > 0 && atoi(e) < slots ? atoi(e) : per_xcd;
-    dim3 gp((unsigned)(per_xcd * NXCD)), bp(8 * 64);
+  static const bool use_v1 = getenv("KWS_GEMM_V1") != nullptr;
+  const NNPlan pl = nn_plan(a.M, a.K, a.N, GATHER);
+  if (pl.ws) {
+    dim3 gp((unsigned)pl.wgs), bp(8 * 64);
     if (wide) {
       if (stats) hipLaunchKernelGGL((gemm_nn_ws_kernel<128, 2, 2, true>), gp, bp, 0, st, a);
       else hipLaunchKernelGGL((gemm_nn_ws_kernel<128, 2, 2, false>), gp, bp, 0, st, a);
@@ -1236,7 +1272,17 @@ int check_gather(const kws_gather_t* g, int B, int N) {
 
 extern "C" {
 
-int kws_gemm_num_row_tiles(int64_t M) { return (int)ceil_div64(M, 128); }
+int kws_gemm_num_row_tiles(int64_t M) {
+  const int64_t t = ceil_div64(M, 128);
+  return (int)(t > 256 ? t : 256);
+}
+
+int kws_gemm_nn_stats_rows(int64_t M, int K, int N) {
+  const NNPlan pl = nn_plan(M, K, N, false);
+  return pl.ws ? pl.wgs : pl.m_tiles;
+}
+
+int kws_gemm_gather_stats_rows(int64_t M) { return (int)ceil_div64(M, 128); }
 
 int kws_gemm_nn_f32(const float* A, const float* W, float* C, int64_t M, int K, int N, float* stats_part,
                     void* stream) {

@@ -342,7 +342,7 @@ int kws_net_train_fwd_bwd(const kws_net_t* net, const float* params, float* stat
   {
     const int64_t M = (int64_t)B * net->L1;
     KWS_TRY(kws_gemm_gather_f32(x, &net->gather1, params + net->conv1, ws + lo.y[0], B, net->C1, part, st));
-    KWS_TRY(kws_bn_stats_finalize(part, kws_gemm_num_row_tiles(M), M, net->C1, params + net->bn1.gamma,
+    KWS_TRY(kws_bn_stats_finalize(part, kws_gemm_gather_stats_rows(M), M, net->C1, params + net->bn1.gamma,
                                   params + net->bn1.beta, BN_EPS, BN_MOMENTUM, state + net->bn1.mm, state + net->bn1.mv,
                                   bn_at(0), red, st));
   }
@@ -352,7 +352,7 @@ int kws_net_train_fwd_bwd(const kws_net_t* net, const float* params, float* stat
     KWS_TRY(kws_dwconv_fwd_f32(ws + lo.y[i], bn_at(i), params + b.dw, ws + lo.z[i], B, b.Lin, b.Lout, b.cin, b.stride,
                                b.pad_l, st));
     KWS_TRY(kws_gemm_nn_f32(ws + lo.z[i], params + b.pw, ws + lo.y[i + 1], M, b.cin, b.cout, part, st));
-    KWS_TRY(kws_bn_stats_finalize(part, kws_gemm_num_row_tiles(M), M, b.cout, params + b.bn.gamma, params + b.bn.beta,
+    KWS_TRY(kws_bn_stats_finalize(part, kws_gemm_nn_stats_rows(M, b.cin, b.cout), M, b.cout, params + b.bn.gamma, params + b.bn.beta,
                                   BN_EPS, BN_MOMENTUM, state + b.bn.mm, state + b.bn.mv, bn_at(i + 1), red, st));
   }
   // ---------------- tail forward + backward ----------------

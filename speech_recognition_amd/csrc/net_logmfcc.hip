@@ -126,9 +126,9 @@ struct Ctx {
 };
 
 // BN statistics -> table (training) or moving statistics -> table (inference)
-int bn_table(const Ctx& c, const BnRef& r, int idx, int64_t M) {
+int bn_table(const Ctx& c, const BnRef& r, int idx, int64_t M, int stat_rows) {
   if (c.training)
-    return kws_bn_stats_finalize(c.ws + c.lo.part, kws_gemm_num_row_tiles(M), M, r.C, c.params + r.gamma,
+    return kws_bn_stats_finalize(c.ws + c.lo.part, stat_rows, M, r.C, c.params + r.gamma,
                                  c.params + r.beta, KWS_BN_EPS, KWS_BN_MOMENTUM, c.state + r.mm, c.state + r.mv,
                                  c.bn_at(idx), c.ws + c.lo.red, c.st);
   return kws_bn_infer_prepare(c.params + r.gamma, c.params + r.beta, c.state + r.mm, c.state + r.mv, KWS_BN_EPS, r.C,
@@ -142,7 +142,7 @@ int forward(const Ctx& c, const float* x, kws_lm_tail_args* t) {
   const int B = c.B;
   float* stats = c.training ? ws + lo.part : nullptr;
   KWS_TRY(kws_gemm_gather_f32(x, &p.g0, c.params + p.conv1, ws + lo.y0, B, p.C0, stats, c.st));
-  KWS_TRY(bn_table(c, p.bn0, 1, (int64_t)B * p.L0));
+  KWS_TRY(bn_table(c, p.bn0, 1, (int64_t)B * p.L0, kws_gemm_gather_stats_rows((int64_t)B * p.L0)));
   KWS_TRY(kws_bn_relu6_apply(ws + lo.y0, c.bn_at(1), ws + lo.a0, (int64_t)B * p.L0, p.C0, 1, c.st));
   const float* xin = ws + lo.a0;
   for (size_t i = 0; i < p.blocks.size(); ++i) {
@@ -150,15 +150,15 @@ int forward(const Ctx& c, const float* x, kws_lm_tail_args* t) {
     const int64_t M = (int64_t)B * b.Lin;
     if (b.has_short) {
       KWS_TRY(kws_gemm_gather_f32(xin, &b.gs, c.params + b.ws, ws + lo.ys[i], B, b.nf, stats, c.st));
-      KWS_TRY(bn_table(c, b.bns, b.bns_idx, (int64_t)B * b.Lout));
+      KWS_TRY(bn_table(c, b.bns, b.bns_idx, (int64_t)B * b.Lout, kws_gemm_gather_stats_rows((int64_t)B * b.Lout)));
     }
     KWS_TRY(kws_dwconv_fwd_f32(xin, nullptr, c.params + b.dw1, ws + lo.z1[i], B, b.Lin, b.Lin, b.cin, 1, 1, c.st));
     KWS_TRY(kws_gemm_nn_f32(ws + lo.z1[i], c.params + b.pw1, ws + lo.y1[i], M, b.cin, b.nf, stats, c.st));
-    KWS_TRY(bn_table(c, b.bn1, b.bn1_idx, M));
+    KWS_TRY(bn_table(c, b.bn1, b.bn1_idx, M, kws_gemm_nn_stats_rows(M, b.cin, b.nf)));
     KWS_TRY(kws_dwconv_fwd_f32(ws + lo.y1[i], c.bn_at(b.bn1_idx), c.params + b.dw2, ws + lo.z2[i], B, b.Lin, b.Lin,
                                b.nf, 1, 1, c.st));
     KWS_TRY(kws_gemm_nn_f32(ws + lo.z2[i], c.params + b.pw2, ws + lo.y2[i], M, b.nf, b.nf, stats, c.st));
-    KWS_TRY(bn_table(c, b.bn2, b.bn2_idx, M));
+    KWS_TRY(bn_table(c, b.bn2, b.bn2_idx, M, kws_gemm_nn_stats_rows(M, b.nf, b.nf)));
     KWS_TRY(kws_block_out_fwd(ws + lo.y2[i], c.bn_at(b.bn2_idx), b.has_short ? ws + lo.ys[i] : xin,
                               b.has_short ? c.bn_at(b.bns_idx) : nullptr, ws + lo.o[i], B, b.Lin, b.nf, b.stride, c.st));
     xin = ws + lo.o[i];

@@ -357,26 +357,57 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__
   for (int k = 1; k < S; ++k) s += in[(int64_t)k * n + i];
   out[i] = s;
 }
-__global__ __launch_bounds__(64) void colsum_kernel(const float* __restrict__ D, float* __restrict__ out, int B, int N) {
-  const int k = threadIdx.x;
-  if (k >= N) return;
-  float s = 0.f;
-  for (int b = 0; b < B; ++b) s += D[(int64_t)b * N + k];
-  out[k] = s;
+// out[k] = sum_b D[b, k]: KP columns x 256/KP row groups, each group sums its rows b = g, g+G, ... in
+// ascending order, the groups are combined in ascending order (fixed order, one workgroup).
+template <int KP>
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ D, float* __restrict__ out, int B, int N) {
+  constexpr int G = 256 / KP;
+  __shared__ float red[G][KP];
+  const int k = threadIdx.x % KP, g = threadIdx.x / KP;
+  float s0 = 0.f, s1 = 0.f;
+  if (k < N) {
+    int b = g;
+    for (; b + G < B; b += 2 * G) {
+      s0 += D[(int64_t)b * N + k];
+      s1 += D[(int64_t)(b + G) * N + k];
+    }
+    if (b < B) s0 += D[(int64_t)b * N + k];
+  }
+  red[g][k] = s0 + s1;
+  __syncthreads();
+  if (g == 0 && k < N) {
+    float s = red[0][k];
+    for (int q = 1; q < G; ++q) s += red[q][k];
+    out[k] = s;
+  }
 }
-// metrics[0] = sum per_loss, metrics[1] = sum per_correct (fixed order)
-__global__ __launch_bounds__(64) void metrics_kernel(const float* per_loss, const float* per_correct, int B,
-                                                     float* metrics) {
+// metrics[0] = sum per_loss (double accumulation), metrics[1] = sum per_correct: thread t sums elements
+// t, t+256, ... and the 256 partials are combined in ascending order (fixed order, one workgroup).
+__global__ __launch_bounds__(256) void metrics_kernel(const float* per_loss, const float* per_correct, int B,
+                                                      float* metrics) {
+  __shared__ double rl[256];
+  __shared__ float rc[256];
+  double sl = 0.0;
+  float sc = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    sl += (double)per_loss[b];
+    sc += per_correct[b];
+  }
+  rl[threadIdx.x] = sl;
+  rc[threadIdx.x] = sc;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) {
+      rl[threadIdx.x] += rl[threadIdx.x + w];
+      rc[threadIdx.x] += rc[threadIdx.x + w];
+    }
+    __syncthreads();
+  }
   if (threadIdx.x == 0) {
-    double s = 0.0;
-    for (int b = 0; b < B; ++b) s += (double)per_loss[b];
-    metrics[0] = (float)s;
-  } else if (threadIdx.x == 1) {
-    float s = 0.f;
-    for (int b = 0; b < B; ++b) s += per_correct[b];
-    metrics[1] = s;
-  } else if (threadIdx.x < 4) {
-    metrics[threadIdx.x] = 0.f;
+    metrics[0] = (float)rl[0];
+    metrics[1] = rc[0];
+    metrics[2] = 0.f;
+    metrics[3] = 0.f;
   }
 }
 
@@ -440,14 +471,15 @@ int kws_small_wgrad_launch(const float* X, const float* D, float* out, float* ou
   }
   if (out_bias) {
     KWS_REQUIRE(N <= 64, "small_wgrad: N=%d > 64", N);
-    hipLaunchKernelGGL(colsum_kernel, dim3(1), dim3(64), 0, st, D, out_bias, B, N);
+    if (N <= 16) hipLaunchKernelGGL(colsum_kernel<16>, dim3(1), dim3(256), 0, st, D, out_bias, B, N);
+    else hipLaunchKernelGGL(colsum_kernel<64>, dim3(1), dim3(256), 0, st, D, out_bias, B, N);
     KWS_LAUNCH_CHECK("colsum_kernel");
   }
   return KWS_OK;
 }
 
 int kws_metrics_launch(const float* per_loss, const float* per_correct, int B, float* metrics, hipStream_t st) {
-  hipLaunchKernelGGL(metrics_kernel, dim3(1), dim3(64), 0, st, per_loss, per_correct, B, metrics);
+  hipLaunchKernelGGL(metrics_kernel, dim3(1), dim3(256), 0, st, per_loss, per_correct, B, metrics);
   KWS_LAUNCH_CHECK("metrics_kernel");
   return KWS_OK;
 }

@@ -54,13 +54,17 @@ def test_gemm_nn_and_stats(M, K, N):
     W = (rng.randn(K, N) * 0.1).astype(np.float32)
     dA, dW = dev(A), dev(W)
     C = torch.full((M, N), float("nan"), device="cuda")
-    nt = _lib.load().kws_gemm_num_row_tiles(M)
+    nt = _lib.load().kws_gemm_num_row_tiles(M)              # buffer bound
+    rows = _lib.load().kws_gemm_nn_stats_rows(M, K, N)      # rows this shape writes
+    assert 0 < rows <= nt
     part = torch.full((nt, 2, N), float("nan"), device="cuda")
     _lib.call("kws_gemm_nn_f32", _lib.ptr(dA), _lib.ptr(dW), _lib.ptr(C), M, K, N, _lib.ptr(part), S())
     ref = A.astype(np.float64) @ W.astype(np.float64)
     got = C.cpu().numpy()
     assert rel_err(got, ref) < 2e-6          # f32 MFMA fma chain vs f64
     p = part.cpu().numpy().astype(np.float64)
+    assert np.isfinite(p[:rows]).all() and np.isnan(p[rows:]).all()   # exactly `rows` rows are written
+    p = p[:rows]
     np.testing.assert_allclose(p[:, 0].sum(0), ref.sum(0), rtol=0, atol=2e-4 * np.abs(ref).sum(0).max())
     np.testing.assert_allclose(p[:, 1].sum(0), (ref ** 2).sum(0), rtol=2e-5)
     # no-stats variant gives the same C
@@ -190,11 +194,12 @@ def test_bn_stats_finalize_and_apply():
     mv = (1 + rng.rand(N)).astype(np.float32)
     y = torch.empty((M, N), device="cuda")
     nt = _lib.load().kws_gemm_num_row_tiles(M)
-    part = torch.empty((nt, 2, N), device="cuda")
+    rows = _lib.load().kws_gemm_nn_stats_rows(M, K, N)
+    part = torch.full((nt, 2, N), float("nan"), device="cuda")
     _lib.call("kws_gemm_nn_f32", _lib.ptr(dev(A)), _lib.ptr(dev(W)), _lib.ptr(y), M, K, N, _lib.ptr(part), S())
     bn = torch.empty(4 * N, device="cuda")
     dmm, dmv = dev(mm), dev(mv)
-    _lib.call("kws_bn_stats_finalize", _lib.ptr(part), nt, M, N, _lib.ptr(dev(gamma)), _lib.ptr(dev(beta)), 1e-3, 0.99,
+    _lib.call("kws_bn_stats_finalize", _lib.ptr(part), rows, M, N, _lib.ptr(dev(gamma)), _lib.ptr(dev(beta)), 1e-3, 0.99,
               _lib.ptr(dmm), _lib.ptr(dmv), _lib.ptr(bn), None, S())
     y64 = y.cpu().numpy().astype(np.float64)[None]
     pre, (mean, var, rstd) = OL.bn_train_fwd(y64, gamma.astype(np.float64), beta.astype(np.float64))
