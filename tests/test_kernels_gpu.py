@@ -47,7 +47,12 @@ def _need_gpu():
 
 
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("M,K,N", [(1000, 128, 128), (777, 192, 320), (129, 512, 512), (5, 120, 64), (2560, 384, 192)])
+# shapes: wave-specialised kernel with 1..many tiles per workgroup, idle workgroups, ragged last row tile,
+# nk = 2 (K = 64), 64- and 128-wide column tiles, N = 1024 (its widest statistics row); (5, 120, 64) and
+# (300, 48, 128) fall back to the 4-wave persistent kernel (K % 32 != 0 / K < 64)
+@pytest.mark.parametrize("M,K,N", [(1000, 128, 128), (777, 192, 320), (129, 512, 512), (5, 120, 64), (2560, 384, 192),
+                                   (128, 64, 64), (1, 64, 128), (127, 96, 192), (40000, 64, 128), (33000, 128, 256),
+                                   (4100, 256, 1024), (300, 48, 128), (70000, 160, 64)])
 def test_gemm_nn_and_stats(M, K, N):
     rng = np.random.RandomState(M + K + N)
     A = rng.randn(M, K).astype(np.float32)
@@ -66,7 +71,8 @@ def test_gemm_nn_and_stats(M, K, N):
     assert np.isfinite(p[:rows]).all() and np.isnan(p[rows:]).all()   # exactly `rows` rows are written
     p = p[:rows]
     np.testing.assert_allclose(p[:, 0].sum(0), ref.sum(0), rtol=0, atol=2e-4 * np.abs(ref).sum(0).max())
-    np.testing.assert_allclose(p[:, 1].sum(0), (ref ** 2).sum(0), rtol=2e-5)
+    # (a column whose few products cancel has no relative accuracy of its own: scale the floor by the widest column)
+    np.testing.assert_allclose(p[:, 1].sum(0), (ref ** 2).sum(0), rtol=2e-5, atol=1e-5 * (ref ** 2).sum(0).max())
     # no-stats variant gives the same C
     C2 = torch.empty_like(C)
     _lib.call("kws_gemm_nn_f32", _lib.ptr(dA), _lib.ptr(dW), _lib.ptr(C2), M, K, N, None, S())
