@@ -1086,6 +1086,183 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Wave-specialised TN (wgrad) kernel: the same role split as gemm_nn_ws_kernel.  One workgroup = one
+// (M-split, output tile) work item:
+//   4 MFMA waves: each owns a 64 x 64 accumulator block and 32 rows of every M-stage (a 128 x 128 tile
+//              is 2 x 2 blocks over a 32-row stage; a 128 x 64 / 64 x 128 tile is 2 blocks x 2 row
+//              halves of a 64-row stage; a 64 x 64 tile is 4 row quarters of a 128-row stage), so every
+//              wave issues 64 MFMAs per barrier whatever the tile shape; blocks that were split over rows
+//              are summed through LDS in wave order at the end;
+//   NLW loader waves: a stage is U = 1 / 2 / 4 "units" of 32 rows x (BKO + BNO) columns; unit x is owned by
+//              loader wave x % NLW, written into LDS during the stage before it is used and re-issued
+//              (buffer loads, SGPR row offsets, descriptor range check zero-fills rows past the split)
+//              right after, so each load has about a full stage to land.
+// Host-checked: K % BKO == 0, N % BNO == 0, chunk % 128 == 0, 32-bit byte offsets inside a split.
+template <int BKO, int BNO>
+__global__ __launch_bounds__((4 + ((128 / BKO) * (128 / BNO) > 2 ? 4 : 2)) * 64, 1) void gemm_tn_ws_kernel(TNArgs p) {
+  constexpr int WK = BKO / 64, WN = BNO / 64, WS = 4 / (WK * WN);
+  constexpr int U = WS;                             // 32-row units per stage
+  constexpr int NLW = U > 2 ? 4 : 2;
+  constexpr int NCT = 256;
+  constexpr int COLS = BKO + BNO;
+  constexpr int UNIT = 32 * COLS;                   // floats per unit: Z rows then G rows, row-major [32][COLS]
+  constexpr int SLOT = U * UNIT;
+  constexpr int RED = WS > 1 ? 4 * 64 * 64 : 0;
+  constexpr int SMEM = 2 * SLOT > RED ? 2 * SLOT : RED;
+  static_assert(SMEM * 4 <= 160 * 1024, "LDS budget");
+  __shared__ __attribute__((aligned(16))) float smem[SMEM];
+
+  const int n_out_tiles = p.k_tiles * p.n_tiles;
+  const int xcd = blockIdx.x % NXCD, slot_id = blockIdx.x / NXCD;
+  const int tile = slot_id % n_out_tiles;
+  const int split = (slot_id / n_out_tiles) * NXCD + xcd;
+  if (split >= p.S) return;
+  const int tile_k = tile / p.n_tiles, tile_n = tile % p.n_tiles;
+  const int tid = threadIdx.x;
+  const int k0 = tile_k * BKO, n0 = tile_n * BNO;
+  const int K = p.K, N = p.N;
+  const int64_t m_begin = (int64_t)split * p.chunk;
+  const int64_t m_end = (m_begin + p.chunk < p.M) ? m_begin + p.chunk : p.M;
+  const int rows = (int)(m_end - m_begin);
+  const int G = (rows + 32 * U - 1) / (32 * U);     // stages; barriers per wave: 1 + G (+ 1 when WS > 1)
+
+  if (tid < NCT) {
+    // ------------------------------------------------------------------ MFMA waves
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wms = wave % WS, wkn = wave / WS;
+    const int wk = wkn / WN, wn = wkn % WN;
+    const int li = lane & 31, lh = lane >> 5;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+    __syncthreads();
+    for (int g = 0; g < G; ++g) {
+      // my 32 rows of this stage = unit wms of slot g & 1; lane half lh takes the odd / even row of a pair
+      const float* cz = smem + (g & 1) * SLOT + wms * UNIT + lh * COLS + wk * 64 + li;
+      const float* cg = cz + BKO - wk * 64 + wn * 64;
+      float a0[2], b0[2], a1[2], b1[2];
+      auto ld = [&](float (&a)[2], float (&b)[2], int s) {
+        a[0] = cz[2 * s * COLS];
+        a[1] = cz[2 * s * COLS + 32];
+        b[0] = cg[2 * s * COLS];
+        b[1] = cg[2 * s * COLS + 32];
+      };
+      auto mm = [&](const float (&a)[2], const float (&b)[2]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      };
+      ld(a0, b0, 0);
+      ld(a1, b1, 1);
+#pragma unroll
+      for (int s = 0; s < 16; s += 2) {
+        __builtin_amdgcn_sched_barrier(0);
+        mm(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 2 < 16) ld(a0, b0, s + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 3 < 16) ld(a1, b1, s + 3);
+      }
+      __syncthreads();
+    }
+    float* out = p.ws + (int64_t)split * K * N;
+    if (WS == 1) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int col = n0 + wn * 64 + j * 32 + li;
+#pragma unroll
+          for (int v = 0; v < 16; ++v) {
+            const int row = k0 + wk * 64 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh;
+            out[(int64_t)row * N + col] = acc[i][j][v];
+          }
+        }
+    } else {
+      // the pipeline slots are idle now: every wave parks its block, then the WS waves of a block share its
+      // rows and add the WS copies in wave order
+      float* mine = smem + wave * 4096;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int v = 0; v < 16; ++v)
+            mine[(i * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh) * 64 + j * 32 + li] = acc[i][j][v];
+      __syncthreads();
+      const float* blk = smem + wkn * WS * 4096;
+      const int t = wms * 64 + lane;
+      for (int f4 = t; f4 < 1024; f4 += WS * 64) {
+        float4 s = *reinterpret_cast<const float4*>(blk + f4 * 4);
+#pragma unroll
+        for (int w = 1; w < WS; ++w) {
+          const float4 u = *reinterpret_cast<const float4*>(blk + w * 4096 + f4 * 4);
+          s.x += u.x; s.y += u.y; s.z += u.z; s.w += u.w;
+        }
+        const int row = k0 + wk * 64 + f4 / 16, col = n0 + wn * 64 + (f4 % 16) * 4;
+        *reinterpret_cast<float4*>(out + (int64_t)row * N + col) = s;
+      }
+    }
+  } else {
+    // ------------------------------------------------------------------ loader waves
+    const int lane = tid & 63;
+    const int lw = __builtin_amdgcn_readfirstlane((tid - NCT) >> 6);
+    // one wave instruction loads RZ (RG) whole rows of the unit's Z (G) part: lane -> (row in group, column)
+    constexpr int ZC4 = BKO / 4, GC4 = BNO / 4;     // float4 per Z / G row
+    constexpr int RZ = 64 / ZC4, RG = 64 / GC4;     // rows per instruction: 2 or 4
+    constexpr int Z_F4 = 32 / RZ, G_F4 = 32 / RG;   // instructions per unit: 16 or 8 each
+    const int zrow = lane / ZC4, zc = (lane % ZC4) * 4;
+    const int grow = lane / GC4, gc = (lane % GC4) * 4;
+    const int z_voff = (zrow * K + k0 + zc) * 4, g_voff = (grow * N + n0 + gc) * 4;
+    const __amdgpu_buffer_rsrc_t zres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.A + m_begin * K), 0, rows * K * 4, KWS_BUFFER_RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t gres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.G + m_begin * N), 0, rows * N * 4, KWS_BUFFER_RSRC_FLAGS);
+    float4 rz[Z_F4], rg[G_F4];
+    auto issue = [&](int x) {                       // unit x = rows [32 x, 32 x + 32) of my split
+#pragma unroll
+      for (int r = 0; r < Z_F4; ++r) rz[r] = buf_ld4(zres, z_voff, (x * 32 + RZ * r) * K * 4);
+#pragma unroll
+      for (int r = 0; r < G_F4; ++r) rg[r] = buf_ld4(gres, g_voff, (x * 32 + RG * r) * N * 4);
+    };
+    auto write_lds = [&](int x) {
+      float* dst = smem + ((x / U) & 1) * SLOT + (x % U) * UNIT;
+      float* dz = dst + zrow * COLS + zc;
+      float* dg = dst + grow * COLS + BKO + gc;
+#pragma unroll
+      for (int r = 0; r < Z_F4; ++r) *reinterpret_cast<float4*>(dz + RZ * r * COLS) = rz[r];
+#pragma unroll
+      for (int r = 0; r < G_F4; ++r) *reinterpret_cast<float4*>(dg + RG * r * COLS) = rg[r];
+    };
+    int x = lw;                                     // my next unit
+    if (x < U) {
+      issue(x);
+      write_lds(x);
+      x += NLW;
+    }
+    issue(x);
+    __syncthreads();
+    for (int g = 0; g < G; ++g) {
+      if (x / U == g + 1) {                         // my unit belongs to the next stage: write it, re-issue
+        write_lds(x);
+        x += NLW;
+        issue(x);
+      }
+      __syncthreads();
+    }
+    if (WS > 1) __syncthreads();
+  }
+}
+
 // out[i] = sum_k ws[k][i], k ascending within 4 interleaved groups that are combined in a fixed order
 // (bit-reproducible).  64 float4 columns x 4 slab groups per workgroup so that the S slabs of the small
 // K x N outputs are read by S/4-deep loops on many workgroups instead of S-deep loops on a few.
@@ -1139,23 +1316,34 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* in, float* 
 
 // split heuristic of the TN kernel: enough workgroups to fill 256 CUs, slabs no larger than needed
 struct TNPlan {
-  int bko;  // 128 or 64 (square tiles)
+  int bko, bno;  // 128 or 64 each
   int k_tiles, n_tiles, S;
   int64_t chunk;
 };
-TNPlan tn_plan(int64_t M, int K, int N) {
+// ws: the wave-specialised kernel (tile width chosen per dimension); otherwise the 4-wave kernel (square tiles)
+bool tn_ws_eligible(int K, int N, bool gather) {
+  static const bool no_ws = getenv("KWS_GEMM_TN_V1") != nullptr;   // 4-wave kernel, A/B only
+  return !gather && !no_ws && K % 64 == 0 && N % 64 == 0;
+}
+TNPlan tn_plan(int64_t M, int K, int N, bool ws) {
   TNPlan pl;
-  pl.bko = (K % 128 == 0 && N % 128 == 0) ? 128 : 64;
+  if (ws) {
+    pl.bko = (K % 128 == 0) ? 128 : 64;
+    pl.bno = (N % 128 == 0) ? 128 : 64;
+  } else {
+    pl.bko = pl.bno = (K % 128 == 0 && N % 128 == 0) ? 128 : 64;
+  }
   pl.k_tiles = ceil_div(K, pl.bko);
-  pl.n_tiles = ceil_div(N, pl.bko);
+  pl.n_tiles = ceil_div(N, pl.bno);
   const int tiles = pl.k_tiles * pl.n_tiles;
   int64_t S = ceil_div64(768, tiles);   // ~3 workgroups per CU in flight
-  if (S > 256) S = 256;                 // bounds the partial-slab traffic (S * K * N floats)
+  static const int max_s = getenv("KWS_TN_MAX_S") ? atoi(getenv("KWS_TN_MAX_S")) : 256;
+  if (S > max_s) S = max_s;             // bounds the partial-slab traffic (S * K * N floats)
   const int64_t maxS = M / 256 > 1 ? M / 256 : 1;
   if (S > maxS) S = maxS;
   if (S < 1) S = 1;
-  int64_t chunk = ceil_div64(ceil_div64(M, S), MS) * MS;
-  if (chunk < MS) chunk = MS;
+  int64_t chunk = ceil_div64(ceil_div64(M, S), 128) * 128;   // whole stages of every tile shape (32 / 64 / 128 rows)
+  if (chunk < 128) chunk = 128;
   pl.chunk = chunk;
   pl.S = (int)ceil_div64(M > 0 ? M : 1, chunk);
   return pl;
@@ -1242,14 +1430,24 @@ int launch_nn(const NNArgs& a0, hipStream_t st) {
 
 template <bool GATHER>
 int launch_tn(TNArgs a, float* dW, hipStream_t st) {
-  const TNPlan pl = tn_plan(a.M, a.K, a.N);
+  bool ws_ok = tn_ws_eligible(a.K, a.N, GATHER);
+  const TNPlan pl = tn_plan(a.M, a.K, a.N, ws_ok);
+  ws_ok = ws_ok && pl.chunk * (int64_t)(a.K > a.N ? a.K : a.N) * 4 < (1ll << 31);   // 32-bit offsets inside a split
   a.chunk = pl.chunk;
   a.k_tiles = pl.k_tiles;
   a.n_tiles = pl.n_tiles;
   a.S = pl.S;
   dim3 g((unsigned)(pl.k_tiles * pl.n_tiles * ceil_div(pl.S, NXCD) * NXCD)), b(256);
-  if (pl.bko == 128) hipLaunchKernelGGL((gemm_tn_kernel<128, 128, GATHER>), g, b, 0, st, a);
-  else hipLaunchKernelGGL((gemm_tn_kernel<64, 64, GATHER>), g, b, 0, st, a);
+  if (ws_ok) {
+    if (pl.bko == 128 && pl.bno == 128) hipLaunchKernelGGL((gemm_tn_ws_kernel<128, 128>), g, dim3(6 * 64), 0, st, a);
+    else if (pl.bko == 128) hipLaunchKernelGGL((gemm_tn_ws_kernel<128, 64>), g, dim3(6 * 64), 0, st, a);
+    else if (pl.bno == 128) hipLaunchKernelGGL((gemm_tn_ws_kernel<64, 128>), g, dim3(6 * 64), 0, st, a);
+    else hipLaunchKernelGGL((gemm_tn_ws_kernel<64, 64>), g, dim3(8 * 64), 0, st, a);
+  } else if (pl.bko == 128) {
+    hipLaunchKernelGGL((gemm_tn_kernel<128, 128, GATHER>), g, b, 0, st, a);
+  } else {
+    hipLaunchKernelGGL((gemm_tn_kernel<64, 64, GATHER>), g, b, 0, st, a);
+  }
   KWS_LAUNCH_CHECK("gemm_tn_kernel");
   const int64_t n4 = (int64_t)a.K * a.N / 4;
   hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)ceil_div64(n4, 64)), dim3(256), 0, st, a.ws, dW, n4, pl.S);
@@ -1307,8 +1505,9 @@ int kws_gemm_gather_f32(const float* X, const kws_gather_t* g, const float* W, f
 }
 
 int64_t kws_gemm_tn_workspace_floats(int64_t M, int K, int N) {
-  const TNPlan pl = tn_plan(M, K, N);
-  return (int64_t)pl.S * K * N;
+  // callers size one buffer for the plain and the gathered call: the larger of the two plans
+  const int s_plain = tn_plan(M, K, N, tn_ws_eligible(K, N, false)).S, s_gather = tn_plan(M, K, N, false).S;
+  return (int64_t)(s_plain > s_gather ? s_plain : s_gather) * K * N;
 }
 
 int kws_gemm_tn_f32(const float* A, const float* G, float* dW, int64_t M, int K, int N, float* workspace,
