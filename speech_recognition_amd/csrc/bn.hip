@@ -7,7 +7,7 @@
 namespace {
 
 // finalise kernels: 256 threads = FIN_CG channels x FIN_RG row groups; up to 256 partial rows are summed
-// directly (<= 16 per thread), row group r takes rows r, r+FIN_RG, ... and the groups are combined in order
+// directly (<= 16 per thread; more rows with only C/16 workgroups is latency-bound: 2048 rows took 35 us), row group r takes rows r, r+FIN_RG, ... and the groups are combined in order
 constexpr int FIN_CG = 16, FIN_RG = 16;
 
 // part[n_tiles][2][C] -> bn[4C] = scale | shift | mean | rstd ; moving stats update in place.
@@ -194,7 +194,7 @@ int kws_bn_stats_finalize(const float* stats_part, int n_tiles, int64_t count, i
   const float omm = (float)(1.0 - (double)momentum);
   KwsProfScope prof("bn_finalize", 0.0, 8.0 * n_tiles * C, (hipStream_t)stream);
   KWS_TRY(pre_reduce(stats_part, n_tiles, 2 * C, scratch, (hipStream_t)stream, &stats_part, &n_tiles));
-  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((unsigned)ceil_div(C, FIN_CG)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((unsigned)ceil_div(C, FIN_CG)), dim3(FIN_CG * FIN_RG), 0, (hipStream_t)stream,
                      stats_part, n_tiles, 1.0 / (double)count, C, gamma, beta, eps, omm, moving_mean, moving_var, bn);
   KWS_LAUNCH_CHECK("bn_stats_finalize_kernel");
   return KWS_OK;
@@ -223,7 +223,7 @@ int kws_dw_bwd_finalize(const float* part, int n_parts, int64_t count, int C, fl
   KWS_REQUIRE(part && n_parts > 0 && count > 0 && C > 0, "dw_bwd_finalize: bad arguments");
   KwsProfScope prof("bn_finalize", 0.0, 20.0 * n_parts * C, (hipStream_t)stream);
   KWS_TRY(pre_reduce(part, n_parts, 5 * C, scratch, (hipStream_t)stream, &part, &n_parts));
-  hipLaunchKernelGGL(dw_bwd_finalize_kernel, dim3((unsigned)ceil_div(C, FIN_CG)), dim3(256), 0, (hipStream_t)stream, part,
+  hipLaunchKernelGGL(dw_bwd_finalize_kernel, dim3((unsigned)ceil_div(C, FIN_CG)), dim3(FIN_CG * FIN_RG), 0, (hipStream_t)stream, part,
                      n_parts, 1.0 / (double)count, C, dw, dgamma, dbeta, coef);
   KWS_LAUNCH_CHECK("dw_bwd_finalize_kernel");
   return KWS_OK;

@@ -92,21 +92,25 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const float* __restrict
   const int tid = threadIdx.x;
   const int r = tid / C4, c4 = tid - r * C4;
   const int c = c4 * 4;
-  const int64_t unit = (int64_t)blockIdx.x * R + r;
-  const int64_t b = unit / nchunks;
-  const int chunk = (int)(unit - b * nchunks);
   float4 sg = f4_zero(), sgx = f4_zero(), sw0 = f4_zero(), sw1 = f4_zero(), sw2 = f4_zero();
-  if (b < B) {
-    float4 sc = f4_zero(), sh = f4_zero(), mean = f4_zero(), rstd = f4_zero();
-    if (HAS_BN) {
-      sc = *reinterpret_cast<const float4*>(bn + c);
-      sh = *reinterpret_cast<const float4*>(bn + C + c);
-      mean = *reinterpret_cast<const float4*>(bn + 2 * C + c);
-      rstd = *reinterpret_cast<const float4*>(bn + 3 * C + c);
-    }
-    const float4 w0 = *reinterpret_cast<const float4*>(w + c);
-    const float4 w1 = *reinterpret_cast<const float4*>(w + C + c);
-    const float4 w2 = *reinterpret_cast<const float4*>(w + 2 * C + c);
+  float4 sc = f4_zero(), sh = f4_zero(), mean = f4_zero(), rstd = f4_zero();
+  if (HAS_BN) {
+    sc = *reinterpret_cast<const float4*>(bn + c);
+    sh = *reinterpret_cast<const float4*>(bn + C + c);
+    mean = *reinterpret_cast<const float4*>(bn + 2 * C + c);
+    rstd = *reinterpret_cast<const float4*>(bn + 3 * C + c);
+  }
+  const float4 w0 = *reinterpret_cast<const float4*>(w + c);
+  const float4 w1 = *reinterpret_cast<const float4*>(w + C + c);
+  const float4 w2 = *reinterpret_cast<const float4*>(w + 2 * C + c);
+  // grid-stride over the (clip, time-chunk) units: the grid is capped so that a launch leaves at most
+  // KWS_DW_BWD_MAX_PARTS partial rows (summed per thread in unit order), which kws_dw_bwd_finalize folds
+  // without a pre-reduction pass
+  for (int64_t ub = blockIdx.x; ub * R < (int64_t)B * nchunks; ub += gridDim.x) {
+    const int64_t unit = ub * R + r;
+    const int64_t b = unit / nchunks;
+    const int chunk = (int)(unit - b * nchunks);
+    if (b >= B) continue;
     const float* yb = y + b * (int64_t)Lin * C + c;
     float* gb = g + b * (int64_t)Lin * C + c;
     const float* dzb = dz + b * (int64_t)Lout * C + c;
@@ -179,6 +183,9 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const float* __restrict
   }
 }
 
+// measured at batch 1024 (ms per step, dwconv_bwd + finalisation): 256 rows 1.37, 512 1.02, 1024 0.86, 2048 0.91,
+// uncapped (6400) 1.03: four resident workgroups per CU stream best and leave few rows to fold
+constexpr int KWS_DW_BWD_MAX_PARTS = 1024;
 struct BwdGeom {
   int nchunks, R, block;
   int64_t grid;
@@ -191,6 +198,7 @@ BwdGeom bwd_geom(int B, int Lin, int C) {
   if (g.R < 1) g.R = 1;
   g.block = g.R * C4;
   g.grid = ceil_div64((int64_t)B * g.nchunks, g.R);
+  if (g.grid > KWS_DW_BWD_MAX_PARTS) g.grid = KWS_DW_BWD_MAX_PARTS;
   return g;
 }
 
