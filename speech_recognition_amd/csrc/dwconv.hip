@@ -21,61 +21,66 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict
                                                          const float* __restrict__ w, float* __restrict__ z,
                                                          int B, int Lin, int Lout, int C, int pad_l, int nchunks) {
   const int C4 = C >> 2;
-  const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int c4 = (int)(id % C4);
-  const int64_t rest = id / C4;
-  const int chunk = (int)(rest % nchunks);
-  const int64_t b = rest / nchunks;
-  if (b >= B) return;
-  const int c = c4 * 4;
-  float4 sc = f4_zero(), sh = f4_zero();
-  if (HAS_BN) {
-    sc = *reinterpret_cast<const float4*>(bn + c);
-    sh = *reinterpret_cast<const float4*>(bn + C + c);
-  }
-  const float4 w0 = *reinterpret_cast<const float4*>(w + c);
-  const float4 w1 = *reinterpret_cast<const float4*>(w + C + c);
-  const float4 w2 = *reinterpret_cast<const float4*>(w + 2 * C + c);
-  const float* yb = y + b * (int64_t)Lin * C + c;
-  float* zb = z + b * (int64_t)Lout * C + c;
-  auto act = [&](int u) -> float4 {
-    if (u < 0 || u >= Lin) return f4_zero();
-    float4 v = *reinterpret_cast<const float4*>(yb + (int64_t)u * C);
+  const int64_t total = (int64_t)B * nchunks * C4;
+  // grid-stride over (clip, time chunk, channel quad) units with a capped grid: a few resident workgroups per
+  // CU that keep streaming beat tens of thousands of short-lived ones (same finding as dwconv_bwd)
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+    const int c4 = (int)(id % C4);
+    const int64_t rest = id / C4;
+    const int chunk = (int)(rest % nchunks);
+    const int64_t b = rest / nchunks;
+    const int c = c4 * 4;
+    float4 sc = f4_zero(), sh = f4_zero();
     if (HAS_BN) {
-      v.x = relu6f(fmaf(v.x, sc.x, sh.x));
-      v.y = relu6f(fmaf(v.y, sc.y, sh.y));
-      v.z = relu6f(fmaf(v.z, sc.z, sh.z));
-      v.w = relu6f(fmaf(v.w, sc.w, sh.w));
+      sc = *reinterpret_cast<const float4*>(bn + c);
+      sh = *reinterpret_cast<const float4*>(bn + C + c);
     }
-    return v;
-  };
-  const int t0 = chunk * TT;
-  float4 a0 = f4_zero(), a1 = f4_zero(), a2;
-#pragma unroll
-  for (int i = 0; i < TT; ++i) {
-    const int t = t0 + i;
-    if (t >= Lout) break;
-    const int u = S * t - pad_l;
-    if (S == 1) {
-      if (i == 0) {
-        a0 = act(u);
-        a1 = act(u + 1);
+    const float4 w0 = *reinterpret_cast<const float4*>(w + c);
+    const float4 w1 = *reinterpret_cast<const float4*>(w + C + c);
+    const float4 w2 = *reinterpret_cast<const float4*>(w + 2 * C + c);
+    const float* yb = y + b * (int64_t)Lin * C + c;
+    float* zb = z + b * (int64_t)Lout * C + c;
+    // SAME padding pads the ACTIVATION with zeros: the load is unconditional (a branch per load would put a
+    // vmcnt(0) wait behind each one), out-of-range taps read position 0 and are zeroed after the activation
+    auto act = [&](int u) -> float4 {
+      const bool ok = u >= 0 && u < Lin;
+      float4 v = *reinterpret_cast<const float4*>(yb + (int64_t)(ok ? u : 0) * C);
+      if (HAS_BN) {
+        v.x = relu6f(fmaf(v.x, sc.x, sh.x));
+        v.y = relu6f(fmaf(v.y, sc.y, sh.y));
+        v.z = relu6f(fmaf(v.z, sc.z, sh.z));
+        v.w = relu6f(fmaf(v.w, sc.w, sh.w));
       }
-      a2 = act(u + 2);
-    } else {
-      if (i == 0) a0 = act(u);
-      a1 = act(u + 1);
-      a2 = act(u + 2);
-    }
-    float4 o = f4_mul(w0, a0);
-    o = f4_fma(w1, a1, o);
-    o = f4_fma(w2, a2, o);
-    *reinterpret_cast<float4*>(zb + (int64_t)t * C) = o;
-    if (S == 1) {
-      a0 = a1;
-      a1 = a2;
-    } else {
-      a0 = a2;
+      return ok ? v : f4_zero();
+    };
+    const int t0 = chunk * TT;
+    float4 a0 = f4_zero(), a1 = f4_zero(), a2;
+#pragma unroll
+    for (int i = 0; i < TT; ++i) {
+      const int t = t0 + i;
+      if (t >= Lout) break;
+      const int u = S * t - pad_l;
+      if (S == 1) {
+        if (i == 0) {
+          a0 = act(u);
+          a1 = act(u + 1);
+        }
+        a2 = act(u + 2);
+      } else {
+        if (i == 0) a0 = act(u);
+        a1 = act(u + 1);
+        a2 = act(u + 2);
+      }
+      float4 o = f4_mul(w0, a0);
+      o = f4_fma(w1, a1, o);
+      o = f4_fma(w2, a2, o);
+      *reinterpret_cast<float4*>(zb + (int64_t)t * C) = o;
+      if (S == 1) {
+        a0 = a1;
+        a1 = a2;
+      } else {
+        a0 = a2;
+      }
     }
   }
 }
@@ -215,8 +220,8 @@ int kws_dwconv_fwd_f32(const float* y, const float* bn, const float* w, float* z
   KWS_REQUIRE(pad_l >= 0 && stride * (L_out - 1) + 2 - pad_l < L_in + 2, "dwconv_fwd: geometry reads past padding");
   const int nchunks = ceil_div(L_out, TT);
   const int64_t threads = (int64_t)B * nchunks * (C / 4);
-  const int64_t grid = ceil_div64(threads, 256);
-  KWS_REQUIRE(grid < 0x7FFFFFFF, "dwconv_fwd: grid too large");
+  int64_t grid = ceil_div64(threads, 256);
+  if (grid > 4096) grid = 4096;   // grid-stride; 1024 .. uncapped measured within noise of each other
   dim3 g((unsigned)grid), b(256);
   hipStream_t st = (hipStream_t)stream;
   KwsProfScope prof("dwconv_fwd", 6.0 * B * L_out * C, 4.0 * ((double)B * L_in * C + (double)B * L_out * C), st);
