@@ -23,8 +23,12 @@ out = []
 for M, K, N in shapes:
     A = torch.randn(M, K, device='cuda'); W = torch.randn(K, N, device='cuda') * 0.1; C = torch.empty(M, N, device='cuda')
     part = torch.empty(lib.kws_gemm_num_row_tiles(M) * 2 * N, device='cuda')
-    t1 = timeit(lambda: _lib.call("kws_gemm_nn_f32", _lib.ptr(A), _lib.ptr(W), _lib.ptr(C), M, K, N, _lib.ptr(part), S))
-    t2 = timeit(lambda: _lib.call("kws_gemm_nn_f32", _lib.ptr(A), _lib.ptr(W), _lib.ptr(C), M, K, N, None, S))
+    f_stats = lambda: _lib.call("kws_gemm_nn_f32", _lib.ptr(A), _lib.ptr(W), _lib.ptr(C), M, K, N, _lib.ptr(part), S)
+    f_plain = lambda: _lib.call("kws_gemm_nn_f32", _lib.ptr(A), _lib.ptr(W), _lib.ptr(C), M, K, N, None, S)
+    if os.environ.get("PLAIN_FIRST"):
+        t2 = timeit(f_plain); t1 = timeit(f_stats)
+    else:
+        t1 = timeit(f_stats); t2 = timeit(f_plain)
     f = 2.0 * M * K * N
     out.append("K=%d: %.0f/%.0f us (%.0f/%.0f TF)" % (K, t1 * 1e3, t2 * 1e3, f / t1 / 1e9, f / t2 / 1e9))
 print(os.environ.get("KWS_LIB_PATH", "default"), " | ".join(out))

@@ -564,8 +564,12 @@ __device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, int voff, in
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
-template <int BN, int NLW, int NSW, bool STATS>
+// KB = K-slab depth per barrier: 32 for the 128-wide column tiles; the 64-wide tiles (N = 192, 320) take 64 so
+// that an MFMA wave still issues 64 MFMAs per barrier (LDS: 2 x 50.8 KB slots + 34.8 KB staging).
+template <int BN, int KB, int NLW, int NSW, bool STATS>
 __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNArgs p) {
+  constexpr int PBK = KB, PLDA = KB + 4;            // shadow the 32-deep constants of the 4-wave kernels
+  constexpr int NQ = KB / 8;                        // 8-deep k-groups per slab
   constexpr int BM = 128, WM = 2, WN = 2;
   constexpr int NCT = WM * WN * 64;                 // compute threads
   constexpr int NLT = NLW * 64;                     // loader threads
@@ -741,17 +745,17 @@ __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNA
         Frag f0, f1;
         load_frag(f0, 0);
         load_frag(f1, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(f0);
-        __builtin_amdgcn_sched_barrier(0);
-        load_frag(f0, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(f1);
-        __builtin_amdgcn_sched_barrier(0);
-        load_frag(f1, 3);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(f0);
-        mma(f1);
+#pragma unroll
+        for (int q = 0; q < NQ; q += 2) {           // fragments of k-group q+2 / q+3 fly under the MFMAs of q / q+1
+          __builtin_amdgcn_sched_barrier(0);
+          mma(f0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (q + 2 < NQ) load_frag(f0, q + 2);
+          __builtin_amdgcn_sched_barrier(0);
+          mma(f1);
+          __builtin_amdgcn_sched_barrier(0);
+          if (q + 3 < NQ) load_frag(f1, q + 3);
+        }
         __builtin_amdgcn_sched_barrier(0);
         WT(t_mma);
         if (have_prev) {
@@ -807,7 +811,8 @@ __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNA
     // ------------------------------------------------------------------ loader waves
     const int lane = tid & 63;
     const int lw = __builtin_amdgcn_readfirstlane((tid - NCT) >> 6);   // my slabs: s = lw (mod NLW)
-    const int arow = lane / PBK4;                   // + 8 r
+    constexpr int AROWS = 64 / PBK4;                // A rows covered by one wave instruction: 8 or 4
+    const int arow = lane / PBK4;                   // + AROWS r
     const int acol = (lane % PBK4) * 4;
     const int brow = lane / BN4;                    // + BROWS r
     const int bcol = (lane % BN4) * 4;
@@ -830,7 +835,7 @@ __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNA
           const_cast<float*>(p.W + n0), 0, tile_ok ? (K * N - n0) * 4 : 0, KWS_BUFFER_RSRC_FLAGS);
       const int k0 = ld_kt * PBK;
 #pragma unroll
-      for (int r = 0; r < A_F4; ++r) ra[r] = buf_ld4(ares, a_voff, (k0 + 8 * r * K) * 4);
+      for (int r = 0; r < A_F4; ++r) ra[r] = buf_ld4(ares, a_voff, (k0 + AROWS * r * K) * 4);
 #pragma unroll
       for (int r = 0; r < B_F4; ++r) rb[r] = buf_ld4(bres, b_voff, (k0 + BROWS * r) * N * 4);
       ld_kt += NLW;
@@ -842,7 +847,7 @@ __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNA
     auto write_lds = [&](int slot) {
       float* sA = smem + slot * STAGE + arow * PLDA + acol;
 #pragma unroll
-      for (int r = 0; r < A_F4; ++r) *reinterpret_cast<float4*>(sA + 8 * r * PLDA) = ra[r];
+      for (int r = 0; r < A_F4; ++r) *reinterpret_cast<float4*>(sA + AROWS * r * PLDA) = ra[r];
       float* sB = smem + slot * STAGE + BM * PLDA + brow * BN + bcol;
 #pragma unroll
       for (int r = 0; r < B_F4; ++r) *reinterpret_cast<float4*>(sB + BROWS * r * BN) = rb[r];
@@ -1352,6 +1357,7 @@ TNPlan tn_plan(int64_t M, int K, int N, bool ws) {
 // which kernel kws_gemm_nn_f32 runs for a shape, and how many statistics rows it writes
 struct NNPlan {
   bool ws;          // wave-specialised kernel
+  int kb;           // its K-slab depth
   int wgs;          // its grid (= statistics rows: one per workgroup)
   int m_tiles;      // statistics rows of the tile-per-row kernels
 };
@@ -1360,12 +1366,13 @@ NNPlan nn_plan(int64_t M, int K, int N, bool gather) {
   static const bool use_persist = getenv("KWS_GEMM_PERSIST") != nullptr;  // 4-wave persistent kernel, A/B only
   NNPlan pl;
   const int BN = (N % 128 == 0) ? 128 : 64;
+  pl.kb = (BN == 64 && K % 64 == 0 && K >= 128) ? 64 : 32;
   pl.m_tiles = (int)ceil_div64(M, 128);
   const int64_t slots = ceil_div64(pl.m_tiles, NXCD) * ceil_div(N, BN);
   // wave-specialised kernel (default): needs whole K-slabs and column tiles, and 32-bit byte offsets
   // inside one tile's buffer views (128 rows of A / C, all of W); everything else (the gathered first
   // convolution, ragged K or N) takes the persistent kernel
-  pl.ws = !gather && !use_v1 && !use_persist && K % PBK == 0 && K >= 2 * PBK && N % BN == 0 && N <= KWS_WS_MAX_N &&
+  pl.ws = !gather && !use_v1 && !use_persist && K % pl.kb == 0 && K >= 2 * pl.kb && N % BN == 0 && N <= KWS_WS_MAX_N &&
           (int64_t)K * N * 4 < (1ll << 31) && 128ll * K * 4 < (1ll << 31) && 128ll * N * 4 < (1ll << 31);
   int per_xcd = (int)(slots < 32 ? slots : 32);    // one 8-wave workgroup per CU (153 KB LDS), 32 CUs per XCD
   if (const char* e = getenv("KWS_GEMM_WGS_PER_XCD")) per_xcd = atoi(e) > 0 && atoi(e) < slots ? atoi(e) : per_xcd;
@@ -1392,11 +1399,14 @@ int launch_nn(const NNArgs& a0, hipStream_t st) {
   if (pl.ws) {
     dim3 gp((unsigned)pl.wgs), bp(8 * 64);
     if (wide) {
-      if (stats) hipLaunchKernelGGL((gemm_nn_ws_kernel<128, 2, 2, true>), gp, bp, 0, st, a);
-      else hipLaunchKernelGGL((gemm_nn_ws_kernel<128, 2, 2, false>), gp, bp, 0, st, a);
+      if (stats) hipLaunchKernelGGL((gemm_nn_ws_kernel<128, 32, 2, 2, true>), gp, bp, 0, st, a);
+      else hipLaunchKernelGGL((gemm_nn_ws_kernel<128, 32, 2, 2, false>), gp, bp, 0, st, a);
+    } else if (pl.kb == 64) {
+      if (stats) hipLaunchKernelGGL((gemm_nn_ws_kernel<64, 64, 2, 2, true>), gp, bp, 0, st, a);
+      else hipLaunchKernelGGL((gemm_nn_ws_kernel<64, 64, 2, 2, false>), gp, bp, 0, st, a);
     } else {
-      if (stats) hipLaunchKernelGGL((gemm_nn_ws_kernel<64, 2, 2, true>), gp, bp, 0, st, a);
-      else hipLaunchKernelGGL((gemm_nn_ws_kernel<64, 2, 2, false>), gp, bp, 0, st, a);
+      if (stats) hipLaunchKernelGGL((gemm_nn_ws_kernel<64, 32, 2, 2, true>), gp, bp, 0, st, a);
+      else hipLaunchKernelGGL((gemm_nn_ws_kernel<64, 32, 2, 2, false>), gp, bp, 0, st, a);
     }
     KWS_LAUNCH_CHECK("gemm_nn_ws_kernel");
     return KWS_OK;
