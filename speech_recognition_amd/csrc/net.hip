@@ -125,7 +125,7 @@ struct Layout {
   int64_t total = 0;  // bytes
   std::vector<int64_t> y;   // y[l], l = 0..11 (float offsets)
   std::vector<int64_t> z;   // z[i], i = 0..10
-  int64_t G = 0, DZ = 0, bn = 0, part = 0, coef = 0, WT = 0, tn = 0, red = 0, swg = 0;
+  int64_t G = 0, G2 = 0, DZ = 0, bn = 0, part = 0, coef = 0, WT = 0, tn = 0, red = 0, swg = 0;
   int64_t xd = 0, fd = 0, dl1 = 0, dl2 = 0, per_loss = 0, per_correct = 0, att = 0;
   int64_t bn_stride = 0;
 };
@@ -161,6 +161,7 @@ void make_layout(const kws_net* n, int B, bool training, Layout* lo) {
       lo->y[i + 1] = bp.take((int64_t)B * b.Lout * b.cout);
     }
     lo->G = bp.take(max_y);
+    lo->G2 = bp.take(max_y);
     lo->DZ = bp.take(max_z);
     const int64_t tail_part = (int64_t)B * 5 * n->C;
     lo->part = bp.take(std::max(std::max(max_part, max_dwpart), tail_part));
@@ -218,7 +219,14 @@ int kws_net_create(const kws_net_config_t* cfg, kws_net_t** out) {
 }
 
 int kws_net_destroy(kws_net_t* net) {
-  if (net) lm_free(net);
+  if (net) {
+    lm_free(net);
+    if (net->ev_fork) (void)hipEventDestroy(net->ev_fork);
+    if (net->ev_wgrad[0]) (void)hipEventDestroy(net->ev_wgrad[0]);
+    if (net->ev_wgrad[1]) (void)hipEventDestroy(net->ev_wgrad[1]);
+    if (net->ev_join) (void)hipEventDestroy(net->ev_join);
+    if (net->side) (void)hipStreamDestroy(net->side);
+  }
   delete net;
   return KWS_OK;
 }
@@ -332,7 +340,6 @@ int kws_net_train_fwd_bwd(const kws_net_t* net, const float* params, float* stat
   const int nb = (int)net->blocks.size();
   auto bn_at = [&](int l) { return ws + lo.bn + lo.bn_stride * l; };
   float* part = ws + lo.part;
-  float* G = ws + lo.G;
   float* DZ = ws + lo.DZ;
   float* coef = ws + lo.coef;
   float* red = ws + lo.red;
@@ -359,7 +366,7 @@ int kws_net_train_fwd_bwd(const kws_net_t* net, const float* params, float* stat
   kws_ts_tail_args t;
   memset(&t, 0, sizeof(t));
   t.y = ws + lo.y[nb]; t.bn = bn_at(nb); t.W1 = params + net->d1k; t.b1 = params + net->d1b;
-  t.W2 = params + net->d2k; t.labels = y_onehot; t.probs = probs; t.g = G; t.part = part; t.xd = ws + lo.xd;
+  t.W2 = params + net->d2k; t.labels = y_onehot; t.probs = probs; t.g = ws + ((nb % 2) ? lo.G2 : lo.G); t.part = part; t.xd = ws + lo.xd;
   t.fd = ws + lo.fd; t.dl1 = ws + lo.dl1; t.dl2 = ws + lo.dl2; t.per_loss = ws + lo.per_loss;
   t.per_correct = ws + lo.per_correct; t.att = ws + lo.att; t.B = B; t.T = net->T; t.C = net->C; t.NC = net->NC; t.seed = seed;
   t.step = step; t.keep_prob = DROP_KEEP; t.label_smoothing = LABEL_SMOOTH; t.loss_batch = loss_batch;
@@ -375,16 +382,47 @@ int kws_net_train_fwd_bwd(const kws_net_t* net, const float* params, float* stat
                                 grads + r.beta, coef, red, st));
   }
   // ---------------- backward through the blocks ----------------
+  // The weight-gradient GEMM of a block depends only on dy and z; the rest of the chain (dgrad -> depthwise
+  // backward -> BN reductions -> next block's dy) does not need it.  It therefore runs on a side stream right
+  // after the block's dgrad GEMM, beside the HBM-bound depthwise / BN kernels of the main chain: the MFMA-bound
+  // and the bandwidth-bound halves of the backward pass overlap instead of alternating.  The masked gradient
+  // ping-pongs between two buffers so that the depthwise backward never overwrites a dy the side stream
+  // still reads (it waits for the wgrad of two blocks ago, which used the same buffer).
+  static const bool overlap = getenv("KWS_NO_OVERLAP") == nullptr;
+  if (overlap && net->side == nullptr) {
+    KWS_HIP(hipStreamCreateWithFlags(&net->side, hipStreamNonBlocking));
+    KWS_HIP(hipEventCreateWithFlags(&net->ev_fork, hipEventDisableTiming));
+    KWS_HIP(hipEventCreateWithFlags(&net->ev_wgrad[0], hipEventDisableTiming));
+    KWS_HIP(hipEventCreateWithFlags(&net->ev_wgrad[1], hipEventDisableTiming));
+    KWS_HIP(hipEventCreateWithFlags(&net->ev_join, hipEventDisableTiming));
+  }
+  hipStream_t sw = overlap ? net->side : st;
+  float* Gb[2] = {ws + lo.G, ws + lo.G2};          // gradient wrt y[l] lives in Gb[l % 2]; the tail wrote Gb[nb % 2]
+  bool wgrad_pending[2] = {false, false};
   for (int i = nb - 1; i >= 0; --i) {
     const Block& b = net->blocks[i];
     const int64_t M = (int64_t)B * b.Lout;
-    // G = masked gradient wrt bn output of this block -> dy (in place)
-    KWS_TRY(kws_bn_bwd_apply(G, ws + lo.y[i + 1], bn_at(i + 1), params + b.bn.gamma, coef, M, b.cout, st));
+    float* Gcur = Gb[(i + 1) % 2];
+    float* Gnext = Gb[i % 2];
+    // Gcur = masked gradient wrt bn output of this block -> dy (in place)
+    KWS_TRY(kws_bn_bwd_apply(Gcur, ws + lo.y[i + 1], bn_at(i + 1), params + b.bn.gamma, coef, M, b.cout, st));
     KWS_TRY(kws_transpose_f32(params + b.pw, ws + lo.WT, b.cin, b.cout, st));
-    KWS_TRY(kws_gemm_nn_f32(G, ws + lo.WT, DZ, M, b.cout, b.cin, nullptr, st));
-    KWS_TRY(kws_gemm_tn_f32(ws + lo.z[i], G, grads + b.pw, M, b.cin, b.cout, ws + lo.tn, st));
+    KWS_TRY(kws_gemm_nn_f32(Gcur, ws + lo.WT, DZ, M, b.cout, b.cin, nullptr, st));
+    if (overlap) {
+      KWS_HIP(hipEventRecord(net->ev_fork, st));
+      KWS_HIP(hipStreamWaitEvent(sw, net->ev_fork, 0));
+    }
+    KWS_TRY(kws_gemm_tn_f32(ws + lo.z[i], Gcur, grads + b.pw, M, b.cin, b.cout, ws + lo.tn, sw));
+    if (overlap) {
+      KWS_HIP(hipEventRecord(net->ev_wgrad[(i + 1) % 2], sw));
+      wgrad_pending[(i + 1) % 2] = true;
+      if (wgrad_pending[i % 2]) {                   // the wgrad of block i+1 read Gnext
+        KWS_HIP(hipStreamWaitEvent(st, net->ev_wgrad[i % 2], 0));
+        wgrad_pending[i % 2] = false;
+      }
+    }
     const BnRef& prev = (i == 0) ? net->bn1 : net->blocks[i - 1].bn;
-    KWS_TRY(kws_dwconv_bwd_f32(DZ, ws + lo.y[i], bn_at(i), params + b.dw, G, part, B, b.Lin, b.Lout, b.cin, b.stride,
+    KWS_TRY(kws_dwconv_bwd_f32(DZ, ws + lo.y[i], bn_at(i), params + b.dw, Gnext, part, B, b.Lin, b.Lout, b.cin, b.stride,
                                b.pad_l, st));
     const int n_parts = (int)(kws_dwconv_bwd_part_floats(B, b.Lin, b.cin) / (5 * b.cin));
     KWS_TRY(kws_dw_bwd_finalize(part, n_parts, (int64_t)B * b.Lin, b.cin, grads + b.dw,
@@ -392,8 +430,12 @@ int kws_net_train_fwd_bwd(const kws_net_t* net, const float* params, float* stat
   }
   {
     const int64_t M = (int64_t)B * net->L1;
-    KWS_TRY(kws_bn_bwd_apply(G, ws + lo.y[0], bn_at(0), params + net->bn1.gamma, coef, M, net->C1, st));
-    KWS_TRY(kws_gemm_tn_gather_f32(x, &net->gather1, G, grads + net->conv1, B, net->C1, ws + lo.tn, st));
+    KWS_TRY(kws_bn_bwd_apply(Gb[0], ws + lo.y[0], bn_at(0), params + net->bn1.gamma, coef, M, net->C1, st));
+    if (overlap) {                                  // the side stream's TN workspace is free once its queue drains
+      KWS_HIP(hipEventRecord(net->ev_join, sw));
+      KWS_HIP(hipStreamWaitEvent(st, net->ev_join, 0));
+    }
+    KWS_TRY(kws_gemm_tn_gather_f32(x, &net->gather1, Gb[0], grads + net->conv1, B, net->C1, ws + lo.tn, st));
   }
   return KWS_OK;
 }

@@ -41,6 +41,10 @@ struct kws_net {
   kws_gather_t gather1;
   // LOG_MFCC
   LmProgram* lm = nullptr;
+  // side stream of the training step (weight-gradient GEMMs run beside the memory-bound backward kernels);
+  // created on first use on the caller's current device
+  mutable hipStream_t side = nullptr;
+  mutable hipEvent_t ev_fork = nullptr, ev_wgrad[2] = {nullptr, nullptr}, ev_join = nullptr;
 };
 
 // Appends a Keras-named tensor to the flat parameter (or state) buffer; returns its float offset.
