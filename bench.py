@@ -163,7 +163,7 @@ def main():
     gen = data_gen(proc, None, batch_size=B, mode='training', pseudo_frequency=0.6)
     model = speech_model('conv_1d_time_sliced_with_attention', settings['desired_samples'],
                          num_classes=settings['label_count'])
-    model.seed = 87654321 + rank
+    model.seed = 87654321            # one dropout stream for the global batch: rank r uses rows [r*B, (r+1)*B)
     ring = torch.zeros((args.warmup + args.steps + args.profile_steps + 8, 4), dtype=torch.float32, device=device)
     enq = GeneratorEnqueuer(gen, max_queue_size=10, device=device)
     enq.start()
