@@ -5,12 +5,17 @@
 //   TN : dW[K,N] = A^T[K,M] * G[M,N]        wgrad, split over M, partial slabs reduced in a fixed
 //                                            order (bit-reproducible, no float atomics)
 //
-// gfx950 mapping: v_mfma_f32_32x32x2_f32 (exact f32, 64 cycles/SIMD), 256-thread workgroups =
-// 4 waves, each wave owns TMxTN 32x32 accumulator tiles.  Operands are staged global -> VGPR ->
-// LDS with a register prefetch of the next K-tile (one barrier per K-tile).  The A tile is kept
-// row-major with a 4-float row pad so that one ds_read_b128 per lane fetches 4 consecutive k of
-// its row conflict-free; the k order inside an 8-wide group is permuted consistently for A and B
-// (lane half h owns k = 8q+4h+r), which the MFMA sum does not care about.
+// gfx950 mapping: v_mfma_f32_32x32x2_f32 (exact f32 fma chain, 64 cycles per SIMD).  Three kernels:
+//   gemm_nn_ws_kernel / gemm_tn_ws_kernel  the default paths: ONE workgroup per CU (NN) or per work item (TN)
+//       whose waves are specialised - MFMA waves, loader waves (buffer loads -> registers -> LDS) and, for
+//       NN, storer waves (LDS staging tile -> global); see the comments at the kernels for the measurements
+//       that shaped them;
+//   gemm_nn_persist_kernel / gemm_tn_kernel  4-wave kernels (every wave loads, computes and stores) kept for
+//       the gathered first convolution and ragged K / N.
+// Common layout choices: A tiles row-major in LDS with a 4-float row pad so that one ds_read_b128 per lane
+// fetches 4 consecutive k of its row conflict-free; the k order inside an 8-wide group is permuted
+// consistently for A and B (lane half h owns k = 8q+4h+r), which the MFMA sum does not care about.
+// -DKWS_GEMM_STAMP builds add s_memtime stamps to the wave-specialised NN kernel (scripts/stamps_ws.py).
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -20,19 +25,10 @@ __device__ unsigned long long g_stamps[8192][8];
 extern "C" int kws_debug_read_stamps(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(g_stamps));
 }
-#define STAMP(i) do { if (tid == 0 && bid < 8192) g_stamps[bid][i] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define STAMP(i)
 #endif
 
 namespace {
 
-#ifndef KWS_GEMM_BK
-#define KWS_GEMM_BK 16
-#endif
-constexpr int BK = KWS_GEMM_BK;  // K-tile (16: 36 KB LDS per workgroup -> 4 workgroups per CU, out-of-phase overlap)
-constexpr int BK4 = BK / 4;
-constexpr int LDA = BK + 4;   // padded A-tile row (floats); 144 B keeps 16-B alignment
 constexpr int NXCD = 8;
 
 struct NNArgs {
@@ -74,203 +70,9 @@ __device__ __forceinline__ float4 gather4(const float* xb, int pos, int x_len) {
   return v;
 }
 
-template <int BM, int BN, int WM, int WN, bool GATHER, bool STATS>
-__global__ __launch_bounds__(256, 4) void gemm_nn_kernel(NNArgs p) {
-  constexpr int TM = BM / WM / 32;
-  constexpr int TN = BN / WN / 32;
-  constexpr int A_F4 = BM * BK / 4 / 256;
-  constexpr int B_F4 = BK * BN / 4 / 256;
-  constexpr int BN4 = BN / 4;
-  static_assert(WM * WN == 4, "4 waves");
-  static_assert(A_F4 >= 1 && B_F4 >= 1, "tile too small");
-  __shared__ __attribute__((aligned(16))) float smem[2 * (BM * LDA + BK * BN)];
-  constexpr int STAGE = BM * LDA + BK * BN;  // floats per pipeline stage: A tile then B tile
-
-  // XCD-aware tile order: blocks b and b+8 share an XCD (observed round-robin dispatch), so the
-  // n-tiles of one row panel are given to consecutive slots of ONE XCD and hit its L2.
-  const int bid = blockIdx.x;
-  const int xcd = bid % NXCD;
-  const int slot = bid / NXCD;
-  const int tile_n = slot % p.n_tiles;
-  const int tile_m = (slot / p.n_tiles) * NXCD + xcd;
-  if (tile_m >= p.m_tiles) return;  // whole workgroup leaves together
-#ifdef KWS_GEMM_STAGGER
-  // All workgroups of the first residency round start together and, doing identical work, stay in
-  // lockstep: their store-bound epilogues then coincide instead of hiding under another workgroup's MFMA
-  // loop.  A one-off pseudo-random start delay (first round only) de-phases the workgroups that share a
-  // CU; later rounds inherit the spread.  Speed only - never correctness.
-  if (bid < 256 * 4) {
-    const unsigned d = ((unsigned)bid * 2654435761u >> 29) & 3u;
-    for (unsigned q = 0; q < d * KWS_GEMM_STAGGER; ++q) __builtin_amdgcn_s_sleep(127);
-  }
-#endif
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
-  const int li = lane & 31, lh = lane >> 5;
-  const int64_t m0 = (int64_t)tile_m * BM;
-  const int n0 = tile_n * BN;
-  const int K = p.K, N = p.N;
-  const int64_t M = p.M;
-
-  // per-thread A row bookkeeping (rows do not change across K-tiles)
-  const float* a_row[A_F4];
-  bool a_ok[A_F4];
-  int a_t[A_F4];
-#pragma unroll
-  for (int r = 0; r < A_F4; ++r) {
-    const int idx = tid + r * 256;
-    const int row = idx / BK4;
-    const int64_t gm = m0 + row;
-    a_ok[r] = gm < M;
-    if (GATHER) {
-      const int64_t b = a_ok[r] ? gm / p.g.L_out : 0;
-      a_t[r] = a_ok[r] ? (int)(gm - b * p.g.L_out) : 0;
-      a_row[r] = p.A + b * p.g.x_batch_stride;
-    } else {
-      a_t[r] = 0;
-      a_row[r] = p.A + (a_ok[r] ? gm : 0) * (int64_t)K;
-    }
-  }
-
-  float4 ra[A_F4], rb[B_F4];
-  auto load_global = [&](int k0) {
-#pragma unroll
-    for (int r = 0; r < A_F4; ++r) {
-      const int idx = tid + r * 256;
-      const int gk = k0 + (idx % BK4) * 4;
-      if (GATHER) {
-        if (a_ok[r] && gk < K) {
-          const int j = gk / p.g.cin;
-          const int c = gk - j * p.g.cin;
-          ra[r] = gather4(a_row[r], a_t[r] * p.g.stride_t + j * p.g.stride_j + c + p.g.base_off, p.g.x_len);
-        } else {
-          ra[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-      } else {
-        ra[r] = ld4_or_zero(a_row[r] + gk, a_ok[r] && gk < K);
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < B_F4; ++r) {
-      const int idx = tid + r * 256;
-      const int row = idx / BN4, c4 = idx % BN4;
-      const int gk = k0 + row, gn = n0 + c4 * 4;
-      rb[r] = ld4_or_zero(p.W + (int64_t)gk * N + gn, gk < K && gn < N);
-    }
-  };
-  auto store_lds = [&](int buf) {
-#pragma unroll
-    for (int r = 0; r < A_F4; ++r) {
-      const int idx = tid + r * 256;
-      *reinterpret_cast<float4*>(&smem[buf * STAGE + (idx / BK4) * LDA + (idx % BK4) * 4]) = ra[r];
-    }
-#pragma unroll
-    for (int r = 0; r < B_F4; ++r) {
-      const int idx = tid + r * 256;
-      *reinterpret_cast<float4*>(&smem[buf * STAGE + BM * LDA + (idx / BN4) * BN + (idx % BN4) * 4]) = rb[r];
-    }
-  };
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
-
-  const int nk = (K + BK - 1) / BK;
-  STAMP(0);
-  load_global(0);
-  store_lds(0);
-  __syncthreads();
-  STAMP(1);
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) load_global((kt + 1) * BK);
-    const float* cA = smem + cur * STAGE + (wm * TM * 32 + li) * LDA + lh * 4;
-    const float* cB = smem + cur * STAGE + BM * LDA + (lh * 4) * BN + wn * TN * 32 + li;
-#pragma unroll
-    for (int q = 0; q < BK / 8; ++q) {
-      float4 a[TM];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const float4*>(cA + i * 32 * LDA + q * 8);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float b[TN];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) b[j] = cB[(q * 8 + r) * BN + j * 32];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          const float av = r == 0 ? a[i].x : (r == 1 ? a[i].y : (r == 2 ? a[i].z : a[i].w));
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[j], acc[i][j], 0, 0, 0);
-        }
-      }
-    }
-    if (kt + 1 < nk) store_lds(cur ^ 1);
-    __syncthreads();
-  }
-
-  STAMP(2);
-  // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (v&3) + 8*(v>>2) + 4*(lane>>5)
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = n0 + wn * TN * 32 + j * 32 + li;
-#pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        const int64_t row = m0 + wm * TM * 32 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh;
-        if (row < M && col < N) p.C[row * N + col] = acc[i][j][v];
-      }
-    }
-  }
-
-  STAMP(3);
-  if (STATS) {
-    // BatchNorm partial sums of this row tile (rows >= M are exact zeros and add nothing).
-    float* red = smem;  // [2][WM][BN]
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      float s = 0.f, ss = 0.f;
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int v = 0; v < 16; ++v) {
-          const float x = acc[i][j][v];
-          s += x;
-          ss += x * x;
-        }
-      s += __shfl_xor(s, 32);
-      ss += __shfl_xor(ss, 32);
-      if (lh == 0) {
-        const int c = wn * TN * 32 + j * 32 + li;
-        red[(0 * WM + wm) * BN + c] = s;
-        red[(1 * WM + wm) * BN + c] = ss;
-      }
-    }
-    __syncthreads();
-    if (tid < BN && n0 + tid < N) {
-      float s = 0.f, ss = 0.f;
-#pragma unroll
-      for (int w = 0; w < WM; ++w) {
-        s += red[(0 * WM + w) * BN + tid];
-        ss += red[(1 * WM + w) * BN + tid];
-      }
-      p.stats[((int64_t)tile_m * 2 + 0) * N + n0 + tid] = s;
-      p.stats[((int64_t)tile_m * 2 + 1) * N + n0 + tid] = ss;
-    }
-  }
-  STAMP(4);
-}
-
 // ------------------------------------------------------------------------------------------------
-// Persistent NN kernel (default).  Same tile math as gemm_nn_kernel, restructured around what the
-// in-kernel stamps of the one-tile-per-workgroup version showed (6.1 k cycles exposed first-load
+// Persistent 4-wave NN kernel (the gathered first convolution and ragged K / N; the wave-specialised kernel
+// below takes everything else).  One-tile-per-workgroup kernels showed, in in-kernel stamps, (6.1 k cycles exposed first-load
 // latency + 9.4 k cycles of 4-byte-per-lane stores per 16.4 k cycles of MFMA work, and co-resident
 // workgroups in lockstep so none of it overlapped):
 //   * each workgroup walks a list of tiles; while it computes the LAST K-slab of tile t it already has
@@ -280,9 +82,6 @@ __global__ __launch_bounds__(256, 4) void gemm_nn_kernel(NNArgs p) {
 //     256-byte contiguous segments instead of 128-byte ones; the stores drain while the next tile's
 //     main loop runs.
 constexpr int PBK = 32;
-#ifndef KWS_WS_DBG
-#define KWS_WS_DBG 0   // role-isolation experiments: 1 no global loads, 2 no global stores, 4 1/8 of the MFMAs
-#endif
 constexpr int PLDA = PBK + 4;
 
 template <int BM, int BN, int WM, int WN, bool GATHER, bool STATS>
@@ -733,8 +532,7 @@ __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNA
               const float av = r == 0 ? f.a[i].x : (r == 1 ? f.a[i].y : (r == 2 ? f.a[i].z : f.a[i].w));
 #pragma unroll
               for (int j = 0; j < TN; ++j)   // swapped operands: lane <-> C row, register <-> C column
-                if (!(KWS_WS_DBG & 4) || (r == 0 && i == 0))
-                  acc.t[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.b[r][j], av, acc.t[i][j], 0, 0, 0);
+                acc.t[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.b[r][j], av, acc.t[i][j], 0, 0, 0);
             }
         };
         // column sums of the staged tile: first half at kt = 1, second half at kt = 2 (both at kt = 1 when nk = 2)
@@ -823,7 +621,7 @@ __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNA
     float4 ra[A_F4], rb[B_F4];
     auto issue = [&]() {
       const int loc = wg_in_xcd + ld_i * wgs_per_xcd;
-      const bool tile_ok = !(KWS_WS_DBG & 1) && ld_i < n_my;
+      const bool tile_ok = ld_i < n_my;
       const int tile_m = (loc / p.n_tiles) * NXCD + xcd;
       const int64_t m0 = (int64_t)tile_m * BM;
       const int n0 = (loc % p.n_tiles) * BN;
@@ -897,7 +695,7 @@ __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNA
       const int n0 = (loc % p.n_tiles) * BN;
       const int64_t m0 = (int64_t)tile_m * BM;
       const int64_t rows_left = M - m0;
-      const int rows = (KWS_WS_DBG & 2) ? 0 : (int)(rows_left < BM ? rows_left : BM);
+      const int rows = (int)(rows_left < BM ? rows_left : BM);
       // view of C starting at (m0, n0): rows past M fall outside rows*N floats and are dropped
       cres = __builtin_amdgcn_make_buffer_rsrc(p.C + m0 * N + n0, 0, rows > 0 ? (rows * N - n0) * 4 : 0,
                                                KWS_BUFFER_RSRC_FLAGS);
@@ -934,7 +732,7 @@ __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNA
           t_mark = __builtin_amdgcn_s_memtime();
 #endif
           const int lo = (kt - 1) * ppi, hi = lo + ppi < NPASS ? lo + ppi : NPASS;
-          if (lo < NPASS && !(KWS_WS_DBG & 32)) move_rows(lo, hi);
+          if (lo < NPASS) move_rows(lo, hi);
           WT(t_store);
         }
       }
@@ -1362,7 +1160,6 @@ struct NNPlan {
   int m_tiles;      // statistics rows of the tile-per-row kernels
 };
 NNPlan nn_plan(int64_t M, int K, int N, bool gather) {
-  static const bool use_v1 = getenv("KWS_GEMM_V1") != nullptr;            // one-tile-per-workgroup kernel, A/B only
   static const bool use_persist = getenv("KWS_GEMM_PERSIST") != nullptr;  // 4-wave persistent kernel, A/B only
   NNPlan pl;
   const int BN = (N % 128 == 0) ? 128 : 64;
@@ -1372,7 +1169,7 @@ NNPlan nn_plan(int64_t M, int K, int N, bool gather) {
   // wave-specialised kernel (default): needs whole K-slabs and column tiles, and 32-bit byte offsets
   // inside one tile's buffer views (128 rows of A / C, all of W); everything else (the gathered first
   // convolution, ragged K or N) takes the persistent kernel
-  pl.ws = !gather && !use_v1 && !use_persist && K % pl.kb == 0 && K >= 2 * pl.kb && N % BN == 0 && N <= KWS_WS_MAX_N &&
+  pl.ws = !gather && !use_persist && K % pl.kb == 0 && K >= 2 * pl.kb && N % BN == 0 && N <= KWS_WS_MAX_N &&
           (int64_t)K * N * 4 < (1ll << 31) && 128ll * K * 4 < (1ll << 31) && 128ll * N * 4 < (1ll << 31);
   int per_xcd = (int)(slots < 32 ? slots : 32);    // one 8-wave workgroup per CU (153 KB LDS), 32 CUs per XCD
   if (const char* e = getenv("KWS_GEMM_WGS_PER_XCD")) per_xcd = atoi(e) > 0 && atoi(e) < slots ? atoi(e) : per_xcd;
@@ -1394,7 +1191,6 @@ int launch_nn(const NNArgs& a0, hipStream_t st) {
     return KWS_E_INVALID;
   }
   const bool stats = a.stats != nullptr;
-  static const bool use_v1 = getenv("KWS_GEMM_V1") != nullptr;
   const NNPlan pl = nn_plan(a.M, a.K, a.N, GATHER);
   if (pl.ws) {
     dim3 gp((unsigned)pl.wgs), bp(8 * 64);
@@ -1411,7 +1207,7 @@ int launch_nn(const NNArgs& a0, hipStream_t st) {
     KWS_LAUNCH_CHECK("gemm_nn_ws_kernel");
     return KWS_OK;
   }
-  if (!use_v1) {
+  {
     // persistent: 2 workgroups per CU (69.6 KB LDS each), 32 CUs per XCD
     int per_xcd = (int)(slots < 64 ? slots : 64);
     if (const char* e = getenv("KWS_GEMM_WGS_PER_XCD")) per_xcd = atoi(e) > 0 && atoi(e) < slots ? atoi(e) : per_xcd;
@@ -1424,17 +1220,7 @@ int launch_nn(const NNArgs& a0, hipStream_t st) {
       else hipLaunchKernelGGL((gemm_nn_persist_kernel<128, 64, 2, 2, GATHER, false>), gp, bp, 0, st, a);
     }
     KWS_LAUNCH_CHECK("gemm_nn_persist_kernel");
-    return KWS_OK;
   }
-  dim3 g((unsigned)grid), b(256);
-  if (wide) {
-    if (stats) hipLaunchKernelGGL((gemm_nn_kernel<128, 128, 2, 2, GATHER, true>), g, b, 0, st, a);
-    else hipLaunchKernelGGL((gemm_nn_kernel<128, 128, 2, 2, GATHER, false>), g, b, 0, st, a);
-  } else {
-    if (stats) hipLaunchKernelGGL((gemm_nn_kernel<128, 64, 2, 2, GATHER, true>), g, b, 0, st, a);
-    else hipLaunchKernelGGL((gemm_nn_kernel<128, 64, 2, 2, GATHER, false>), g, b, 0, st, a);
-  }
-  KWS_LAUNCH_CHECK("gemm_nn_kernel");
   return KWS_OK;
 }
 
