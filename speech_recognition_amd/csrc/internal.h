@@ -31,3 +31,5 @@ struct kws_stft_plan {
   float* dct64;       // [n_mel][64] zero padded
 };
 int kws_stft2_launch(const kws_stft_plan* pl, const float* x, int B, int L, int F, float* out, hipStream_t st);
+int kws_stft3_lds_bytes(const kws_stft_plan* pl);
+int kws_stft3_launch(const kws_stft_plan* pl, const float* x, int B, int L, int F, float* out, hipStream_t st);

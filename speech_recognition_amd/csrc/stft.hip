@@ -306,8 +306,12 @@ int kws_stft_mel_f32(const kws_stft_plan_t* plan, const float* x, int B, int L, 
   const double fl = (double)B * a.F * (5.0 * 256 * 8 + 12.0 * 257 + 2.0 * plan->n_w + 2.0 * plan->n_mel * plan->n_out);
   KwsProfScope prof("stft_mel", fl, 4.0 * ((double)B * L + (double)B * a.F * width), st);
   static const bool force_v1 = getenv("KWS_STFT_V1") != nullptr;
-  if (out_kind == 0 && plan->n_out <= 64 && plan->n_mel <= 128 && plan->frame_len % 2 == 0 && !force_v1)
+  static const bool force_v2 = getenv("KWS_STFT_V2") != nullptr;
+  if (out_kind == 0 && plan->n_out <= 64 && plan->n_mel <= 128 && plan->frame_len % 2 == 0 && !force_v1) {
+    if (!force_v2 && plan->n_mel % 4 == 0 && kws_stft3_lds_bytes(plan) <= 160 * 1024)
+      return kws_stft3_launch(plan, x, B, L, a.F, out, st);   // tables in registers, DCT on the matrix pipe
     return kws_stft2_launch(plan, x, B, L, a.F, out, st);
+  }
   if (a.F % 14 == 0) {
     a.run_samples = (7 * 2 - 1) * plan->frame_step + plan->frame_len;
     return launch_stft<7, 2>(a, B, st);

@@ -239,6 +239,214 @@ __global__ __launch_bounds__(NW2 * 64, 1) void stft2_kernel(Stft2Args a) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Third generation.  The second kernel is LDS-bandwidth bound (about 290 LDS instructions per lane and
+// frame, 100 of them the 16-byte reads of the DCT table).  Here
+//   * the per-lane constants of the FFT (window, W256 twiddles, W512 split factors: 94 registers) live in
+//     registers - 8 waves per workgroup leave 256 VGPRs per lane;
+//   * a wave takes FOUR quads (16 frames) per pass and parks their log-mel rows in LDS; the DCT of the 16
+//     frames is then one [16 x n_mel] x [n_mel x 64] product on the matrix pipe (v_mfma_f32_16x16x4_f32,
+//     exact f32 fma chain): 5 four-byte LDS reads per 4 MFMAs instead of 100 sixteen-byte reads and 320
+//     FMAs per frame.
+// LDS per workgroup (n_mel = 80): 8 waves x (4 transpose tiles + 16 x 81 log-mel) + DCT table [80][80]
+// (row stride 80: the four k rows of an MFMA B operand fall on the two bank halves) + CSR = 141 KB.
+constexpr int NW3 = 8;
+constexpr int DSTR = 80;            // DCT table row stride (floats)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(NW3 * 64, 1) void stft3_kernel(Stft2Args a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const kws_stft_plan& pl = a.pl;
+  const int n_mel = pl.n_mel, n_out = pl.n_out;
+  const int LMS = n_mel + 1;                                       // log-mel row stride (odd: conflict-free columns)
+  float* s_dct = lds;                                              // [n_mel][DSTR]
+  float* s_bw = s_dct + n_mel * DSTR;                              // [n_w]
+  int* s_csr = reinterpret_cast<int*>(s_bw + ((pl.n_w + 3) & ~3)); // [3][128] start | cnt | ofs
+  float* s_wave = reinterpret_cast<float*>(s_csr + 3 * 128);
+  constexpr int FR_FLOATS = 16 * TP * 2;                           // one frame's transpose tile (544 floats)
+  const int wave_floats = 4 * FR_FLOATS + ((16 * LMS + 3) & ~3);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l16 = lane & 15, fq = lane >> 4;
+  float* s_fr = s_wave + wave * wave_floats + fq * FR_FLOATS;      // this frame's scratch
+  float* s_lm16 = s_wave + wave * wave_floats + 4 * FR_FLOATS;     // [16][LMS] log-mel rows of the super-quad
+
+  for (int i = tid; i < n_mel * DSTR; i += NW3 * 64) {
+    const int m = i / DSTR, q = i - m * DSTR;
+    s_dct[i] = q < 64 ? pl.dct64[m * 64 + q] : 0.f;
+  }
+  for (int i = tid; i < pl.n_w; i += NW3 * 64) s_bw[i] = pl.band_w[i];
+  for (int i = tid; i < 128; i += NW3 * 64) {
+    s_csr[i] = i < n_mel ? pl.band_start[i] : 0;
+    s_csr[128 + i] = i < n_mel ? pl.band_cnt[i] : 0;
+    s_csr[256 + i] = i < n_mel ? pl.band_ofs[i] : 0;
+  }
+  // per-lane FFT constants
+  float2 r_win[16], r_tw[16], r_w512[16];
+#pragma unroll
+  for (int n1 = 0; n1 < 16; ++n1) r_win[n1] = *reinterpret_cast<const float2*>(pl.window + 2 * (16 * n1 + l16));
+#pragma unroll
+  for (int k1 = 0; k1 < 16; ++k1) r_tw[k1] = pl.tw16[l16 * 16 + k1];
+#pragma unroll
+  for (int k2 = 0; k2 < 16; ++k2) r_w512[k2] = pl.w512[l16 + 16 * k2];
+  __syncthreads();
+
+  const int64_t n_super = (a.total_quads + 3) / 4;
+  const int64_t wave_global = (int64_t)blockIdx.x * NW3 + wave;
+  const int64_t wave_stride = (int64_t)gridDim.x * NW3;
+  const int nb_mel = (n_mel + 15) >> 4;   // mel bands per lane
+  const int n_blk = (n_out + 15) >> 4;    // 16-column output blocks
+  for (int64_t sq = wave_global; sq < n_super; sq += wave_stride) {
+#pragma unroll 1
+    for (int qq = 0; qq < 4; ++qq) {
+      const int64_t quad = sq * 4 + qq;
+      const bool quad_ok = quad < a.total_quads;
+      const int64_t b = quad_ok ? quad / a.quads_per_clip : 0;
+      const int f = quad_ok ? (int)(quad - b * a.quads_per_clip) * 4 + fq : 0;
+      const bool live = quad_ok && f < a.F;
+      const float* fx = a.x + b * (int64_t)a.L + (int64_t)(live ? f : 0) * pl.frame_step;
+      // ---- load + window: lane n2 = l16 takes z[16 n1 + n2] -----------------------------------------
+      float2 z[16];
+#pragma unroll
+      for (int n1 = 0; n1 < 16; ++n1) {
+        const int s = 2 * (16 * n1 + l16);
+        const int sc = s < pl.frame_len ? s : pl.frame_len - 2;   // clamped; the padded window zeroes the tail
+        const float2 xv = *reinterpret_cast<const float2*>(fx + sc);
+        z[n1] = make_float2(xv.x * r_win[n1].x, xv.y * r_win[n1].y);
+      }
+      fft16(z);
+#pragma unroll
+      for (int k1 = 1; k1 < 16; ++k1) z[k1] = cmul(z[k1], r_tw[k1]);
+      float2* tile = reinterpret_cast<float2*>(s_fr);
+#pragma unroll
+      for (int k1 = 0; k1 < 16; ++k1) tile[k1 * TP + l16] = z[k1];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int n2 = 0; n2 < 16; ++n2) z[n2] = tile[l16 * TP + n2];
+      fft16(z);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // ---- real-input split + magnitude -------------------------------------------------------------
+      float* s_mag = s_fr;                            // [260]
+      const int partner = (16 - l16) & 15;
+#pragma unroll
+      for (int k2 = 0; k2 < 16; ++k2) {
+        const float2 pa = z[15 - k2], pb = z[(16 - k2) & 15];
+        const float px = __shfl(pa.x, partner, 16), py = __shfl(pa.y, partner, 16);
+        const float2 zn0 = (l16 == 0) ? pb : make_float2(px, py);
+        const float2 zk = z[k2];
+        const float2 zn = make_float2(zn0.x, -zn0.y);
+        const float2 E = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y + zn.y));
+        const float2 dd = csub(zk, zn);
+        const float2 O = make_float2(0.5f * dd.y, -0.5f * dd.x);
+        const float2 X = cadd(E, cmul(r_w512[k2], O));
+        s_mag[l16 + 16 * k2] = __builtin_amdgcn_sqrtf(X.x * X.x + X.y * X.y);
+      }
+      if (l16 == 0) s_mag[256] = fabsf(z[0].x - z[0].y);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // ---- sparse mel bands + log -> row 4 qq + fq of the super-quad's log-mel block ----------------------
+      float* lm_row = s_lm16 + (4 * qq + fq) * LMS;
+      for (int i = 0; i < nb_mel; ++i) {
+        const int m = l16 + 16 * i;
+        if (m < n_mel) {
+          const int st0 = s_csr[m], cnt = s_csr[128 + m], ofs = s_csr[256 + m];
+          float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+          for (int j = 0; j < cnt; j += 4) {
+            const int j1 = j + 1 < cnt ? j + 1 : j, j2 = j + 2 < cnt ? j + 2 : j, j3 = j + 3 < cnt ? j + 3 : j;
+            const float m0 = s_mag[st0 + j], m1 = s_mag[st0 + j1], m2 = s_mag[st0 + j2], m3 = s_mag[st0 + j3];
+            const float w0 = s_bw[ofs + j];
+            const float w1 = j + 1 < cnt ? s_bw[ofs + j1] : 0.f;
+            const float w2 = j + 2 < cnt ? s_bw[ofs + j2] : 0.f;
+            const float w3 = j + 3 < cnt ? s_bw[ofs + j3] : 0.f;
+            s0 = fmaf(m0, w0, s0);
+            s1 = fmaf(m1, w1, s1);
+            s2 = fmaf(m2, w2, s2);
+            s3 = fmaf(m3, w3, s3);
+          }
+          float sm = ((s0 + s1) + (s2 + s3)) + pl.log_offset;
+          if (pl.log_floor > 0.f) sm = fmaxf(sm, pl.log_floor);
+          lm_row[m] = __logf(sm);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();                // s_mag reads done before the next quad reuses the tile
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    // ---- DCT of the 16 frames on the matrix pipe: D[frame][q] = sum_m logmel[frame][m] dct[m][q] ----------
+    // A: lane -> (frame = lane % 16, k = lane / 16); B: lane -> (k = lane / 16, q = 16 nb + lane % 16);
+    // D: lane -> q = 16 nb + lane % 16, frames 4 (lane / 16) + v, i.e. quad lane/16, frame-in-quad v
+    f32x4 acc[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* pa = s_lm16 + l16 * LMS + fq;
+    const float* pb = s_dct + fq * DSTR + l16;
+    for (int ks = 0; ks < n_mel; ks += 4) {
+      const float av = pa[ks];
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb)
+        if (nb < n_blk) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, pb[ks * DSTR + 16 * nb], acc[nb], 0, 0, 0);
+    }
+    {
+      const int64_t quad = sq * 4 + fq;               // lane group fq holds the frames of quad fq
+      if (quad < a.total_quads) {
+        const int64_t b = quad / a.quads_per_clip;
+        const int f0 = (int)(quad - b * a.quads_per_clip) * 4;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          if (f0 + v < a.F) {
+            float* orow = a.out + (b * a.F + f0 + v) * (int64_t)n_out + l16;
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+              if (16 * nb + l16 < n_out) orow[16 * nb] = acc[nb][v];
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();                  // log-mel reads done before the next super-quad's writes
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
+}  // namespace
+
+int kws_stft3_lds_bytes(const kws_stft_plan* pl) {
+  const size_t floats = (size_t)pl->n_mel * DSTR + ((pl->n_w + 3) & ~3) + 3 * 128 +
+                        (size_t)NW3 * (4 * (16 * TP * 2) + ((16 * (pl->n_mel + 1) + 3) & ~3));
+  return (int)(floats * 4);
+}
+
+int kws_stft3_launch(const kws_stft_plan* pl, const float* x, int B, int L, int F, float* out, hipStream_t st) {
+  KWS_REQUIRE(pl->n_out <= 64 && pl->n_mel % 4 == 0 && pl->n_mel <= 128, "stft3: n_mel=%d n_out=%d unsupported",
+              pl->n_mel, pl->n_out);
+  KWS_REQUIRE(F > 0 && (pl->frame_step % 2) == 0 && (L % 2) == 0, "stft3: bad geometry");
+  Stft2Args a;
+  a.pl = *pl;
+  a.x = x; a.out = out; a.B = B; a.L = L; a.F = F;
+  a.quads_per_clip = (F + 3) / 4;
+  a.total_quads = (int64_t)B * a.quads_per_clip;
+  const int bytes = kws_stft3_lds_bytes(pl);
+  KWS_REQUIRE(bytes <= 160 * 1024, "stft3: LDS need %d B exceeds 160 KiB", bytes);
+  static bool attr_done = false;
+  if (!attr_done) {
+    KWS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&stft3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024));
+    attr_done = true;
+  }
+  int64_t wgs = ((a.total_quads + 3) / 4 + NW3 - 1) / NW3;
+  if (wgs > 256) wgs = 256;   // persistent: one workgroup per CU, tables staged once
+  hipLaunchKernelGGL(stft3_kernel, dim3((unsigned)wgs), dim3(NW3 * 64), (size_t)bytes, st, a);
+  KWS_LAUNCH_CHECK("stft3_kernel");
+  return KWS_OK;
+}
+
+namespace {
+
 }  // namespace
 
 int kws_stft2_launch(const kws_stft_plan* pl, const float* x, int B, int L, int F, float* out, hipStream_t st) {
