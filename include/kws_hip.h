@@ -195,6 +195,14 @@ int64_t kws_dwconv_bwd_part_floats(int B, int L_in, int C);
 int kws_dwconv_bwd_f32(const float* dz, const float* y, const float* bn, const float* w, float* g,
                        float* part, int B, int L_in, int L_out, int C, int stride, int pad_l,
                        void* stream);
+/* The same backward with the consumer's BatchNorm backward fused in, without materialising g
+ * (reference: the BatchNormalization + relu6 + DepthwiseConv2D backward chain of model.py:34-51):
+ *   pass 1: part only (fold with kws_dw_bwd_finalize -> dw, dgamma, dbeta and coef = [c1 | c2]);
+ *   pass 2: dy[b,u,c] = scale[c] * (g - c1[c] - xhat * c2[c]), g recomputed from the same operands
+ *           (bit-identical to kws_dwconv_bwd_f32 followed by kws_bn_bwd_apply).  bn must not be NULL. */
+int kws_dwconv_bwd_bn_f32(const float* dz, const float* y, const float* bn, const float* w,
+                          const float* coef, float* dy, float* part, int pass, int B, int L_in,
+                          int L_out, int C, int stride, int pad_l, void* stream);
 /* reduces part -> dw[3,C] (may be NULL), dgamma[C], dbeta[C], and coef[2*C] = (c1, c2) used by
  * kws_bn_bwd_apply; n_parts = part floats / (5*C) */
 int kws_dw_bwd_finalize(const float* part, int n_parts, int64_t count, int C, float* dw,

@@ -93,6 +93,7 @@ SIGNATURES = {
     "kws_dwconv_fwd_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "kws_dwconv_bwd_part_floats": (_I64, [_I, _I, _I]),
     "kws_dwconv_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "kws_dwconv_bwd_bn_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "kws_dw_bwd_finalize": (_I, [_P, _I, _I64, _I, _P, _P, _P, _P, _P, _P]),
     "kws_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _I64, _I, _P]),
     "kws_rmsprop_step": (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _P]),

@@ -87,9 +87,15 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict
 
 // Backward: one thread per (clip, run of TT input positions, float4 of channels).
 // part[block][5][C] = per-block sums of (g, g*xhat, dz*a@tap0, dz*a@tap1, dz*a@tap2).
-template <int S, bool HAS_BN>
+// MODE 0: store g and the partial sums (kws_dwconv_bwd_f32).
+// MODE 1 / 2: the two passes of kws_dwconv_bwd_bn_f32, which never materialises g: pass 1 only reduces, pass 2
+//   recomputes g from the same operands (bit-identical) and stores the BatchNorm input gradient
+//   dy = scale * (g - c1 - xhat * c2) directly - 5 tensor passes instead of the 6 of "store g, then
+//   kws_bn_bwd_apply" for a stride-1 layer, 4 instead of 5.5 for a stride-2 layer.
+template <int S, bool HAS_BN, int MODE>
 __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ y,
                                                          const float* __restrict__ bn, const float* __restrict__ w,
+                                                         const float* __restrict__ coef,
                                                          float* __restrict__ g, float* __restrict__ part, int B,
                                                          int Lin, int Lout, int C, int pad_l, int nchunks, int R) {
   __shared__ float red[5][256 * 4];
@@ -108,6 +114,11 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const float* __restrict
   const float4 w0 = *reinterpret_cast<const float4*>(w + c);
   const float4 w1 = *reinterpret_cast<const float4*>(w + C + c);
   const float4 w2 = *reinterpret_cast<const float4*>(w + 2 * C + c);
+  float4 c1 = f4_zero(), c2 = f4_zero();
+  if (MODE == 2) {
+    c1 = *reinterpret_cast<const float4*>(coef + c);
+    c2 = *reinterpret_cast<const float4*>(coef + C + c);
+  }
   // grid-stride over the (clip, time-chunk) units: the grid is capped so that a launch leaves at most
   // KWS_DW_BWD_MAX_PARTS partial rows (summed per thread in unit order), which kws_dw_bwd_finalize folds
   // without a pre-reduction pass
@@ -165,7 +176,17 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const float* __restrict
       da = f4_fma(w1, d1, da);
       da = f4_fma(w2, d2, da);
       const float4 gv = f4_mul(da, mk);
-      *reinterpret_cast<float4*>(gb + (int64_t)u * C) = gv;
+      if (MODE == 2) {
+        // same expression as bn_bwd_apply_kernel (bn.hip), with scale = gamma * rstd from the BN table
+        float4 o;
+        o.x = sc.x * (gv.x - c1.x - (yv.x - mean.x) * rstd.x * c2.x);
+        o.y = sc.y * (gv.y - c1.y - (yv.y - mean.y) * rstd.y * c2.y);
+        o.z = sc.z * (gv.z - c1.z - (yv.z - mean.z) * rstd.z * c2.z);
+        o.w = sc.w * (gv.w - c1.w - (yv.w - mean.w) * rstd.w * c2.w);
+        *reinterpret_cast<float4*>(gb + (int64_t)u * C) = o;
+        continue;
+      }
+      if (MODE == 0) *reinterpret_cast<float4*>(gb + (int64_t)u * C) = gv;
       sg.x += gv.x; sg.y += gv.y; sg.z += gv.z; sg.w += gv.w;
       sgx = f4_fma(gv, xh, sgx);
       sw0 = f4_fma(d0, a, sw0);
@@ -173,6 +194,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const float* __restrict
       sw2 = f4_fma(d2, a, sw2);
     }
   }
+  if (MODE == 2) return;
   *reinterpret_cast<float4*>(&red[0][tid * 4]) = sg;
   *reinterpret_cast<float4*>(&red[1][tid * 4]) = sgx;
   *reinterpret_cast<float4*>(&red[2][tid * 4]) = sw0;
@@ -207,6 +229,25 @@ BwdGeom bwd_geom(int B, int Lin, int C) {
   return g;
 }
 
+}  // namespace
+
+namespace {
+template <int MODE>
+int launch_dw_bwd(const float* dz, const float* y, const float* bn, const float* w, const float* coef, float* g,
+                  float* part, int B, int L_in, int L_out, int C, int stride, int pad_l, hipStream_t st) {
+  const BwdGeom ge = bwd_geom(B, L_in, C);
+  KWS_REQUIRE(ge.grid < 0x7FFFFFFF, "dwconv_bwd: grid too large");
+  dim3 gr((unsigned)ge.grid), b((unsigned)ge.block);
+  if (stride == 1) {
+    if (bn) hipLaunchKernelGGL((dwconv_bwd_kernel<1, true, MODE>), gr, b, 0, st, dz, y, bn, w, coef, g, part, B, L_in, L_out, C, pad_l, ge.nchunks, ge.R);
+    else hipLaunchKernelGGL((dwconv_bwd_kernel<1, false, MODE>), gr, b, 0, st, dz, y, bn, w, coef, g, part, B, L_in, L_out, C, pad_l, ge.nchunks, ge.R);
+  } else {
+    if (bn) hipLaunchKernelGGL((dwconv_bwd_kernel<2, true, MODE>), gr, b, 0, st, dz, y, bn, w, coef, g, part, B, L_in, L_out, C, pad_l, ge.nchunks, ge.R);
+    else hipLaunchKernelGGL((dwconv_bwd_kernel<2, false, MODE>), gr, b, 0, st, dz, y, bn, w, coef, g, part, B, L_in, L_out, C, pad_l, ge.nchunks, ge.R);
+  }
+  KWS_LAUNCH_CHECK("dwconv_bwd_kernel");
+  return KWS_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -248,20 +289,25 @@ int kws_dwconv_bwd_f32(const float* dz, const float* y, const float* bn, const f
   KWS_REQUIRE(B > 0 && L_in > 0 && L_out > 0 && C > 0 && C % 4 == 0 && C <= 1024,
               "dwconv_bwd: bad shape B=%d L=%d->%d C=%d", B, L_in, L_out, C);
   KWS_REQUIRE(stride == 1 || stride == 2, "dwconv_bwd: stride %d unsupported", stride);
-  const BwdGeom ge = bwd_geom(B, L_in, C);
-  KWS_REQUIRE(ge.grid < 0x7FFFFFFF, "dwconv_bwd: grid too large");
-  dim3 gr((unsigned)ge.grid), b((unsigned)ge.block);
   hipStream_t st = (hipStream_t)stream;
   KwsProfScope prof("dwconv_bwd", 12.0 * B * L_in * C, 4.0 * (2.0 * B * L_in * C + (double)B * L_out * C), st);
-  if (stride == 1) {
-    if (bn) hipLaunchKernelGGL((dwconv_bwd_kernel<1, true>), gr, b, 0, st, dz, y, bn, w, g, part, B, L_in, L_out, C, pad_l, ge.nchunks, ge.R);
-    else hipLaunchKernelGGL((dwconv_bwd_kernel<1, false>), gr, b, 0, st, dz, y, bn, w, g, part, B, L_in, L_out, C, pad_l, ge.nchunks, ge.R);
-  } else {
-    if (bn) hipLaunchKernelGGL((dwconv_bwd_kernel<2, true>), gr, b, 0, st, dz, y, bn, w, g, part, B, L_in, L_out, C, pad_l, ge.nchunks, ge.R);
-    else hipLaunchKernelGGL((dwconv_bwd_kernel<2, false>), gr, b, 0, st, dz, y, bn, w, g, part, B, L_in, L_out, C, pad_l, ge.nchunks, ge.R);
-  }
-  KWS_LAUNCH_CHECK("dwconv_bwd_kernel");
-  return KWS_OK;
+  return launch_dw_bwd<0>(dz, y, bn, w, nullptr, g, part, B, L_in, L_out, C, stride, pad_l, st);
+}
+
+int kws_dwconv_bwd_bn_f32(const float* dz, const float* y, const float* bn, const float* w, const float* coef,
+                          float* dy, float* part, int pass, int B, int L_in, int L_out, int C, int stride, int pad_l,
+                          void* stream) {
+  KWS_REQUIRE(dz && y && bn && w, "dwconv_bwd_bn: NULL pointer");
+  KWS_REQUIRE(pass == 1 ? part != nullptr : (pass == 2 && coef != nullptr && dy != nullptr),
+              "dwconv_bwd_bn: pass %d needs %s", pass, pass == 1 ? "part" : "coef and dy");
+  KWS_REQUIRE(B > 0 && L_in > 0 && L_out > 0 && C > 0 && C % 4 == 0 && C <= 1024,
+              "dwconv_bwd_bn: bad shape B=%d L=%d->%d C=%d", B, L_in, L_out, C);
+  KWS_REQUIRE(stride == 1 || stride == 2, "dwconv_bwd_bn: stride %d unsupported", stride);
+  hipStream_t st = (hipStream_t)stream;
+  KwsProfScope prof("dwconv_bwd", 12.0 * B * L_in * C,
+                    4.0 * ((pass == 2 ? 2.0 : 1.0) * B * L_in * C + (double)B * L_out * C), st);
+  if (pass == 1) return launch_dw_bwd<1>(dz, y, bn, w, nullptr, nullptr, part, B, L_in, L_out, C, stride, pad_l, st);
+  return launch_dw_bwd<2>(dz, y, bn, w, coef, dy, nullptr, B, L_in, L_out, C, stride, pad_l, st);
 }
 
 }  // extern "C"

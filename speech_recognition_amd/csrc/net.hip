@@ -404,8 +404,10 @@ int kws_net_train_fwd_bwd(const kws_net_t* net, const float* params, float* stat
     const int64_t M = (int64_t)B * b.Lout;
     float* Gcur = Gb[(i + 1) % 2];
     float* Gnext = Gb[i % 2];
-    // Gcur = masked gradient wrt bn output of this block -> dy (in place)
-    KWS_TRY(kws_bn_bwd_apply(Gcur, ws + lo.y[i + 1], bn_at(i + 1), params + b.bn.gamma, coef, M, b.cout, st));
+    // Gcur holds dy of this block's pointwise output: written by the depthwise backward of block i+1 (pass 2
+    // below); only the tail hands over a masked gradient that still needs its BatchNorm backward
+    if (i == nb - 1)
+      KWS_TRY(kws_bn_bwd_apply(Gcur, ws + lo.y[i + 1], bn_at(i + 1), params + b.bn.gamma, coef, M, b.cout, st));
     KWS_TRY(kws_transpose_f32(params + b.pw, ws + lo.WT, b.cin, b.cout, st));
     KWS_TRY(kws_gemm_nn_f32(Gcur, ws + lo.WT, DZ, M, b.cout, b.cin, nullptr, st));
     if (overlap) {
@@ -422,15 +424,19 @@ int kws_net_train_fwd_bwd(const kws_net_t* net, const float* params, float* stat
       }
     }
     const BnRef& prev = (i == 0) ? net->bn1 : net->blocks[i - 1].bn;
-    KWS_TRY(kws_dwconv_bwd_f32(DZ, ws + lo.y[i], bn_at(i), params + b.dw, Gnext, part, B, b.Lin, b.Lout, b.cin, b.stride,
-                               b.pad_l, st));
+    // depthwise backward + BatchNorm backward of this block's input without materialising the masked
+    // gradient: reduce, fold (dw, dgamma, dbeta, c1 | c2), recompute and write dy of the previous block
+    KWS_TRY(kws_dwconv_bwd_bn_f32(DZ, ws + lo.y[i], bn_at(i), params + b.dw, nullptr, nullptr, part, 1, B, b.Lin, b.Lout,
+                                  b.cin, b.stride, b.pad_l, st));
     const int n_parts = (int)(kws_dwconv_bwd_part_floats(B, b.Lin, b.cin) / (5 * b.cin));
     KWS_TRY(kws_dw_bwd_finalize(part, n_parts, (int64_t)B * b.Lin, b.cin, grads + b.dw,
                                 grads + prev.gamma, grads + prev.beta, coef, red, st));
+    KWS_TRY(kws_dwconv_bwd_bn_f32(DZ, ws + lo.y[i], bn_at(i), params + b.dw, coef, Gnext, nullptr, 2, B, b.Lin, b.Lout,
+                                  b.cin, b.stride, b.pad_l, st));
   }
   {
     const int64_t M = (int64_t)B * net->L1;
-    KWS_TRY(kws_bn_bwd_apply(Gb[0], ws + lo.y[0], bn_at(0), params + net->bn1.gamma, coef, M, net->C1, st));
+    (void)M;                                        // Gb[0] already holds dy of the first convolution
     if (overlap) {                                  // the side stream's TN workspace is free once its queue drains
       KWS_HIP(hipEventRecord(net->ev_join, sw));
       KWS_HIP(hipStreamWaitEvent(st, net->ev_join, 0));

@@ -187,6 +187,16 @@ def test_dwconv_fwd_bwd(Lin, stride, pad, C, with_bn):
         _lib.call("kws_bn_bwd_apply", _lib.ptr(g), _lib.ptr(dev(y)), _lib.ptr(dbn), _lib.ptr(dev(gamma)),
                   _lib.ptr(coef), B * Lin, C, S())
         assert np.abs(g.cpu().numpy() - dy_ref).max() < 5e-5 * max(1.0, np.abs(dy_ref).max())
+        # the fused two-pass variant (no g in memory): same partial sums, same dy
+        part2 = torch.full((n_part,), float("nan"), device="cuda")
+        _lib.call("kws_dwconv_bwd_bn_f32", _lib.ptr(dev(dz)), _lib.ptr(dev(y)), _lib.ptr(dbn), _lib.ptr(dev(w)), None,
+                  None, _lib.ptr(part2), 1, B, Lin, Lout, C, stride, pad[0], S())
+        assert torch.equal(part2, part)
+        dy2 = torch.full((B, Lin, C), float("nan"), device="cuda")
+        _lib.call("kws_dwconv_bwd_bn_f32", _lib.ptr(dev(dz)), _lib.ptr(dev(y)), _lib.ptr(dbn), _lib.ptr(dev(w)),
+                  _lib.ptr(coef), _lib.ptr(dy2), None, 2, B, Lin, Lout, C, stride, pad[0], S())
+        assert np.abs(dy2.cpu().numpy() - dy_ref).max() < 5e-5 * max(1.0, np.abs(dy_ref).max())
+        assert float((dy2 - g).abs().max()) <= 1e-6 * max(1.0, float(g.abs().max()))   # vs the three-kernel path
 
 
 def test_bn_stats_finalize_and_apply():
