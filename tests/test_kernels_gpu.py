@@ -108,7 +108,11 @@ def test_gemm_gather_is_frame_plus_conv1():
     assert rel_err(dWt.cpu().numpy(), ref_dw) < 5e-6
 
 
-@pytest.mark.parametrize("M,K,N", [(4000, 128, 128), (999, 192, 256), (130, 320, 320), (9216, 512, 512)])
+# wave-specialised wgrad kernel: all four tile shapes (128x128, 128x64, 64x128, 64x64), a single short split,
+# ragged last stage, M below one stage; (2000, 120, 128) and (777, 64, 100) fall back to the 4-wave kernel
+@pytest.mark.parametrize("M,K,N", [(4000, 128, 128), (999, 192, 256), (130, 320, 320), (9216, 512, 512), (100, 64, 64),
+                                   (5000, 64, 128), (70000, 128, 64), (33, 256, 192), (2000, 120, 128),
+                                   (100000, 192, 192), (777, 64, 100), (1, 128, 128)])
 def test_gemm_tn(M, K, N):
     rng = np.random.RandomState(M)
     A = rng.randn(M, K).astype(np.float32)
