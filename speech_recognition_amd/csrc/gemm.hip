@@ -1155,6 +1155,7 @@ TNPlan tn_plan(int64_t M, int K, int N, bool ws) {
 // which kernel kws_gemm_nn_f32 runs for a shape, and how many statistics rows it writes
 struct NNPlan {
   bool ws;          // wave-specialised kernel
+  int bn;           // column-tile width: 128 or 64
   int kb;           // its K-slab depth
   int wgs;          // its grid (= statistics rows: one per workgroup)
   int m_tiles;      // statistics rows of the tile-per-row kernels
@@ -1162,9 +1163,18 @@ struct NNPlan {
 NNPlan nn_plan(int64_t M, int K, int N, bool gather) {
   static const bool use_persist = getenv("KWS_GEMM_PERSIST") != nullptr;  // 4-wave persistent kernel, A/B only
   NNPlan pl;
-  const int BN = (N % 128 == 0) ? 128 : 64;
-  pl.kb = (BN == 64 && K % 64 == 0 && K >= 128) ? 64 : 32;
   pl.m_tiles = (int)ceil_div64(M, 128);
+  int BN = (N % 128 == 0) ? 128 : 64;
+  if (BN == 128 && !gather && K % 64 == 0 && K >= 128) {
+    // One workgroup per CU walks ceil(tiles / 256) rounds of tiles; the small late layers have 1.1 - 2.3
+    // 128-wide tiles per CU and lose 25 - 44 % to the last partial round.  64-wide tiles (0.55 of the time of
+    // a 128-wide one with the 64-deep K-slabs) quantise finer: take them when they make the walk shorter.
+    const int64_t t128 = (int64_t)pl.m_tiles * (N / 128);
+    const double cost128 = (double)ceil_div64(t128, 256), cost64 = 0.55 * (double)ceil_div64(2 * t128, 256);
+    if (cost64 < cost128) BN = 64;
+  }
+  pl.bn = BN;
+  pl.kb = (BN == 64 && K % 64 == 0 && K >= 128) ? 64 : 32;
   const int64_t slots = ceil_div64(pl.m_tiles, NXCD) * ceil_div(N, BN);
   // wave-specialised kernel (default): needs whole K-slabs and column tiles, and 32-bit byte offsets
   // inside one tile's buffer views (128 rows of A / C, all of W); everything else (the gathered first
@@ -1180,8 +1190,9 @@ NNPlan nn_plan(int64_t M, int K, int N, bool gather) {
 template <bool GATHER>
 int launch_nn(const NNArgs& a0, hipStream_t st) {
   NNArgs a = a0;
-  const bool wide = (a.N % 128 == 0);
-  const int BN = wide ? 128 : 64;
+  const NNPlan pl = nn_plan(a.M, a.K, a.N, GATHER);
+  const bool wide = pl.bn == 128;
+  const int BN = pl.bn;
   a.m_tiles = (int)ceil_div64(a.M, 128);
   a.n_tiles = ceil_div(a.N, BN);
   const int64_t slots = ceil_div64(a.m_tiles, NXCD) * a.n_tiles;
@@ -1191,7 +1202,6 @@ int launch_nn(const NNArgs& a0, hipStream_t st) {
     return KWS_E_INVALID;
   }
   const bool stats = a.stats != nullptr;
-  const NNPlan pl = nn_plan(a.M, a.K, a.N, GATHER);
   if (pl.ws) {
     dim3 gp((unsigned)pl.wgs), bp(8 * 64);
     if (wide) {
