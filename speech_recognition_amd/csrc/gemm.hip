@@ -1139,9 +1139,15 @@ TNPlan tn_plan(int64_t M, int K, int N, bool ws) {
   pl.k_tiles = ceil_div(K, pl.bko);
   pl.n_tiles = ceil_div(N, pl.bno);
   const int tiles = pl.k_tiles * pl.n_tiles;
-  int64_t S = ceil_div64(768, tiles);   // ~3 workgroups per CU in flight
-  static const int max_s = getenv("KWS_TN_MAX_S") ? atoi(getenv("KWS_TN_MAX_S")) : 256;
-  if (S > max_s) S = max_s;             // bounds the partial-slab traffic (S * K * N floats)
+  int64_t S;
+  if (ws) {
+    // the work items (tile, split) should fill whole residency rounds: 2 workgroups per CU for the 64 KB
+    // 128x128 kernel, 1 per CU for the others; ~512 items measured best (768 leaves half-empty rounds)
+    S = 512 / tiles;                    // floor: tiles * S <= 512 = 1 round of 512 slots or 2 rounds of 256
+  } else {
+    S = ceil_div64(768, tiles);         // 4-wave kernel: ~3 workgroups per CU in flight
+  }
+  if (S > 256) S = 256;                 // bounds the partial-slab traffic (S * K * N floats)
   const int64_t maxS = M / 256 > 1 ? M / 256 : 1;
   if (S > maxS) S = maxS;
   if (S < 1) S = 1;
