@@ -77,9 +77,8 @@ template <bool TRAIN, int TT>
 __global__ __launch_bounds__(256) void ts_tail_kernel(TailArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int T = a.T, C = a.C, NC = a.NC, TC = T * C;
-  float* xs = lds;                 // [TC]
-  float* xd = xs + TC;             // [TC]   dropped x, later dx
-  float* feat = xd + TC;           // [2C]
+  float* xs = lds;                 // [TC]   x = relu6(bn(y)); overwritten in place by dx in the backward half
+  float* feat = xs + TC;           // [2C]   (one [TC] tile keeps the workgroup at 30 KB of LDS: all 1024 clips resident)
   float* dfeat = feat + 2 * C;     // [2C]
   float* scratch = dfeat + 2 * C;  // [4*MAXNC]
   float* l1 = scratch + 4 * MAXNC; // [MAXT] logits1 / att
@@ -101,13 +100,15 @@ __global__ __launch_bounds__(256) void ts_tail_kernel(TailArgs a) {
     const int c = e % C;
     const float x = relu6f(fmaf(yb[e], a.bn[c], a.bn[C + c]));
     xs[e] = x;
-    float d = x;
-    if (TRAIN) d = kws_keep(row * (uint32_t)TC + (uint32_t)e, a.key1, a.thresh) ? x * a.inv_keep : 0.f;
-    xd[e] = d;
-    if (TRAIN) a.xd[(int64_t)b * TC + e] = d;
+    if (TRAIN)   // the dropped activations are only stored for the dW1 reduction; the logits recompute the mask
+      a.xd[(int64_t)b * TC + e] = kws_keep(row * (uint32_t)TC + (uint32_t)e, a.key1, a.thresh) ? x * a.inv_keep : 0.f;
   }
+  auto dropped = [&](float x, int e) -> float {
+    if (!TRAIN) return x;
+    return kws_keep(row * (uint32_t)TC + (uint32_t)e, a.key1, a.thresh) ? x * a.inv_keep : 0.f;
+  };
   __syncthreads();
-  // ---- logits1 = xd . W1 + b1 ------------------------------------------------------------------
+  // ---- logits1 = dropout(x) . W1 + b1 ------------------------------------------------------------------
   {
     if (TT > 0) {
       // thread <- row groups rg, rg+256, ...: 4 rows of W1 = TT float4, 4 x values = one LDS float4
@@ -123,8 +124,9 @@ __global__ __launch_bounds__(256) void ts_tail_kernel(TailArgs a) {
           const float4 w4 = wp[i];
           wv[4 * i] = w4.x; wv[4 * i + 1] = w4.y; wv[4 * i + 2] = w4.z; wv[4 * i + 3] = w4.w;
         }
-        const float4 x4 = *reinterpret_cast<const float4*>(xd + rg * 4);
-        const float xr[4] = {x4.x, x4.y, x4.z, x4.w};
+        const float4 x4 = *reinterpret_cast<const float4*>(xs + rg * 4);
+        const float xr[4] = {dropped(x4.x, rg * 4), dropped(x4.y, rg * 4 + 1), dropped(x4.z, rg * 4 + 2),
+                             dropped(x4.w, rg * 4 + 3)};
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(256) void ts_tail_kernel(TailArgs a) {
       const int t = tid & 15, sl = tid >> 4;
       float s = 0.f;
       if (t < T)
-        for (int e = sl; e < TC; e += 16) s = fmaf(xd[e], a.W1[(int64_t)e * T + t], s);
+        for (int e = sl; e < TC; e += 16) s = fmaf(dropped(xs[e], e), a.W1[(int64_t)e * T + t], s);
       part16[sl * 16 + t] = s;
       __syncthreads();
       if (tid < T) {
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(256) void ts_tail_kernel(TailArgs a) {
       if (t < T) {
         const float xv = xs[t * C + c];
         const float dxa = (xv * att[t] == mx) ? share : 0.f;
-        xd[t * C + c] = dxa * att[t] + davg;  // xd now holds dx
+        xs[t * C + c] = dxa * att[t] + davg;  // in place: x at this position is not needed again
         dattl[t] += dxa * xv;
       }
     }
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(256) void ts_tail_kernel(TailArgs a) {
   if (tid < T) a.dl1[(int64_t)b * T + tid] = dl1[tid];
   // ---- dx += (W1 . dl1) * mask1 / keep ; g = dx * relu6'(pre) ; BN-backward partial sums ------
   if (TT > 0) {
-    // coalesced pass over W1 (same 4-row groups as the forward): xd (= dx) += dropout-masked W1 . dl1
+    // coalesced pass over W1 (same 4-row groups as the forward): dx (held in xs) += dropout-masked W1 . dl1
     constexpr int TV = TT > 0 ? TT : 1;
     float dv[TV];
 #pragma unroll
@@ -299,9 +301,9 @@ __global__ __launch_bounds__(256) void ts_tail_kernel(TailArgs a) {
         const bool keep = kws_keep(row * (uint32_t)TC + (uint32_t)(rg * 4 + r), a.key1, a.thresh);
         sr[r] = keep ? s * a.inv_keep : 0.f;
       }
-      float4 d4 = *reinterpret_cast<float4*>(xd + rg * 4);
+      float4 d4 = *reinterpret_cast<float4*>(xs + rg * 4);
       d4.x += sr[0]; d4.y += sr[1]; d4.z += sr[2]; d4.w += sr[3];
-      *reinterpret_cast<float4*>(xd + rg * 4) = d4;
+      *reinterpret_cast<float4*>(xs + rg * 4) = d4;
     }
     __syncthreads();
   }
@@ -311,7 +313,7 @@ __global__ __launch_bounds__(256) void ts_tail_kernel(TailArgs a) {
     float sg = 0.f, sgx = 0.f;
     for (int t = 0; t < T; ++t) {
       const int e = t * C + c;
-      float dx = xd[e];
+      float dx = xs[e];
       if (TT == 0) {
         float s = 0.f;
         for (int q = 0; q < T; ++q) s = fmaf(a.W1[(int64_t)e * T + q], dl1[q], s);
@@ -417,7 +419,7 @@ int kws_ts_tail_launch(const kws_ts_tail_args* p, hipStream_t st) {
   KWS_REQUIRE(p->T > 0 && p->T <= MAXT && p->NC > 0 && p->NC <= MAXNC && p->C > 0, "ts_tail: bad shape T=%d NC=%d",
               p->T, p->NC);
   const int TC = p->T * p->C;
-  const size_t lds_floats = (size_t)2 * TC + 4 * p->C + 4 * MAXNC + 4 * MAXT + 3 * MAXNC + 256;
+  const size_t lds_floats = (size_t)TC + 4 * p->C + 4 * MAXNC + 4 * MAXT + 3 * MAXNC + 256;
   KWS_REQUIRE(lds_floats * 4 <= 160 * 1024, "ts_tail: T*C=%d does not fit LDS", TC);
   TailArgs a{};
   a.y = p->y; a.bn = p->bn; a.W1 = p->W1; a.b1 = p->b1; a.W2 = p->W2; a.labels = p->labels; a.probs = p->probs;
