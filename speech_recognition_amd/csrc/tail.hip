@@ -185,14 +185,36 @@ __global__ __launch_bounds__(256) void ts_tail_kernel(TailArgs a) {
   __syncthreads();
   // ---- logits2 = fd . W2 : thread (k = tid%64, slice = tid/64) -------------------------------
   {
-    const int k = tid & 63, sl = tid >> 6;
-    float s = 0.f;
-    if (k < NC)
-      for (int i = sl; i < 2 * C; i += 4) s = fmaf(dfeat[i], a.W2[(int64_t)i * NC + k], s);
-    scratch[sl * MAXNC + k] = s;
-    __syncthreads();
-    if (tid < NC) l2[tid] = ((scratch[tid] + scratch[MAXNC + tid]) + scratch[2 * MAXNC + tid]) + scratch[3 * MAXNC + tid];
-    __syncthreads();
+    if ((NC & 3) == 0 && NC <= 16) {
+      // thread <- rows i, i+256, ...: a row of W2 is NC/4 whole 16-byte vectors (the per-class walk below issued
+      // 256 dependent 4-byte loads per thread on 12 of 64 lanes: 153 k of this kernel's 250 k cycles)
+      float pl[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) pl[q] = 0.f;
+      for (int i = tid; i < 2 * C; i += 256) {
+        const float f = dfeat[i];
+        const float4* wp = reinterpret_cast<const float4*>(a.W2 + (int64_t)i * NC);
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+          if (4 * v < NC) {
+            const float4 w4 = wp[v];
+            pl[4 * v] = fmaf(f, w4.x, pl[4 * v]);
+            pl[4 * v + 1] = fmaf(f, w4.y, pl[4 * v + 1]);
+            pl[4 * v + 2] = fmaf(f, w4.z, pl[4 * v + 2]);
+            pl[4 * v + 3] = fmaf(f, w4.w, pl[4 * v + 3]);
+          }
+      }
+      block_sum(pl, NC, scratch, l2);
+    } else {
+      const int k = tid & 63, sl = tid >> 6;
+      float s = 0.f;
+      if (k < NC)
+        for (int i = sl; i < 2 * C; i += 4) s = fmaf(dfeat[i], a.W2[(int64_t)i * NC + k], s);
+      scratch[sl * MAXNC + k] = s;
+      __syncthreads();
+      if (tid < NC) l2[tid] = ((scratch[tid] + scratch[MAXNC + tid]) + scratch[2 * MAXNC + tid]) + scratch[3 * MAXNC + tid];
+      __syncthreads();
+    }
     if (tid == 0) {
       float m = l2[0];
       for (int q = 1; q < NC; ++q) m = fmaxf(m, l2[q]);
@@ -244,7 +266,18 @@ __global__ __launch_bounds__(256) void ts_tail_kernel(TailArgs a) {
   // ---- dfeat = (W2 . dl2) * mask2 / keep ------------------------------------------------------
   for (int i = tid; i < 2 * C; i += 256) {
     float s = 0.f;
-    for (int q = 0; q < NC; ++q) s = fmaf(a.W2[(int64_t)i * NC + q], dl2[q], s);
+    if ((NC & 3) == 0) {
+      const float4* wp = reinterpret_cast<const float4*>(a.W2 + (int64_t)i * NC);
+      for (int v = 0; v < NC / 4; ++v) {
+        const float4 w4 = wp[v];
+        s = fmaf(w4.x, dl2[4 * v], s);
+        s = fmaf(w4.y, dl2[4 * v + 1], s);
+        s = fmaf(w4.z, dl2[4 * v + 2], s);
+        s = fmaf(w4.w, dl2[4 * v + 3], s);
+      }
+    } else {
+      for (int q = 0; q < NC; ++q) s = fmaf(a.W2[(int64_t)i * NC + q], dl2[q], s);
+    }
     const bool keep = kws_keep(row * (uint32_t)(2 * C) + (uint32_t)i, a.key2, a.thresh);
     dfeat[i] = keep ? s * a.inv_keep : 0.f;
   }
