@@ -16,6 +16,18 @@ __device__ __forceinline__ float bank_sample<int16_t>(const int16_t* p, int i) {
   return (float)p[i] * (1.0f / 32768.0f);  // DecodeWav: int16 / 32768, exact in f32
 }
 
+typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));     // 4-byte aligned 16-byte vector
+typedef short i16x4_u __attribute__((ext_vector_type(4), aligned(2)));
+__device__ __forceinline__ void load4_unaligned(const float* p, float (&f)[4]) {
+  const f32x4_u v = *reinterpret_cast<const f32x4_u*>(p);
+  f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+}
+__device__ __forceinline__ void load4_unaligned(const int16_t* p, float (&f)[4]) {
+  const i16x4_u v = *reinterpret_cast<const i16x4_u*>(p);
+  f[0] = (float)v.x * (1.0f / 32768.0f); f[1] = (float)v.y * (1.0f / 32768.0f);
+  f[2] = (float)v.z * (1.0f / 32768.0f); f[3] = (float)v.w * (1.0f / 32768.0f);
+}
+
 // out[b,t] = noise[off_b + t] * bgv_b  +  bank[idx_b][(t - s_b) mod L] * fg_b
 // Separate (unfused) multiplies and add, in the operand order of the TF graph
 // (input_data.py:340-355: multiply, roll, multiply, add(background_mul, shifted_foreground)), so the
@@ -43,22 +55,38 @@ __global__ __launch_bounds__(256) void augment_kernel(const BankT* __restrict__ 
   int p = t0 - s;
   if (p < 0) p += L;
   float v[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int t = t0 + e;
-    float r = 0.f;
-    if (t < L) {
-      int pe = p + e;
-      if (pe >= L) pe -= L;
-      const float f = __fmul_rn(bank_sample<BankT>(src, pe), fg);
-      float n = 0.f;
-      if (noise != nullptr && bgv != 0.f) {
-        const int64_t o = noise_off[b] + t;
-        n = __fmul_rn((o >= 0 && o < noise_len) ? noise[o] : 0.f, bgv);
-      }
-      r = __fadd_rn(n, f);
+  const bool use_noise = noise != nullptr && bgv != 0.f;
+  const int64_t o0 = use_noise ? noise_off[b] + t0 : 0;
+  // Fast path (all but the threads at the roll seam, the clip end or the noise ends): the four source samples
+  // are contiguous, so each stream is ONE unaligned 16-byte (8-byte for int16) load instead of four dependent,
+  // branch-guarded dword loads.
+  if (t0 + 3 < L && p + 3 < L && (!use_noise || (o0 >= 0 && o0 + 3 < noise_len))) {
+    float f[4], n[4] = {0.f, 0.f, 0.f, 0.f};
+    load4_unaligned(src + p, f);
+    if (use_noise) {
+      const f32x4_u nv = *reinterpret_cast<const f32x4_u*>(noise + o0);
+      n[0] = nv.x; n[1] = nv.y; n[2] = nv.z; n[3] = nv.w;
     }
-    v[e] = r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = __fadd_rn(use_noise ? __fmul_rn(n[e], bgv) : 0.f, __fmul_rn(f[e], fg));
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int t = t0 + e;
+      float r = 0.f;
+      if (t < L) {
+        int pe = p + e;
+        if (pe >= L) pe -= L;
+        const float f = __fmul_rn(bank_sample<BankT>(src, pe), fg);
+        float n = 0.f;
+        if (use_noise) {
+          const int64_t o = o0 + e;
+          n = __fmul_rn((o >= 0 && o < noise_len) ? noise[o] : 0.f, bgv);
+        }
+        r = __fadd_rn(n, f);
+      }
+      v[e] = r;
+    }
   }
   float* ob = out + (int64_t)b * L + t0;
   if (t0 + 3 < L && (L & 3) == 0) {
