@@ -793,6 +793,25 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs p) {
   const int64_t m_end = (m_begin + p.chunk < p.M) ? m_begin + p.chunk : p.M;
 
   float4 rz[Z_F4], rg[G_F4];
+  // gathered A: a thread's columns never change and its rows advance by MS per stage, so the clip / row split
+  // (an integer division) is done once and carried incrementally
+  int gz_koff[Z_F4], gz_t[Z_F4];
+  int64_t gz_b[Z_F4];
+  bool gz_kok[Z_F4];
+  if (GATHER) {
+#pragma unroll
+    for (int r = 0; r < Z_F4; ++r) {
+      const int idx = tid + r * 256;
+      const int row = idx / BKO4, c4 = idx % BKO4;
+      const int gk = k0 + c4 * 4;
+      const int j = gk / p.g.cin;
+      gz_kok[r] = gk < K;
+      gz_koff[r] = j * p.g.stride_j + (gk - j * p.g.cin) + p.g.base_off;
+      const int64_t gm = m_begin + row;
+      gz_b[r] = gm / p.g.L_out;
+      gz_t[r] = (int)(gm - gz_b[r] * p.g.L_out);
+    }
+  }
   auto load_global = [&](int64_t mb) {
 #pragma unroll
     for (int r = 0; r < Z_F4; ++r) {
@@ -802,15 +821,15 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs p) {
       const int gk = k0 + c4 * 4;
       const bool ok = gm < m_end && gk < K;
       if (GATHER) {
-        if (ok) {
-          const int64_t b = gm / p.g.L_out;
-          const int t = (int)(gm - b * p.g.L_out);
-          const int j = gk / p.g.cin;
-          const int c = gk - j * p.g.cin;
-          rz[r] = gather4(p.A + b * p.g.x_batch_stride,
-                          t * p.g.stride_t + j * p.g.stride_j + c + p.g.base_off, p.g.x_len);
+        if (gm < m_end && gz_kok[r]) {
+          rz[r] = gather4(p.A + gz_b[r] * p.g.x_batch_stride, gz_t[r] * p.g.stride_t + gz_koff[r], p.g.x_len);
         } else {
           rz[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        gz_t[r] += MS;                               // next stage: MS rows further
+        while (gz_t[r] >= p.g.L_out) {
+          gz_t[r] -= p.g.L_out;
+          ++gz_b[r];
         }
       } else {
         rz[r] = ld4_or_zero(p.A + (ok ? gm : 0) * (int64_t)K + gk, ok);
