@@ -1,0 +1,84 @@
+"""Throughput of the other BASELINE.json configurations on one MI355X (informative lines for DESIGN.md; bench.py is
+the contract benchmark for configs[1]):
+
+  C3  configs[2]: 32-class conv_1d_log_mfcc net on 40 x 98 log-mel features, batch 2048: STFT/mel(40,40) of the
+      raw clips + forward/backward + RMSprop (6e-4), inputs resident in HBM;
+  C5  configs[4]: TTA inference (identity + 1.2x volume + 1500-sample roll, make_submission.py:125-135) of the
+      12-class raw-waveform net, batches of 4096 clips; and plain inference for comparison.
+
+Prints one JSON line per configuration."""
+import ctypes
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from speech_recognition_amd import _lib  # noqa: E402
+from speech_recognition_amd.features import path_b_tables  # noqa: E402
+from speech_recognition_amd.keras_api import Model, RMSprop  # noqa: E402
+from speech_recognition_amd.net import DeviceNet  # noqa: E402
+from speech_recognition_amd.tta import predict_tta  # noqa: E402
+
+
+def timed(fn, warm, n):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / n
+
+
+def clips(B, seed):
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    return (torch.randn((B, 16000), generator=g, device="cuda") * 0.0774).clamp_(-1, 1).contiguous()
+
+
+def c3():
+    B = 2048
+    lib = _lib.load()
+    t = path_b_tables(480, 40, 40)
+    plan = ctypes.c_void_p()
+    _lib.check(lib.kws_stft_plan_create(480, 160, 512, 40, 40, t['window'].ctypes.data_as(ctypes.c_void_p),
+                                        t['mel'].ctypes.data_as(ctypes.c_void_p), t['dct'].ctypes.data_as(ctypes.c_void_p),
+                                        1e-6, 0.0, ctypes.byref(plan)), "plan")
+    net = DeviceNet(_lib.KWS_NET_LOG_MFCC, 32, input_size=98 * 40, spectrogram_length=98, num_features=40)
+    net.initialize(seed=3)
+    model = Model(net, RMSprop(lr=6e-4), loss='cce')
+    x = clips(B, 1)
+    y = torch.eye(32, device="cuda")[torch.randint(0, 32, (B,), device="cuda")].contiguous()
+    feats = torch.empty((B, 98 * 40), device="cuda")
+    row = torch.zeros(4, device="cuda")
+
+    def step():
+        _lib.call("kws_stft_mel_f32", plan, _lib.ptr(x), B, 16000, _lib.ptr(feats), 0, _lib.stream_ptr())
+        model._train_step_async(feats, y, row)
+
+    ms = timed(step, 5, 30)
+    print(json.dumps({"config": "C3: 32-class conv_1d_log_mfcc, log-mel 40x98 from raw clips, batch 2048, fwd+bwd+RMSprop",
+                      "ms_per_step": ms, "clips_per_s": B / ms * 1e3, "n_gpus": 1, "dtype": "f32", "data": "synthetic"}))
+
+
+def c5():
+    B = 4096
+    net = DeviceNet(_lib.KWS_NET_TS_ATTENTION, 12)
+    net.initialize(seed=3)
+    model = Model(net, RMSprop())
+    x = clips(B, 2)
+    ms_plain = timed(lambda: net.predict(x), 3, 10)
+    ms_tta = timed(lambda: predict_tta(model, x), 3, 10)
+    print(json.dumps({"config": "C5: 12-class raw-waveform net, TTA inference x3 (identity, 1.2x, roll 1500), batch 4096",
+                      "ms_per_batch": ms_tta, "clips_per_s": B / ms_tta * 1e3, "plain_inference_clips_per_s": B / ms_plain * 1e3,
+                      "n_gpus": 1, "dtype": "f32", "data": "synthetic"}))
+
+
+if __name__ == "__main__":
+    c3()
+    c5()
