@@ -120,6 +120,9 @@ def main():
     # (data_gen's per-epoch "[Ep:...]" line mirrors the reference and goes to stdout) is sent to stderr
     json_out = sys.stdout
     sys.stdout = sys.stderr
+    if os.environ.get("KWS_BENCH_TRACE"):        # debugging aid: dump every thread's stack after N seconds and exit
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["KWS_BENCH_TRACE"]), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -133,6 +136,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("KWS_BENCH_ONE_DEVICE"):   # test hook: N ranks on ONE GPU over gloo (1-GPU boxes cannot run RCCL x N)
+        local_rank = 0
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback of the product path")
     torch.cuda.set_device(local_rank)
@@ -141,7 +146,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if os.environ.get("KWS_BENCH_ONE_DEVICE"):
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
     from speech_recognition_amd import _lib
@@ -196,16 +204,20 @@ def main():
     # ---- per-kernel durations of the same step, HIP events on the launch stream -------------------
     prof = None
     roof = None
-    if rank == 0 and args.profile_steps > 0:
+    if args.profile_steps > 0:
+        # EVERY rank runs the profiled steps (each step contains the gradient all-reduce: a rank that skipped them
+        # would leave the others waiting in the collective); only rank 0 records and reports the kernel times
         lib = _lib.load()
-        if hasattr(lib, "kws_profile_enable"):
+        if rank == 0:
             lib.kws_profile_enable(1)
-            for i in range(args.profile_steps):
-                step(args.warmup + args.steps + i)
-            torch.cuda.synchronize()
-            prof = _lib.profile_collect()
-            lib.kws_profile_enable(0)
-            k = prof.get("gemm_nn")
+        for i in range(args.profile_steps):
+            step(args.warmup + args.steps + i)
+        barrier()
+    if rank == 0 and args.profile_steps > 0:
+        prof = _lib.profile_collect()
+        lib.kws_profile_enable(0)
+        k = prof.get("gemm_nn")
+        if True:
             if k and k["ms"] > 0:
                 ach = k["flops"] / (k["ms"] * 1e-3) / 1e12
                 traffic = None   # HBM bytes per launch from the separate rocprofv3 --pmc passes (profiles/)

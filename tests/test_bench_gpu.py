@@ -1,0 +1,35 @@
+"""bench.py control flow with more than one rank.  A 1-GPU box cannot run RCCL across two ranks, so the test hook
+KWS_BENCH_ONE_DEVICE puts both ranks on cuda:0 over gloo: every collective of the data-parallel path (gradient
+all-reduce inside each step, barriers, the MAX of the timings) and the rank-0-only reporting are exercised exactly as
+under torch.distributed.run --nproc-per-node N on an N-GPU node.  (A rank-0-only profiling loop once left the other
+ranks out of the per-step all-reduce and hung the job: this test is the guard.)"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_two_ranks_print_one_json_line():
+    env = dict(os.environ, KWS_BENCH_ONE_DEVICE="1", KWS_BENCH_TRACE="240", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6",
+           "--warmup", "2", "--bank", "8192", "--batch", "256"]
+    res = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=400)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    lines = [l for l in res.stdout.decode().splitlines() if l.strip()]
+    json_lines = [l for l in lines if l.lstrip().startswith("{")]
+    other = [l for l in lines if not l.lstrip().startswith("{")]
+    assert len(json_lines) == 1, lines                 # rank 0 prints ONE JSON line, rank 1 nothing
+    assert all("bench.py" not in l for l in other), other    # anything else on stdout is the launcher's own banner
+    out = json.loads(json_lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 6 and out["warmup"] == 2 and out["scaling"] == "weak"
+    assert out["config"]["global_batch"] == 512 and out["config"]["parallelism"] == "dp2"
+    assert out["value"] > 0 and out["roofline"] is not None and out["cpu_baseline"] is None
+    assert out["train_loss_first_last"][0] == out["train_loss_first_last"][0]      # finite
+    print("non-JSON stdout lines of the launcher:", other)
