@@ -353,11 +353,13 @@ int lm_train(const kws_net* n, const float* params, float* state, const float* x
     KWS_TRY(kws_gemm_nn_f32(G, ws + lo.WT, DZ, M, b.nf, b.nf, nullptr, st));
     KWS_TRY(kws_gemm_tn_f32(ws + lo.z2[i], G, grads + b.pw2, M, b.nf, b.nf, ws + lo.tn, st));
     // depthwise 2 -> BN1 -> pointwise 1
-    KWS_TRY(kws_dwconv_bwd_f32(DZ, ws + lo.y1[i], c.bn_at(b.bn1_idx), params + b.dw2, G, part, B, b.Lin, b.Lin, b.nf, 1,
-                               1, st));
+    // (two passes over dz and y1 instead of "store g, then kws_bn_bwd_apply": the masked gradient is never stored)
+    KWS_TRY(kws_dwconv_bwd_bn_f32(DZ, ws + lo.y1[i], c.bn_at(b.bn1_idx), params + b.dw2, nullptr, nullptr, part, 1, B,
+                                  b.Lin, b.Lin, b.nf, 1, 1, st));
     np = (int)(kws_dwconv_bwd_part_floats(B, b.Lin, b.nf) / (5 * b.nf));
     KWS_TRY(kws_dw_bwd_finalize(part, np, M, b.nf, grads + b.dw2, grads + b.bn1.gamma, grads + b.bn1.beta, coef, red, st));
-    KWS_TRY(kws_bn_bwd_apply(G, ws + lo.y1[i], c.bn_at(b.bn1_idx), params + b.bn1.gamma, coef, M, b.nf, st));
+    KWS_TRY(kws_dwconv_bwd_bn_f32(DZ, ws + lo.y1[i], c.bn_at(b.bn1_idx), params + b.dw2, coef, G, nullptr, 2, B, b.Lin,
+                                  b.Lin, b.nf, 1, 1, st));
     KWS_TRY(kws_transpose_f32(params + b.pw1, ws + lo.WT, b.cin, b.nf, st));
     KWS_TRY(kws_gemm_nn_f32(G, ws + lo.WT, DZ, M, b.nf, b.cin, nullptr, st));
     KWS_TRY(kws_gemm_tn_f32(ws + lo.z1[i], G, grads + b.pw1, M, b.cin, b.nf, ws + lo.tn, st));
