@@ -251,9 +251,6 @@ __global__ __launch_bounds__(NW2 * 64, 1) void stft2_kernel(Stft2Args a) {
 //     FMAs per frame.
 // LDS per workgroup (n_mel = 80): 8 waves x (4 transpose tiles + 16 x 81 log-mel) + DCT table [80][80]
 // (row stride 80: the four k rows of an MFMA B operand fall on the two bank halves) + CSR = 141 KB.
-// LDS hand-off inside one wave: LDS operations of a wave execute in issue order, so only the COMPILER has to be
-// kept from reordering them (a release/acquire fence pair would also wait for every outstanding global load)
-#define WAVE_LDS_SYNC() do { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); } while (0)
 constexpr int NW3 = 8;
 constexpr int DSTR = 80;            // DCT table row stride (floats)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -266,8 +263,7 @@ __global__ __launch_bounds__(NW3 * 64, 1) void stft3_kernel(Stft2Args a) {
   float* s_dct = lds;                                              // [n_mel][DSTR]
   float* s_bw = s_dct + n_mel * DSTR;                              // [n_w]
   int* s_csr = reinterpret_cast<int*>(s_bw + ((pl.n_w + 3) & ~3)); // [3][128] start | cnt | ofs
-  float2* s_w512 = reinterpret_cast<float2*>(s_csr + 3 * 128);     // [258] split factors (registers are spent on the prefetch)
-  float* s_wave = reinterpret_cast<float*>(s_w512 + 258);
+  float* s_wave = reinterpret_cast<float*>(s_csr + 3 * 128);
   constexpr int FR_FLOATS = 16 * TP * 2;                           // one frame's transpose tile (544 floats)
   const int wave_floats = 4 * FR_FLOATS + ((16 * LMS + 3) & ~3);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -280,18 +276,19 @@ __global__ __launch_bounds__(NW3 * 64, 1) void stft3_kernel(Stft2Args a) {
     s_dct[i] = q < 64 ? pl.dct64[m * 64 + q] : 0.f;
   }
   for (int i = tid; i < pl.n_w; i += NW3 * 64) s_bw[i] = pl.band_w[i];
-  for (int i = tid; i < 257; i += NW3 * 64) s_w512[i] = pl.w512[i];
   for (int i = tid; i < 128; i += NW3 * 64) {
     s_csr[i] = i < n_mel ? pl.band_start[i] : 0;
     s_csr[128 + i] = i < n_mel ? pl.band_cnt[i] : 0;
     s_csr[256 + i] = i < n_mel ? pl.band_ofs[i] : 0;
   }
   // per-lane FFT constants
-  float2 r_win[16], r_tw[16];
+  float2 r_win[16], r_tw[16], r_w512[16];
 #pragma unroll
   for (int n1 = 0; n1 < 16; ++n1) r_win[n1] = *reinterpret_cast<const float2*>(pl.window + 2 * (16 * n1 + l16));
 #pragma unroll
   for (int k1 = 0; k1 < 16; ++k1) r_tw[k1] = pl.tw16[l16 * 16 + k1];
+#pragma unroll
+  for (int k2 = 0; k2 < 16; ++k2) r_w512[k2] = pl.w512[l16 + 16 * k2];
   __syncthreads();
 
   const int64_t n_super = (a.total_quads + 3) / 4;
@@ -299,44 +296,39 @@ __global__ __launch_bounds__(NW3 * 64, 1) void stft3_kernel(Stft2Args a) {
   const int64_t wave_stride = (int64_t)gridDim.x * NW3;
   const int nb_mel = (n_mel + 15) >> 4;   // mel bands per lane
   const int n_blk = (n_out + 15) >> 4;    // 16-column output blocks
-  // raw PCM of the NEXT quad is fetched while the current one is transformed: with two waves per SIMD the ~2 us
-  // global-load latency is otherwise a third of the kernel (phase stamps).  The wave-level LDS hand-offs below
-  // must not be release/acquire fences for this to work: those wait for every outstanding load.
-  auto load_raw = [&](int64_t quad, float2 (&xr)[16]) {
-    const bool quad_ok = quad < a.total_quads;
-    const unsigned qu = quad_ok ? (unsigned)quad : 0u;          // total_quads < 2^31 (host check): 32-bit division
-    const unsigned b = qu / (unsigned)a.quads_per_clip;
-    const int f = quad_ok ? (int)(qu - b * (unsigned)a.quads_per_clip) * 4 + fq : 0;
-    const float* fx = a.x + (int64_t)b * a.L + (int64_t)(f < a.F ? f : 0) * pl.frame_step;
-#pragma unroll
-    for (int n1 = 0; n1 < 16; ++n1) {
-      const int s = 2 * (16 * n1 + l16);
-      const int sc = s < pl.frame_len ? s : pl.frame_len - 2;   // clamped; the padded window zeroes the tail
-      xr[n1] = *reinterpret_cast<const float2*>(fx + sc);
-    }
-  };
-  float2 xn[16];
-  if (wave_global < n_super) load_raw(wave_global * 4, xn);
   for (int64_t sq = wave_global; sq < n_super; sq += wave_stride) {
 #pragma unroll 1
     for (int qq = 0; qq < 4; ++qq) {
-      // ---- window the prefetched samples: lane n2 = l16 holds z[16 n1 + n2] ----------------------------
+      const int64_t quad = sq * 4 + qq;
+      const bool quad_ok = quad < a.total_quads;
+      const int64_t b = quad_ok ? quad / a.quads_per_clip : 0;
+      const int f = quad_ok ? (int)(quad - b * a.quads_per_clip) * 4 + fq : 0;
+      const bool live = quad_ok && f < a.F;
+      const float* fx = a.x + b * (int64_t)a.L + (int64_t)(live ? f : 0) * pl.frame_step;
+      // ---- load + window: lane n2 = l16 takes z[16 n1 + n2] -----------------------------------------
       float2 z[16];
 #pragma unroll
-      for (int n1 = 0; n1 < 16; ++n1) z[n1] = make_float2(xn[n1].x * r_win[n1].x, xn[n1].y * r_win[n1].y);
-      if (qq < 3) load_raw(sq * 4 + qq + 1, xn);
-      else if (sq + wave_stride < n_super) load_raw((sq + wave_stride) * 4, xn);
+      for (int n1 = 0; n1 < 16; ++n1) {
+        const int s = 2 * (16 * n1 + l16);
+        const int sc = s < pl.frame_len ? s : pl.frame_len - 2;   // clamped; the padded window zeroes the tail
+        const float2 xv = *reinterpret_cast<const float2*>(fx + sc);
+        z[n1] = make_float2(xv.x * r_win[n1].x, xv.y * r_win[n1].y);
+      }
       fft16(z);
 #pragma unroll
       for (int k1 = 1; k1 < 16; ++k1) z[k1] = cmul(z[k1], r_tw[k1]);
       float2* tile = reinterpret_cast<float2*>(s_fr);
 #pragma unroll
       for (int k1 = 0; k1 < 16; ++k1) tile[k1 * TP + l16] = z[k1];
-      WAVE_LDS_SYNC();
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
       for (int n2 = 0; n2 < 16; ++n2) z[n2] = tile[l16 * TP + n2];
       fft16(z);
-      WAVE_LDS_SYNC();
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       // ---- real-input split + magnitude -------------------------------------------------------------
       float* s_mag = s_fr;                            // [260]
       const int partner = (16 - l16) & 15;
@@ -350,11 +342,13 @@ __global__ __launch_bounds__(NW3 * 64, 1) void stft3_kernel(Stft2Args a) {
         const float2 E = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y + zn.y));
         const float2 dd = csub(zk, zn);
         const float2 O = make_float2(0.5f * dd.y, -0.5f * dd.x);
-        const float2 X = cadd(E, cmul(s_w512[l16 + 16 * k2], O));
+        const float2 X = cadd(E, cmul(r_w512[k2], O));
         s_mag[l16 + 16 * k2] = __builtin_amdgcn_sqrtf(X.x * X.x + X.y * X.y);
       }
       if (l16 == 0) s_mag[256] = fabsf(z[0].x - z[0].y);
-      WAVE_LDS_SYNC();
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       // ---- sparse mel bands + log -> row 4 qq + fq of the super-quad's log-mel block ----------------------
       float* lm_row = s_lm16 + (4 * qq + fq) * LMS;
       for (int i = 0; i < nb_mel; ++i) {
@@ -379,7 +373,9 @@ __global__ __launch_bounds__(NW3 * 64, 1) void stft3_kernel(Stft2Args a) {
           lm_row[m] = __logf(sm);
         }
       }
-      WAVE_LDS_SYNC();                // s_mag reads done before the next quad reuses the tile
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();                // s_mag reads done before the next quad reuses the tile
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     // ---- DCT of the 16 frames on the matrix pipe: D[frame][q] = sum_m logmel[frame][m] dct[m][q] ----------
     // A: lane -> (frame = lane % 16, k = lane / 16); B: lane -> (k = lane / 16, q = 16 nb + lane % 16);
@@ -398,12 +394,12 @@ __global__ __launch_bounds__(NW3 * 64, 1) void stft3_kernel(Stft2Args a) {
     {
       const int64_t quad = sq * 4 + fq;               // lane group fq holds the frames of quad fq
       if (quad < a.total_quads) {
-        const unsigned b = (unsigned)quad / (unsigned)a.quads_per_clip;
-        const int f0 = (int)((unsigned)quad - b * (unsigned)a.quads_per_clip) * 4;
+        const int64_t b = quad / a.quads_per_clip;
+        const int f0 = (int)(quad - b * a.quads_per_clip) * 4;
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           if (f0 + v < a.F) {
-            float* orow = a.out + ((int64_t)b * a.F + f0 + v) * (int64_t)n_out + l16;
+            float* orow = a.out + (b * a.F + f0 + v) * (int64_t)n_out + l16;
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb)
               if (16 * nb + l16 < n_out) orow[16 * nb] = acc[nb][v];
@@ -411,14 +407,16 @@ __global__ __launch_bounds__(NW3 * 64, 1) void stft3_kernel(Stft2Args a) {
         }
       }
     }
-    WAVE_LDS_SYNC();                  // log-mel reads done before the next super-quad's writes
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();                  // log-mel reads done before the next super-quad's writes
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
 }
 
 }  // namespace
 
 int kws_stft3_lds_bytes(const kws_stft_plan* pl) {
-  const size_t floats = (size_t)pl->n_mel * DSTR + ((pl->n_w + 3) & ~3) + 3 * 128 + 2 * 258 +
+  const size_t floats = (size_t)pl->n_mel * DSTR + ((pl->n_w + 3) & ~3) + 3 * 128 +
                         (size_t)NW3 * (4 * (16 * TP * 2) + ((16 * (pl->n_mel + 1) + 3) & ~3));
   return (int)(floats * 4);
 }
@@ -426,8 +424,7 @@ int kws_stft3_lds_bytes(const kws_stft_plan* pl) {
 int kws_stft3_launch(const kws_stft_plan* pl, const float* x, int B, int L, int F, float* out, hipStream_t st) {
   KWS_REQUIRE(pl->n_out <= 64 && pl->n_mel % 4 == 0 && pl->n_mel <= 128, "stft3: n_mel=%d n_out=%d unsupported",
               pl->n_mel, pl->n_out);
-  KWS_REQUIRE(F > 0 && (pl->frame_step % 2) == 0 && (L % 2) == 0 && (int64_t)B * ((F + 3) / 4) < (1ll << 31),
-              "stft3: bad geometry");
+  KWS_REQUIRE(F > 0 && (pl->frame_step % 2) == 0 && (L % 2) == 0, "stft3: bad geometry");
   Stft2Args a;
   a.pl = *pl;
   a.x = x; a.out = out; a.B = B; a.L = L; a.F = F;
