@@ -282,13 +282,13 @@ __global__ __launch_bounds__(NW3 * 64, 1) void stft3_kernel(Stft2Args a) {
     s_csr[256 + i] = i < n_mel ? pl.band_ofs[i] : 0;
   }
   // per-lane FFT constants
-  float2 r_win[16], r_tw[16], r_w512[16];
+  float2 r_win[16], r_tw[16], r_w512[8];
 #pragma unroll
   for (int n1 = 0; n1 < 16; ++n1) r_win[n1] = *reinterpret_cast<const float2*>(pl.window + 2 * (16 * n1 + l16));
 #pragma unroll
   for (int k1 = 0; k1 < 16; ++k1) r_tw[k1] = pl.tw16[l16 * 16 + k1];
 #pragma unroll
-  for (int k2 = 0; k2 < 16; ++k2) r_w512[k2] = pl.w512[l16 + 16 * k2];
+  for (int k2 = 0; k2 < 8; ++k2) r_w512[k2] = pl.w512[l16 + 16 * k2];
   __syncthreads();
 
   const int64_t n_super = (a.total_quads + 3) / 4;
@@ -331,9 +331,12 @@ __global__ __launch_bounds__(NW3 * 64, 1) void stft3_kernel(Stft2Args a) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       // ---- real-input split + magnitude -------------------------------------------------------------
       float* s_mag = s_fr;                            // [260]
+      // X[k] = E + T and X[256-k] = conj(E - T) with E = (Z[k] + conj Z[256-k]) / 2, T = W512^k (Z[k] - conj Z[256-k]) / 2i:
+      // one twiddle product serves both bins, so a lane only walks its bins k = l16 + 16 k2 < 128 (k = 0 also
+      // yields the Nyquist bin 256); bin 128 pairs with itself
       const int partner = (16 - l16) & 15;
 #pragma unroll
-      for (int k2 = 0; k2 < 16; ++k2) {
+      for (int k2 = 0; k2 < 8; ++k2) {
         const float2 pa = z[15 - k2], pb = z[(16 - k2) & 15];
         const float px = __shfl(pa.x, partner, 16), py = __shfl(pa.y, partner, 16);
         const float2 zn0 = (l16 == 0) ? pb : make_float2(px, py);
@@ -342,10 +345,17 @@ __global__ __launch_bounds__(NW3 * 64, 1) void stft3_kernel(Stft2Args a) {
         const float2 E = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y + zn.y));
         const float2 dd = csub(zk, zn);
         const float2 O = make_float2(0.5f * dd.y, -0.5f * dd.x);
-        const float2 X = cadd(E, cmul(r_w512[k2], O));
-        s_mag[l16 + 16 * k2] = __builtin_amdgcn_sqrtf(X.x * X.x + X.y * X.y);
+        const float2 T = cmul(r_w512[k2], O);
+        const float2 Xp = cadd(E, T), Xm = csub(E, T);
+        const int kk = l16 + 16 * k2;
+        s_mag[kk] = __builtin_amdgcn_sqrtf(Xp.x * Xp.x + Xp.y * Xp.y);
+        s_mag[256 - kk] = __builtin_amdgcn_sqrtf(Xm.x * Xm.x + Xm.y * Xm.y);
       }
-      if (l16 == 0) s_mag[256] = fabsf(z[0].x - z[0].y);
+      if (l16 == 0) {                                 // bin 128: Z[128] with itself, W512^128 = -i
+        const float2 zk = z[8];
+        // E = Re Z (real part) .. general formula with zn = conj(zk): E = (Re zk, 0), O = (Im zk, 0), T = -i * Im zk
+        s_mag[128] = __builtin_amdgcn_sqrtf(zk.x * zk.x + zk.y * zk.y);
+      }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
