@@ -182,15 +182,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_persist_kernel(NNArgs p) {
   };
 
   f32x16 acc[TM][TN];
-#ifdef KWS_GEMM_STAMP
-  unsigned long long t_load = 0, t_comp = 0, t_store = 0, t_sync = 0, t_epi = 0, t_mark = 0, n_tiles_done = 0;
-  const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
-#define PT0() t_mark = __builtin_amdgcn_s_memtime()
-#define PT(acc_) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc_ += now_ - t_mark; t_mark = now_; } while (0)
-#else
-#define PT0()
-#define PT(acc_)
-#endif
   setup(local);
   load_global(0);
   store_lds(0);
@@ -208,14 +199,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_persist_kernel(NNArgs p) {
         for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
     for (int kt = 0; kt < nk; ++kt) {
       const int cur = kt & 1;
-      PT0();
       if (kt + 1 < nk) {
         load_global((kt + 1) * PBK);
       } else if (has_next) {
         setup(next);        // first K-slab of the NEXT tile flies while this tile's last slab is computed
         load_global(0);
       }
-      PT(t_load);
       const float* cA = smem + cur * STAGE + (wm * TM * 32 + li) * PLDA + lh * 4;
       const float* cB = smem + cur * STAGE + BM * PLDA + (lh * 4) * BN + wn * TN * 32 + li;
 #pragma unroll
@@ -237,13 +226,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_persist_kernel(NNArgs p) {
           }
         }
       }
-      PT(t_comp);
       if (kt + 1 < nk) store_lds(cur ^ 1);
-      PT(t_store);
       __syncthreads();   // after the last slab: every wave is done reading the pipeline buffers
-      PT(t_sync);
     }
-    PT0();
 
     // ---- epilogue: registers -> this wave's LDS staging region -> 16-byte global stores --------------
     float* stg = smem + wave * (WROWS * WCOLS);
@@ -308,23 +293,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_persist_kernel(NNArgs p) {
         p.stats[((int64_t)ctile_m * 2 + 1) * N + cn0 + tid] = ss;
       }
     }
-#ifdef KWS_GEMM_STAMP
-    n_tiles_done++;
-#endif
     if (!has_next) break;
     __syncthreads();   // staging / stats scratch fully consumed before the pipeline buffers are refilled
     store_lds(0);
     __syncthreads();
-    PT(t_epi);
     local = next;
   }
-#ifdef KWS_GEMM_STAMP
-  if (tid == 0 && blockIdx.x < 8192) {
-    g_stamps[blockIdx.x][0] = t_load; g_stamps[blockIdx.x][1] = t_comp; g_stamps[blockIdx.x][2] = t_store;
-    g_stamps[blockIdx.x][3] = t_sync; g_stamps[blockIdx.x][4] = t_epi; g_stamps[blockIdx.x][5] = n_tiles_done;
-    g_stamps[blockIdx.x][6] = __builtin_amdgcn_s_memtime() - t_begin;
-  }
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------
