@@ -98,6 +98,25 @@ int kws_tta_transform(const float* x, float* out, int B, int L, int kind, void* 
 int kws_tta_combine(const float* const* probs, int n_terms, float divisor, float* out_probs,
                     int32_t* out_argmax, int B, int C, void* stream);
 
+/* Speed-TTA time stretch: reference create_tta_set.py:9-22 -
+ * librosa.effects.time_stretch(np.float32(pcm) / 32767, rate)[-keep:] -> np.int16(. * 32767) -> wav, read back
+ * by make_submission.py:86-100 through DecodeWav (/ 32768) for the slow predict passes (:133-136).
+ * librosa 0.5.x defaults (STFT 2048 / 512, periodic Hann, centred reflect padding, phase vocoder, ISTFT with
+ * window-sum-square normalisation trimmed by 1024 each side); the stretched signal has
+ * kws_stretch_out_samples() = 512 * (ceil((1 + n_samples / 512) / rate) - 1) samples.
+ *   x   [B, n_samples] f32 (multiplied by in_scale on load) or int16 (divided by 32767 like the reference)
+ *   out [B, keep]: the LAST `keep` stretched samples; zero padded at the end when fewer exist
+ *   quantize != 0 reproduces the int16 wav round trip: (int16)(v * 32767) / 32768 (C-cast truncation)
+ * rate <= 0 is KWS_E_INVALID (librosa raises ParameterError). */
+typedef struct kws_stretch_plan kws_stretch_plan_t;
+int kws_stretch_plan_create(int n_samples, double rate, kws_stretch_plan_t** plan);
+int kws_stretch_plan_destroy(kws_stretch_plan_t* plan);
+int kws_stretch_out_samples(const kws_stretch_plan_t* plan);
+int kws_time_stretch_f32(const kws_stretch_plan_t* plan, const float* x, float in_scale, float* out, int B,
+                         int keep, int quantize, void* stream);
+int kws_time_stretch_i16(const kws_stretch_plan_t* plan, const int16_t* x, float* out, int B, int keep,
+                         int quantize, void* stream);
+
 /* a18 32->12 head, reference freeze_graph_32_classes.py:55-69.
  * map[i] in [0,12): output slot of input class i (slot 1 = max over all classes mapped to 1). */
 int kws_head32to12(const float* p_in, int C_in, const int32_t* map, int C_out, float* p_out,

@@ -74,6 +74,11 @@ SIGNATURES = {
     "kws_tta_transform": (_I, [_P, _P, _I, _I, _I, _P]),
     "kws_tta_combine": (_I, [ctypes.POINTER(_P), _I, _F, _P, _P, _I, _I, _P]),
     "kws_head32to12": (_I, [_P, _I, _P, _I, _P, _I, _P]),
+    "kws_stretch_plan_create": (_I, [_I, ctypes.c_double, ctypes.POINTER(_P)]),
+    "kws_stretch_plan_destroy": (_I, [_P]),
+    "kws_stretch_out_samples": (_I, [_P]),
+    "kws_time_stretch_f32": (_I, [_P, _P, _F, _P, _I, _I, _I, _P]),
+    "kws_time_stretch_i16": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "kws_stft_plan_create": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _F, _F, ctypes.POINTER(_P)]),
     "kws_stft_plan_destroy": (_I, [_P]),
     "kws_stft_num_frames": (_I, [_P, _I]),

@@ -17,14 +17,18 @@ from .device_array import as_device_f32
 IDENTITY, ROLL_LEFT_1500, LOUD_1_2, SLOW_LOUD_CLIP_1_1, QUIET_0_9 = 0, 1, 2, 3, 4
 
 
-def predict_tta(model, X, X_slow=None):
+def predict_tta(model, X, X_slow=None, use_speed_tta=False):
     """Returns (probs [B, C] f32 CUDA tensor, argmax [B] int32 CUDA tensor).
 
     X: raw clips [B, 16000] (DeviceArray / tensor / array).  X_slow: optional time-stretched clips
     (make_submission.py `use_speed_tta`): adds the three slow terms and divides the SUM OF SIX by 10, the
-    reference's scaling (make_submission.py:137-140; it does not change the argmax)."""
+    reference's scaling (make_submission.py:137-140; it does not change the argmax).  With
+    `use_speed_tta` and no X_slow the slow clips are made here by `time_stretch(X, 0.9)` instead of being
+    read from the offline set of create_tta_set.py."""
     net = model.net
     xd = as_device_f32(X, net.device)
+    if use_speed_tta and X_slow is None:
+        X_slow = time_stretch(xd, 0.9, keep=xd.shape[1], device=net.device)
     B, L = xd.shape
     s = _lib.stream_ptr()
     terms = []
@@ -54,6 +58,55 @@ def predict_tta(model, X, X_slow=None):
     amax = torch.empty(B, dtype=torch.int32, device=net.device)
     _lib.call("kws_tta_combine", ptrs, len(terms), divisor, _lib.ptr(probs), _lib.ptr(amax), B, C, s)
     return probs, amax
+
+
+_PLANS = {}
+
+
+def _stretch_plan(n_samples, rate):
+    key = (int(n_samples), float(rate))
+    if key not in _PLANS:
+        plan = ctypes.c_void_p()
+        _lib.check(_lib.load().kws_stretch_plan_create(key[0], key[1], ctypes.byref(plan)), "kws_stretch_plan_create")
+        _PLANS[key] = plan
+    return _PLANS[key]
+
+
+def time_stretch(X, rate=0.9, keep=16000, wav_round_trip=True, device=None):
+    """The reference's offline slow set (create_tta_set.py:9-22), on the device and batched:
+    librosa.effects.time_stretch(pcm / 32767, rate)[-keep:], and with `wav_round_trip` the int16 file the
+    script writes as make_submission.py reads it back (np.int16(. * 32767) then DecodeWav's / 32768).
+
+    X: [B, L] int16 PCM (torch tensor / array: the reference's `wavfile.read` input), or float clips in
+    DecodeWav scale (int16 / 32768: DeviceArray / tensor / array), which are rescaled by 32768 / 32767 on load.
+    Returns a [B, keep] f32 CUDA tensor.  rate <= 0 raises (librosa: ParameterError)."""
+    if rate <= 0:
+        raise ValueError("rate must be a positive number")
+    if isinstance(X, torch.Tensor) and X.dtype == torch.int16 or getattr(X, 'dtype', None) == 'int16':
+        dev = device or (X.device if isinstance(X, torch.Tensor) and X.is_cuda else torch.device("cuda", torch.cuda.current_device()))
+        xd = (X if isinstance(X, torch.Tensor) else torch.from_numpy(X)).to(dev).contiguous()
+        i16 = True
+    else:
+        xd = as_device_f32(X, device or torch.device("cuda", torch.cuda.current_device()))
+        i16 = False
+    if xd.dim() == 1:
+        xd = xd.reshape(1, -1)
+    B, L = xd.shape
+    plan = _stretch_plan(L, rate)
+    out = torch.empty((B, keep), dtype=torch.float32, device=xd.device)
+    with torch.cuda.device(xd.device):
+        s = _lib.stream_ptr()
+        if i16:
+            _lib.call("kws_time_stretch_i16", plan, _lib.ptr(xd), _lib.ptr(out), B, keep, int(wav_round_trip), s)
+        else:
+            _lib.call("kws_time_stretch_f32", plan, _lib.ptr(xd), 32768.0 / 32767.0, _lib.ptr(out), B, keep,
+                      int(wav_round_trip), s)
+    return out
+
+
+def stretched_samples(n_samples, rate):
+    """Length of librosa 0.5's time_stretch output for an n_samples clip."""
+    return _lib.load().kws_stretch_out_samples(_stretch_plan(n_samples, rate))
 
 
 def shard_range(n_items):

@@ -1,0 +1,151 @@
+"""GPU parity of the speed-TTA time stretch against oracle/stretch.py - the restatement of
+librosa 0.5.x's effects.time_stretch as create_tta_set.py:9-22 uses it (parity unpinned: librosa is neither
+pinned by the reference nor installed here).  The f64 oracle is the value both librosa's complex64 arithmetic
+and the f32 kernel approximate; `test_closer_than_the_reference_rounding` shows the kernel is an order of
+magnitude closer to it than librosa's own float32 phase accumulator."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import stretch as OS
+from speech_recognition_amd import _lib, tta
+
+pytestmark = pytest.mark.gpu
+
+
+def clips(seed, B, L=16000):
+    rng = np.random.RandomState(seed)
+    x = (rng.randn(B, L) * 0.0774).clip(-1, 1)
+    t = np.arange(L) / 16000.0
+    for b in range(B):
+        x[b] += 0.05 * np.sin(2 * np.pi * 200.0 * (1 + b % 12) * t)       # SURVEY 8d synthetic tone
+    return x.astype(np.float32)
+
+
+def special_clips(L=16000):
+    x = clips(5, 6, L)
+    x[1] = 0.0                                    # silence: every bin is 0, angle(0) = 0
+    x[2, :7000] = 0.0                             # leading digital silence: zero columns then signal
+    x[3] = np.sign(x[3]) * 0.999                  # full-scale square-ish noise
+    x[4] = 0.5 * np.sin(2 * np.pi * 440.0 * np.arange(L) / 16000.0)      # pure tone: most bins ~1e-7
+    x[5, 9000:] = 0.0
+    return x
+
+
+@pytest.mark.parametrize("rate,keep", [(0.9, 16000), (1.1, 14000), (0.5, 16000), (2.5, 5000)])
+def test_float_path_matches_oracle(rate, keep):
+    x = special_clips()
+    out = tta.time_stretch(torch.from_numpy(x).cuda(), rate, keep=keep, wav_round_trip=False).cpu().numpy()
+    for b in range(len(x)):
+        ref = OS.time_stretch(np.float32(x[b]) * np.float32(32768.0 / 32767.0), rate)
+        want = np.zeros(keep)
+        tail = ref[-keep:]
+        want[:len(tail)] = tail
+        # f32 FFTs of 2048 points over signals of peak <= 1: 2e-5 absolute
+        err = np.abs(out[b] - want)
+        if b == 4:
+            # A mathematically pure tone leaves most bins at the f32 rounding floor of the FFT, so their
+            # accumulated phases are arbitrary in ANY single-precision vocoder; they only become audible where
+            # the reflect-padded clip end excites every bin.  librosa's own complex64 / float32 arithmetic
+            # shows the same 1e-2 there (oracle literal_f32; measured 0.011 vs 0.013 on the device) and
+            # 1e-4 of noise in the clip removes the effect.  Interior: the usual bound.
+            n_in = int(0.8 * keep)
+            assert err[:n_in].max() < 2e-5, err[:n_in].max()
+            assert err.max() < 5e-2
+        else:
+            assert err.max() < 2e-5, (b, err.max())
+    assert np.all(out[1] == 0)
+
+
+def test_int16_wav_round_trip():
+    """create_tta_set.py end to end: int16 in, int16 file out, DecodeWav scale."""
+    x = special_clips()
+    pcm = np.int16(x * 32767)
+    out = tta.time_stretch(torch.from_numpy(pcm).cuda(), 0.9).cpu().numpy()
+    lsb = 1.0 / 32768
+    n_diff = 0
+    for b in range(len(x)):
+        want = OS.tta_slow_clip(pcm[b])
+        d = np.abs(out[b] - want)
+        if b == 4:                                # pure tone: see test_float_path_matches_oracle
+            assert d[:12800].max() <= lsb + 1e-9 and d.max() < 5e-2
+            d = d[:12800]
+        else:
+            assert d.max() <= lsb + 1e-9, (b, d.max() / lsb)   # truncation: a 1e-5 difference is at most one step
+        n_diff += int((d > 0).sum())
+    assert n_diff < 0.03 * out.size
+    # exactly representable int16 / 32768 values
+    assert np.all(out * 32768 == np.round(out * 32768))
+
+
+def test_closer_than_the_reference_rounding():
+    x = clips(11, 2)
+    out = tta.time_stretch(torch.from_numpy(x).cuda(), 0.9, wav_round_trip=False).cpu().numpy()
+    for b in range(2):
+        xin = np.float32(x[b]) * np.float32(32768.0 / 32767.0)
+        exact = OS.time_stretch(xin, 0.9)[-16000:]
+        literal = OS.time_stretch(xin, 0.9, literal_f32=True)[-16000:]
+        e_dev = np.abs(out[b] - exact).max()
+        e_ref = np.abs(literal - exact).max()
+        assert e_dev < 2e-5 and e_dev * 5 < e_ref, (e_dev, e_ref)
+
+
+def test_short_clip_is_zero_padded_like_decode_wav():
+    L = 12000
+    x = clips(3, 3, L)
+    n = tta.stretched_samples(L, 0.9)
+    assert n == OS.stretched_length(L, 0.9) < 16000
+    out = tta.time_stretch(torch.from_numpy(x).cuda(), 0.9, keep=16000, wav_round_trip=False).cpu().numpy()
+    for b in range(3):
+        ref = OS.time_stretch(np.float32(x[b]) * np.float32(32768.0 / 32767.0), 0.9)
+        assert len(ref) == n
+        assert np.abs(out[b, :n] - ref).max() < 2e-5
+        assert np.all(out[b, n:] == 0)
+
+
+def test_full_batch_properties():
+    """B = 1024 (config C5's per-GPU batch): rate 1 reproduces the input (every vocoder step lands on a
+    frame), the stretch is homogeneous of degree 1, and two runs are bit-identical."""
+    B = 1024
+    g = torch.Generator(device="cuda")
+    g.manual_seed(7)
+    x = (torch.randn((B, 16000), generator=g, device="cuda") * 0.0774).clamp_(-1, 1)
+    n1 = tta.stretched_samples(16000, 1.0)
+    assert n1 == 15872
+    same = tta.time_stretch(x, 1.0, keep=n1, wav_round_trip=False)
+    assert (same - x[:, :n1] * (32768.0 / 32767.0)).abs().max().item() < 5e-6
+    a = tta.time_stretch(x, 0.9, wav_round_trip=False)
+    b = tta.time_stretch(x, 0.9, wav_round_trip=False)
+    assert torch.equal(a, b)
+    c = tta.time_stretch(x * 0.5, 0.9, wav_round_trip=False)
+    assert (c - 0.5 * a).abs().max().item() < 2e-6   # power-of-two scale: exact up to the unit() roundings
+    assert torch.isfinite(a).all()
+    # energy per second is preserved to a few percent by a phase vocoder on noise
+    r = (a.pow(2).mean() / x.pow(2).mean()).item()
+    assert 0.3 < r < 1.2
+
+
+def test_speed_tta_predict_path():
+    from speech_recognition_amd.keras_api import Model, RMSprop
+    from speech_recognition_amd.net import DeviceNet
+    net = DeviceNet(_lib.KWS_NET_TS_ATTENTION, 12)
+    net.initialize(seed=3)
+    model = Model(net, RMSprop())
+    x = torch.from_numpy(clips(2, 8)).cuda()
+    slow = tta.time_stretch(x, 0.9)
+    p_explicit, a_explicit = tta.predict_tta(model, x, X_slow=slow)
+    p_auto, a_auto = tta.predict_tta(model, x, use_speed_tta=True)
+    assert torch.equal(p_explicit, p_auto) and torch.equal(a_explicit, a_auto)
+    # make_submission.py:137-140: six terms, divided by 10
+    assert abs(p_auto.sum(1).mean().item() - 0.6) < 1e-5
+
+
+def test_errors():
+    import ctypes
+    lib = _lib.load()
+    plan = ctypes.c_void_p()
+    assert lib.kws_stretch_plan_create(16000, 0.0, ctypes.byref(plan)) == -1
+    assert lib.kws_stretch_plan_create(16000, -1.0, ctypes.byref(plan)) == -1
+    assert lib.kws_stretch_plan_create(1024, 0.9, ctypes.byref(plan)) == -1
+    with pytest.raises(ValueError):
+        tta.time_stretch(torch.zeros(1, 16000), 0.0)
