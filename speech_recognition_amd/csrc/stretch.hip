@@ -39,6 +39,9 @@ struct kws_stretch_plan {
 namespace {
 
 constexpr int NFFT = 2048, HOP = 512, MC = 1024, NT = 256;
+#ifndef KWS_STRETCH_WPE
+#define KWS_STRETCH_WPE 4  // waves per SIMD the register budget is sized for
+#endif
 
 struct StretchArgs {
   const void* x;
@@ -79,12 +82,13 @@ __device__ __forceinline__ void fft4(float2 (&u)[4]) {
   }
 }
 
-// Passes of the 1024-point Stockham FFT.  `twr[s][r]` = twiddles of pass s+1 (Ns = 4^(s+1)).
+// Passes of the 1024-point Stockham FFT.  `tw` = e^{-2 pi j m / 1024}, m < 768, in LDS (pass s of thread j uses
+// entries r * (j mod 4^s) * 4^(4-s): holding the 12 of them in registers costs more occupancy than the reads).
 // FIRST_REGS: pass 0 takes its operands from u (else from src); LAST_REGS: pass 4 leaves its results in u
 // (else writes dst).  Returns with the result in `u` or in the buffer that was written last; buffers
 // alternate a -> b -> a ...  One barrier after every LDS write.
 template <bool INV, bool FIRST_REGS, bool LAST_REGS>
-__device__ __forceinline__ float2* fft1024(float2 (&u)[4], float2* a, float2* b, const float2 (&twr)[4][3], int j) {
+__device__ __forceinline__ float2* fft1024(float2 (&u)[4], float2* a, float2* b, const float2* tw, int j) {
   float2* src = a;
   float2* dst = b;
 #pragma unroll
@@ -96,7 +100,10 @@ __device__ __forceinline__ float2* fft1024(float2 (&u)[4], float2* a, float2* b,
     }
     if (s > 0) {
 #pragma unroll
-      for (int r = 1; r < 4; ++r) u[r] = INV ? cmulc(u[r], twr[s - 1][r - 1]) : cmul(u[r], twr[s - 1][r - 1]);
+      for (int r = 1; r < 4; ++r) {
+        const float2 tq = tw[r * (j & (Ns - 1)) * (NT / Ns)];
+        u[r] = INV ? cmulc(u[r], tq) : cmul(u[r], tq);
+      }
     }
     fft4<INV>(u);
     if (s == 4 && LAST_REGS) return src;
@@ -112,10 +119,6 @@ __device__ __forceinline__ float2* fft1024(float2 (&u)[4], float2* a, float2* b,
   return src;  // holds the result
 }
 
-__device__ __forceinline__ float2 unit_or_one(float2 c, float m) {
-  return m > 0.f ? make_float2(c.x / m, c.y / m) : make_float2(1.f, 0.f);
-}
-
 template <typename TIn>
 __device__ __forceinline__ float load_pcm(const TIn* x, int o, float scale);
 template <>
@@ -127,14 +130,44 @@ __device__ __forceinline__ float load_pcm<int16_t>(const int16_t* x, int o, floa
   return (float)x[o] / scale;  // create_tta_set.py:18  np.float32(data) / 32767
 }
 
-// Bin ownership of thread j: item 0 -> (j, 1024-j) [j = 0: (0, 1024), both real], item 1 -> (j+256, 768-j),
-// item 2 (thread 0 only) -> 512 (its own mirror).  Slot 2*i holds bin p, slot 2*i+1 the mirror.
-constexpr int NSLOT = 6;
+// One STFT bin in the form the vocoder consumes: magnitude and unit phasor (angle(0) = 0 -> phasor 1).
+struct Polar {
+  float m;
+  float2 n;
+};
+__device__ __forceinline__ Polar to_polar(float2 c) {
+  const float s = c.x * c.x + c.y * c.y;
+  const bool nz = s > 1e-37f;
+  const float inv = nz ? __builtin_amdgcn_rsqf(s) : 0.f;
+  Polar p;
+  p.m = s * inv;
+  p.n = nz ? make_float2(c.x * inv, c.y * inv) : make_float2(1.f, 0.f);
+  return p;
+}
+// one vocoder step of a bin: returns the synthesis bin, advances the accumulator u by angle(b) - angle(a)
+__device__ __forceinline__ float2 vocode(const Polar& a, const Polar& b, float al, float2& u) {
+  const float mag = (1.f - al) * a.m + al * b.m;
+  const float2 y = make_float2(mag * u.x, mag * u.y);
+  const float2 un = cmulc(cmul(u, b.n), a.n);
+  const float h = 1.5f - 0.5f * (un.x * un.x + un.y * un.y);  // Newton step back to |u| = 1
+  u = make_float2(un.x * h, un.y * h);
+  return y;
+}
+
+// Bin ownership of thread j for the whole clip: slot 0 -> bin j (j = 0: DC), slot 1 -> 1024 - j (j = 0: Nyquist),
+// slot 2 -> j + 256, slot 3 -> 768 - j.  Bin 512 (its own mirror) belongs to thread 0 and lives in LDS.
+constexpr int NSLOT = 4;
+struct Column {
+  Polar p[NSLOT];
+};
 
 template <typename TIn>
-__global__ __launch_bounds__(NT) void stretch_kernel(StretchArgs a) {
+__global__ __launch_bounds__(NT, KWS_STRETCH_WPE) void stretch_kernel(StretchArgs a) {
   __shared__ float2 bufA[MC];
   __shared__ float2 bufB[MC];
+  __shared__ float2 twl[768];
+  __shared__ Polar mid[2];  // bin 512 of the two live columns (thread 0 only)
+  __shared__ float2 mid_u;
   const int j = threadIdx.x;
   const int clip = blockIdx.x;
   const TIn* x = reinterpret_cast<const TIn*>(a.x) + (size_t)clip * a.L;
@@ -147,26 +180,22 @@ __global__ __launch_bounds__(NT) void stretch_kernel(StretchArgs a) {
     w[r][0] = a.win[2 * j + HOP * r];
     w[r][1] = a.win[2 * j + HOP * r + 1];
   }
-  float2 twr[4][3];
-#pragma unroll
-  for (int s = 1; s < 5; ++s) {
-    const int Ns = 1 << (2 * s);
-    const int k = j & (Ns - 1);
-#pragma unroll
-    for (int r = 1; r < 4; ++r) twr[s - 1][r - 1] = a.tw[r * k * (NT / Ns)];
-  }
-  const float2 ws0 = a.tws[j], ws1 = a.tws[j + NT], ws2 = a.tws[512];
+  for (int m = j; m < 768; m += NT) twl[m] = a.tw[m];
+  __syncthreads();
+  const float2 ws0 = a.tws[j], ws1 = a.tws[j + NT];
 
-  float2 Ca[NSLOT], Cb[NSLOT], U[NSLOT];
+  Column Ca, Cb;
+  float2 U[NSLOT];
   float ola[4][2];
 #pragma unroll
   for (int r = 0; r < 4; ++r) ola[r][0] = ola[r][1] = 0.f;
 
   // ---- analysis: STFT column f into C (zeros beyond the last frame: the two padded columns) ----
-  auto analyse = [&](int f, float2 (&C)[NSLOT]) {
+  auto analyse = [&](int f, Column& C, Polar& C512) {
     if (f >= a.n_frames) {
 #pragma unroll
-      for (int i = 0; i < NSLOT; ++i) C[i] = make_float2(0.f, 0.f);
+      for (int i = 0; i < NSLOT; ++i) C.p[i] = to_polar(make_float2(0.f, 0.f));
+      if (j == 0) C512 = to_polar(make_float2(0.f, 0.f));
       return;
     }
     float2 u[4];
@@ -182,37 +211,35 @@ __global__ __launch_bounds__(NT) void stretch_kernel(StretchArgs a) {
       }
       u[r] = make_float2(v[0], v[1]);
     }
-    const float2* Z = fft1024<false, true, false>(u, bufA, bufB, twr, j);
+    const float2* Z = fft1024<false, true, false>(u, bufA, bufB, twl, j);
     // split: X[k] = E + T, X[1024-k] = conj(E - T), E = (Z[k] + conj Z[M-k]) / 2, T = -j W^k (Z[k] - conj Z[M-k]) / 2
-    auto split = [&](int k, float2 wk, float2& Xk, float2& Xm) {
+    auto split = [&](int k, float2 wk, Polar& Xk, Polar& Xm) {
       const float2 za = Z[k], zb = cconj(Z[(MC - k) & (MC - 1)]);
       const float2 E = make_float2(0.5f * (za.x + zb.x), 0.5f * (za.y + zb.y));
       const float2 D = make_float2(0.5f * (za.x - zb.x), 0.5f * (za.y - zb.y));
       const float2 wd = cmul(wk, D);
       const float2 T = make_float2(wd.y, -wd.x);  // -j * wd
-      Xk = cadd(E, T);
-      Xm = cconj(csub(E, T));
+      Xk = to_polar(cadd(E, T));
+      Xm = to_polar(cconj(csub(E, T)));
     };
+    split(j, ws0, C.p[0], C.p[1]);
     if (j == 0) {
       const float2 z0 = Z[0];
-      C[0] = make_float2(z0.x + z0.y, 0.f);
-      C[1] = make_float2(z0.x - z0.y, 0.f);
-      float2 dummy;
-      split(512, ws2, C[4], dummy);
-    } else {
-      split(j, ws0, C[0], C[1]);
-      C[4] = C[5] = make_float2(0.f, 0.f);
+      C.p[0] = to_polar(make_float2(z0.x + z0.y, 0.f));  // DC and Nyquist are real
+      C.p[1] = to_polar(make_float2(z0.x - z0.y, 0.f));
+      const float2 z5 = Z[512];                           // W^512 = -j:  X[512] = conj(Z[512])
+      C512 = to_polar(cconj(z5));
     }
-    split(j + NT, ws1, C[2], C[3]);
-    C[5] = make_float2(0.f, 0.f);
+    split(j + NT, ws1, C.p[2], C.p[3]);
     __syncthreads();  // Z fully consumed before the buffers are reused
   };
 
-  analyse(0, Ca);
-  analyse(1, Cb);
+  analyse(0, Ca, mid[0]);
+  analyse(1, Cb, mid[1]);
 #pragma unroll
-  for (int i = 0; i < NSLOT; ++i) U[i] = unit_or_one(Ca[i], sqrtf(Ca[i].x * Ca[i].x + Ca[i].y * Ca[i].y));
-  int cur = 0;  // Ca = column cur, Cb = column cur + 1
+  for (int i = 0; i < NSLOT; ++i) U[i] = Ca.p[i].n;
+  if (j == 0) mid_u = mid[0].n;
+  int cur = 0;  // Ca = column cur, Cb = column cur + 1; mid[cur & 1], mid[(cur + 1) & 1]
 
   const int Ltrim = HOP * (a.T - 1);
   const int skip = Ltrim > a.keep ? Ltrim - a.keep : 0;
@@ -252,43 +279,39 @@ __global__ __launch_bounds__(NT) void stretch_kernel(StretchArgs a) {
     const int s = a.sidx[t];
     const float al = a.salpha[t];
     while (cur < s) {
-#pragma unroll
-      for (int i = 0; i < NSLOT; ++i) Ca[i] = Cb[i];
-      analyse(cur + 2, Cb);
+      Ca = Cb;
+      analyse(cur + 2, Cb, mid[cur & 1]);  // column cur + 2 replaces column cur
       ++cur;
     }
-    // ---- phase vocoder step on the owned bins ----
-    float2 Y[NSLOT];
-#pragma unroll
-    for (int i = 0; i < NSLOT; ++i) {
-      const float m0 = sqrtf(Ca[i].x * Ca[i].x + Ca[i].y * Ca[i].y);
-      const float m1 = sqrtf(Cb[i].x * Cb[i].x + Cb[i].y * Cb[i].y);
-      const float mag = (1.f - al) * m0 + al * m1;
-      Y[i] = make_float2(mag * U[i].x, mag * U[i].y);
-      float2 un = cmulc(cmul(U[i], unit_or_one(Cb[i], m1)), unit_or_one(Ca[i], m0));
-      const float n = sqrtf(un.x * un.x + un.y * un.y);
-      U[i] = unit_or_one(un, n);
-    }
-    // ---- inverse pack: Z'[k] = E + jO, Z'[M-k] = conj(E - jO), E = (X_k + conj X_m)/2, O = conj(W^k) (X_k - conj X_m)/2
-    auto pack = [&](int k, float2 wk, float2 Xk, float2 Xm, bool mirror) {
+    // ---- phase vocoder step on the owned bins, then the inverse pack:
+    //      Z'[k] = E + jO, Z'[M-k] = conj(E - jO), E = (X_k + conj X_m)/2, O = conj(W^k) (X_k - conj X_m)/2
+    auto pack = [&](int k, float2 wk, float2 Xk, float2 Xm) {
       const float2 xm = cconj(Xm);
       const float2 E = make_float2(0.5f * (Xk.x + xm.x), 0.5f * (Xk.y + xm.y));
       const float2 T = make_float2(0.5f * (Xk.x - xm.x), 0.5f * (Xk.y - xm.y));
       const float2 O = cmulc(T, wk);
       const float2 jO = make_float2(-O.y, O.x);
       bufA[k] = cadd(E, jO);
-      if (mirror) bufA[MC - k] = cconj(csub(E, jO));
+      bufA[(MC - k) & (MC - 1)] = cconj(csub(E, jO));
     };
-    if (j == 0) {
-      bufA[0] = make_float2(0.5f * (Y[0].x + Y[1].x), 0.5f * (Y[0].x - Y[1].x));  // irfft ignores Im of DC / Nyquist
-      pack(512, ws2, Y[4], Y[4], false);
-    } else {
-      pack(j, ws0, Y[0], Y[1], true);
+    {
+      const float2 y0 = vocode(Ca.p[0], Cb.p[0], al, U[0]);
+      const float2 y1 = vocode(Ca.p[1], Cb.p[1], al, U[1]);
+      if (j != 0) pack(j, ws0, y0, y1);
+      const float2 y2 = vocode(Ca.p[2], Cb.p[2], al, U[2]);
+      const float2 y3 = vocode(Ca.p[3], Cb.p[3], al, U[3]);
+      pack(j + NT, ws1, y2, y3);
+      if (j == 0) {
+        bufA[0] = make_float2(0.5f * (y0.x + y1.x), 0.5f * (y0.x - y1.x));  // irfft ignores Im of DC / Nyquist
+        float2 u5 = mid_u;
+        const float2 y5 = vocode(mid[cur & 1], mid[(cur + 1) & 1], al, u5);
+        mid_u = u5;
+        bufA[512] = cconj(y5);
+      }
     }
-    pack(j + NT, ws1, Y[2], Y[3], true);
     __syncthreads();
     float2 u[4];
-    fft1024<true, false, true>(u, bufA, bufB, twr, j);
+    fft1024<true, false, true>(u, bufA, bufB, twl, j);
     __syncthreads();  // every thread has read its last-pass operands before bufA is packed again
 #pragma unroll
     for (int r = 0; r < 4; ++r) {

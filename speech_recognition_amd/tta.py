@@ -72,13 +72,14 @@ def _stretch_plan(n_samples, rate):
     return _PLANS[key]
 
 
-def time_stretch(X, rate=0.9, keep=16000, wav_round_trip=True, device=None):
+def time_stretch(X, rate=0.9, keep=16000, wav_round_trip=True, device=None, in_scale=32768.0 / 32767.0):
     """The reference's offline slow set (create_tta_set.py:9-22), on the device and batched:
     librosa.effects.time_stretch(pcm / 32767, rate)[-keep:], and with `wav_round_trip` the int16 file the
     script writes as make_submission.py reads it back (np.int16(. * 32767) then DecodeWav's / 32768).
 
     X: [B, L] int16 PCM (torch tensor / array: the reference's `wavfile.read` input), or float clips in
-    DecodeWav scale (int16 / 32768: DeviceArray / tensor / array), which are rescaled by 32768 / 32767 on load.
+    DecodeWav scale (int16 / 32768: DeviceArray / tensor / array), which are rescaled by `in_scale` = 32768 / 32767
+    on load (pass 1.0 for clips that already are pcm / 32767).
     Returns a [B, keep] f32 CUDA tensor.  rate <= 0 raises (librosa: ParameterError)."""
     if rate <= 0:
         raise ValueError("rate must be a positive number")
@@ -99,7 +100,7 @@ def time_stretch(X, rate=0.9, keep=16000, wav_round_trip=True, device=None):
         if i16:
             _lib.call("kws_time_stretch_i16", plan, _lib.ptr(xd), _lib.ptr(out), B, keep, int(wav_round_trip), s)
         else:
-            _lib.call("kws_time_stretch_f32", plan, _lib.ptr(xd), 32768.0 / 32767.0, _lib.ptr(out), B, keep,
+            _lib.call("kws_time_stretch_f32", plan, _lib.ptr(xd), float(in_scale), _lib.ptr(out), B, keep,
                       int(wav_round_trip), s)
     return out
 

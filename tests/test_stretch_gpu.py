@@ -149,3 +149,27 @@ def test_errors():
     assert lib.kws_stretch_plan_create(1024, 0.9, ctypes.byref(plan)) == -1
     with pytest.raises(ValueError):
         tta.time_stretch(torch.zeros(1, 16000), 0.0)
+
+
+def test_librosa_shim_serves_create_tta_set(repo_root):
+    """create_tta_set.py:15-22 through the drop-in `librosa.effects`: same calls, one clip at a time."""
+    import importlib
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(repo_root, 'dropin'))
+    try:
+        effects = importlib.import_module('librosa.effects')
+        pcm = np.int16(clips(21, 1)[0] * 32767)
+        data = np.float32(pcm) / 32767
+        data = effects.time_stretch(data, 0.9)
+        assert data.dtype == np.float32 and len(data) == 17920
+        data = data[-16000:]
+        got = np.int16(data * 32767)
+        want = np.round(OS.tta_slow_clip(pcm) * 32768).astype(np.int16)
+        assert np.abs(got.astype(np.int32) - want).max() <= 1
+        with pytest.raises(ValueError):
+            effects.time_stretch(data, 0.0)
+    finally:
+        sys.path.remove(os.path.join(repo_root, 'dropin'))
+        for m in [m for m in sys.modules if m == 'librosa' or m.startswith('librosa.')]:
+            del sys.modules[m]
