@@ -72,7 +72,7 @@ def build_synthetic(device, n_bank, seed, L=16000):
         'training': [(r, word_of_row[r]) for r in train_rows] + [(0, SILENCE_LABEL)] * n_sil +
                     [(r, word_of_row[r]) for r in unk_rows[:n_unk]],
         'pseudo': [(r, word_of_row[r]) for r in pseudo_rows] + [(r, word_of_row[r]) for r in unk_rows[n_unk:n_unk + n_pseudo // 2]],
-        'validation': [(r, word_of_row[r]) for r in range(0, 4096)],
+        'validation': [(r, word_of_row[r]) for r in range(0, min(4096, n_bank))],
         'testing': [],
     }
     return {'bank': cb, 'index': index}

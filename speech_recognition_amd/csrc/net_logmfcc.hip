@@ -29,6 +29,7 @@ struct LmBlock {
 
 struct LmProgram {
   int T0, F, C0, L0;
+  int Fp;  // F rounded up to the 16-byte vectors of the gathered GEMM (spectrogram input: 257 -> 260)
   int64_t conv1;
   BnRef bn0;
   kws_gather_t g0;
@@ -49,6 +50,7 @@ struct LmLayout {
   int64_t bn = 0, bn_stride = 0, part = 0, red = 0, coef = 0, WT = 0, tn = 0, swg = 0;
   int64_t dOa = 0, dOb = 0, G = 0, DZ = 0, DXS = 0;
   int64_t u = 0, fd = 0, dl = 0, gu = 0, coef2 = 0, per_loss = 0, per_correct = 0, att = 0;
+  int64_t xpad = 0, wpad = 0, gwpad = 0;  // only when Fp != F
 };
 
 void lm_layout(const kws_net* n, int B, LmLayout* lo) {
@@ -65,7 +67,7 @@ void lm_layout(const kws_net* n, int B, LmLayout* lo) {
     max_wt = std::max(max_wt, (int64_t)K * N);
     max_tn = std::max(max_tn, kws_gemm_tn_workspace_floats(M, K, N));
   };
-  upd_gemm((int64_t)B * p.L0, 3 * p.F, p.C0);
+  upd_gemm((int64_t)B * p.L0, 3 * p.Fp, p.C0);
   max_part = std::max(max_part, kws_block_out_bwd_part_floats(B, p.L0, p.C0, 1));
   for (int i = 0; i < nb; ++i) {
     const LmBlock& b = p.blocks[i];
@@ -109,6 +111,11 @@ void lm_layout(const kws_net* n, int B, LmLayout* lo) {
   lo->per_loss = bp.take(B);
   lo->per_correct = bp.take(B);
   lo->att = bp.take((int64_t)B * 16);
+  if (p.Fp != p.F) {
+    lo->xpad = bp.take((int64_t)B * p.T0 * p.Fp);
+    lo->wpad = bp.take((int64_t)3 * p.Fp * p.C0);
+    lo->gwpad = bp.take((int64_t)3 * p.Fp * p.C0);
+  }
   lo->total = bp.cur * 4;
 }
 
@@ -135,13 +142,55 @@ int bn_table(const Ctx& c, const BnRef& r, int idx, int64_t M, int stat_rows) {
                               c.bn_at(idx), c.st);
 }
 
+// rows of F floats -> rows of Fp floats (Fp % 4 == 0), zero filled; one 16-byte store per thread
+__global__ __launch_bounds__(256) void repitch_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t rows,
+                                                      int F, int Fp) {
+  const int q = Fp / 4;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < rows * q; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / q;
+    const int f = (int)(i - r * q) * 4;
+    const float* src = in + r * F + f;
+    float4 v;
+    v.x = f + 0 < F ? src[0] : 0.f;
+    v.y = f + 1 < F ? src[1] : 0.f;
+    v.z = f + 2 < F ? src[2] : 0.f;
+    v.w = f + 3 < F ? src[3] : 0.f;
+    *reinterpret_cast<float4*>(out + r * Fp + f) = v;
+  }
+}
+
+// Feature counts that are not a multiple of 4 (conv_1d_spectrogram: 257 bins): the gathered GEMM reads 16-byte
+// vectors, so the input rows and the [3, F, 64] kernel are re-pitched to Fp with zero columns / rows (plain 2-D
+// copies), and the padded weight gradient is copied back without them.
+int pad_first_conv(const Ctx& c, const float* x, const float** x_used, const float** w_used) {
+  const LmProgram& p = *c.p;
+  *x_used = x;
+  *w_used = c.params + p.conv1;
+  if (p.Fp == p.F) return KWS_OK;
+  float* xp = c.ws + c.lo.xpad;
+  float* wp = c.ws + c.lo.wpad;
+  const size_t rows = (size_t)c.B * p.T0;
+  const int64_t n4 = (int64_t)rows * (p.Fp / 4);
+  hipLaunchKernelGGL(repitch_kernel, dim3((unsigned)std::min<int64_t>(ceil_div64(n4, 256), 8192)), dim3(256), 0, c.st, x, xp,
+                     (int64_t)rows, p.F, p.Fp);
+  KWS_LAUNCH_CHECK("repitch_kernel");
+  KWS_HIP(hipMemsetAsync(wp, 0, (size_t)3 * p.Fp * p.C0 * 4, c.st));
+  KWS_HIP(hipMemcpy2DAsync(wp, (size_t)p.Fp * p.C0 * 4, c.params + p.conv1, (size_t)p.F * p.C0 * 4, (size_t)p.F * p.C0 * 4, 3,
+                           hipMemcpyDeviceToDevice, c.st));
+  *x_used = xp;
+  *w_used = wp;
+  return KWS_OK;
+}
+
 int forward(const Ctx& c, const float* x, kws_lm_tail_args* t) {
   const LmProgram& p = *c.p;
   const LmLayout& lo = c.lo;
   float* ws = c.ws;
   const int B = c.B;
   float* stats = c.training ? ws + lo.part : nullptr;
-  KWS_TRY(kws_gemm_gather_f32(x, &p.g0, c.params + p.conv1, ws + lo.y0, B, p.C0, stats, c.st));
+  const float *x0, *w0;
+  KWS_TRY(pad_first_conv(c, x, &x0, &w0));
+  KWS_TRY(kws_gemm_gather_f32(x0, &p.g0, w0, ws + lo.y0, B, p.C0, stats, c.st));
   KWS_TRY(bn_table(c, p.bn0, 1, (int64_t)B * p.L0, kws_gemm_gather_stats_rows((int64_t)B * p.L0)));
   KWS_TRY(kws_bn_relu6_apply(ws + lo.y0, c.bn_at(1), ws + lo.a0, (int64_t)B * p.L0, p.C0, 1, c.st));
   const float* xin = ws + lo.a0;
@@ -178,10 +227,9 @@ int forward(const Ctx& c, const float* x, kws_lm_tail_args* t) {
 int lm_build(kws_net* n) {
   const kws_net_config_t& c = n->cfg;
   KWS_REQUIRE(c.num_classes >= 2 && c.num_classes <= 64, "net: num_classes %d out of range", c.num_classes);
-  KWS_REQUIRE(c.spectrogram_length >= 19 && c.num_features >= 4 && c.num_features % 4 == 0 &&
+  KWS_REQUIRE(c.spectrogram_length >= 19 && c.num_features >= 4 &&
                   c.input_size == c.spectrogram_length * c.num_features,
-              "net: log-mfcc input %d != %d x %d (num_features %% 4)", c.input_size, c.spectrogram_length,
-              c.num_features);
+              "net: log-mfcc input %d != %d x %d", c.input_size, c.spectrogram_length, c.num_features);
   KWS_REQUIRE((c.spectrogram_length - 2) % 8 == 0, "net: spectrogram_length-2 = %d must be a multiple of 8",
               c.spectrogram_length - 2);
   LmProgram* p = new LmProgram();
@@ -207,8 +255,9 @@ int lm_build(kws_net* n) {
   int idx0;
   p->bn0 = bn(p->C0, &idx0);
   kws_gather_t g0;
-  g0.L_out = p->L0; g0.cin = p->F; g0.taps = 3; g0.stride_t = p->F; g0.stride_j = p->F; g0.base_off = 0;
-  g0.x_len = p->T0 * p->F; g0.x_batch_stride = p->T0 * p->F;
+  p->Fp = (p->F + 3) & ~3;
+  g0.L_out = p->L0; g0.cin = p->Fp; g0.taps = 3; g0.stride_t = p->Fp; g0.stride_j = p->Fp; g0.base_off = 0;
+  g0.x_len = p->T0 * p->Fp; g0.x_batch_stride = p->T0 * p->Fp;
   p->g0 = g0;
   static const int spec[10][2] = {{64, 1}, {64, 1}, {128, 2}, {128, 1}, {192, 2}, {192, 1}, {192, 1}, {256, 2},
                                   {256, 1}, {256, 1}};  // model.py:1453-1462
@@ -390,7 +439,14 @@ int lm_train(const kws_net* n, const float* params, float* state, const float* x
     const int np = (int)(kws_block_out_bwd_part_floats(B, p.L0, p.C0, 1) / (5 * p.C0));
     KWS_TRY(kws_dw_bwd_finalize(part, np, M, p.C0, nullptr, grads + p.bn0.gamma, grads + p.bn0.beta, coef, red, st));
     KWS_TRY(kws_bn_bwd_apply(G, ws + lo.y0, c.bn_at(1), params + p.bn0.gamma, coef, M, p.C0, st));
-    KWS_TRY(kws_gemm_tn_gather_f32(x, &p.g0, G, grads + p.conv1, B, p.C0, ws + lo.tn, st));
+    if (p.Fp == p.F) {
+      KWS_TRY(kws_gemm_tn_gather_f32(x, &p.g0, G, grads + p.conv1, B, p.C0, ws + lo.tn, st));
+    } else {  // the forward of this step left the padded input in xpad
+      float* gw = ws + lo.gwpad;
+      KWS_TRY(kws_gemm_tn_gather_f32(ws + lo.xpad, &p.g0, G, gw, B, p.C0, ws + lo.tn, st));
+      KWS_HIP(hipMemcpy2DAsync(grads + p.conv1, (size_t)p.F * p.C0 * 4, gw, (size_t)p.Fp * p.C0 * 4, (size_t)p.F * p.C0 * 4, 3,
+                               hipMemcpyDeviceToDevice, st));
+    }
   }
   return KWS_OK;
 }

@@ -6,7 +6,7 @@ from . import _lib
 from .keras_api import Model, RMSprop
 from .net import DeviceNet
 
-ACCELERATED = ('conv_1d_time_sliced_with_attention', 'conv_1d_log_mfcc')
+ACCELERATED = ('conv_1d_time_sliced_with_attention', 'conv_1d_log_mfcc', 'conv_1d_spectrogram')
 REFERENCE_MODEL_TYPES = (
     'simple', 'snn', 'conv_1d_time_stacked', 'conv_1d_multi_time_sliced', 'conv_1d_time_sliced',
     'conv_1d_time_sliced_group', 'conv_1d_heavy', 'conv_1d_simple', 'conv_1d_gru', 'conv_2d', 'conv_2d_fast',
@@ -44,11 +44,23 @@ def conv_1d_log_mfcc_model(input_size=16000, num_classes=11, *args, **kwargs):
     return Model(net, RMSprop(lr=6e-4), name='conv_1d_log_mfcc', loss='cce')
 
 
+def conv_1d_spectrogram_model(input_size=16000, num_classes=11, *args, **kwargs):
+    """reference model.py:1482-1561: the conv_1d_log_mfcc architecture on the generator's 'spec' output
+    ([spectrogram_length, spectrogram_frequencies = 257] magnitudes), RMSprop(3e-4), categorical CE."""
+    time_size = kwargs.get('spectrogram_length', 65)
+    frequency_size = kwargs.get('spectrogram_frequencies', 257)
+    net = DeviceNet(_lib.KWS_NET_LOG_MFCC, num_classes, input_size=input_size, spectrogram_length=time_size,
+                    num_features=frequency_size)
+    return Model(net, RMSprop(lr=3e-4), name='conv_1d_spectrogram', loss='cce')
+
+
 def speech_model(model_type, input_size, num_classes=11, *args, **kwargs):
     if model_type == 'conv_1d_time_sliced_with_attention':
         return conv_1d_time_sliced_with_attention_model(input_size, num_classes)
     if model_type == 'conv_1d_log_mfcc':
         return conv_1d_log_mfcc_model(input_size, num_classes, *args, **kwargs)
+    if model_type == 'conv_1d_spectrogram':
+        return conv_1d_spectrogram_model(input_size, num_classes, *args, **kwargs)
     if model_type in REFERENCE_MODEL_TYPES:
         raise NotImplementedError(
             "model '%s' is outside the accelerated hot path (SURVEY.md 8: only %s are built natively)"

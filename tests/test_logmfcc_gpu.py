@@ -17,8 +17,8 @@ from speech_recognition_amd.net import DeviceNet
 pytestmark = pytest.mark.gpu
 
 
-def _pair(num_classes=32, seed=11):
-    ora = LogMfccNet(num_classes=num_classes, dtype=np.float64)
+def _pair(num_classes=32, seed=11, F=40):
+    ora = LogMfccNet(num_classes=num_classes, num_features=F, dtype=np.float64)
     rng = np.random.RandomState(seed)
     for k in ora.params:
         if k.endswith('gamma'):
@@ -30,15 +30,15 @@ def _pair(num_classes=32, seed=11):
             ora.state[k] = (0.05 * rng.randn(*ora.state[k].shape)).astype(np.float32)
         else:
             ora.state[k] = (1.0 + 0.2 * rng.rand(*ora.state[k].shape)).astype(np.float32)
-    net = DeviceNet(_lib.KWS_NET_LOG_MFCC, num_classes, input_size=98 * 40, spectrogram_length=98, num_features=40)
+    net = DeviceNet(_lib.KWS_NET_LOG_MFCC, num_classes, input_size=98 * F, spectrogram_length=98, num_features=F)
     net.set_weights(dict(ora.params, **ora.state))
     return ora, net
 
 
-def _batch(B, nc, seed):
+def _batch(B, nc, seed, F=40):
     rng = np.random.RandomState(seed)
     lab = rng.randint(0, nc, B)
-    x = rng.randn(B, 98, 40) * 2.0 - 0.7 + 0.5 * np.sin(np.arange(40)[None, None, :] * (1 + lab)[:, None, None] * 0.1)
+    x = rng.randn(B, 98, F) * 2.0 - 0.7 + 0.5 * np.sin(np.arange(F)[None, None, :] * (1 + lab)[:, None, None] * 0.1)
     return x.reshape(B, -1).astype(np.float32), np.eye(nc, dtype=np.float32)[lab]
 
 
@@ -84,19 +84,23 @@ def test_tensor_table_matches_oracle():
         assert net.tensors[k].shape == v.shape, k
 
 
-def test_predict_matches_oracle():
-    ora, net = _pair()
-    x, _ = _batch(7, 32, 1)
+@pytest.mark.parametrize("nc,F", [(32, 40), (12, 257)])
+def test_predict_matches_oracle(nc, F):
+    ora, net = _pair(nc, F=F)
+    x, _ = _batch(7, nc, 1, F)
     p = net.predict(torch.from_numpy(x).cuda()).cpu().numpy()
     ref = ora.forward(x.astype(np.float64), training=False)
     assert np.abs(p - ref).max() < 1e-5
     assert np.array_equal(p.argmax(1), ref.argmax(1))
 
 
-@pytest.mark.parametrize("B", [4, 19])
-def test_train_fwd_bwd_matches_oracle(B):
-    ora, net = _pair()
-    x, y = _batch(B, 32, B)
+# F = 257, 12 classes: conv_1d_spectrogram (model.py:1482-1561) - the same program on the
+# generator's 'spec' output; 257 is not a multiple of the gathered GEMM's 16-byte vectors, so the first
+# convolution runs on re-pitched copies (net_logmfcc.hip: pad_first_conv)
+@pytest.mark.parametrize("B,nc,F", [(4, 32, 40), (19, 32, 40), (5, 12, 257)])
+def test_train_fwd_bwd_matches_oracle(B, nc, F):
+    ora, net = _pair(nc, F=F)
+    x, y = _batch(B, nc, B, F)
     probs = net.train_fwd_bwd(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(), seed=77, step=2)
     torch.cuda.synchronize()
     masks, args = _decisions(net, ora, B)
@@ -161,3 +165,32 @@ def test_config_c3_features_net_head32to12():
     assert np.abs(p12.cpu().numpy() - ref12).max() < 1e-3          # north_star tolerance on softmax
     assert np.array_equal(p12.cpu().numpy().argmax(1), ref12.argmax(1))
     lib.kws_stft_plan_destroy(plan)
+
+
+def test_spectrogram_family_on_the_spec_generator(repo_root):
+    """conv_1d_spectrogram end to end like train.py would drive it: AudioProcessor(output_representation='spec')
+    -> data_gen -> speech_model('conv_1d_spectrogram', fingerprint_size, **model_settings) -> train_on_batch."""
+    import sys
+    sys.path.insert(0, repo_root)
+    import bench
+    from speech_recognition_amd.input_data import AudioProcessor, prepare_words_list
+    from speech_recognition_amd.model import prepare_model_settings, speech_model
+    from speech_recognition_amd.utils import data_gen
+    dev = torch.device("cuda", 0)
+    settings = prepare_model_settings(label_count=len(prepare_words_list(bench.WANTED)), sample_rate=16000,
+                                      clip_duration_ms=1000, window_size_ms=30.0, window_stride_ms=10.0,
+                                      dct_coefficient_count=80, num_log_mel_features=60, output_representation='spec')
+    assert settings['fingerprint_size'] == 98 * 257
+    proc = AudioProcessor(bench.build_synthetic(dev, 8192, seed=59185), 13.0, 60.0, bench.WANTED, 10.0, 0.0, settings,
+                          output_representation='spec', device=dev)
+    np.random.seed(1234)
+    gen = data_gen(proc, None, batch_size=64, mode='training')
+    model = speech_model('conv_1d_spectrogram', settings['fingerprint_size'], num_classes=settings['label_count'],
+                         **settings)
+    assert model.name == 'conv_1d_spectrogram' and abs(float(model.optimizer.lr) - 3e-4) < 1e-9  # f32 variable
+    losses = []
+    for _ in range(12):
+        X, y = next(gen)
+        assert np.asarray(X).shape == (64, 98 * 257)
+        losses.append(float(model.train_on_batch(X, y)[0]))
+    assert np.all(np.isfinite(losses)) and np.mean(losses[-3:]) < np.mean(losses[:3])
