@@ -85,6 +85,12 @@ int build_ts_attention(kws_net* n) {
   g.L_out = n->L1; g.cin = 40; g.taps = 3; g.stride_t = 2 * 20; g.stride_j = 20; g.base_off = -plf;
   g.x_len = n->L_in; g.x_batch_stride = n->L_in;
   n->gather1 = g;
+  // The three taps overlap (tap j covers samples 20 j .. 20 j + 39 of an 80-sample span): the convolution is a GEMM
+  // over the 80 DISTINCT samples with the kernel rows that hit the same sample added up front - 2/3 of the FLOPs.
+  n->K1f = g.stride_j * (g.taps - 1) + g.cin;
+  kws_gather_t gf = g;
+  gf.cin = n->K1f; gf.taps = 1; gf.stride_j = 0;
+  n->gather1f = gf;
   static const int spec[11][2] = {{1, 128}, {2, 192}, {1, 192}, {2, 256}, {1, 256}, {2, 320},
                                   {1, 320}, {2, 384}, {1, 384}, {2, 512}, {1, 512}};  // model.py:812-817
   int L = n->L1, cin = n->C1;
@@ -120,6 +126,47 @@ int build_ts_attention(kws_net* n) {
   return KWS_OK;
 }
 
+// ---- first convolution with overlapping taps, folded -------------------------------------------------
+// Weff[s, n] = sum over taps j (ascending) with 0 <= s - hop*j < cin of W[j, s - hop*j, n]
+__global__ __launch_bounds__(256) void fold_taps_kernel(const float* __restrict__ W, float* __restrict__ Weff, int taps,
+                                                        int cin, int hop, int Kf, int N) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= Kf * N) return;
+  const int s = i / N, n = i - s * N;
+  float acc = 0.f;
+  for (int j = 0; j < taps; ++j) {
+    const int c = s - hop * j;
+    if (c >= 0 && c < cin) acc += W[((int64_t)j * cin + c) * N + n];
+  }
+  Weff[i] = acc;
+}
+// dW[j, c, n] = dWeff[hop*j + c, n]: every tap row reads the gradient of the sample it multiplies - the same sum
+// over (clip, frame) as the unfolded weight-gradient GEMM, not a regrouping
+__global__ __launch_bounds__(256) void unfold_taps_kernel(const float* __restrict__ dWeff, float* __restrict__ dW, int taps,
+                                                          int cin, int hop, int N) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= taps * cin * N) return;
+  const int n = i % N, jc = i / N;
+  const int j = jc / cin, c = jc - j * cin;
+  dW[i] = dWeff[(int64_t)(hop * j + c) * N + n];
+}
+int fold_conv1(const kws_net* net, const float* params, float* w1f, hipStream_t st) {
+  const kws_gather_t& g = net->gather1;
+  const int n = net->K1f * net->C1;
+  hipLaunchKernelGGL(fold_taps_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, params + net->conv1, w1f, g.taps, g.cin,
+                     g.stride_j, net->K1f, net->C1);
+  KWS_LAUNCH_CHECK("fold_taps_kernel");
+  return KWS_OK;
+}
+int unfold_conv1(const kws_net* net, const float* g1f, float* grads, hipStream_t st) {
+  const kws_gather_t& g = net->gather1;
+  const int n = g.taps * g.cin * net->C1;
+  hipLaunchKernelGGL(unfold_taps_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, g1f, grads + net->conv1, g.taps, g.cin,
+                     g.stride_j, net->C1);
+  KWS_LAUNCH_CHECK("unfold_taps_kernel");
+  return KWS_OK;
+}
+
 // ---- workspace layout ------------------------------------------------------------------------------
 struct Layout {
   int64_t total = 0;  // bytes
@@ -127,6 +174,7 @@ struct Layout {
   std::vector<int64_t> z;   // z[i], i = 0..10
   int64_t G = 0, G2 = 0, DZ = 0, bn = 0, part = 0, coef = 0, WT = 0, tn = 0, red = 0, swg = 0;
   int64_t xd = 0, fd = 0, dl1 = 0, dl2 = 0, per_loss = 0, per_correct = 0, att = 0;
+  int64_t w1f = 0, g1f = 0;  // folded first-convolution kernel and its gradient [K1f, C1]
   int64_t bn_stride = 0;
 };
 
@@ -138,7 +186,7 @@ void make_layout(const kws_net* n, int B, bool training, Layout* lo) {
   int64_t max_y = (int64_t)B * n->L1 * n->C1, max_z = 0, max_part = 0, max_dwpart = 0, max_wt = 0, max_tn = 0;
   int maxC = n->C1;
   max_part = (int64_t)kws_gemm_num_row_tiles((int64_t)B * n->L1) * 2 * n->C1;
-  max_tn = kws_gemm_tn_workspace_floats((int64_t)B * n->L1, 120, n->C1);
+  max_tn = kws_gemm_tn_workspace_floats((int64_t)B * n->L1, n->K1f, n->C1);
   for (int i = 0; i < nb; ++i) {
     const Block& b = n->blocks[i];
     const int64_t M = (int64_t)B * b.Lout;
@@ -178,6 +226,7 @@ void make_layout(const kws_net* n, int B, bool training, Layout* lo) {
     lo->per_loss = bp.take(B);
     lo->per_correct = bp.take(B);
     lo->att = bp.take((int64_t)B * 16);
+    lo->g1f = bp.take((int64_t)n->K1f * n->C1);
   } else {
     // inference ping-pong: two y buffers and one z buffer
     const int64_t ya = bp.take(max_y), yb = bp.take(max_y), zz = bp.take(max_z);
@@ -188,6 +237,7 @@ void make_layout(const kws_net* n, int B, bool training, Layout* lo) {
     }
     lo->part = bp.take(64);
   }
+  lo->w1f = bp.take((int64_t)n->K1f * n->C1);
   lo->bn_stride = (4 * maxC + 63) / 64 * 64;
   lo->bn = bp.take(lo->bn_stride * (nb + 1));
   lo->total = bp.cur * 4;
@@ -302,7 +352,8 @@ int kws_net_predict(const kws_net_t* net, const float* params, const float* stat
   };
   KWS_TRY(prep(net->bn1, 0));
   for (int i = 0; i < nb; ++i) KWS_TRY(prep(net->blocks[i].bn, i + 1));
-  KWS_TRY(kws_gemm_gather_f32(x, &net->gather1, params + net->conv1, ws + lo.y[0], B, net->C1, nullptr, st));
+  KWS_TRY(fold_conv1(net, params, ws + lo.w1f, st));
+  KWS_TRY(kws_gemm_gather_f32(x, &net->gather1f, ws + lo.w1f, ws + lo.y[0], B, net->C1, nullptr, st));
   for (int i = 0; i < nb; ++i) {
     const Block& b = net->blocks[i];
     KWS_TRY(kws_dwconv_fwd_f32(ws + lo.y[i], bn_at(i), params + b.dw, ws + lo.z[i], B, b.Lin, b.Lout, b.cin, b.stride,
@@ -348,7 +399,8 @@ int kws_net_train_fwd_bwd(const kws_net_t* net, const float* params, float* stat
   // ---------------- forward ----------------
   {
     const int64_t M = (int64_t)B * net->L1;
-    KWS_TRY(kws_gemm_gather_f32(x, &net->gather1, params + net->conv1, ws + lo.y[0], B, net->C1, part, st));
+    KWS_TRY(fold_conv1(net, params, ws + lo.w1f, st));
+    KWS_TRY(kws_gemm_gather_f32(x, &net->gather1f, ws + lo.w1f, ws + lo.y[0], B, net->C1, part, st));
     KWS_TRY(kws_bn_stats_finalize(part, kws_gemm_gather_stats_rows(M), M, net->C1, params + net->bn1.gamma,
                                   params + net->bn1.beta, BN_EPS, BN_MOMENTUM, state + net->bn1.mm, state + net->bn1.mv,
                                   bn_at(0), red, st));
@@ -396,7 +448,7 @@ int kws_net_train_fwd_bwd(const kws_net_t* net, const float* params, float* stat
     KWS_HIP(hipEventCreateWithFlags(&net->ev_wgrad[1], hipEventDisableTiming));
     KWS_HIP(hipEventCreateWithFlags(&net->ev_join, hipEventDisableTiming));
   }
-  hipStream_t sw = overlap ? net->side : st;
+  static const int overlap_from = getenv("KWS_OVERLAP_FROM") ? atoi(getenv("KWS_OVERLAP_FROM")) : 0;  // experiment knob
   float* Gb[2] = {ws + lo.G, ws + lo.G2};          // gradient wrt y[l] lives in Gb[l % 2]; the tail wrote Gb[nb % 2]
   bool wgrad_pending[2] = {false, false};
   for (int i = nb - 1; i >= 0; --i) {
@@ -410,18 +462,23 @@ int kws_net_train_fwd_bwd(const kws_net_t* net, const float* params, float* stat
       KWS_TRY(kws_bn_bwd_apply(Gcur, ws + lo.y[i + 1], bn_at(i + 1), params + b.bn.gamma, coef, M, b.cout, st));
     KWS_TRY(kws_transpose_f32(params + b.pw, ws + lo.WT, b.cin, b.cout, st));
     KWS_TRY(kws_gemm_nn_f32(Gcur, ws + lo.WT, DZ, M, b.cout, b.cin, nullptr, st));
-    if (overlap) {
+    const bool ov = overlap && i >= overlap_from;
+    hipStream_t sw = ov ? net->side : st;
+    if (ov) {
       KWS_HIP(hipEventRecord(net->ev_fork, st));
       KWS_HIP(hipStreamWaitEvent(sw, net->ev_fork, 0));
+    } else if (overlap) {                           // the TN workspace is shared: drain the side stream first
+      KWS_HIP(hipEventRecord(net->ev_join, net->side));
+      KWS_HIP(hipStreamWaitEvent(st, net->ev_join, 0));
     }
     KWS_TRY(kws_gemm_tn_f32(ws + lo.z[i], Gcur, grads + b.pw, M, b.cin, b.cout, ws + lo.tn, sw));
-    if (overlap) {
+    if (ov) {
       KWS_HIP(hipEventRecord(net->ev_wgrad[(i + 1) % 2], sw));
       wgrad_pending[(i + 1) % 2] = true;
-      if (wgrad_pending[i % 2]) {                   // the wgrad of block i+1 read Gnext
-        KWS_HIP(hipStreamWaitEvent(st, net->ev_wgrad[i % 2], 0));
-        wgrad_pending[i % 2] = false;
-      }
+    }
+    if (overlap && wgrad_pending[i % 2]) {          // the wgrad of block i+1 read Gnext
+      KWS_HIP(hipStreamWaitEvent(st, net->ev_wgrad[i % 2], 0));
+      wgrad_pending[i % 2] = false;
     }
     const BnRef& prev = (i == 0) ? net->bn1 : net->blocks[i - 1].bn;
     // depthwise backward + BatchNorm backward of this block's input without materialising the masked
@@ -438,10 +495,11 @@ int kws_net_train_fwd_bwd(const kws_net_t* net, const float* params, float* stat
     const int64_t M = (int64_t)B * net->L1;
     (void)M;                                        // Gb[0] already holds dy of the first convolution
     if (overlap) {                                  // the side stream's TN workspace is free once its queue drains
-      KWS_HIP(hipEventRecord(net->ev_join, sw));
+      KWS_HIP(hipEventRecord(net->ev_join, net->side));
       KWS_HIP(hipStreamWaitEvent(st, net->ev_join, 0));
     }
-    KWS_TRY(kws_gemm_tn_gather_f32(x, &net->gather1, Gb[0], grads + net->conv1, B, net->C1, ws + lo.tn, st));
+    KWS_TRY(kws_gemm_tn_gather_f32(x, &net->gather1f, Gb[0], ws + lo.g1f, B, net->C1, ws + lo.tn, st));
+    KWS_TRY(unfold_conv1(net, ws + lo.g1f, grads, st));
   }
   return KWS_OK;
 }

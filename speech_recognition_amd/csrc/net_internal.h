@@ -38,7 +38,9 @@ struct kws_net {
   std::vector<Block> blocks;
   int T = 0, C = 0, NC = 0;
   int64_t d1k = 0, d1b = 0, d2k = 0;
-  kws_gather_t gather1;
+  kws_gather_t gather1;   // the reference's view: 3 taps of 40 samples, taps 20 samples apart (K = 120)
+  kws_gather_t gather1f;  // folded view used by the GEMMs: ONE tap of 80 contiguous samples (see net.hip fold_taps_kernel)
+  int K1f = 0;            // folded K
   // LOG_MFCC
   LmProgram* lm = nullptr;
   // side stream of the training step (weight-gradient GEMMs run beside the memory-bound backward kernels);
