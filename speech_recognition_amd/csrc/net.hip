@@ -434,13 +434,14 @@ int kws_net_train_fwd_bwd(const kws_net_t* net, const float* params, float* stat
                                 grads + r.beta, coef, red, st));
   }
   // ---------------- backward through the blocks ----------------
-  // The weight-gradient GEMM of a block depends only on dy and z; the rest of the chain (dgrad -> depthwise
-  // backward -> BN reductions -> next block's dy) does not need it.  It therefore runs on a side stream right
-  // after the block's dgrad GEMM, beside the HBM-bound depthwise / BN kernels of the main chain: the MFMA-bound
-  // and the bandwidth-bound halves of the backward pass overlap instead of alternating.  The masked gradient
-  // ping-pongs between two buffers so that the depthwise backward never overwrites a dy the side stream
-  // still reads (it waits for the wgrad of two blocks ago, which used the same buffer).
-  static const bool overlap = getenv("KWS_NO_OVERLAP") == nullptr;
+  // One stream by default.  The weight-gradient GEMM of a block depends only on dy and z, so it CAN run on a side
+  // stream beside the HBM-bound depthwise / BN kernels of the main chain (KWS_OVERLAP=1; the masked gradient then
+  // ping-pongs between two buffers so that the depthwise backward never overwrites a dy the side stream still
+  // reads).  That bought 3 % while the depthwise backward was one unfused pass; with the fused two-pass kernels both
+  // orders take the same 5.14 - 5.20 ms: the early-layer GEMMs (32 FLOP/B) draw 3.7 TB/s themselves, so each side
+  // slows the other by what the overlap gains.  Moving only the small off-chain kernels (transposes, slab sums,
+  // the tail's weight gradients) to a helper stream was measured too: the event traffic costs what it hides.
+  static const bool overlap = getenv("KWS_OVERLAP") != nullptr;
   if (overlap && net->side == nullptr) {
     KWS_HIP(hipStreamCreateWithFlags(&net->side, hipStreamNonBlocking));
     KWS_HIP(hipEventCreateWithFlags(&net->ev_fork, hipEventDisableTiming));
