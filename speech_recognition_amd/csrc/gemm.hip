@@ -17,6 +17,7 @@
 // consistently for A and B (lane half h owns k = 8q+4h+r), which the MFMA sum does not care about.
 // -DKWS_GEMM_STAMP builds add s_memtime stamps to the wave-specialised NN kernel (scripts/stamps_ws.py).
 #include "common.h"
+#include "internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -1110,6 +1111,36 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* in, float* 
   }
 }
 
+// up to KWS_TRANSPOSE_BATCH matrices in one launch (the dgrad GEMMs' transposed pointwise kernels: eleven
+// 5 us launches otherwise)
+struct TransposeBatch {
+  const float* in[KWS_TRANSPOSE_BATCH];
+  float* out[KWS_TRANSPOSE_BATCH];
+  int rows[KWS_TRANSPOSE_BATCH], cols[KWS_TRANSPOSE_BATCH], tile_end[KWS_TRANSPOSE_BATCH];
+  int n;
+};
+__global__ __launch_bounds__(256) void transpose_batch_kernel(TransposeBatch b) {
+  __shared__ float tile[32][33];
+  int m = 0;
+  while (m + 1 < b.n && (int)blockIdx.x >= b.tile_end[m]) ++m;
+  const int t = blockIdx.x - (m ? b.tile_end[m - 1] : 0);
+  const int rows = b.rows[m], cols = b.cols[m];
+  const int tx_n = (cols + 31) / 32;
+  const int bx = (t % tx_n) * 32, by = (t / tx_n) * 32;
+  const float* in = b.in[m];
+  float* out = b.out[m];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const int y = by + r, x = bx + tx;
+    tile[r][tx] = (y < rows && x < cols) ? in[(int64_t)y * cols + x] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int y = bx + r, x = by + tx;  // out is [cols][rows]
+    if (y < cols && x < rows) out[(int64_t)y * rows + x] = tile[tx][r];
+  }
+}
+
 // split heuristic of the TN kernel: enough workgroups to fill 256 CUs, slabs no larger than needed
 struct TNPlan {
   int bko, bno;  // 128 or 64 each
@@ -1343,6 +1374,27 @@ int kws_transpose_f32(const float* in, float* out, int rows, int cols, void* str
   dim3 g((unsigned)ceil_div(cols, 32), (unsigned)ceil_div(rows, 32));
   hipLaunchKernelGGL(transpose_kernel, g, dim3(256), 0, (hipStream_t)stream, in, out, rows, cols);
   KWS_LAUNCH_CHECK("transpose_kernel");
+  return KWS_OK;
+}
+
+// internal (net.hip): n <= KWS_TRANSPOSE_BATCH row-major [rows[i], cols[i]] matrices -> their transposes, one launch
+int kws_transpose_batch_f32(const float* const* in, float* const* out, const int* rows, const int* cols, int n,
+                            hipStream_t stream) {
+  KWS_REQUIRE(in && out && rows && cols && n > 0 && n <= KWS_TRANSPOSE_BATCH, "transpose_batch: bad arguments (n=%d)", n);
+  TransposeBatch b;
+  int tiles = 0;
+  double bytes = 0;
+  for (int i = 0; i < n; ++i) {
+    KWS_REQUIRE(in[i] && out[i] && rows[i] > 0 && cols[i] > 0, "transpose_batch: bad matrix %d", i);
+    b.in[i] = in[i]; b.out[i] = out[i]; b.rows[i] = rows[i]; b.cols[i] = cols[i];
+    tiles += ceil_div(rows[i], 32) * ceil_div(cols[i], 32);
+    b.tile_end[i] = tiles;
+    bytes += 8.0 * rows[i] * cols[i];
+  }
+  b.n = n;
+  KwsProfScope prof("transpose", 0.0, bytes, stream);
+  hipLaunchKernelGGL(transpose_batch_kernel, dim3((unsigned)tiles), dim3(256), 0, stream, b);
+  KWS_LAUNCH_CHECK("transpose_batch_kernel");
   return KWS_OK;
 }
 

@@ -13,6 +13,9 @@ constexpr int KWS_SMALL_WGRAD_SLICES = 32;  // scratch: KWS_SMALL_WGRAD_SLICES *
 int kws_small_wgrad_launch(const float* X, const float* D, float* out, float* out_bias, int B, int K, int N,
                            float* scratch, hipStream_t st);
 int kws_metrics_launch(const float* per_loss, const float* per_correct, int B, float* metrics, hipStream_t st);
+constexpr int KWS_TRANSPOSE_BATCH = 16;
+extern "C" int kws_transpose_batch_f32(const float* const* in, float* const* out, const int* rows, const int* cols, int n,
+                                       hipStream_t stream);
 
 // ---- STFT plan (device tables), shared by stft.hip (v1, generic) and stft2.hip (v2, features) ------
 struct kws_stft_plan {

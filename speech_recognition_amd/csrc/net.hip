@@ -172,7 +172,8 @@ struct Layout {
   int64_t total = 0;  // bytes
   std::vector<int64_t> y;   // y[l], l = 0..11 (float offsets)
   std::vector<int64_t> z;   // z[i], i = 0..10
-  int64_t G = 0, G2 = 0, DZ = 0, bn = 0, part = 0, coef = 0, WT = 0, tn = 0, red = 0, swg = 0;
+  int64_t G = 0, G2 = 0, DZ = 0, bn = 0, part = 0, coef = 0, tn = 0, red = 0, swg = 0;
+  std::vector<int64_t> WT;  // transposed pointwise kernel of block i (dgrad GEMM operand)
   int64_t xd = 0, fd = 0, dl1 = 0, dl2 = 0, per_loss = 0, per_correct = 0, att = 0;
   int64_t w1f = 0, g1f = 0;  // folded first-convolution kernel and its gradient [K1f, C1]
   int64_t bn_stride = 0;
@@ -183,7 +184,7 @@ void make_layout(const kws_net* n, int B, bool training, Layout* lo) {
   const int nb = (int)n->blocks.size();
   lo->y.assign(nb + 1, 0);
   lo->z.assign(nb, 0);
-  int64_t max_y = (int64_t)B * n->L1 * n->C1, max_z = 0, max_part = 0, max_dwpart = 0, max_wt = 0, max_tn = 0;
+  int64_t max_y = (int64_t)B * n->L1 * n->C1, max_z = 0, max_part = 0, max_dwpart = 0, max_tn = 0;
   int maxC = n->C1;
   max_part = (int64_t)kws_gemm_num_row_tiles((int64_t)B * n->L1) * 2 * n->C1;
   max_tn = kws_gemm_tn_workspace_floats((int64_t)B * n->L1, n->K1f, n->C1);
@@ -196,7 +197,6 @@ void make_layout(const kws_net* n, int B, bool training, Layout* lo) {
     if (p > max_part) max_part = p;
     const int64_t dp = kws_dwconv_bwd_part_floats(B, b.Lin, b.cin);
     if (dp > max_dwpart) max_dwpart = dp;
-    if ((int64_t)b.cin * b.cout > max_wt) max_wt = (int64_t)b.cin * b.cout;
     const int64_t t = kws_gemm_tn_workspace_floats(M, b.cin, b.cout);
     if (t > max_tn) max_tn = t;
     if (b.cout > maxC) maxC = b.cout;
@@ -217,7 +217,8 @@ void make_layout(const kws_net* n, int B, bool training, Layout* lo) {
     lo->red = bp.take((int64_t)KWS_REDUCE_SLICES * 5 * maxC);
     lo->swg = bp.take((int64_t)KWS_SMALL_WGRAD_SLICES *
                       std::max((int64_t)n->T * n->C * n->T, (int64_t)2 * n->C * n->NC));
-    lo->WT = bp.take(max_wt);
+    lo->WT.assign(nb, 0);
+    for (int i = 0; i < nb; ++i) lo->WT[i] = bp.take((int64_t)n->blocks[i].cin * n->blocks[i].cout);
     lo->tn = bp.take(max_tn);
     lo->xd = bp.take((int64_t)B * n->T * n->C);
     lo->fd = bp.take((int64_t)B * 2 * n->C);
@@ -450,6 +451,18 @@ int kws_net_train_fwd_bwd(const kws_net_t* net, const float* params, float* stat
     KWS_HIP(hipEventCreateWithFlags(&net->ev_join, hipEventDisableTiming));
   }
   static const int overlap_from = getenv("KWS_OVERLAP_FROM") ? atoi(getenv("KWS_OVERLAP_FROM")) : 0;  // experiment knob
+  {  // the dgrad GEMMs read the pointwise kernels transposed: all of them in one launch
+    static_assert(KWS_TRANSPOSE_BATCH >= 11, "one batch holds every block");
+    const float* tin[KWS_TRANSPOSE_BATCH];
+    float* tout[KWS_TRANSPOSE_BATCH];
+    int trows[KWS_TRANSPOSE_BATCH], tcols[KWS_TRANSPOSE_BATCH];
+    KWS_REQUIRE(nb <= KWS_TRANSPOSE_BATCH, "net: %d blocks exceed the transpose batch", nb);
+    for (int i = 0; i < nb; ++i) {
+      tin[i] = params + net->blocks[i].pw; tout[i] = ws + lo.WT[i];
+      trows[i] = net->blocks[i].cin; tcols[i] = net->blocks[i].cout;
+    }
+    KWS_TRY(kws_transpose_batch_f32(tin, tout, trows, tcols, nb, st));
+  }
   float* Gb[2] = {ws + lo.G, ws + lo.G2};          // gradient wrt y[l] lives in Gb[l % 2]; the tail wrote Gb[nb % 2]
   bool wgrad_pending[2] = {false, false};
   for (int i = nb - 1; i >= 0; --i) {
@@ -461,8 +474,7 @@ int kws_net_train_fwd_bwd(const kws_net_t* net, const float* params, float* stat
     // below); only the tail hands over a masked gradient that still needs its BatchNorm backward
     if (i == nb - 1)
       KWS_TRY(kws_bn_bwd_apply(Gcur, ws + lo.y[i + 1], bn_at(i + 1), params + b.bn.gamma, coef, M, b.cout, st));
-    KWS_TRY(kws_transpose_f32(params + b.pw, ws + lo.WT, b.cin, b.cout, st));
-    KWS_TRY(kws_gemm_nn_f32(Gcur, ws + lo.WT, DZ, M, b.cout, b.cin, nullptr, st));
+    KWS_TRY(kws_gemm_nn_f32(Gcur, ws + lo.WT[i], DZ, M, b.cout, b.cin, nullptr, st));
     const bool ov = overlap && i >= overlap_from;
     hipStream_t sw = ov ? net->side : st;
     if (ov) {
