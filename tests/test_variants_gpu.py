@@ -1,0 +1,27 @@
+"""The A/B paths the library keeps behind environment variables stay correct: the kernel and
+network parity suites are re-run in a child process with every alternative selected (the switches are read once
+per process, so they cannot be flipped inside this one)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("env", [
+    {"KWS_GEMM_PERSIST": "1", "KWS_GEMM_TN_V1": "1", "KWS_TAIL_GENERIC": "1"},
+    {"KWS_OVERLAP": "1"},
+    {"KWS_STFT_V2": "1"},
+])
+def test_alternative_paths_pass_the_parity_suites(repo_root, env):
+    e = dict(os.environ)
+    e.update(env)
+    files = ["tests/test_kernels_gpu.py", "tests/test_net_gpu.py"] if "KWS_STFT_V2" not in env else \
+        ["tests/test_kernels_gpu.py", "tests/test_logmfcc_gpu.py", "-k", "stft or c3"]
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider"] + files, cwd=repo_root,
+                       env=e, capture_output=True, text=True, timeout=900)
+    tail = "\n".join(r.stdout.splitlines()[-15:])
+    assert r.returncode == 0, tail
+    assert " passed" in tail and "failed" not in tail
