@@ -459,3 +459,175 @@ class LogMfccNet(object):
         for k in self.l2_names:
             grads[k] = grads[k] + dt(2.0 * L.L2_COEF) * self._p(k)
         return loss, p, OrderedDict((k, grads[k]) for k in self.params), cache
+
+
+# ----------------------------------------------------------------------------------------------------------
+# steffeNet (reference model.py:1663-1726)
+# ----------------------------------------------------------------------------------------------------------
+STEFFE_WIDTHS = [320, 384, 512, 768, 1024, 1536]                   # model.py:1709
+
+
+class SteffeNet(LogMfccNet):
+    """Raw waveform -> Conv1D(256, 75, strides=50, same, no bias, no regulariser) + BN + ReLU6 ->
+    _context_conv(256, 3, same) -> 6 x [residual block stride 2, residual block stride 1] ->
+    GlobalMaxPooling1D ++ GlobalAveragePooling1D -> Dropout(.5) -> Dense(num_classes, no bias) + softmax,
+    label-smoothed CE (0.1), RMSprop(1e-3).
+
+    A residual block (model.py:1690-1701) differs from conv_1d_log_mfcc's in where the stride sits: the FIRST
+    depthwise convolution is strided (SAME), there is no max-pool, and the sum is not activated.  Keras names in
+    layer creation order, as in LogMfccNet (shortcut Conv1D + BN first)."""
+
+    def __init__(self, num_classes=12, input_size=16000, filter_widths=STEFFE_WIDTHS, c0=256, seed=87654321,
+                 dtype=np.float64):
+        self.dtype = dtype
+        self.num_classes = num_classes
+        self.L_in = input_size
+        rng = np.random.RandomState(seed)
+        P, S = OrderedDict(), OrderedDict()
+        self.cnt = dict(conv=0, bn=0, dw=0)
+        self.l2_names = []
+
+        def conv(k, cin, cout, l2):
+            self.cnt['conv'] += 1
+            name = 'conv1d_%d/kernel' % self.cnt['conv']
+            P[name] = glorot_uniform(rng, (k, cin, cout), k * cin, k * cout)
+            if l2:
+                self.l2_names.append(name)
+            return name
+
+        def bn(c):
+            self.cnt['bn'] += 1
+            TimeSlicedAttentionNet._add_bn(P, S, self.cnt['bn'], c)
+            return self.cnt['bn']
+
+        def dw(c):
+            self.cnt['dw'] += 1
+            name = 'depthwise_conv2d_%d/depthwise_kernel' % self.cnt['dw']
+            P[name] = glorot_uniform(rng, (1, 3, c, 1), 3 * c, 3)
+            self.l2_names.append(name)
+            return name
+
+        self.K0, self.S0, self.C0 = 75, 50, c0
+        self.L0, self.pl0, self.pr0 = L.same_pad(input_size, self.K0, self.S0)
+        self.first = (conv(self.K0, 1, c0, False), bn(c0))                     # model.py:1705-1707
+        self.ctx = (dw(c0), conv(1, c0, c0, True), bn(c0))                     # _context_conv(x, 256, 3, 'same')
+        self.blocks = []
+        cin, Lc = c0, self.L0
+        for nh in filter_widths:
+            for stride in (2, 1):
+                Lout, pl, pr = L.same_pad(Lc, 3, stride)
+                blk = dict(nf=nh, stride=stride, cin=cin, Lin=Lc, Lout=Lout, pad1=(pl, pr))
+                if stride != 1:
+                    blk['short'] = (conv(1, cin, nh, False), bn(nh))
+                blk['dw1'], blk['pw1'], blk['bn1'] = dw(cin), conv(1, cin, nh, True), bn(nh)
+                blk['dw2'], blk['pw2'], blk['bn2'] = dw(nh), conv(1, nh, nh, True), bn(nh)
+                self.blocks.append(blk)
+                cin, Lc = nh, Lout
+        self.T, self.C = Lc, cin
+        P['dense_1/kernel'] = glorot_uniform(rng, (2 * cin, num_classes), 2 * cin, num_classes)
+        self.l2_names.append('dense_1/kernel')
+        self.params, self.state = P, S
+        self.drop_keep = 0.5                                                   # Dropout(0.5), model.py:1716
+        self.label_smoothing = 0.1                                             # model.py:1722-1724
+
+    def forward(self, x, training=False, seed=0, step=0, cache=None, drop_offset=0):
+        dt = self.dtype
+        cache = {} if cache is None else cache
+        B = x.shape[0]
+        h = np.asarray(x, dtype=dt).reshape(B, self.L_in, 1)                   # Reshape([-1, 1])
+        y, cols = L.conv1d_fwd(h, self._p(self.first[0]), stride=self.S0, pad=(self.pl0, self.pr0))
+        cache['conv1_cols'] = cols
+        h = self._bn(self.first[1], y, training, cache)
+        wc = self._p(self.ctx[0]).reshape(3, self.C0)
+        zc = L.dwconv_fwd(h, wc, 1, (1, 1))
+        Wc = self._p(self.ctx[1]).reshape(self.C0, self.C0)
+        cache['ctx'] = (h, wc, zc, Wc)
+        h = self._bn(self.ctx[2], L.pw_fwd(zc, Wc), training, cache)
+        for i, blk in enumerate(self.blocks):
+            c = {'x': h}
+            if 'short' in blk:
+                xs = h[:, ::blk['stride'], :]                                  # Conv1D(nh, 1, strides, same)
+                Ws = self._p(blk['short'][0]).reshape(blk['cin'], blk['nf'])
+                c['xs'], c['Ws'] = xs, Ws
+                res = self._bn(blk['short'][1], L.pw_fwd(xs, Ws), training, cache, relu=False)
+            else:
+                res = h
+            w1 = self._p(blk['dw1']).reshape(3, blk['cin'])
+            z1 = L.dwconv_fwd(h, w1, blk['stride'], blk['pad1'])
+            W1 = self._p(blk['pw1']).reshape(blk['cin'], blk['nf'])
+            a1 = self._bn(blk['bn1'], L.pw_fwd(z1, W1), training, cache)
+            w2 = self._p(blk['dw2']).reshape(3, blk['nf'])
+            z2 = L.dwconv_fwd(a1, w2, 1, (1, 1))
+            W2 = self._p(blk['pw2']).reshape(blk['nf'], blk['nf'])
+            a2 = self._bn(blk['bn2'], L.pw_fwd(z2, W2), training, cache)
+            c.update(w1=w1, z1=z1, W1=W1, a1=a1, w2=w2, z2=z2, W2=W2)
+            cache['blk%d' % i] = c
+            h = a2 + res                                                       # Add, no activation
+        xmax, xavg = h.max(axis=1), h.mean(axis=1)
+        feat = np.concatenate([xmax, xavg], axis=1)                            # Concatenate()([x_max, x_avg])
+        if training:
+            m = L.dropout_mask(L.dropout_key(seed, step, 1), B * 2 * self.C, self.drop_keep,
+                               drop_offset * 2 * self.C).reshape(B, 2 * self.C)
+            fd = feat * m / dt(self.drop_keep)
+        else:
+            m, fd = None, feat
+        Wd = self._p('dense_1/kernel')
+        p = L.softmax(fd @ Wd, axis=1)
+        cache['tail'] = (h, xmax, m, fd, Wd, p)
+        return p
+
+    def loss_and_grads(self, x, y_onehot, seed=0, step=0, drop_offset=0, loss_scale_B=None, relu_masks=None,
+                       pool_ind=None):
+        dt = self.dtype
+        cache = {'relu_masks': relu_masks}
+        p = self.forward(x, training=True, seed=seed, step=step, cache=cache, drop_offset=drop_offset)
+        y_onehot = np.asarray(y_onehot, dtype=dt)
+        loss, per, dp = L.smooth_cce_fwd_bwd(p, y_onehot, self.label_smoothing)
+        B = x.shape[0]
+        if loss_scale_B is not None:
+            dp = dp * dt(B) / dt(loss_scale_B)
+        grads = OrderedDict()
+        h, xmax, m, fd, Wd, p = cache['tail']
+        dl = L.softmax_bwd(dp, p, axis=1)
+        grads['dense_1/kernel'] = fd.T @ dl
+        dfeat = (dl @ Wd.T) * m / dt(self.drop_keep)
+        dxmax, dxavg = dfeat[:, :self.C], dfeat[:, self.C:]
+        ind = (h == xmax[:, None, :]).astype(dt)                               # reduce_max: ties share the gradient
+        if pool_ind is not None:
+            ind = np.asarray(pool_ind, dtype=dt).reshape(h.shape)
+        ind = ind / ind.sum(axis=1, keepdims=True)
+        dh = ind * dxmax[:, None, :] + dxavg[:, None, :] / dt(self.T)
+        for i in reversed(range(len(self.blocks))):
+            blk, c = self.blocks[i], cache['blk%d' % i]
+            dy2 = self._bn_bwd(blk['bn2'], dh, cache, grads)
+            dz2, dW2 = L.pw_bwd(dy2, c['z2'], c['W2'])
+            grads[blk['pw2']] = dW2.reshape(1, blk['nf'], blk['nf'])
+            da1, dw2 = L.dwconv_bwd(dz2, c['a1'], c['w2'], 1, (1, 1))
+            grads[blk['dw2']] = dw2.reshape(1, 3, blk['nf'], 1)
+            dy1 = self._bn_bwd(blk['bn1'], da1, cache, grads)
+            dz1, dW1 = L.pw_bwd(dy1, c['z1'], c['W1'])
+            grads[blk['pw1']] = dW1.reshape(1, blk['cin'], blk['nf'])
+            dx, dw1 = L.dwconv_bwd(dz1, c['x'], c['w1'], blk['stride'], blk['pad1'])
+            grads[blk['dw1']] = dw1.reshape(1, 3, blk['cin'], 1)
+            if 'short' in blk:
+                dys = self._bn_bwd(blk['short'][1], dh, cache, grads, relu=False)
+                dxs, dWs = L.pw_bwd(dys, c['xs'], c['Ws'])
+                grads[blk['short'][0]] = dWs.reshape(1, blk['cin'], blk['nf'])
+                dx = dx.copy()
+                dx[:, ::blk['stride'], :] += dxs
+            else:
+                dx = dx + dh
+            dh = dx
+        hc, wc, zc, Wc = cache['ctx']
+        dyc = self._bn_bwd(self.ctx[2], dh, cache, grads)
+        dzc, dWc = L.pw_bwd(dyc, zc, Wc)
+        grads[self.ctx[1]] = dWc.reshape(1, self.C0, self.C0)
+        dh0, dwc = L.dwconv_bwd(dzc, hc, wc, 1, (1, 1))
+        grads[self.ctx[0]] = dwc.reshape(1, 3, self.C0, 1)
+        dy = self._bn_bwd(self.first[1], dh0, cache, grads)
+        W0 = self._p(self.first[0])
+        B2, Lo, Co = dy.shape
+        grads[self.first[0]] = (cache['conv1_cols'].T @ dy.reshape(B2 * Lo, Co)).reshape(W0.shape)
+        for k in self.l2_names:
+            grads[k] = grads[k] + dt(2.0 * L.L2_COEF) * self._p(k)
+        return loss, p, OrderedDict((k, grads[k]) for k in self.params), cache

@@ -162,3 +162,73 @@ def test_logmfcc_grads_match_torch_autograd():
     for k, g in grads.items():
         tg = tparams[k].grad.numpy().reshape(g.shape)
         assert np.abs(g - tg).max() / max(np.abs(tg).max(), 1e-12) < 1e-8, k
+
+
+# ---- steffeNet --------------------------------------------------------------------------
+def _torch_steffe(net, params, x, y, seed, step):
+    B = x.shape[0]
+    dt = torch.float64
+
+    def bn(h, idx, relu=True):
+        g = params['batch_normalization_%d/gamma' % idx]
+        b = params['batch_normalization_%d/beta' % idx]
+        h = F.batch_norm(h, None, None, g, b, training=True, eps=1e-3)
+        return torch.clamp(h, 0, 6) if relu else h
+
+    def dwpw(h, dwn, pwn, cin, cout, stride=1, pad=(1, 1)):
+        w = params[dwn].reshape(3, cin)
+        h = F.conv1d(F.pad(h, pad), w.t().unsqueeze(1), groups=cin, stride=stride)
+        return F.conv1d(h, params[pwn].reshape(cin, cout).t().unsqueeze(2))
+    h = torch.from_numpy(x).to(dt).reshape(B, 1, net.L_in)
+    h = F.conv1d(F.pad(h, (net.pl0, net.pr0)), params[net.first[0]].permute(2, 1, 0), stride=net.S0)
+    h = bn(h, net.first[1])
+    h = bn(dwpw(h, net.ctx[0], net.ctx[1], net.C0, net.C0), net.ctx[2])
+    for blk in net.blocks:
+        if 'short' in blk:
+            res = bn(F.conv1d(h, params[blk['short'][0]].reshape(blk['cin'], blk['nf']).t().unsqueeze(2), stride=blk['stride']),
+                     blk['short'][1], relu=False)
+        else:
+            res = h
+        a = bn(dwpw(h, blk['dw1'], blk['pw1'], blk['cin'], blk['nf'], blk['stride'], blk['pad1']), blk['bn1'])
+        a = bn(dwpw(a, blk['dw2'], blk['pw2'], blk['nf'], blk['nf']), blk['bn2'])
+        h = a + res
+    feat = torch.cat([h.max(dim=2).values, h.mean(dim=2)], dim=1)
+    m = torch.from_numpy(L.dropout_mask(L.dropout_key(seed, step, 1), B * 2 * net.C, 0.5).reshape(B, 2 * net.C)).to(dt)
+    p = torch.softmax((feat * m / 0.5) @ params['dense_1/kernel'], dim=1)
+    yt = torch.from_numpy(y).to(dt)
+    ys = yt * 0.9 + 0.1 / yt.shape[1]                       # utils.py:87-108 smooth_categorical_crossentropy
+    logits = torch.log(torch.clamp(p, 1e-7, 1 - 1e-7))
+    loss = -(ys * torch.log_softmax(logits, dim=1)).sum(dim=1).mean()
+    reg = sum(1e-5 * (params[k] ** 2).sum() for k in net.l2_names)
+    return p, loss, reg
+
+
+def test_steffenet_shapes_and_grads_match_torch_autograd():
+    from oracle.net import SteffeNet
+    full = SteffeNet(num_classes=12)
+    assert [b['Lout'] for b in full.blocks] == [160, 160, 80, 80, 40, 40, 20, 20, 10, 10, 5, 5]
+    assert (full.L0, full.pl0, full.pr0, full.T, full.C) == (320, 12, 13, 5, 1536)
+    assert list(full.params)[:8] == ['conv1d_1/kernel', 'batch_normalization_1/gamma', 'batch_normalization_1/beta',
+                                     'depthwise_conv2d_1/depthwise_kernel', 'conv1d_2/kernel',
+                                     'batch_normalization_2/gamma', 'batch_normalization_2/beta', 'conv1d_3/kernel']
+    assert 'dense_1/bias' not in full.params and 'conv1d_1/kernel' not in full.l2_names
+    # small widths keep the float64 torch cross-check fast; same structure
+    net = SteffeNet(num_classes=12, input_size=3200, filter_widths=[24, 32], c0=16, dtype=np.float64)
+    rng = np.random.RandomState(6)
+    for k in net.params:
+        if k.endswith('gamma'):
+            net.params[k] = (1.0 + 0.1 * rng.randn(*net.params[k].shape)).astype(np.float32)
+        if k.endswith('beta'):
+            net.params[k] = (0.1 * rng.randn(*net.params[k].shape)).astype(np.float32)
+    B = 3
+    x = (rng.randn(B, 3200) * 0.3).astype(np.float64)
+    y = np.eye(12)[[3, 0, 11]]
+    loss, p, grads, _ = net.loss_and_grads(x, y, seed=9, step=2)
+    tparams = {k: torch.tensor(v.astype(np.float64), requires_grad=True) for k, v in net.params.items()}
+    pt, tloss, treg = _torch_steffe(net, tparams, x, y, 9, 2)
+    (tloss + treg).backward()
+    np.testing.assert_allclose(p, pt.detach().numpy(), rtol=1e-9, atol=1e-12)
+    assert abs(loss - tloss.item()) < 1e-10
+    for k, g in grads.items():
+        tg = tparams[k].grad.numpy().reshape(g.shape)
+        assert np.abs(g - tg).max() / max(np.abs(tg).max(), 1e-12) < 1e-8, k
