@@ -97,12 +97,14 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const float* __restrict
                                                          const float* __restrict__ bn, const float* __restrict__ w,
                                                          const float* __restrict__ coef,
                                                          float* __restrict__ g, float* __restrict__ part, int B,
-                                                         int Lin, int Lout, int C, int pad_l, int nchunks, int R) {
+                                                         int Lin, int Lout, int C, int pad_l, int nchunks, int R,
+                                                         int Cb) {
+  // blockIdx.y selects a slice of Cb <= 1024 channels (Cb = C unless C > 1024)
   __shared__ float red[5][256 * 4];
-  const int C4 = C >> 2;
+  const int C4 = Cb >> 2;
   const int tid = threadIdx.x;
   const int r = tid / C4, c4 = tid - r * C4;
-  const int c = c4 * 4;
+  const int c = blockIdx.y * Cb + c4 * 4;
   float4 sg = f4_zero(), sgx = f4_zero(), sw0 = f4_zero(), sw1 = f4_zero(), sw2 = f4_zero();
   float4 sc = f4_zero(), sh = f4_zero(), mean = f4_zero(), rstd = f4_zero();
   if (HAS_BN) {
@@ -202,11 +204,11 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const float* __restrict
   *reinterpret_cast<float4*>(&red[4][tid * 4]) = sw2;
   __syncthreads();
   // fixed-order reduction over the R rows of this block: thread (q, channel)
-  for (int o = tid; o < 5 * C; o += blockDim.x) {
-    const int q = o / C, ch = o - q * C;
+  for (int o = tid; o < 5 * Cb; o += blockDim.x) {
+    const int q = o / Cb, ch = o - q * Cb;
     float s = 0.f;
     for (int rr = 0; rr < R; ++rr) s += red[q][(rr * C4) * 4 + ch];
-    part[((int64_t)blockIdx.x * 5 + q) * C + ch] = s;
+    part[((int64_t)blockIdx.x * 5 + q) * C + blockIdx.y * Cb + ch] = s;
   }
 }
 
@@ -214,12 +216,15 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const float* __restrict
 // uncapped (6400) 1.03: four resident workgroups per CU stream best and leave few rows to fold
 constexpr int KWS_DW_BWD_MAX_PARTS = 1024;
 struct BwdGeom {
-  int nchunks, R, block;
+  int nchunks, R, block, ny, Cb;
   int64_t grid;
 };
+bool bwd_geom_ok(int C) { return C > 0 && C % 4 == 0 && (C / 4) % ceil_div(C / 4, 256) == 0; }
 BwdGeom bwd_geom(int B, int Lin, int C) {
   BwdGeom g;
-  const int C4 = C / 4;
+  g.ny = ceil_div(C / 4, 256);   // channel slices of at most 1024 channels
+  g.Cb = C / g.ny;
+  const int C4 = g.Cb / 4;
   g.nchunks = ceil_div(Lin, TT);
   g.R = 256 / C4;
   if (g.R < 1) g.R = 1;
@@ -237,13 +242,13 @@ int launch_dw_bwd(const float* dz, const float* y, const float* bn, const float*
                   float* part, int B, int L_in, int L_out, int C, int stride, int pad_l, hipStream_t st) {
   const BwdGeom ge = bwd_geom(B, L_in, C);
   KWS_REQUIRE(ge.grid < 0x7FFFFFFF, "dwconv_bwd: grid too large");
-  dim3 gr((unsigned)ge.grid), b((unsigned)ge.block);
+  dim3 gr((unsigned)ge.grid, (unsigned)ge.ny), b((unsigned)ge.block);
   if (stride == 1) {
-    if (bn) hipLaunchKernelGGL((dwconv_bwd_kernel<1, true, MODE>), gr, b, 0, st, dz, y, bn, w, coef, g, part, B, L_in, L_out, C, pad_l, ge.nchunks, ge.R);
-    else hipLaunchKernelGGL((dwconv_bwd_kernel<1, false, MODE>), gr, b, 0, st, dz, y, bn, w, coef, g, part, B, L_in, L_out, C, pad_l, ge.nchunks, ge.R);
+    if (bn) hipLaunchKernelGGL((dwconv_bwd_kernel<1, true, MODE>), gr, b, 0, st, dz, y, bn, w, coef, g, part, B, L_in, L_out, C, pad_l, ge.nchunks, ge.R, ge.Cb);
+    else hipLaunchKernelGGL((dwconv_bwd_kernel<1, false, MODE>), gr, b, 0, st, dz, y, bn, w, coef, g, part, B, L_in, L_out, C, pad_l, ge.nchunks, ge.R, ge.Cb);
   } else {
-    if (bn) hipLaunchKernelGGL((dwconv_bwd_kernel<2, true, MODE>), gr, b, 0, st, dz, y, bn, w, coef, g, part, B, L_in, L_out, C, pad_l, ge.nchunks, ge.R);
-    else hipLaunchKernelGGL((dwconv_bwd_kernel<2, false, MODE>), gr, b, 0, st, dz, y, bn, w, coef, g, part, B, L_in, L_out, C, pad_l, ge.nchunks, ge.R);
+    if (bn) hipLaunchKernelGGL((dwconv_bwd_kernel<2, true, MODE>), gr, b, 0, st, dz, y, bn, w, coef, g, part, B, L_in, L_out, C, pad_l, ge.nchunks, ge.R, ge.Cb);
+    else hipLaunchKernelGGL((dwconv_bwd_kernel<2, false, MODE>), gr, b, 0, st, dz, y, bn, w, coef, g, part, B, L_in, L_out, C, pad_l, ge.nchunks, ge.R, ge.Cb);
   }
   KWS_LAUNCH_CHECK("dwconv_bwd_kernel");
   return KWS_OK;
@@ -278,7 +283,7 @@ int kws_dwconv_fwd_f32(const float* y, const float* bn, const float* w, float* z
 }
 
 int64_t kws_dwconv_bwd_part_floats(int B, int L_in, int C) {
-  if (B <= 0 || L_in <= 0 || C <= 0 || C % 4 != 0 || C > 1024) return 0;
+  if (B <= 0 || L_in <= 0 || !bwd_geom_ok(C)) return 0;
   const BwdGeom g = bwd_geom(B, L_in, C);
   return g.grid * 5 * C;
 }
@@ -286,7 +291,7 @@ int64_t kws_dwconv_bwd_part_floats(int B, int L_in, int C) {
 int kws_dwconv_bwd_f32(const float* dz, const float* y, const float* bn, const float* w, float* g, float* part,
                        int B, int L_in, int L_out, int C, int stride, int pad_l, void* stream) {
   KWS_REQUIRE(dz && y && w && g && part, "dwconv_bwd: NULL pointer");
-  KWS_REQUIRE(B > 0 && L_in > 0 && L_out > 0 && C > 0 && C % 4 == 0 && C <= 1024,
+  KWS_REQUIRE(B > 0 && L_in > 0 && L_out > 0 && bwd_geom_ok(C),
               "dwconv_bwd: bad shape B=%d L=%d->%d C=%d", B, L_in, L_out, C);
   KWS_REQUIRE(stride == 1 || stride == 2, "dwconv_bwd: stride %d unsupported", stride);
   hipStream_t st = (hipStream_t)stream;
@@ -300,7 +305,7 @@ int kws_dwconv_bwd_bn_f32(const float* dz, const float* y, const float* bn, cons
   KWS_REQUIRE(dz && y && bn && w, "dwconv_bwd_bn: NULL pointer");
   KWS_REQUIRE(pass == 1 ? part != nullptr : (pass == 2 && coef != nullptr && dy != nullptr),
               "dwconv_bwd_bn: pass %d needs %s", pass, pass == 1 ? "part" : "coef and dy");
-  KWS_REQUIRE(B > 0 && L_in > 0 && L_out > 0 && C > 0 && C % 4 == 0 && C <= 1024,
+  KWS_REQUIRE(B > 0 && L_in > 0 && L_out > 0 && bwd_geom_ok(C),
               "dwconv_bwd_bn: bad shape B=%d L=%d->%d C=%d", B, L_in, L_out, C);
   KWS_REQUIRE(stride == 1 || stride == 2, "dwconv_bwd_bn: stride %d unsupported", stride);
   hipStream_t st = (hipStream_t)stream;

@@ -65,6 +65,7 @@ struct Bump {
 
 // ---- conv_1d_log_mfcc program -----------------------------------------------------------------------
 int lm_build(kws_net* n);
+int steffe_build(kws_net* n);
 void lm_free(kws_net* n);
 int64_t lm_workspace_bytes(const kws_net* n, int B, int training);
 int lm_debug_view(const kws_net* n, int B, int training, int what, int index, int64_t* offset_floats, int64_t* count);
@@ -108,5 +109,21 @@ struct kws_lm_tail_args {
   float* per_loss; float* per_correct; float* att;
   int B, T, C, NC; uint64_t seed; uint32_t step; float keep_prob; int loss_batch; int64_t row_offset;
 };
+// steffeNet tail (model.py:1712-1718, 1722-1724): GlobalMaxPooling1D ++ GlobalAveragePooling1D -> Dropout -> Dense(no
+// bias) + softmax -> label-smoothed CE; training also writes dX, the dropped features and dlogits (dense wgrad)
+struct kws_gp_tail_args {
+  const float* x;       // [B, T, C] block-stack output
+  const float* Wd;      // [2C, NC]
+  const float* labels;  // [B, NC]
+  float* probs;         // [B, NC]
+  float* dX;            // [B, T, C]
+  float* fd;            // [B, 2C]
+  float* dl;            // [B, NC]
+  float* per_loss;
+  float* per_correct;
+  int B, T, C, NC;
+  uint64_t seed; uint32_t step; float keep_prob; float label_smoothing; int loss_batch; int64_t row_offset;
+};
+int kws_gp_tail_launch(const kws_gp_tail_args* a, int training, hipStream_t st);
 int kws_lm_tail_fwd(const kws_lm_tail_args* a, int training, hipStream_t st);   // logits -> BN stats -> probs (+ tail backward when training)
 int kws_lm_tail_bwd(const kws_lm_tail_args* a, hipStream_t st);                 // attention BN backward + dX accumulation + per-clip partials

@@ -12,9 +12,14 @@
 namespace {
 
 constexpr float DROP_KEEP = 0.8f;  // Dropout(0.2), model.py:1471
+constexpr float STEFFE_DROP_KEEP = 0.5f;     // Dropout(0.5), model.py:1716
+constexpr float STEFFE_LABEL_SMOOTH = 0.1f;  // model.py:1722-1724
 
 struct LmBlock {
   int nf, stride, cin, Lin, Lout;
+  // where the stride sits: log-mfcc blocks pool after the second pointwise (s1 = 1, pool = stride, Lmid = Lin);
+  // steffeNet blocks stride their FIRST depthwise convolution (s1 = stride, pool = 1, Lmid = Lout)
+  int s1, pool, Lmid, pad1;
   bool has_short;
   int64_t ws;
   BnRef bns;
@@ -39,6 +44,14 @@ struct LmProgram {
   BnRef att_bn;
   int att_bn_idx;
   int n_bn;
+  int maxC;
+  // steffeNet (style 1): raw input, first convolution of K0 = 75 taps on one channel (gathered as ONE tap of
+  // K0p = 76 samples against a zero-padded kernel), a context block between the first convolution and the
+  // residual stack, global max ++ average pooling tail
+  int style = 0, K0 = 0, K0p = 0;
+  int64_t ctx_dw = 0, ctx_pw = 0;
+  BnRef ctx_bn;
+  int ctx_bn_idx = 0;
 };
 
 namespace {
@@ -50,7 +63,8 @@ struct LmLayout {
   int64_t bn = 0, bn_stride = 0, part = 0, red = 0, coef = 0, WT = 0, tn = 0, swg = 0;
   int64_t dOa = 0, dOb = 0, G = 0, DZ = 0, DXS = 0;
   int64_t u = 0, fd = 0, dl = 0, gu = 0, coef2 = 0, per_loss = 0, per_correct = 0, att = 0;
-  int64_t xpad = 0, wpad = 0, gwpad = 0;  // only when Fp != F
+  int64_t xpad = 0, wpad = 0, gwpad = 0;  // only when Fp != F (style 0) / always (style 1: padded first kernel)
+  int64_t zc = 0, yc = 0, ac = 0;          // steffeNet context block
 };
 
 void lm_layout(const kws_net* n, int B, LmLayout* lo) {
@@ -67,51 +81,63 @@ void lm_layout(const kws_net* n, int B, LmLayout* lo) {
     max_wt = std::max(max_wt, (int64_t)K * N);
     max_tn = std::max(max_tn, kws_gemm_tn_workspace_floats(M, K, N));
   };
-  upd_gemm((int64_t)B * p.L0, 3 * p.Fp, p.C0);
+  upd_gemm((int64_t)B * p.L0, p.style == 1 ? p.K0p : 3 * p.Fp, p.C0);
   max_part = std::max(max_part, kws_block_out_bwd_part_floats(B, p.L0, p.C0, 1));
+  if (p.style == 1) {
+    lo->zc = bp.take((int64_t)B * p.L0 * p.C0);
+    lo->yc = bp.take((int64_t)B * p.L0 * p.C0);
+    lo->ac = bp.take((int64_t)B * p.L0 * p.C0);
+    max_z = (int64_t)B * p.L0 * p.C0;
+    upd_gemm((int64_t)B * p.L0, p.C0, p.C0);
+    max_part = std::max(max_part, kws_dwconv_bwd_part_floats(B, p.L0, p.C0));
+  }
   for (int i = 0; i < nb; ++i) {
     const LmBlock& b = p.blocks[i];
     if (b.has_short) lo->ys[i] = bp.take((int64_t)B * b.Lout * b.nf);
-    lo->z1[i] = bp.take((int64_t)B * b.Lin * b.cin);
-    lo->y1[i] = bp.take((int64_t)B * b.Lin * b.nf);
-    lo->z2[i] = bp.take((int64_t)B * b.Lin * b.nf);
-    lo->y2[i] = bp.take((int64_t)B * b.Lin * b.nf);
+    lo->z1[i] = bp.take((int64_t)B * b.Lmid * b.cin);
+    lo->y1[i] = bp.take((int64_t)B * b.Lmid * b.nf);
+    lo->z2[i] = bp.take((int64_t)B * b.Lmid * b.nf);
+    lo->y2[i] = bp.take((int64_t)B * b.Lmid * b.nf);
     lo->o[i] = bp.take((int64_t)B * b.Lout * b.nf);
     max_o = std::max(max_o, std::max((int64_t)B * b.Lout * b.nf, (int64_t)B * b.Lin * b.cin));
-    max_y = std::max(max_y, (int64_t)B * b.Lin * b.nf);
-    max_z = std::max(max_z, std::max((int64_t)B * b.Lin * b.cin, (int64_t)B * b.Lin * b.nf));
+    max_y = std::max(max_y, (int64_t)B * b.Lmid * b.nf);
+    max_z = std::max(max_z, std::max((int64_t)B * b.Lmid * b.cin, (int64_t)B * b.Lmid * b.nf));
     max_xs = std::max(max_xs, (int64_t)B * b.Lout * b.cin);
-    upd_gemm((int64_t)B * b.Lin, b.cin, b.nf);
-    upd_gemm((int64_t)B * b.Lin, b.nf, b.nf);
+    upd_gemm((int64_t)B * b.Lmid, b.cin, b.nf);
+    upd_gemm((int64_t)B * b.Lmid, b.nf, b.nf);
     if (b.has_short) upd_gemm((int64_t)B * b.Lout, b.cin, b.nf);
     max_part = std::max(max_part, kws_dwconv_bwd_part_floats(B, b.Lin, b.cin));
-    max_part = std::max(max_part, kws_dwconv_bwd_part_floats(B, b.Lin, b.nf));
-    max_part = std::max(max_part, kws_block_out_bwd_part_floats(B, b.Lin, b.nf, b.stride));
+    max_part = std::max(max_part, kws_dwconv_bwd_part_floats(B, b.Lmid, b.nf));
+    max_part = std::max(max_part, kws_block_out_bwd_part_floats(B, b.Lmid, b.nf, b.pool));
     max_part = std::max(max_part, kws_block_out_bwd_part_floats(B, b.Lout, b.nf, 1));
   }
   max_part = std::max(max_part, (int64_t)B * 5 * p.C);
-  lo->bn_stride = 4 * 256;
+  const int feat = p.style == 1 ? 2 * p.C : p.C;   // width of the dense layer's input
+  lo->bn_stride = 4 * p.maxC;
   lo->bn = bp.take(lo->bn_stride * (p.n_bn + 1));
   lo->part = bp.take(max_part);
-  lo->red = bp.take((int64_t)KWS_REDUCE_SLICES * 5 * 256);
-  lo->coef = bp.take(2 * 256);
+  lo->red = bp.take((int64_t)KWS_REDUCE_SLICES * 5 * p.maxC);
+  lo->coef = bp.take(2 * p.maxC);
   lo->WT = bp.take(max_wt);
   lo->tn = bp.take(max_tn);
-  lo->swg = bp.take((int64_t)KWS_SMALL_WGRAD_SLICES * p.C * p.NC);
+  lo->swg = bp.take((int64_t)KWS_SMALL_WGRAD_SLICES * feat * p.NC);
   lo->dOa = bp.take(max_o);
   lo->dOb = bp.take(max_o);
   lo->G = bp.take(max_y);
   lo->DZ = bp.take(max_z);
   lo->DXS = bp.take(max_xs);
   lo->u = bp.take((int64_t)B * 16);
-  lo->fd = bp.take((int64_t)B * p.C);
+  lo->fd = bp.take((int64_t)B * feat);
   lo->dl = bp.take((int64_t)B * p.NC);
   lo->gu = bp.take((int64_t)B * 16);
   lo->coef2 = bp.take(4);
   lo->per_loss = bp.take(B);
   lo->per_correct = bp.take(B);
   lo->att = bp.take((int64_t)B * 16);
-  if (p.Fp != p.F) {
+  if (p.style == 1) {
+    lo->wpad = bp.take((int64_t)p.K0p * p.C0);
+    lo->gwpad = bp.take((int64_t)p.K0p * p.C0);
+  } else if (p.Fp != p.F) {
     lo->xpad = bp.take((int64_t)B * p.T0 * p.Fp);
     lo->wpad = bp.take((int64_t)3 * p.Fp * p.C0);
     lo->gwpad = bp.take((int64_t)3 * p.Fp * p.C0);
@@ -166,6 +192,13 @@ int pad_first_conv(const Ctx& c, const float* x, const float** x_used, const flo
   const LmProgram& p = *c.p;
   *x_used = x;
   *w_used = c.params + p.conv1;
+  if (p.style == 1) {  // [75, 1, C0] kernel + one zero row: the gather reads 76 samples per output row
+    float* wp = c.ws + c.lo.wpad;
+    KWS_HIP(hipMemcpyAsync(wp, c.params + p.conv1, (size_t)p.K0 * p.C0 * 4, hipMemcpyDeviceToDevice, c.st));
+    KWS_HIP(hipMemsetAsync(wp + (size_t)p.K0 * p.C0, 0, (size_t)(p.K0p - p.K0) * p.C0 * 4, c.st));
+    *w_used = wp;
+    return KWS_OK;
+  }
   if (p.Fp == p.F) return KWS_OK;
   float* xp = c.ws + c.lo.xpad;
   float* wp = c.ws + c.lo.wpad;
@@ -194,25 +227,35 @@ int forward(const Ctx& c, const float* x, kws_lm_tail_args* t) {
   KWS_TRY(bn_table(c, p.bn0, 1, (int64_t)B * p.L0, kws_gemm_gather_stats_rows((int64_t)B * p.L0)));
   KWS_TRY(kws_bn_relu6_apply(ws + lo.y0, c.bn_at(1), ws + lo.a0, (int64_t)B * p.L0, p.C0, 1, c.st));
   const float* xin = ws + lo.a0;
+  if (p.style == 1) {  // _context_conv(x, 256, 3, 'same'): depthwise -> pointwise -> BN -> ReLU6, materialised
+    const int64_t M = (int64_t)B * p.L0;
+    KWS_TRY(kws_dwconv_fwd_f32(xin, nullptr, c.params + p.ctx_dw, ws + lo.zc, B, p.L0, p.L0, p.C0, 1, 1, c.st));
+    KWS_TRY(kws_gemm_nn_f32(ws + lo.zc, c.params + p.ctx_pw, ws + lo.yc, M, p.C0, p.C0, stats, c.st));
+    KWS_TRY(bn_table(c, p.ctx_bn, p.ctx_bn_idx, M, kws_gemm_nn_stats_rows(M, p.C0, p.C0)));
+    KWS_TRY(kws_bn_relu6_apply(ws + lo.yc, c.bn_at(p.ctx_bn_idx), ws + lo.ac, M, p.C0, 1, c.st));
+    xin = ws + lo.ac;
+  }
   for (size_t i = 0; i < p.blocks.size(); ++i) {
     const LmBlock& b = p.blocks[i];
-    const int64_t M = (int64_t)B * b.Lin;
+    const int64_t M = (int64_t)B * b.Lmid;
     if (b.has_short) {
       KWS_TRY(kws_gemm_gather_f32(xin, &b.gs, c.params + b.ws, ws + lo.ys[i], B, b.nf, stats, c.st));
       KWS_TRY(bn_table(c, b.bns, b.bns_idx, (int64_t)B * b.Lout, kws_gemm_gather_stats_rows((int64_t)B * b.Lout)));
     }
-    KWS_TRY(kws_dwconv_fwd_f32(xin, nullptr, c.params + b.dw1, ws + lo.z1[i], B, b.Lin, b.Lin, b.cin, 1, 1, c.st));
+    KWS_TRY(kws_dwconv_fwd_f32(xin, nullptr, c.params + b.dw1, ws + lo.z1[i], B, b.Lin, b.Lmid, b.cin, b.s1, b.pad1, c.st));
     KWS_TRY(kws_gemm_nn_f32(ws + lo.z1[i], c.params + b.pw1, ws + lo.y1[i], M, b.cin, b.nf, stats, c.st));
     KWS_TRY(bn_table(c, b.bn1, b.bn1_idx, M, kws_gemm_nn_stats_rows(M, b.cin, b.nf)));
-    KWS_TRY(kws_dwconv_fwd_f32(ws + lo.y1[i], c.bn_at(b.bn1_idx), c.params + b.dw2, ws + lo.z2[i], B, b.Lin, b.Lin,
+    KWS_TRY(kws_dwconv_fwd_f32(ws + lo.y1[i], c.bn_at(b.bn1_idx), c.params + b.dw2, ws + lo.z2[i], B, b.Lmid, b.Lmid,
                                b.nf, 1, 1, c.st));
     KWS_TRY(kws_gemm_nn_f32(ws + lo.z2[i], c.params + b.pw2, ws + lo.y2[i], M, b.nf, b.nf, stats, c.st));
     KWS_TRY(bn_table(c, b.bn2, b.bn2_idx, M, kws_gemm_nn_stats_rows(M, b.nf, b.nf)));
     KWS_TRY(kws_block_out_fwd(ws + lo.y2[i], c.bn_at(b.bn2_idx), b.has_short ? ws + lo.ys[i] : xin,
-                              b.has_short ? c.bn_at(b.bns_idx) : nullptr, ws + lo.o[i], B, b.Lin, b.nf, b.stride, c.st));
+                              b.has_short ? c.bn_at(b.bns_idx) : nullptr, ws + lo.o[i], B, b.Lmid, b.nf, b.pool, c.st));
     xin = ws + lo.o[i];
   }
   memset(t, 0, sizeof(*t));
+  t->x = xin;
+  if (p.style == 1) return KWS_OK;  // the caller sets up the global-pooling tail
   t->x = xin; t->wa = c.params + p.att_dw; t->Wa = c.params + p.att_pw;
   t->bn_gamma = c.params + p.att_bn.gamma; t->bn_beta = c.params + p.att_bn.beta;
   t->mm = c.state + p.att_bn.mm; t->mv = c.state + p.att_bn.mv;
@@ -266,6 +309,7 @@ int lm_build(kws_net* n) {
     LmBlock b;
     b.nf = spec[i][0]; b.stride = spec[i][1]; b.cin = cin; b.Lin = L; b.Lout = L / b.stride;
     b.has_short = b.stride != 1;
+    b.s1 = 1; b.pool = b.stride; b.Lmid = b.Lin; b.pad1 = 1;
     b.ws = 0; b.bns_idx = 0;
     memset(&b.gs, 0, sizeof(b.gs));
     if (b.has_short) {
@@ -294,6 +338,90 @@ int lm_build(kws_net* n) {
   p->dk = kws_net_add_tensor(n, "dense_1/kernel", {cin, p->NC}, false, KWS_L2_COEF, cin, p->NC, 0.f);
   p->db = kws_net_add_tensor(n, "dense_1/bias", {p->NC}, false, 0.f, 0, 0, 0.f);
   p->n_bn = n_bn;
+  p->maxC = 256;
+  return KWS_OK;
+}
+
+// steffeNet, reference model.py:1663-1726
+int steffe_build(kws_net* n) {
+  const kws_net_config_t& c = n->cfg;
+  KWS_REQUIRE(c.num_classes >= 2 && c.num_classes <= 64, "net: num_classes %d out of range", c.num_classes);
+  KWS_REQUIRE(c.input_size >= 3200 && c.input_size % 2 == 0, "net: steffeNet input_size %d", c.input_size);
+  LmProgram* p = new LmProgram();
+  n->lm = p;
+  p->style = 1;
+  int n_conv = 0, n_bn = 0, n_dw = 0;
+  auto conv = [&](int k, int cin, int cout, bool l2) {
+    ++n_conv;
+    return kws_net_add_tensor(n, "conv1d_" + std::to_string(n_conv) + "/kernel", {k, cin, cout}, false,
+                              l2 ? KWS_L2_COEF : 0.f, k * cin, k * cout, 0.f);
+  };
+  auto bn = [&](int C, int* idx) {
+    ++n_bn;
+    *idx = n_bn;
+    return kws_net_add_bn(n, n_bn, C);
+  };
+  auto dw = [&](int C) {
+    ++n_dw;
+    return kws_net_add_tensor(n, "depthwise_conv2d_" + std::to_string(n_dw) + "/depthwise_kernel", {1, 3, C, 1}, false,
+                              KWS_L2_COEF, 3 * C, 3, 0.f);
+  };
+  auto same = [](int L, int k, int stride, int* Lout, int* pad_l) {   // TF 'SAME'
+    *Lout = (L + stride - 1) / stride;
+    const int pad = std::max((*Lout - 1) * stride + k - L, 0);
+    *pad_l = pad / 2;
+  };
+  // Conv1D(256, 75, strides=50, padding='same', use_bias=False): no kernel_regularizer (model.py:1705)
+  p->K0 = 75; p->K0p = 76; p->C0 = 256; p->T0 = c.input_size; p->F = 1; p->Fp = 1;
+  int pl0;
+  same(c.input_size, p->K0, 50, &p->L0, &pl0);
+  KWS_REQUIRE(pl0 % 2 == 0, "net: steffeNet left padding %d must be even (8-byte gather loads)", pl0);
+  p->conv1 = conv(p->K0, 1, p->C0, false);
+  int idx0;
+  p->bn0 = bn(p->C0, &idx0);
+  kws_gather_t g0;
+  g0.L_out = p->L0; g0.cin = p->K0p; g0.taps = 1; g0.stride_t = 50; g0.stride_j = 0; g0.base_off = -pl0;
+  g0.x_len = c.input_size; g0.x_batch_stride = c.input_size;
+  p->g0 = g0;
+  p->ctx_dw = dw(p->C0);                                  // _context_conv(x, 256, 3, padding='same'), model.py:1708
+  p->ctx_pw = conv(1, p->C0, p->C0, true);
+  p->ctx_bn = bn(p->C0, &p->ctx_bn_idx);
+  static const int widths[6] = {320, 384, 512, 768, 1024, 1536};  // model.py:1709
+  int cin = p->C0, L = p->L0;
+  p->maxC = p->C0;
+  for (int wi = 0; wi < 6; ++wi) {
+    for (int stride = 2; stride >= 1; --stride) {
+      LmBlock b;
+      b.nf = widths[wi]; b.stride = stride; b.cin = cin; b.Lin = L;
+      same(L, 3, stride, &b.Lout, &b.pad1);
+      b.s1 = stride; b.pool = 1; b.Lmid = b.Lout;
+      b.has_short = stride != 1;
+      b.ws = 0; b.bns_idx = 0;
+      memset(&b.gs, 0, sizeof(b.gs));
+      if (b.has_short) {
+        b.ws = conv(1, cin, b.nf, false);                 // Conv1D(nh, 1, strides, 'same', no bias), model.py:1692-1693
+        b.bns = bn(b.nf, &b.bns_idx);
+        b.gs.L_out = b.Lout; b.gs.cin = cin; b.gs.taps = 1; b.gs.stride_t = stride * cin; b.gs.stride_j = 0;
+        b.gs.base_off = 0; b.gs.x_len = L * cin; b.gs.x_batch_stride = (int64_t)L * cin;
+      } else {
+        KWS_REQUIRE(cin == b.nf, "net: identity shortcut needs cin == nf");
+      }
+      b.dw1 = dw(cin);
+      b.pw1 = conv(1, cin, b.nf, true);
+      b.bn1 = bn(b.nf, &b.bn1_idx);
+      b.dw2 = dw(b.nf);
+      b.pw2 = conv(1, b.nf, b.nf, true);
+      b.bn2 = bn(b.nf, &b.bn2_idx);
+      p->blocks.push_back(b);
+      cin = b.nf;
+      L = b.Lout;
+      p->maxC = std::max(p->maxC, b.nf);
+    }
+  }
+  p->T = L; p->C = cin; p->NC = c.num_classes;
+  KWS_REQUIRE(p->T >= 1 && p->T <= 64, "net: %d time steps at the tail", p->T);
+  p->dk = kws_net_add_tensor(n, "dense_1/kernel", {2 * cin, p->NC}, false, KWS_L2_COEF, 2 * cin, p->NC, 0.f);
+  p->n_bn = n_bn;
   return KWS_OK;
 }
 
@@ -320,18 +448,20 @@ int lm_debug_view(const kws_net* n, int B, int training, int what, int index, in
   if (what == 2) {
     KWS_REQUIRE(index >= 1 && index <= p.n_bn, "lm_debug_view: bn index %d", index);
     *offset_floats = lo.bn + lo.bn_stride * index;
-    *count = 4 * 256;
+    *count = 4 * p.maxC;
     return KWS_OK;
   }
   if (what == 3) { *offset_floats = lo.att; *count = (int64_t)B * p.T; return KWS_OK; }
   if (what == 4) { *offset_floats = lo.u; *count = (int64_t)B * p.T; return KWS_OK; }
+  if (what == 5) { *offset_floats = lo.o[nb - 1]; *count = (int64_t)B * p.T * p.C; return KWS_OK; }
   if (what == 0) {
     if (index == 1) { *offset_floats = lo.y0; *count = (int64_t)B * p.L0 * p.C0; return KWS_OK; }
+    if (p.style == 1 && index == p.ctx_bn_idx) { *offset_floats = lo.yc; *count = (int64_t)B * p.L0 * p.C0; return KWS_OK; }
     for (int i = 0; i < nb; ++i) {
       const LmBlock& b = p.blocks[i];
       if (b.has_short && index == b.bns_idx) { *offset_floats = lo.ys[i]; *count = (int64_t)B * b.Lout * b.nf; return KWS_OK; }
-      if (index == b.bn1_idx) { *offset_floats = lo.y1[i]; *count = (int64_t)B * b.Lin * b.nf; return KWS_OK; }
-      if (index == b.bn2_idx) { *offset_floats = lo.y2[i]; *count = (int64_t)B * b.Lin * b.nf; return KWS_OK; }
+      if (index == b.bn1_idx) { *offset_floats = lo.y1[i]; *count = (int64_t)B * b.Lmid * b.nf; return KWS_OK; }
+      if (index == b.bn2_idx) { *offset_floats = lo.y2[i]; *count = (int64_t)B * b.Lmid * b.nf; return KWS_OK; }
     }
   }
   kws_set_error("lm_debug_view: unknown view %d/%d", what, index);
@@ -351,6 +481,13 @@ int lm_predict(const kws_net* n, const float* params, const float* state, const 
   }
   kws_lm_tail_args t;
   KWS_TRY(forward(c, x, &t));
+  if (n->lm->style == 1) {
+    kws_gp_tail_args g;
+    memset(&g, 0, sizeof(g));
+    g.x = t.x; g.Wd = params + n->lm->dk; g.probs = probs; g.B = B; g.T = n->lm->T; g.C = n->lm->C; g.NC = n->lm->NC;
+    g.keep_prob = 1.f; g.loss_batch = 1;
+    return kws_gp_tail_launch(&g, 0, st);
+  }
   t.probs = probs;
   return kws_lm_tail_fwd(&t, 0, st);
 }
@@ -379,6 +516,17 @@ int lm_train(const kws_net* n, const float* params, float* state, const float* x
   float* dO = ws + lo.dOa;
   float* dX = ws + lo.dOb;
   // ---- tail forward + backward ----
+  if (p.style == 1) {
+    kws_gp_tail_args g;
+    memset(&g, 0, sizeof(g));
+    g.x = t.x; g.Wd = params + p.dk; g.labels = y_onehot; g.probs = probs; g.dX = dO; g.fd = ws + lo.fd; g.dl = ws + lo.dl;
+    g.per_loss = ws + lo.per_loss; g.per_correct = ws + lo.per_correct; g.B = B; g.T = p.T; g.C = p.C; g.NC = p.NC;
+    g.seed = seed; g.step = step; g.keep_prob = STEFFE_DROP_KEEP; g.label_smoothing = STEFFE_LABEL_SMOOTH;
+    g.loss_batch = loss_batch; g.row_offset = row_offset;
+    KWS_TRY(kws_gp_tail_launch(&g, 1, st));
+    KWS_TRY(kws_metrics_launch(g.per_loss, g.per_correct, B, metrics, st));
+    KWS_TRY(kws_small_wgrad_launch(g.fd, g.dl, grads + p.dk, nullptr, B, 2 * p.C, p.NC, ws + lo.swg, st));
+  } else {
   t.labels = y_onehot; t.probs = probs; t.dX = dO; t.fd = ws + lo.fd; t.dl = ws + lo.dl; t.gu = ws + lo.gu;
   t.part = part; t.coef = ws + lo.coef2; t.d_gamma = grads + p.att_bn.gamma; t.d_beta = grads + p.att_bn.beta;
   t.per_loss = ws + lo.per_loss; t.per_correct = ws + lo.per_correct; t.att = ws + lo.att;
@@ -388,14 +536,15 @@ int lm_train(const kws_net* n, const float* params, float* state, const float* x
   KWS_TRY(kws_small_wgrad_launch(t.fd, t.dl, grads + p.dk, grads + p.db, B, p.C, p.NC, ws + lo.swg, st));
   KWS_TRY(kws_lm_tail_bwd(&t, st));
   KWS_TRY(kws_dw_bwd_finalize(part, B, 1, p.C, grads + p.att_dw, nullptr, grads + p.att_pw, nullptr, red, st));
+  }
   // ---- residual blocks, last to first ----
   for (int i = (int)p.blocks.size() - 1; i >= 0; --i) {
     const LmBlock& b = p.blocks[i];
-    const int64_t M = (int64_t)B * b.Lin;
-    const float* xin = i == 0 ? ws + lo.a0 : ws + lo.o[i - 1];
+    const int64_t M = (int64_t)B * b.Lmid;
+    const float* xin = i == 0 ? (p.style == 1 ? ws + lo.ac : ws + lo.a0) : ws + lo.o[i - 1];
     // main branch: join backward (maxpool routing + ReLU6 mask) -> BN2 -> pointwise 2
-    KWS_TRY(kws_block_out_bwd(dO, ws + lo.y2[i], c.bn_at(b.bn2_idx), G, part, B, b.Lin, b.nf, b.stride, 1, st));
-    int np = (int)(kws_block_out_bwd_part_floats(B, b.Lin, b.nf, b.stride) / (5 * b.nf));
+    KWS_TRY(kws_block_out_bwd(dO, ws + lo.y2[i], c.bn_at(b.bn2_idx), G, part, B, b.Lmid, b.nf, b.pool, 1, st));
+    int np = (int)(kws_block_out_bwd_part_floats(B, b.Lmid, b.nf, b.pool) / (5 * b.nf));
     KWS_TRY(kws_dw_bwd_finalize(part, np, M, b.nf, nullptr, grads + b.bn2.gamma, grads + b.bn2.beta, coef, red, st));
     KWS_TRY(kws_bn_bwd_apply(G, ws + lo.y2[i], c.bn_at(b.bn2_idx), params + b.bn2.gamma, coef, M, b.nf, st));
     KWS_TRY(kws_transpose_f32(params + b.pw2, ws + lo.WT, b.nf, b.nf, st));
@@ -404,21 +553,21 @@ int lm_train(const kws_net* n, const float* params, float* state, const float* x
     // depthwise 2 -> BN1 -> pointwise 1
     // (two passes over dz and y1 instead of "store g, then kws_bn_bwd_apply": the masked gradient is never stored)
     KWS_TRY(kws_dwconv_bwd_bn_f32(DZ, ws + lo.y1[i], c.bn_at(b.bn1_idx), params + b.dw2, nullptr, nullptr, part, 1, B,
-                                  b.Lin, b.Lin, b.nf, 1, 1, st));
-    np = (int)(kws_dwconv_bwd_part_floats(B, b.Lin, b.nf) / (5 * b.nf));
+                                  b.Lmid, b.Lmid, b.nf, 1, 1, st));
+    np = (int)(kws_dwconv_bwd_part_floats(B, b.Lmid, b.nf) / (5 * b.nf));
     KWS_TRY(kws_dw_bwd_finalize(part, np, M, b.nf, grads + b.dw2, grads + b.bn1.gamma, grads + b.bn1.beta, coef, red, st));
-    KWS_TRY(kws_dwconv_bwd_bn_f32(DZ, ws + lo.y1[i], c.bn_at(b.bn1_idx), params + b.dw2, coef, G, nullptr, 2, B, b.Lin,
-                                  b.Lin, b.nf, 1, 1, st));
+    KWS_TRY(kws_dwconv_bwd_bn_f32(DZ, ws + lo.y1[i], c.bn_at(b.bn1_idx), params + b.dw2, coef, G, nullptr, 2, B, b.Lmid,
+                                  b.Lmid, b.nf, 1, 1, st));
     KWS_TRY(kws_transpose_f32(params + b.pw1, ws + lo.WT, b.cin, b.nf, st));
     KWS_TRY(kws_gemm_nn_f32(G, ws + lo.WT, DZ, M, b.nf, b.cin, nullptr, st));
     KWS_TRY(kws_gemm_tn_f32(ws + lo.z1[i], G, grads + b.pw1, M, b.cin, b.nf, ws + lo.tn, st));
     // depthwise 1 on the (materialised) block input
-    KWS_TRY(kws_dwconv_bwd_f32(DZ, xin, nullptr, params + b.dw1, dX, part, B, b.Lin, b.Lin, b.cin, 1, 1, st));
+    KWS_TRY(kws_dwconv_bwd_f32(DZ, xin, nullptr, params + b.dw1, dX, part, B, b.Lin, b.Lmid, b.cin, b.s1, b.pad1, st));
     np = (int)(kws_dwconv_bwd_part_floats(B, b.Lin, b.cin) / (5 * b.cin));
-    KWS_TRY(kws_dw_bwd_finalize(part, np, M, b.cin, grads + b.dw1, nullptr, nullptr, nullptr, red, st));
+    KWS_TRY(kws_dw_bwd_finalize(part, np, (int64_t)B * b.Lin, b.cin, grads + b.dw1, nullptr, nullptr, nullptr, red, st));
     // residual branch
     if (!b.has_short) {
-      KWS_TRY(kws_add_f32(dX, dO, dX, M * b.cin, st));
+      KWS_TRY(kws_add_f32(dX, dO, dX, (int64_t)B * b.Lin * b.cin, st));
     } else {
       const int64_t Mo = (int64_t)B * b.Lout;
       KWS_TRY(kws_block_out_bwd(dO, ws + lo.ys[i], c.bn_at(b.bns_idx), dO, part, B, b.Lout, b.nf, 1, 0, st));
@@ -432,6 +581,20 @@ int lm_train(const kws_net* n, const float* params, float* state, const float* x
     }
     std::swap(dO, dX);
   }
+  if (p.style == 1) {  // ---- context block: dO is the gradient wrt its activated output ----
+    const int64_t M = (int64_t)B * p.L0;
+    KWS_TRY(kws_block_out_bwd(dO, ws + lo.yc, c.bn_at(p.ctx_bn_idx), G, part, B, p.L0, p.C0, 1, 1, st));
+    int np = (int)(kws_block_out_bwd_part_floats(B, p.L0, p.C0, 1) / (5 * p.C0));
+    KWS_TRY(kws_dw_bwd_finalize(part, np, M, p.C0, nullptr, grads + p.ctx_bn.gamma, grads + p.ctx_bn.beta, coef, red, st));
+    KWS_TRY(kws_bn_bwd_apply(G, ws + lo.yc, c.bn_at(p.ctx_bn_idx), params + p.ctx_bn.gamma, coef, M, p.C0, st));
+    KWS_TRY(kws_transpose_f32(params + p.ctx_pw, ws + lo.WT, p.C0, p.C0, st));
+    KWS_TRY(kws_gemm_nn_f32(G, ws + lo.WT, DZ, M, p.C0, p.C0, nullptr, st));
+    KWS_TRY(kws_gemm_tn_f32(ws + lo.zc, G, grads + p.ctx_pw, M, p.C0, p.C0, ws + lo.tn, st));
+    KWS_TRY(kws_dwconv_bwd_f32(DZ, ws + lo.a0, nullptr, params + p.ctx_dw, dX, part, B, p.L0, p.L0, p.C0, 1, 1, st));
+    np = (int)(kws_dwconv_bwd_part_floats(B, p.L0, p.C0) / (5 * p.C0));
+    KWS_TRY(kws_dw_bwd_finalize(part, np, M, p.C0, grads + p.ctx_dw, nullptr, nullptr, nullptr, red, st));
+    std::swap(dO, dX);
+  }
   // ---- first convolution ----
   {
     const int64_t M = (int64_t)B * p.L0;
@@ -439,7 +602,11 @@ int lm_train(const kws_net* n, const float* params, float* state, const float* x
     const int np = (int)(kws_block_out_bwd_part_floats(B, p.L0, p.C0, 1) / (5 * p.C0));
     KWS_TRY(kws_dw_bwd_finalize(part, np, M, p.C0, nullptr, grads + p.bn0.gamma, grads + p.bn0.beta, coef, red, st));
     KWS_TRY(kws_bn_bwd_apply(G, ws + lo.y0, c.bn_at(1), params + p.bn0.gamma, coef, M, p.C0, st));
-    if (p.Fp == p.F) {
+    if (p.style == 1) {  // gradient of the zero-padded [76, C0] kernel; its first 75 rows are the kernel's
+      float* gw = ws + lo.gwpad;
+      KWS_TRY(kws_gemm_tn_gather_f32(x, &p.g0, G, gw, B, p.C0, ws + lo.tn, st));
+      KWS_HIP(hipMemcpyAsync(grads + p.conv1, gw, (size_t)p.K0 * p.C0 * 4, hipMemcpyDeviceToDevice, st));
+    } else if (p.Fp == p.F) {
       KWS_TRY(kws_gemm_tn_gather_f32(x, &p.g0, G, grads + p.conv1, B, p.C0, ws + lo.tn, st));
     } else {  // the forward of this step left the padded input in xpad
       float* gw = ws + lo.gwpad;

@@ -47,12 +47,13 @@ template <int P, bool RELU>
 __global__ __launch_bounds__(256) void block_out_bwd_kernel(const float* __restrict__ dO, const float* __restrict__ y,
                                                             const float* __restrict__ bn, float* __restrict__ g,
                                                             float* __restrict__ part, int B, int Lo, int C,
-                                                            int nchunks, int R) {
+                                                            int nchunks, int R, int Cb) {
+  // blockIdx.y selects a slice of Cb <= 1024 channels (more than 1024 channels: C / Cb slices)
   __shared__ float red[2][256 * 4];
-  const int C4 = C >> 2;
+  const int C4 = Cb >> 2;
   const int tid = threadIdx.x;
   const int r = tid / C4, c4 = tid - r * C4;
-  const int c = c4 * 4;
+  const int c = blockIdx.y * Cb + c4 * 4;
   const int64_t unit = (int64_t)blockIdx.x * R + r;
   const int64_t b = unit / nchunks;
   const int chunk = (int)(unit - b * nchunks);
@@ -100,12 +101,12 @@ __global__ __launch_bounds__(256) void block_out_bwd_kernel(const float* __restr
   *reinterpret_cast<float4*>(&red[0][tid * 4]) = sg;
   *reinterpret_cast<float4*>(&red[1][tid * 4]) = sgx;
   __syncthreads();
-  for (int o = tid; o < 5 * C; o += blockDim.x) {
-    const int q = o / C, ch = o - q * C;
+  for (int o = tid; o < 5 * Cb; o += blockDim.x) {
+    const int q = o / Cb, ch = o - q * Cb;
     float s = 0.f;
     if (q < 2)
-      for (int rr = 0; rr < R; ++rr) s += red[q][rr * C + ch];
-    part[((int64_t)blockIdx.x * 5 + q) * C + ch] = s;
+      for (int rr = 0; rr < R; ++rr) s += red[q][rr * Cb + ch];
+    part[((int64_t)blockIdx.x * 5 + q) * C + blockIdx.y * Cb + ch] = s;
   }
 }
 
@@ -424,12 +425,15 @@ __global__ __launch_bounds__(256) void lm_att_bwd_kernel(LmArgs p) {
 }
 
 struct Geom {
-  int nchunks, R, block;
+  int nchunks, R, block, ny, Cb;
   int64_t grid;
 };
+bool geom_ok(int C) { return C > 0 && C % 4 == 0 && (C / 4) % ceil_div(C / 4, 256) == 0; }
 Geom geom(int B, int Lo, int C) {
   Geom g;
-  const int C4 = C / 4;
+  g.ny = ceil_div(C / 4, 256);          // channel slices of at most 1024 channels (steffeNet: 1536 = 2 x 768)
+  g.Cb = C / g.ny;
+  const int C4 = g.Cb / 4;
   g.nchunks = ceil_div(Lo, TT);
   g.R = 256 / C4 < 1 ? 1 : 256 / C4;
   g.block = g.R * C4;
@@ -447,7 +451,135 @@ LmArgs make_args(const kws_lm_tail_args* a) {
   return p;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// global max ++ average pooling tail (steffeNet)
+// ------------------------------------------------------------------------------------------------------
+constexpr int GP_MAXC = 2048;
+struct GpArgs {
+  kws_gp_tail_args a;
+  uint32_t key, thresh;
+  float inv_keep, inv_loss_batch;
+};
+
+template <bool TRAIN>
+__global__ __launch_bounds__(256) void gp_tail_kernel(GpArgs p) {
+  __shared__ float s_feat[2 * GP_MAXC], s_red[4][LM_MAXNC], s_p[LM_MAXNC], s_dl[LM_MAXNC];
+  const kws_gp_tail_args& a = p.a;
+  const int T = a.T, C = a.C, NC = a.NC, b = blockIdx.x, tid = threadIdx.x;
+  const float* xb = a.x + (int64_t)b * T * C;
+  const uint32_t row = (uint32_t)(a.row_offset + b);
+  for (int c = tid; c < C; c += 256) {
+    float mx = xb[c], sm = xb[c];
+    for (int t = 1; t < T; ++t) {
+      const float v = xb[t * C + c];
+      mx = fmaxf(mx, v);
+      sm += v;
+    }
+    float f0 = mx, f1 = sm / (float)T;
+    if (TRAIN) {
+      f0 = kws_keep(row * (uint32_t)(2 * C) + (uint32_t)c, p.key, p.thresh) ? f0 * p.inv_keep : 0.f;
+      f1 = kws_keep(row * (uint32_t)(2 * C) + (uint32_t)(C + c), p.key, p.thresh) ? f1 * p.inv_keep : 0.f;
+      a.fd[(int64_t)b * 2 * C + c] = f0;
+      a.fd[(int64_t)b * 2 * C + C + c] = f1;
+    }
+    s_feat[c] = f0;
+    s_feat[C + c] = f1;
+  }
+  __syncthreads();
+  {
+    const int k = tid & 63, sl = tid >> 6;
+    float s = 0.f;
+    if (k < NC)
+      for (int i = sl; i < 2 * C; i += 4) s = fmaf(s_feat[i], a.Wd[(int64_t)i * NC + k], s);
+    s_red[sl][k] = s;
+    __syncthreads();
+    if (tid < NC) s_p[tid] = ((s_red[0][tid] + s_red[1][tid]) + s_red[2][tid]) + s_red[3][tid];
+    __syncthreads();
+    if (tid == 0) {
+      float m = s_p[0];
+      for (int q = 1; q < NC; ++q) m = fmaxf(m, s_p[q]);
+      float den = 0.f;
+      for (int q = 0; q < NC; ++q) {
+        s_p[q] = expf(s_p[q] - m);
+        den += s_p[q];
+      }
+      for (int q = 0; q < NC; ++q) s_p[q] /= den;
+    }
+    __syncthreads();
+    if (tid < NC) a.probs[(int64_t)b * NC + tid] = s_p[tid];
+  }
+  if (!TRAIN) return;
+  if (tid == 0) {
+    // softmax-CE on log(clip(p)) with label smoothing (utils.py:100-108), as in the raw-waveform net's tail
+    const float eps = 1e-7f;
+    const float* yl = a.labels + (int64_t)b * NC;
+    float S = 0.f, ysum = 0.f;
+    for (int q = 0; q < NC; ++q) S += fminf(fmaxf(s_p[q], eps), 1.f - eps);
+    const float logS = logf(S);
+    float loss = 0.f;
+    int am_p = 0, am_y = 0;
+    for (int q = 0; q < NC; ++q) {
+      const float ysm = yl[q] * (1.f - a.label_smoothing) + a.label_smoothing / (float)NC;
+      ysum += ysm;
+      const float pc = fminf(fmaxf(s_p[q], eps), 1.f - eps);
+      loss -= ysm * (logf(pc) - logS);
+      if (s_p[q] > s_p[am_p]) am_p = q;
+      if (yl[q] > yl[am_y]) am_y = q;
+    }
+    a.per_loss[b] = loss;
+    a.per_correct[b] = (am_p == am_y) ? 1.f : 0.f;
+    float dot = 0.f;
+    for (int q = 0; q < NC; ++q) {
+      const float ysm = yl[q] * (1.f - a.label_smoothing) + a.label_smoothing / (float)NC;
+      const float pc = fminf(fmaxf(s_p[q], eps), 1.f - eps);
+      const float inside = (s_p[q] >= eps && s_p[q] <= 1.f - eps) ? 1.f : 0.f;
+      const float dp = (-ysm / pc + ysum / S) * p.inv_loss_batch * inside;
+      s_dl[q] = dp;
+      dot += dp * s_p[q];
+    }
+    for (int q = 0; q < NC; ++q) s_dl[q] = s_p[q] * (s_dl[q] - dot);
+  }
+  __syncthreads();
+  if (tid < NC) a.dl[(int64_t)b * NC + tid] = s_dl[tid];
+  // dfeat = (Wd . dl) * mask / keep; reduce_max shares its gradient equally among ties (_MinOrMaxGrad)
+  float* dxb = a.dX + (int64_t)b * T * C;
+  for (int c = tid; c < C; c += 256) {
+    float d0 = 0.f, d1 = 0.f;
+    for (int q = 0; q < NC; ++q) {
+      d0 = fmaf(a.Wd[(int64_t)c * NC + q], s_dl[q], d0);
+      d1 = fmaf(a.Wd[(int64_t)(C + c) * NC + q], s_dl[q], d1);
+    }
+    d0 = kws_keep(row * (uint32_t)(2 * C) + (uint32_t)c, p.key, p.thresh) ? d0 * p.inv_keep : 0.f;
+    d1 = kws_keep(row * (uint32_t)(2 * C) + (uint32_t)(C + c), p.key, p.thresh) ? d1 * p.inv_keep : 0.f;
+    float mx = xb[c];
+    for (int t = 1; t < T; ++t) mx = fmaxf(mx, xb[t * C + c]);
+    int ties = 0;
+    for (int t = 0; t < T; ++t) ties += xb[t * C + c] == mx ? 1 : 0;
+    const float share = d0 / (float)ties, avg = d1 / (float)T;
+    for (int t = 0; t < T; ++t) dxb[t * C + c] = (xb[t * C + c] == mx ? share : 0.f) + avg;
+  }
+}
+
 }  // namespace
+
+int kws_gp_tail_launch(const kws_gp_tail_args* a, int training, hipStream_t st) {
+  KWS_REQUIRE(a && a->x && a->Wd && a->probs && a->B > 0 && a->T > 0 && a->C > 0 && a->C <= GP_MAXC && a->NC > 0 &&
+                  a->NC <= LM_MAXNC,
+              "gp_tail: bad arguments (T=%d C=%d NC=%d)", a ? a->T : 0, a ? a->C : 0, a ? a->NC : 0);
+  KWS_REQUIRE(!training || (a->labels && a->dX && a->fd && a->dl && a->per_loss && a->per_correct),
+              "gp_tail: training needs labels, dX, fd, dl, per_loss, per_correct");
+  GpArgs p;
+  p.a = *a;
+  p.key = kws_dropout_key(a->seed, a->step, 1);
+  p.thresh = kws_dropout_threshold(a->keep_prob);
+  p.inv_keep = (float)(1.0 / (double)a->keep_prob);
+  p.inv_loss_batch = 1.0f / (float)(a->loss_batch > 0 ? a->loss_batch : 1);
+  KwsProfScope prof("gp_tail", 0.0, 4.0 * (double)a->B * a->T * a->C * (training ? 3.0 : 1.0), st);
+  if (training) hipLaunchKernelGGL((gp_tail_kernel<true>), dim3((unsigned)a->B), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((gp_tail_kernel<false>), dim3((unsigned)a->B), dim3(256), 0, st, p);
+  KWS_LAUNCH_CHECK("gp_tail_kernel");
+  return KWS_OK;
+}
 
 int kws_block_out_fwd(const float* y, const float* bn, const float* res, const float* res_bn, float* o, int B, int L,
                       int C, int pool, hipStream_t st) {
@@ -469,22 +601,22 @@ int kws_block_out_fwd(const float* y, const float* bn, const float* res, const f
 }
 
 int64_t kws_block_out_bwd_part_floats(int B, int L, int C, int pool) {
-  if (B <= 0 || L <= 0 || C <= 0 || C % 4 || C > 1024 || pool < 1) return 0;
+  if (B <= 0 || L <= 0 || !geom_ok(C) || pool < 1) return 0;
   return geom(B, L / pool, C).grid * 5 * C;
 }
 
 int kws_block_out_bwd(const float* dO, const float* y, const float* bn, float* g, float* part, int B, int L, int C,
                       int pool, int relu, hipStream_t st) {
-  KWS_REQUIRE(dO && y && bn && g && part && B > 0 && L > 0 && C % 4 == 0 && C <= 1024 && (pool == 1 || pool == 2) &&
+  KWS_REQUIRE(dO && y && bn && g && part && B > 0 && L > 0 && geom_ok(C) && (pool == 1 || pool == 2) &&
                   L % pool == 0 && (relu || pool == 1),
               "block_out_bwd: bad arguments (L=%d C=%d pool=%d relu=%d)", L, C, pool, relu);
   const int Lo = L / pool;
   const Geom ge = geom(B, Lo, C);
   KwsProfScope prof("block_join", 6.0 * B * L * C, 4.0 * (2.0 * B * L * C + (double)B * Lo * C), st);
-  dim3 gr((unsigned)ge.grid), b((unsigned)ge.block);
-  if (pool == 2) hipLaunchKernelGGL((block_out_bwd_kernel<2, true>), gr, b, 0, st, dO, y, bn, g, part, B, Lo, C, ge.nchunks, ge.R);
-  else if (relu) hipLaunchKernelGGL((block_out_bwd_kernel<1, true>), gr, b, 0, st, dO, y, bn, g, part, B, Lo, C, ge.nchunks, ge.R);
-  else hipLaunchKernelGGL((block_out_bwd_kernel<1, false>), gr, b, 0, st, dO, y, bn, g, part, B, Lo, C, ge.nchunks, ge.R);
+  dim3 gr((unsigned)ge.grid, (unsigned)ge.ny), b((unsigned)ge.block);
+  if (pool == 2) hipLaunchKernelGGL((block_out_bwd_kernel<2, true>), gr, b, 0, st, dO, y, bn, g, part, B, Lo, C, ge.nchunks, ge.R, ge.Cb);
+  else if (relu) hipLaunchKernelGGL((block_out_bwd_kernel<1, true>), gr, b, 0, st, dO, y, bn, g, part, B, Lo, C, ge.nchunks, ge.R, ge.Cb);
+  else hipLaunchKernelGGL((block_out_bwd_kernel<1, false>), gr, b, 0, st, dO, y, bn, g, part, B, Lo, C, ge.nchunks, ge.R, ge.Cb);
   KWS_LAUNCH_CHECK("block_out_bwd_kernel");
   return KWS_OK;
 }

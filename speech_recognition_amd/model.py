@@ -6,7 +6,7 @@ from . import _lib
 from .keras_api import Model, RMSprop
 from .net import DeviceNet
 
-ACCELERATED = ('conv_1d_time_sliced_with_attention', 'conv_1d_log_mfcc', 'conv_1d_spectrogram')
+ACCELERATED = ('conv_1d_time_sliced_with_attention', 'conv_1d_log_mfcc', 'conv_1d_spectrogram', 'steffeNet')
 REFERENCE_MODEL_TYPES = (
     'simple', 'snn', 'conv_1d_time_stacked', 'conv_1d_multi_time_sliced', 'conv_1d_time_sliced',
     'conv_1d_time_sliced_group', 'conv_1d_heavy', 'conv_1d_simple', 'conv_1d_gru', 'conv_2d', 'conv_2d_fast',
@@ -54,6 +54,14 @@ def conv_1d_spectrogram_model(input_size=16000, num_classes=11, *args, **kwargs)
     return Model(net, RMSprop(lr=3e-4), name='conv_1d_spectrogram', loss='cce')
 
 
+def steffeNet(input_size=16000, num_classes=11, *args, **kwargs):
+    """reference model.py:1663-1726: raw waveform -> Conv1D(256, 75, strides=50) -> context block -> 12 residual
+    depthwise blocks (320 ... 1536 wide, the first depthwise of every other block strided) -> global max ++
+    average pooling -> Dropout(.5) -> Dense, RMSprop(1e-3), label-smoothed CE (0.1)."""
+    net = DeviceNet(_lib.KWS_NET_STEFFE, num_classes, input_size=input_size)
+    return Model(net, RMSprop(lr=1e-3), name='steffeNet')
+
+
 def speech_model(model_type, input_size, num_classes=11, *args, **kwargs):
     if model_type == 'conv_1d_time_sliced_with_attention':
         return conv_1d_time_sliced_with_attention_model(input_size, num_classes)
@@ -61,6 +69,8 @@ def speech_model(model_type, input_size, num_classes=11, *args, **kwargs):
         return conv_1d_log_mfcc_model(input_size, num_classes, *args, **kwargs)
     if model_type == 'conv_1d_spectrogram':
         return conv_1d_spectrogram_model(input_size, num_classes, *args, **kwargs)
+    if model_type == 'steffeNet':
+        return steffeNet(input_size, num_classes, *args, **kwargs)
     if model_type in REFERENCE_MODEL_TYPES:
         raise NotImplementedError(
             "model '%s' is outside the accelerated hot path (SURVEY.md 8: only %s are built natively)"
