@@ -631,3 +631,198 @@ class SteffeNet(LogMfccNet):
         for k in self.l2_names:
             grads[k] = grads[k] + dt(2.0 * L.L2_COEF) * self._p(k)
         return loss, p, OrderedDict((k, grads[k]) for k in self.params), cache
+
+
+# ----------------------------------------------------------------------------------------------------------
+# conv_1d_residual_model (reference model.py:841-908)
+# ----------------------------------------------------------------------------------------------------------
+RES_BLOCKS = [(128, 2), (256, 2)] + [(256, 1)] * 8 + [(512, 2), (728, 2), (728, 2)]    # model.py:888-894
+
+
+def maxpool3_same_fwd(a, stride):
+    """MaxPool1D(pool_size=3, strides=stride, padding='same') on [B, L, C]: -inf padding (TF pads max-pool windows
+    with the lowest value), the FIRST maximum of a window wins (MaxPoolGrad's strict '>').  Returns (out, arg)
+    with arg in {0, 1, 2} = winner's offset inside its window."""
+    B, Lin, C = a.shape
+    Lout, pl, pr = L.same_pad(Lin, 3, stride)
+    ap = np.pad(a, [[0, 0], [pl, pr], [0, 0]], constant_values=-np.inf)
+    win = np.stack([ap[:, j:j + stride * Lout:stride, :] for j in range(3)], axis=2)     # [B, Lout, 3, C]
+    return win.max(axis=2), win.argmax(axis=2)
+
+
+def maxpool3_same_bwd(do, arg, stride, Lin):
+    B, Lout, C = do.shape
+    _, pl, pr = L.same_pad(Lin, 3, stride)
+    dp = np.zeros((B, Lin + pl + pr, C), dtype=do.dtype)
+    for j in range(3):
+        dp[:, j:j + stride * Lout:stride, :] += do * (arg == j)
+    return dp[:, pl:pl + Lin, :]
+
+
+class Conv1dResidualNet(LogMfccNet):
+    """Raw waveform -> overlapping_time_slice_stack(40, 20) -> Conv1D(64, 3, strides=2) + BN + ReLU6 -> 13 residual
+    blocks of 2 x [depthwise k3 SAME -> pointwise -> BN -> ReLU6] + MaxPool1D(3, strides, 'same') + Add (1x1 strided
+    Conv1D + BN shortcut on the strided blocks) -> _reduce_block(1024) = strided SAME block + VALID block ->
+    GlobalAveragePooling1D -> Dropout(.5) -> Dense(num_classes) + softmax, categorical CE, RMSprop(1e-4)."""
+
+    def __init__(self, num_classes=12, input_size=16000, blocks=RES_BLOCKS, c0=64, c_reduce=1024, seed=87654321,
+                 dtype=np.float64):
+        self.dtype = dtype
+        self.num_classes = num_classes
+        self.L_in = input_size
+        rng = np.random.RandomState(seed)
+        P, S = OrderedDict(), OrderedDict()
+        self.cnt = dict(conv=0, bn=0, dw=0)
+        self.l2_names = []
+
+        def conv(k, cin, cout, l2):
+            self.cnt['conv'] += 1
+            name = 'conv1d_%d/kernel' % self.cnt['conv']
+            P[name] = glorot_uniform(rng, (k, cin, cout), k * cin, k * cout)
+            if l2:
+                self.l2_names.append(name)
+            return name
+
+        def bn(c):
+            self.cnt['bn'] += 1
+            TimeSlicedAttentionNet._add_bn(P, S, self.cnt['bn'], c)
+            return self.cnt['bn']
+
+        def dw(c):
+            self.cnt['dw'] += 1
+            name = 'depthwise_conv2d_%d/depthwise_kernel' % self.cnt['dw']
+            P[name] = glorot_uniform(rng, (1, 3, c, 1), 3 * c, 3)
+            self.l2_names.append(name)
+            return name
+
+        self.C0 = c0
+        Lf = L.same_pad(input_size, 40, 20)[0]
+        self.L0 = L.valid_len(Lf, 3, 2)
+        self.first = (conv(3, 40, c0, True), bn(c0))                           # model.py:883-886
+        self.blocks = []
+        cin, Lc = c0, self.L0
+        for nf, stride in blocks:
+            Lout = L.same_pad(Lc, 3, stride)[0]
+            blk = dict(nf=nf, stride=stride, cin=cin, Lin=Lc, Lout=Lout)
+            if stride != 1:
+                blk['short'] = (conv(1, cin, nf, False), bn(nf))
+            blk['dw1'], blk['pw1'], blk['bn1'] = dw(cin), conv(1, cin, nf, True), bn(nf)
+            blk['dw2'], blk['pw2'], blk['bn2'] = dw(nf), conv(1, nf, nf, True), bn(nf)
+            self.blocks.append(blk)
+            cin, Lc = nf, Lout
+        # _reduce_block(x, 1024, 3): _reduce_conv (strides 2, 'same') then _context_conv ('valid')
+        Lr, plr, prr = L.same_pad(Lc, 3, 2)
+        self.red = [dict(dw=dw(cin), pw=conv(1, cin, c_reduce, True), bn=bn(c_reduce), cin=cin, cout=c_reduce, stride=2,
+                         pad=(plr, prr), Lin=Lc, Lout=Lr),
+                    dict(dw=dw(c_reduce), pw=conv(1, c_reduce, c_reduce, True), bn=bn(c_reduce), cin=c_reduce,
+                         cout=c_reduce, stride=1, pad=(0, 0), Lin=Lr, Lout=Lr - 2)]
+        self.T, self.C = Lr - 2, c_reduce
+        P['dense_1/kernel'] = glorot_uniform(rng, (c_reduce, num_classes), c_reduce, num_classes)
+        P['dense_1/bias'] = np.zeros((num_classes,), np.float32)
+        self.l2_names.append('dense_1/kernel')
+        self.params, self.state = P, S
+        self.drop_keep = 0.5                                                   # Dropout(0.5), model.py:899
+
+    def forward(self, x, training=False, seed=0, step=0, cache=None, drop_offset=0):
+        dt = self.dtype
+        cache = {} if cache is None else cache
+        x = np.asarray(x, dtype=dt)
+        B = x.shape[0]
+        frames = L.frame_same(x, 40, 20)                                       # model.py:881
+        y, cols = L.conv1d_fwd(frames, self._p(self.first[0]), stride=2)
+        cache['conv1_cols'] = cols
+        h = self._bn(self.first[1], y, training, cache)
+        for i, blk in enumerate(self.blocks):
+            c = {'x': h}
+            if 'short' in blk:
+                xs = h[:, ::blk['stride'], :]
+                Ws = self._p(blk['short'][0]).reshape(blk['cin'], blk['nf'])
+                c['xs'], c['Ws'] = xs, Ws
+                res = self._bn(blk['short'][1], L.pw_fwd(xs, Ws), training, cache, relu=False)
+            else:
+                res = h
+            w1 = self._p(blk['dw1']).reshape(3, blk['cin'])
+            z1 = L.dwconv_fwd(h, w1, 1, (1, 1))
+            W1 = self._p(blk['pw1']).reshape(blk['cin'], blk['nf'])
+            a1 = self._bn(blk['bn1'], L.pw_fwd(z1, W1), training, cache)
+            w2 = self._p(blk['dw2']).reshape(3, blk['nf'])
+            z2 = L.dwconv_fwd(a1, w2, 1, (1, 1))
+            W2 = self._p(blk['pw2']).reshape(blk['nf'], blk['nf'])
+            a2 = self._bn(blk['bn2'], L.pw_fwd(z2, W2), training, cache)
+            pooled, arg = maxpool3_same_fwd(a2, blk['stride'])
+            c.update(w1=w1, z1=z1, W1=W1, a1=a1, w2=w2, z2=z2, W2=W2, arg=arg)
+            cache['blk%d' % i] = c
+            h = pooled + res
+        for j, r in enumerate(self.red):
+            w = self._p(r['dw']).reshape(3, r['cin'])
+            z = L.dwconv_fwd(h, w, r['stride'], r['pad'])
+            W = self._p(r['pw']).reshape(r['cin'], r['cout'])
+            cache['red%d' % j] = (h, w, z, W)
+            h = self._bn(r['bn'], L.pw_fwd(z, W), training, cache)
+        feat = h.mean(axis=1)
+        if training:
+            m = L.dropout_mask(L.dropout_key(seed, step, 1), B * self.C, self.drop_keep,
+                               drop_offset * self.C).reshape(B, self.C)
+            fd = feat * m / dt(self.drop_keep)
+        else:
+            m, fd = None, feat
+        Wd, bd = self._p('dense_1/kernel'), self._p('dense_1/bias')
+        p = L.softmax(fd @ Wd + bd, axis=1)
+        cache['tail'] = (m, fd, Wd, p)
+        return p
+
+    def loss_and_grads(self, x, y_onehot, seed=0, step=0, drop_offset=0, loss_scale_B=None, relu_masks=None,
+                       pool_args=None):
+        dt = self.dtype
+        cache = {'relu_masks': relu_masks}
+        p = self.forward(x, training=True, seed=seed, step=step, cache=cache, drop_offset=drop_offset)
+        y_onehot = np.asarray(y_onehot, dtype=dt)
+        loss, per, dp = L.cce_fwd_bwd(p, y_onehot)                             # model.py:905
+        B = x.shape[0]
+        if loss_scale_B is not None:
+            dp = dp * dt(B) / dt(loss_scale_B)
+        grads = OrderedDict()
+        m, fd, Wd, p = cache['tail']
+        dl = L.softmax_bwd(dp, p, axis=1)
+        grads['dense_1/kernel'] = fd.T @ dl
+        grads['dense_1/bias'] = dl.sum(axis=0)
+        dfeat = (dl @ Wd.T) * m / dt(self.drop_keep)
+        dh = np.repeat(dfeat[:, None, :], self.T, axis=1) / dt(self.T)
+        for j in reversed(range(len(self.red))):
+            r = self.red[j]
+            hin, w, z, W = cache['red%d' % j]
+            dy = self._bn_bwd(r['bn'], dh, cache, grads)
+            dz, dW = L.pw_bwd(dy, z, W)
+            grads[r['pw']] = dW.reshape(1, r['cin'], r['cout'])
+            dh, dwk = L.dwconv_bwd(dz, hin, w, r['stride'], r['pad'])
+            grads[r['dw']] = dwk.reshape(1, 3, r['cin'], 1)
+        for i in reversed(range(len(self.blocks))):
+            blk, c = self.blocks[i], cache['blk%d' % i]
+            arg = c['arg'] if pool_args is None or i not in pool_args else pool_args[i]
+            da2 = maxpool3_same_bwd(dh, arg, blk['stride'], blk['Lin'])
+            dy2 = self._bn_bwd(blk['bn2'], da2, cache, grads)
+            dz2, dW2 = L.pw_bwd(dy2, c['z2'], c['W2'])
+            grads[blk['pw2']] = dW2.reshape(1, blk['nf'], blk['nf'])
+            da1, dw2 = L.dwconv_bwd(dz2, c['a1'], c['w2'], 1, (1, 1))
+            grads[blk['dw2']] = dw2.reshape(1, 3, blk['nf'], 1)
+            dy1 = self._bn_bwd(blk['bn1'], da1, cache, grads)
+            dz1, dW1 = L.pw_bwd(dy1, c['z1'], c['W1'])
+            grads[blk['pw1']] = dW1.reshape(1, blk['cin'], blk['nf'])
+            dx, dw1 = L.dwconv_bwd(dz1, c['x'], c['w1'], 1, (1, 1))
+            grads[blk['dw1']] = dw1.reshape(1, 3, blk['cin'], 1)
+            if 'short' in blk:
+                dys = self._bn_bwd(blk['short'][1], dh, cache, grads, relu=False)
+                dxs, dWs = L.pw_bwd(dys, c['xs'], c['Ws'])
+                grads[blk['short'][0]] = dWs.reshape(1, blk['cin'], blk['nf'])
+                dx = dx.copy()
+                dx[:, ::blk['stride'], :] += dxs
+            else:
+                dx = dx + dh
+            dh = dx
+        dy = self._bn_bwd(self.first[1], dh, cache, grads)
+        Wc = self._p(self.first[0])
+        B2, Lo, Co = dy.shape
+        grads[self.first[0]] = (cache['conv1_cols'].T @ dy.reshape(B2 * Lo, Co)).reshape(Wc.shape)
+        for k in self.l2_names:
+            grads[k] = grads[k] + dt(2.0 * L.L2_COEF) * self._p(k)
+        return loss, p, OrderedDict((k, grads[k]) for k in self.params), cache

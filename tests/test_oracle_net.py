@@ -232,3 +232,74 @@ def test_steffenet_shapes_and_grads_match_torch_autograd():
     for k, g in grads.items():
         tg = tparams[k].grad.numpy().reshape(g.shape)
         assert np.abs(g - tg).max() / max(np.abs(tg).max(), 1e-12) < 1e-8, k
+
+
+# ---- conv_1d_residual -------------------------------------------------------------------
+def _torch_residual(net, params, x, y, seed, step):
+    B = x.shape[0]
+    dt = torch.float64
+
+    def bn(h, idx, relu=True):
+        g = params['batch_normalization_%d/gamma' % idx]
+        b = params['batch_normalization_%d/beta' % idx]
+        h = F.batch_norm(h, None, None, g, b, training=True, eps=1e-3)
+        return torch.clamp(h, 0, 6) if relu else h
+
+    def dwpw(h, dwn, pwn, cin, cout, stride=1, pad=(1, 1)):
+        w = params[dwn].reshape(3, cin)
+        h = F.conv1d(F.pad(h, pad), w.t().unsqueeze(1), groups=cin, stride=stride)
+        return F.conv1d(h, params[pwn].reshape(cin, cout).t().unsqueeze(2))
+    xt = torch.from_numpy(x).to(dt)
+    frames = F.pad(xt, (10, 10)).unfold(1, 40, 20)                               # [B, 800, 40]
+    h = bn(F.conv1d(frames.permute(0, 2, 1), params[net.first[0]].permute(2, 1, 0), stride=2), net.first[1])
+    for blk in net.blocks:
+        if 'short' in blk:
+            res = bn(F.conv1d(h, params[blk['short'][0]].reshape(blk['cin'], blk['nf']).t().unsqueeze(2), stride=blk['stride']),
+                     blk['short'][1], relu=False)
+        else:
+            res = h
+        a = bn(dwpw(h, blk['dw1'], blk['pw1'], blk['cin'], blk['nf']), blk['bn1'])
+        a = bn(dwpw(a, blk['dw2'], blk['pw2'], blk['nf'], blk['nf']), blk['bn2'])
+        _, pl, pr = L.same_pad(blk['Lin'], 3, blk['stride'])
+        a = F.max_pool1d(F.pad(a, (pl, pr), value=float('-inf')), 3, blk['stride'])
+        h = a + res
+    for r in net.red:
+        h = bn(dwpw(h, r['dw'], r['pw'], r['cin'], r['cout'], r['stride'], r['pad']), r['bn'])
+    feat = h.mean(dim=2)
+    m = torch.from_numpy(L.dropout_mask(L.dropout_key(seed, step, 1), B * net.C, 0.5).reshape(B, net.C)).to(dt)
+    p = torch.softmax((feat * m / 0.5) @ params['dense_1/kernel'] + params['dense_1/bias'], dim=1)
+    yt = torch.from_numpy(y).to(dt)
+    pn = p / p.sum(dim=1, keepdim=True)
+    loss = -(yt * torch.log(torch.clamp(pn, 1e-7, 1 - 1e-7))).sum(dim=1).mean()
+    reg = sum(1e-5 * (params[k] ** 2).sum() for k in net.l2_names)
+    return p, loss, reg
+
+
+def test_conv1d_residual_shapes_and_grads_match_torch_autograd():
+    from oracle.net import Conv1dResidualNet
+    full = Conv1dResidualNet(num_classes=12)
+    assert full.L0 == 399
+    assert [b['Lout'] for b in full.blocks] == [200, 100] + [100] * 8 + [50, 25, 13]
+    assert [(r['Lin'], r['Lout']) for r in full.red] == [(13, 7), (7, 5)] and (full.T, full.C) == (5, 1024)
+    # small widths / short clip: same structure incl. odd and even lengths under the strided 3-wide pools
+    net = Conv1dResidualNet(num_classes=12, input_size=4000, blocks=[(16, 2), (24, 2), (24, 1), (32, 2)], c0=8,
+                            c_reduce=40, dtype=np.float64)
+    assert [b['Lin'] for b in net.blocks] == [99, 50, 25, 25]
+    rng = np.random.RandomState(8)
+    for k in net.params:
+        if k.endswith('gamma'):
+            net.params[k] = (1.0 + 0.1 * rng.randn(*net.params[k].shape)).astype(np.float32)
+        if k.endswith('beta') or k.endswith('bias'):
+            net.params[k] = (0.1 * rng.randn(*net.params[k].shape)).astype(np.float32)
+    B = 3
+    x = (rng.randn(B, 4000) * 0.3).astype(np.float64)
+    y = np.eye(12)[[3, 0, 11]]
+    loss, p, grads, _ = net.loss_and_grads(x, y, seed=9, step=2)
+    tparams = {k: torch.tensor(v.astype(np.float64), requires_grad=True) for k, v in net.params.items()}
+    pt, tloss, treg = _torch_residual(net, tparams, x, y, 9, 2)
+    (tloss + treg).backward()
+    np.testing.assert_allclose(p, pt.detach().numpy(), rtol=1e-9, atol=1e-12)
+    assert abs(loss - tloss.item()) < 1e-10
+    for k, g in grads.items():
+        tg = tparams[k].grad.numpy().reshape(g.shape)
+        assert np.abs(g - tg).max() / max(np.abs(tg).max(), 1e-12) < 1e-8, k
