@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("KWS_LIB_PATH") or os.path.join(_HERE, "libkws_hip.so"
 KWS_NET_TS_ATTENTION = 1
 KWS_NET_LOG_MFCC = 2
 KWS_NET_STEFFE = 3
+KWS_NET_RESIDUAL = 4
 
 
 class KwsError(RuntimeError):

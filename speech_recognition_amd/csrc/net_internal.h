@@ -66,6 +66,7 @@ struct Bump {
 // ---- conv_1d_log_mfcc program -----------------------------------------------------------------------
 int lm_build(kws_net* n);
 int steffe_build(kws_net* n);
+int residual_build(kws_net* n);
 void lm_free(kws_net* n);
 int64_t lm_workspace_bytes(const kws_net* n, int B, int training);
 int lm_debug_view(const kws_net* n, int B, int training, int what, int index, int64_t* offset_floats, int64_t* count);
@@ -84,6 +85,11 @@ int kws_block_out_fwd(const float* y, const float* bn, const float* res, const f
 int64_t kws_block_out_bwd_part_floats(int B, int L, int C, int pool);
 int kws_block_out_bwd(const float* dO, const float* y, const float* bn, float* g, float* part, int B, int L, int C,
                       int pool, int relu, hipStream_t st);
+int kws_block_out3_fwd(const float* y, const float* bn, const float* res, const float* res_bn, float* o, int B, int L,
+                       int Lo, int C, int stride, int pad_l, hipStream_t st);
+int64_t kws_block_out3_bwd_part_floats(int B, int L, int C);
+int kws_block_out3_bwd(const float* dO, const float* y, const float* bn, float* g, float* part, int B, int L, int Lo,
+                       int C, int stride, int pad_l, hipStream_t st);
 int kws_add_f32(const float* a, const float* b, float* out, int64_t n, hipStream_t st);
 // out[b, stride*t, :] += in[b, t, :]
 int kws_add_strided_f32(float* out, const float* in, int B, int L_out, int L_in, int C, int stride, hipStream_t st);
@@ -109,15 +115,20 @@ struct kws_lm_tail_args {
   float* per_loss; float* per_correct; float* att;
   int B, T, C, NC; uint64_t seed; uint32_t step; float keep_prob; int loss_batch; int64_t row_offset;
 };
-// steffeNet tail (model.py:1712-1718, 1722-1724): GlobalMaxPooling1D ++ GlobalAveragePooling1D -> Dropout -> Dense(no
-// bias) + softmax -> label-smoothed CE; training also writes dX, the dropped features and dlogits (dense wgrad)
+// Global-pooling tails; training also writes dX, the dropped features and dlogits (for the dense wgrad).
+//   steffeNet (model.py:1712-1718, 1722-1724): GlobalMaxPooling1D ++ GlobalAveragePooling1D -> Dropout -> Dense(no
+//     bias) + softmax -> label-smoothed CE: pool_max = 1, bd = NULL, loss_kind = 0
+//   conv_1d_residual (model.py:898-905): GlobalAveragePooling1D -> Dropout -> Dense + softmax -> keras
+//     categorical_crossentropy: pool_max = 0, loss_kind = 1
 struct kws_gp_tail_args {
   const float* x;       // [B, T, C] block-stack output
-  const float* Wd;      // [2C, NC]
+  const float* Wd;      // [F, NC], F = 2C (max ++ avg) or C (avg)
+  const float* bd;      // [NC] or NULL
+  int pool_max, loss_kind;
   const float* labels;  // [B, NC]
   float* probs;         // [B, NC]
   float* dX;            // [B, T, C]
-  float* fd;            // [B, 2C]
+  float* fd;            // [B, F]
   float* dl;            // [B, NC]
   float* per_loss;
   float* per_correct;

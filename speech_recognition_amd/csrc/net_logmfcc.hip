@@ -20,6 +20,7 @@ struct LmBlock {
   // where the stride sits: log-mfcc blocks pool after the second pointwise (s1 = 1, pool = stride, Lmid = Lin);
   // steffeNet blocks stride their FIRST depthwise convolution (s1 = stride, pool = 1, Lmid = Lout)
   int s1, pool, Lmid, pad1;
+  int pool3 = 0, ppad = 0;  // conv_1d_residual: MaxPool1D(3, stride, 'same') join, window of output t starts at t*stride - ppad
   bool has_short;
   int64_t ws;
   BnRef bns;
@@ -31,6 +32,13 @@ struct LmBlock {
 };
 
 }  // namespace
+
+// a depthwise block without a residual (conv_1d_residual's _reduce_block: strided SAME, then VALID)
+struct LmPlain {
+  int64_t dw, pw;
+  BnRef bn;
+  int bn_idx, cin, cout, stride, pad_l, Lin, Lout;
+};
 
 struct LmProgram {
   int T0, F, C0, L0;
@@ -49,6 +57,9 @@ struct LmProgram {
   // K0p = 76 samples against a zero-padded kernel), a context block between the first convolution and the
   // residual stack, global max ++ average pooling tail
   int style = 0, K0 = 0, K0p = 0;
+  // conv_1d_residual (style 2): raw input through the time-slice gather, 3-wide max-pool joins, plain blocks after the
+  // residual stack, global average pooling tail with bias and plain CE
+  std::vector<LmPlain> plain;
   int64_t ctx_dw = 0, ctx_pw = 0;
   BnRef ctx_bn;
   int ctx_bn_idx = 0;
@@ -65,6 +76,8 @@ struct LmLayout {
   int64_t u = 0, fd = 0, dl = 0, gu = 0, coef2 = 0, per_loss = 0, per_correct = 0, att = 0;
   int64_t xpad = 0, wpad = 0, gwpad = 0;  // only when Fp != F (style 0) / always (style 1: padded first kernel)
   int64_t zc = 0, yc = 0, ac = 0;          // steffeNet context block
+  std::vector<int64_t> pz, py;             // plain blocks (style 2)
+  int64_t alast = 0;
 };
 
 void lm_layout(const kws_net* n, int B, LmLayout* lo) {
@@ -108,9 +121,23 @@ void lm_layout(const kws_net* n, int B, LmLayout* lo) {
     if (b.has_short) upd_gemm((int64_t)B * b.Lout, b.cin, b.nf);
     max_part = std::max(max_part, kws_dwconv_bwd_part_floats(B, b.Lin, b.cin));
     max_part = std::max(max_part, kws_dwconv_bwd_part_floats(B, b.Lmid, b.nf));
-    max_part = std::max(max_part, kws_block_out_bwd_part_floats(B, b.Lmid, b.nf, b.pool));
+    max_part = std::max(max_part, b.pool3 ? kws_block_out3_bwd_part_floats(B, b.Lmid, b.nf)
+                                          : kws_block_out_bwd_part_floats(B, b.Lmid, b.nf, b.pool));
     max_part = std::max(max_part, kws_block_out_bwd_part_floats(B, b.Lout, b.nf, 1));
   }
+  lo->pz.assign(p.plain.size(), 0); lo->py.assign(p.plain.size(), 0);
+  for (size_t j = 0; j < p.plain.size(); ++j) {
+    const LmPlain& q = p.plain[j];
+    lo->pz[j] = bp.take((int64_t)B * q.Lout * q.cin);
+    lo->py[j] = bp.take((int64_t)B * q.Lout * q.cout);
+    max_y = std::max(max_y, (int64_t)B * q.Lout * q.cout);
+    max_z = std::max(max_z, (int64_t)B * q.Lout * q.cin);
+    max_o = std::max(max_o, std::max((int64_t)B * q.Lin * q.cin, (int64_t)B * q.Lout * q.cout));
+    upd_gemm((int64_t)B * q.Lout, q.cin, q.cout);
+    max_part = std::max(max_part, kws_dwconv_bwd_part_floats(B, q.Lin, q.cin));
+    max_part = std::max(max_part, kws_block_out_bwd_part_floats(B, q.Lout, q.cout, 1));
+  }
+  if (!p.plain.empty()) lo->alast = bp.take((int64_t)B * p.T * p.C);
   max_part = std::max(max_part, (int64_t)B * 5 * p.C);
   const int feat = p.style == 1 ? 2 * p.C : p.C;   // width of the dense layer's input
   lo->bn_stride = 4 * p.maxC;
@@ -249,13 +276,32 @@ int forward(const Ctx& c, const float* x, kws_lm_tail_args* t) {
                                b.nf, 1, 1, c.st));
     KWS_TRY(kws_gemm_nn_f32(ws + lo.z2[i], c.params + b.pw2, ws + lo.y2[i], M, b.nf, b.nf, stats, c.st));
     KWS_TRY(bn_table(c, b.bn2, b.bn2_idx, M, kws_gemm_nn_stats_rows(M, b.nf, b.nf)));
-    KWS_TRY(kws_block_out_fwd(ws + lo.y2[i], c.bn_at(b.bn2_idx), b.has_short ? ws + lo.ys[i] : xin,
-                              b.has_short ? c.bn_at(b.bns_idx) : nullptr, ws + lo.o[i], B, b.Lmid, b.nf, b.pool, c.st));
+    if (b.pool3)
+      KWS_TRY(kws_block_out3_fwd(ws + lo.y2[i], c.bn_at(b.bn2_idx), b.has_short ? ws + lo.ys[i] : xin,
+                                 b.has_short ? c.bn_at(b.bns_idx) : nullptr, ws + lo.o[i], B, b.Lmid, b.Lout, b.nf, b.stride,
+                                 b.ppad, c.st));
+    else
+      KWS_TRY(kws_block_out_fwd(ws + lo.y2[i], c.bn_at(b.bn2_idx), b.has_short ? ws + lo.ys[i] : xin,
+                                b.has_short ? c.bn_at(b.bns_idx) : nullptr, ws + lo.o[i], B, b.Lmid, b.nf, b.pool, c.st));
     xin = ws + lo.o[i];
+  }
+  if (!p.plain.empty()) {  // _reduce_block: depthwise -> pointwise -> BN -> ReLU6, twice; the last activation is materialised
+    const float* pbn = nullptr;
+    for (size_t j = 0; j < p.plain.size(); ++j) {
+      const LmPlain& q = p.plain[j];
+      const int64_t M = (int64_t)B * q.Lout;
+      KWS_TRY(kws_dwconv_fwd_f32(xin, pbn, c.params + q.dw, ws + lo.pz[j], B, q.Lin, q.Lout, q.cin, q.stride, q.pad_l, c.st));
+      KWS_TRY(kws_gemm_nn_f32(ws + lo.pz[j], c.params + q.pw, ws + lo.py[j], M, q.cin, q.cout, stats, c.st));
+      KWS_TRY(bn_table(c, q.bn, q.bn_idx, M, kws_gemm_nn_stats_rows(M, q.cin, q.cout)));
+      xin = ws + lo.py[j];
+      pbn = c.bn_at(q.bn_idx);
+    }
+    KWS_TRY(kws_bn_relu6_apply(xin, pbn, ws + lo.alast, (int64_t)B * p.T, p.C, 1, c.st));
+    xin = ws + lo.alast;
   }
   memset(t, 0, sizeof(*t));
   t->x = xin;
-  if (p.style == 1) return KWS_OK;  // the caller sets up the global-pooling tail
+  if (p.style != 0) return KWS_OK;  // the caller sets up the global-pooling tail
   t->x = xin; t->wa = c.params + p.att_dw; t->Wa = c.params + p.att_pw;
   t->bn_gamma = c.params + p.att_bn.gamma; t->bn_beta = c.params + p.att_bn.beta;
   t->mm = c.state + p.att_bn.mm; t->mv = c.state + p.att_bn.mv;
@@ -425,6 +471,103 @@ int steffe_build(kws_net* n) {
   return KWS_OK;
 }
 
+// conv_1d_residual_model, reference model.py:841-908
+int residual_build(kws_net* n) {
+  const kws_net_config_t& c = n->cfg;
+  KWS_REQUIRE(c.num_classes >= 2 && c.num_classes <= 64, "net: num_classes %d out of range", c.num_classes);
+  KWS_REQUIRE(c.input_size >= 4000 && c.input_size % 2 == 0, "net: conv_1d_residual input_size %d", c.input_size);
+  const int fm = c.filter_mult > 0 ? c.filter_mult : 1;
+  LmProgram* p = new LmProgram();
+  n->lm = p;
+  p->style = 2;
+  int n_conv = 0, n_bn = 0, n_dw = 0;
+  auto conv = [&](int k, int cin, int cout, bool l2) {
+    ++n_conv;
+    return kws_net_add_tensor(n, "conv1d_" + std::to_string(n_conv) + "/kernel", {k, cin, cout}, false,
+                              l2 ? KWS_L2_COEF : 0.f, k * cin, k * cout, 0.f);
+  };
+  auto bn = [&](int C, int* idx) {
+    ++n_bn;
+    *idx = n_bn;
+    return kws_net_add_bn(n, n_bn, C);
+  };
+  auto dw = [&](int C) {
+    ++n_dw;
+    return kws_net_add_tensor(n, "depthwise_conv2d_" + std::to_string(n_dw) + "/depthwise_kernel", {1, 3, C, 1}, false,
+                              KWS_L2_COEF, 3 * C, 3, 0.f);
+  };
+  auto same = [](int L, int k, int stride, int* Lout, int* pad_l) {   // TF 'SAME'
+    *Lout = (L + stride - 1) / stride;
+    const int pad = std::max((*Lout - 1) * stride + k - L, 0);
+    *pad_l = pad / 2;
+  };
+  // overlapping_time_slice_stack(x, 40, 20) SAME fused with Conv1D(64, 3, strides=2) (model.py:881-884), as the
+  // raw-waveform net's first convolution
+  int Lf, plf;
+  same(c.input_size, 40, 20, &Lf, &plf);
+  p->T0 = c.input_size; p->F = 40; p->Fp = 40; p->C0 = 64 * fm; p->L0 = (Lf - 3) / 2 + 1;
+  p->conv1 = conv(3, 40, p->C0, true);
+  int idx0;
+  p->bn0 = bn(p->C0, &idx0);
+  kws_gather_t g0;
+  g0.L_out = p->L0; g0.cin = 40; g0.taps = 3; g0.stride_t = 2 * 20; g0.stride_j = 20; g0.base_off = -plf;
+  g0.x_len = c.input_size; g0.x_batch_stride = c.input_size;
+  p->g0 = g0;
+  static const int spec[13][2] = {{128, 2}, {256, 2}, {256, 1}, {256, 1}, {256, 1}, {256, 1}, {256, 1}, {256, 1},
+                                  {256, 1}, {256, 1}, {512, 2}, {728, 2}, {728, 2}};  // model.py:888-894
+  int cin = p->C0, L = p->L0;
+  p->maxC = p->C0;
+  for (int i = 0; i < 13; ++i) {
+    LmBlock b;
+    b.nf = spec[i][0] * fm; b.stride = spec[i][1]; b.cin = cin; b.Lin = L;
+    b.s1 = 1; b.pool = b.stride; b.Lmid = L; b.pad1 = 1; b.pool3 = 1;
+    same(L, 3, b.stride, &b.Lout, &b.ppad);
+    b.has_short = b.stride != 1;
+    b.ws = 0; b.bns_idx = 0;
+    memset(&b.gs, 0, sizeof(b.gs));
+    if (b.has_short) {
+      b.ws = conv(1, cin, b.nf, false);
+      b.bns = bn(b.nf, &b.bns_idx);
+      b.gs.L_out = b.Lout; b.gs.cin = cin; b.gs.taps = 1; b.gs.stride_t = b.stride * cin; b.gs.stride_j = 0;
+      b.gs.base_off = 0; b.gs.x_len = L * cin; b.gs.x_batch_stride = (int64_t)L * cin;
+    } else {
+      KWS_REQUIRE(cin == b.nf, "net: identity shortcut needs cin == nf");
+    }
+    b.dw1 = dw(cin);
+    b.pw1 = conv(1, cin, b.nf, true);
+    b.bn1 = bn(b.nf, &b.bn1_idx);
+    b.dw2 = dw(b.nf);
+    b.pw2 = conv(1, b.nf, b.nf, true);
+    b.bn2 = bn(b.nf, &b.bn2_idx);
+    p->blocks.push_back(b);
+    cin = b.nf;
+    L = b.Lout;
+    p->maxC = std::max(p->maxC, b.nf);
+  }
+  // _reduce_block(x, 1024, 3): _reduce_conv (strides 2, 'same') then _context_conv ('valid'), model.py:895
+  const int cr = 1024 * fm;
+  for (int j = 0; j < 2; ++j) {
+    LmPlain q;
+    q.cin = cin; q.cout = cr; q.Lin = L;
+    if (j == 0) { q.stride = 2; same(L, 3, 2, &q.Lout, &q.pad_l); }
+    else { q.stride = 1; q.pad_l = 0; q.Lout = L - 2; }
+    KWS_REQUIRE(q.Lout >= 1, "net: conv_1d_residual input too short");
+    q.dw = dw(cin);
+    q.pw = conv(1, cin, cr, true);
+    q.bn = bn(cr, &q.bn_idx);
+    p->plain.push_back(q);
+    cin = cr;
+    L = q.Lout;
+    p->maxC = std::max(p->maxC, cr);
+  }
+  p->T = L; p->C = cin; p->NC = c.num_classes;
+  KWS_REQUIRE(p->T <= 64, "net: %d time steps at the tail", p->T);
+  p->dk = kws_net_add_tensor(n, "dense_1/kernel", {cin, p->NC}, false, KWS_L2_COEF, cin, p->NC, 0.f);
+  p->db = kws_net_add_tensor(n, "dense_1/bias", {p->NC}, false, 0.f, 0, 0, 0.f);
+  p->n_bn = n_bn;
+  return KWS_OK;
+}
+
 void lm_free(kws_net* n) {
   delete n->lm;
   n->lm = nullptr;
@@ -456,6 +599,8 @@ int lm_debug_view(const kws_net* n, int B, int training, int what, int index, in
   if (what == 5) { *offset_floats = lo.o[nb - 1]; *count = (int64_t)B * p.T * p.C; return KWS_OK; }
   if (what == 0) {
     if (index == 1) { *offset_floats = lo.y0; *count = (int64_t)B * p.L0 * p.C0; return KWS_OK; }
+    for (size_t j = 0; j < p.plain.size(); ++j)
+      if (index == p.plain[j].bn_idx) { *offset_floats = lo.py[j]; *count = (int64_t)B * p.plain[j].Lout * p.plain[j].cout; return KWS_OK; }
     if (p.style == 1 && index == p.ctx_bn_idx) { *offset_floats = lo.yc; *count = (int64_t)B * p.L0 * p.C0; return KWS_OK; }
     for (int i = 0; i < nb; ++i) {
       const LmBlock& b = p.blocks[i];
@@ -481,11 +626,12 @@ int lm_predict(const kws_net* n, const float* params, const float* state, const 
   }
   kws_lm_tail_args t;
   KWS_TRY(forward(c, x, &t));
-  if (n->lm->style == 1) {
+  if (n->lm->style != 0) {
     kws_gp_tail_args g;
     memset(&g, 0, sizeof(g));
     g.x = t.x; g.Wd = params + n->lm->dk; g.probs = probs; g.B = B; g.T = n->lm->T; g.C = n->lm->C; g.NC = n->lm->NC;
-    g.keep_prob = 1.f; g.loss_batch = 1;
+    g.keep_prob = 1.f; g.loss_batch = 1; g.pool_max = n->lm->style == 1;
+    g.bd = n->lm->style == 2 ? params + n->lm->db : nullptr;
     return kws_gp_tail_launch(&g, 0, st);
   }
   t.probs = probs;
@@ -516,16 +662,48 @@ int lm_train(const kws_net* n, const float* params, float* state, const float* x
   float* dO = ws + lo.dOa;
   float* dX = ws + lo.dOb;
   // ---- tail forward + backward ----
-  if (p.style == 1) {
+  if (p.style != 0) {
     kws_gp_tail_args g;
     memset(&g, 0, sizeof(g));
     g.x = t.x; g.Wd = params + p.dk; g.labels = y_onehot; g.probs = probs; g.dX = dO; g.fd = ws + lo.fd; g.dl = ws + lo.dl;
     g.per_loss = ws + lo.per_loss; g.per_correct = ws + lo.per_correct; g.B = B; g.T = p.T; g.C = p.C; g.NC = p.NC;
-    g.seed = seed; g.step = step; g.keep_prob = STEFFE_DROP_KEEP; g.label_smoothing = STEFFE_LABEL_SMOOTH;
+    g.pool_max = p.style == 1; g.loss_kind = p.style == 1 ? 0 : 1;
+    g.bd = p.style == 2 ? params + p.db : nullptr;
+    g.seed = seed; g.step = step; g.keep_prob = STEFFE_DROP_KEEP; g.label_smoothing = STEFFE_LABEL_SMOOTH;  // both Dropout(.5)
     g.loss_batch = loss_batch; g.row_offset = row_offset;
     KWS_TRY(kws_gp_tail_launch(&g, 1, st));
     KWS_TRY(kws_metrics_launch(g.per_loss, g.per_correct, B, metrics, st));
-    KWS_TRY(kws_small_wgrad_launch(g.fd, g.dl, grads + p.dk, nullptr, B, 2 * p.C, p.NC, ws + lo.swg, st));
+    KWS_TRY(kws_small_wgrad_launch(g.fd, g.dl, grads + p.dk, p.style == 2 ? grads + p.db : nullptr, B,
+                                   p.style == 1 ? 2 * p.C : p.C, p.NC, ws + lo.swg, st));
+    // ---- plain blocks after the residual stack, last to first: dO is the gradient wrt the materialised activation
+    for (int j = (int)p.plain.size() - 1; j >= 0; --j) {
+      const LmPlain& q = p.plain[j];
+      const int64_t M = (int64_t)B * q.Lout;
+      if (j == (int)p.plain.size() - 1) {
+        KWS_TRY(kws_block_out_bwd(dO, ws + lo.py[j], c.bn_at(q.bn_idx), G, part, B, q.Lout, q.cout, 1, 1, st));
+        const int np = (int)(kws_block_out_bwd_part_floats(B, q.Lout, q.cout, 1) / (5 * q.cout));
+        KWS_TRY(kws_dw_bwd_finalize(part, np, M, q.cout, nullptr, grads + q.bn.gamma, grads + q.bn.beta, coef, red, st));
+        KWS_TRY(kws_bn_bwd_apply(G, ws + lo.py[j], c.bn_at(q.bn_idx), params + q.bn.gamma, coef, M, q.cout, st));
+      }  // else: G already holds dy of this block (pass 2 of the next block's depthwise backward)
+      KWS_TRY(kws_transpose_f32(params + q.pw, ws + lo.WT, q.cin, q.cout, st));
+      KWS_TRY(kws_gemm_nn_f32(G, ws + lo.WT, DZ, M, q.cout, q.cin, nullptr, st));
+      KWS_TRY(kws_gemm_tn_f32(ws + lo.pz[j], G, grads + q.pw, M, q.cin, q.cout, ws + lo.tn, st));
+      const int np = (int)(kws_dwconv_bwd_part_floats(B, q.Lin, q.cin) / (5 * q.cin));
+      if (j > 0) {
+        const LmPlain& r = p.plain[j - 1];
+        KWS_TRY(kws_dwconv_bwd_bn_f32(DZ, ws + lo.py[j - 1], c.bn_at(r.bn_idx), params + q.dw, nullptr, nullptr, part, 1, B,
+                                      q.Lin, q.Lout, q.cin, q.stride, q.pad_l, st));
+        KWS_TRY(kws_dw_bwd_finalize(part, np, (int64_t)B * q.Lin, q.cin, grads + q.dw, grads + r.bn.gamma, grads + r.bn.beta,
+                                    coef, red, st));
+        KWS_TRY(kws_dwconv_bwd_bn_f32(DZ, ws + lo.py[j - 1], c.bn_at(r.bn_idx), params + q.dw, coef, G, nullptr, 2, B, q.Lin,
+                                      q.Lout, q.cin, q.stride, q.pad_l, st));
+      } else {
+        const float* xin = ws + lo.o[p.blocks.size() - 1];
+        KWS_TRY(kws_dwconv_bwd_f32(DZ, xin, nullptr, params + q.dw, dX, part, B, q.Lin, q.Lout, q.cin, q.stride, q.pad_l, st));
+        KWS_TRY(kws_dw_bwd_finalize(part, np, (int64_t)B * q.Lin, q.cin, grads + q.dw, nullptr, nullptr, nullptr, red, st));
+        std::swap(dO, dX);
+      }
+    }
   } else {
   t.labels = y_onehot; t.probs = probs; t.dX = dO; t.fd = ws + lo.fd; t.dl = ws + lo.dl; t.gu = ws + lo.gu;
   t.part = part; t.coef = ws + lo.coef2; t.d_gamma = grads + p.att_bn.gamma; t.d_beta = grads + p.att_bn.beta;
@@ -543,8 +721,14 @@ int lm_train(const kws_net* n, const float* params, float* state, const float* x
     const int64_t M = (int64_t)B * b.Lmid;
     const float* xin = i == 0 ? (p.style == 1 ? ws + lo.ac : ws + lo.a0) : ws + lo.o[i - 1];
     // main branch: join backward (maxpool routing + ReLU6 mask) -> BN2 -> pointwise 2
-    KWS_TRY(kws_block_out_bwd(dO, ws + lo.y2[i], c.bn_at(b.bn2_idx), G, part, B, b.Lmid, b.nf, b.pool, 1, st));
-    int np = (int)(kws_block_out_bwd_part_floats(B, b.Lmid, b.nf, b.pool) / (5 * b.nf));
+    int np;
+    if (b.pool3) {
+      KWS_TRY(kws_block_out3_bwd(dO, ws + lo.y2[i], c.bn_at(b.bn2_idx), G, part, B, b.Lmid, b.Lout, b.nf, b.stride, b.ppad, st));
+      np = (int)(kws_block_out3_bwd_part_floats(B, b.Lmid, b.nf) / (5 * b.nf));
+    } else {
+      KWS_TRY(kws_block_out_bwd(dO, ws + lo.y2[i], c.bn_at(b.bn2_idx), G, part, B, b.Lmid, b.nf, b.pool, 1, st));
+      np = (int)(kws_block_out_bwd_part_floats(B, b.Lmid, b.nf, b.pool) / (5 * b.nf));
+    }
     KWS_TRY(kws_dw_bwd_finalize(part, np, M, b.nf, nullptr, grads + b.bn2.gamma, grads + b.bn2.beta, coef, red, st));
     KWS_TRY(kws_bn_bwd_apply(G, ws + lo.y2[i], c.bn_at(b.bn2_idx), params + b.bn2.gamma, coef, M, b.nf, st));
     KWS_TRY(kws_transpose_f32(params + b.pw2, ws + lo.WT, b.nf, b.nf, st));

@@ -110,6 +110,105 @@ __global__ __launch_bounds__(256) void block_out_bwd_kernel(const float* __restr
   }
 }
 
+// ---- 3-wide SAME max-pool join (conv_1d_residual, model.py:874-875): window of output t = inputs
+// t*S - PL .. t*S - PL + 2 (positions outside [0, L) are -inf), the FIRST maximum wins --------------------------
+__device__ __forceinline__ float4 act_or_ninf(const float* y, int64_t row0, int u, int L, int C, int c, float4 sc, float4 sh) {
+  if (u < 0 || u >= L) return make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+  return relu6_4(bn4(ld4(y + (row0 + u) * C + c), sc, sh));
+}
+
+template <bool RES_BN>
+__global__ __launch_bounds__(256) void block_out3_fwd_kernel(const float* __restrict__ y, const float* __restrict__ bn,
+                                                             const float* __restrict__ res,
+                                                             const float* __restrict__ res_bn, float* __restrict__ o,
+                                                             int64_t n4, int L, int Lo, int C, int S, int PL) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const int C4 = C >> 2;
+  const int c = (int)(i % C4) * 4;
+  const int64_t bt = i / C4;  // b*Lo + t
+  const int64_t b = bt / Lo;
+  const int t = (int)(bt - b * Lo);
+  const float4 sc = ld4(bn + c), sh = ld4(bn + C + c);
+  const int u0 = t * S - PL;
+  const float4 a0 = act_or_ninf(y, b * L, u0, L, C, c, sc, sh), a1 = act_or_ninf(y, b * L, u0 + 1, L, C, c, sc, sh),
+               a2 = act_or_ninf(y, b * L, u0 + 2, L, C, c, sc, sh);
+  const float4 v = make_float4(fmaxf(fmaxf(a0.x, a1.x), a2.x), fmaxf(fmaxf(a0.y, a1.y), a2.y),
+                               fmaxf(fmaxf(a0.z, a1.z), a2.z), fmaxf(fmaxf(a0.w, a1.w), a2.w));
+  float4 r = ld4(res + bt * C + c);
+  if (RES_BN) r = bn4(r, ld4(res_bn + c), ld4(res_bn + C + c));
+  *reinterpret_cast<float4*>(o + bt * C + c) = make_float4(v.x + r.x, v.y + r.y, v.z + r.z, v.w + r.w);
+}
+
+// offset (0..2) of the first maximum of a window
+__device__ __forceinline__ int first_max3(float a0, float a1, float a2) {
+  int j = 0;
+  float m = a0;
+  if (a1 > m) { m = a1; j = 1; }
+  if (a2 > m) j = 2;
+  return j;
+}
+
+// Backward of the 3-wide join's main branch: one thread = float4 of channels x TT INPUT positions; every input
+// position collects dO of the (at most 3) windows it won, masked by its own ReLU6 gate.
+// part[block][5][C]: sums of (g, g*xhat, 0, 0, 0).
+__global__ __launch_bounds__(256) void block_out3_bwd_kernel(const float* __restrict__ dO, const float* __restrict__ y,
+                                                             const float* __restrict__ bn, float* __restrict__ g,
+                                                             float* __restrict__ part, int B, int L, int Lo, int C,
+                                                             int S, int PL, int nchunks, int R, int Cb) {
+  __shared__ float red[2][256 * 4];
+  const int C4 = Cb >> 2;
+  const int tid = threadIdx.x;
+  const int r = tid / C4, c4 = tid - r * C4;
+  const int c = blockIdx.y * Cb + c4 * 4;
+  const int64_t unit = (int64_t)blockIdx.x * R + r;
+  const int64_t b = unit / nchunks;
+  const int chunk = (int)(unit - b * nchunks);
+  float4 sg = make_float4(0.f, 0.f, 0.f, 0.f), sgx = sg;
+  if (b < B) {
+    const float4 sc = ld4(bn + c), sh = ld4(bn + C + c), mean = ld4(bn + 2 * C + c), rstd = ld4(bn + 3 * C + c);
+    for (int i = 0; i < TT; ++i) {
+      const int u = chunk * TT + i;
+      if (u >= L) break;
+      const float4 yu = ld4(y + (b * L + u) * (int64_t)C + c);
+      const float4 pu = bn4(yu, sc, sh);
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {          // u is element j of window t = (u + PL - j) / S
+        const int num = u + PL - j;
+        if (num < 0 || num % S != 0) continue;
+        const int t = num / S;
+        if (t >= Lo) continue;
+        const int u0 = t * S - PL;
+        const float4 a0 = act_or_ninf(y, b * L, u0, L, C, c, sc, sh), a1 = act_or_ninf(y, b * L, u0 + 1, L, C, c, sc, sh),
+                     a2 = act_or_ninf(y, b * L, u0 + 2, L, C, c, sc, sh);
+        const float4 d = ld4(dO + (b * Lo + t) * (int64_t)C + c);
+        if (first_max3(a0.x, a1.x, a2.x) == j) acc.x += d.x;
+        if (first_max3(a0.y, a1.y, a2.y) == j) acc.y += d.y;
+        if (first_max3(a0.z, a1.z, a2.z) == j) acc.z += d.z;
+        if (first_max3(a0.w, a1.w, a2.w) == j) acc.w += d.w;
+      }
+      const float4 g0 = make_float4(acc.x * mk(pu.x), acc.y * mk(pu.y), acc.z * mk(pu.z), acc.w * mk(pu.w));
+      *reinterpret_cast<float4*>(g + (b * L + u) * (int64_t)C + c) = g0;
+      sg.x += g0.x; sg.y += g0.y; sg.z += g0.z; sg.w += g0.w;
+      sgx.x = fmaf(g0.x, (yu.x - mean.x) * rstd.x, sgx.x);
+      sgx.y = fmaf(g0.y, (yu.y - mean.y) * rstd.y, sgx.y);
+      sgx.z = fmaf(g0.z, (yu.z - mean.z) * rstd.z, sgx.z);
+      sgx.w = fmaf(g0.w, (yu.w - mean.w) * rstd.w, sgx.w);
+    }
+  }
+  *reinterpret_cast<float4*>(&red[0][tid * 4]) = sg;
+  *reinterpret_cast<float4*>(&red[1][tid * 4]) = sgx;
+  __syncthreads();
+  for (int o = tid; o < 5 * Cb; o += blockDim.x) {
+    const int q = o / Cb, ch = o - q * Cb;
+    float s = 0.f;
+    if (q < 2)
+      for (int rr = 0; rr < R; ++rr) s += red[q][rr * Cb + ch];
+    part[((int64_t)blockIdx.x * 5 + q) * C + blockIdx.y * Cb + ch] = s;
+  }
+}
+
 __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                   float* __restrict__ out, int64_t n4) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -466,6 +565,9 @@ __global__ __launch_bounds__(256) void gp_tail_kernel(GpArgs p) {
   __shared__ float s_feat[2 * GP_MAXC], s_red[4][LM_MAXNC], s_p[LM_MAXNC], s_dl[LM_MAXNC];
   const kws_gp_tail_args& a = p.a;
   const int T = a.T, C = a.C, NC = a.NC, b = blockIdx.x, tid = threadIdx.x;
+  const bool pmax = a.pool_max != 0;
+  const int F = pmax ? 2 * C : C;         // features: [max | avg] or [avg]
+  const int avg0 = pmax ? C : 0;          // where the averages start
   const float* xb = a.x + (int64_t)b * T * C;
   const uint32_t row = (uint32_t)(a.row_offset + b);
   for (int c = tid; c < C; c += 256) {
@@ -477,23 +579,24 @@ __global__ __launch_bounds__(256) void gp_tail_kernel(GpArgs p) {
     }
     float f0 = mx, f1 = sm / (float)T;
     if (TRAIN) {
-      f0 = kws_keep(row * (uint32_t)(2 * C) + (uint32_t)c, p.key, p.thresh) ? f0 * p.inv_keep : 0.f;
-      f1 = kws_keep(row * (uint32_t)(2 * C) + (uint32_t)(C + c), p.key, p.thresh) ? f1 * p.inv_keep : 0.f;
-      a.fd[(int64_t)b * 2 * C + c] = f0;
-      a.fd[(int64_t)b * 2 * C + C + c] = f1;
+      if (pmax) f0 = kws_keep(row * (uint32_t)F + (uint32_t)c, p.key, p.thresh) ? f0 * p.inv_keep : 0.f;
+      f1 = kws_keep(row * (uint32_t)F + (uint32_t)(avg0 + c), p.key, p.thresh) ? f1 * p.inv_keep : 0.f;
+      if (pmax) a.fd[(int64_t)b * F + c] = f0;
+      a.fd[(int64_t)b * F + avg0 + c] = f1;
     }
-    s_feat[c] = f0;
-    s_feat[C + c] = f1;
+    if (pmax) s_feat[c] = f0;
+    s_feat[avg0 + c] = f1;
   }
   __syncthreads();
   {
     const int k = tid & 63, sl = tid >> 6;
     float s = 0.f;
     if (k < NC)
-      for (int i = sl; i < 2 * C; i += 4) s = fmaf(s_feat[i], a.Wd[(int64_t)i * NC + k], s);
+      for (int i = sl; i < F; i += 4) s = fmaf(s_feat[i], a.Wd[(int64_t)i * NC + k], s);
     s_red[sl][k] = s;
     __syncthreads();
-    if (tid < NC) s_p[tid] = ((s_red[0][tid] + s_red[1][tid]) + s_red[2][tid]) + s_red[3][tid];
+    if (tid < NC)
+      s_p[tid] = (((s_red[0][tid] + s_red[1][tid]) + s_red[2][tid]) + s_red[3][tid]) + (a.bd ? a.bd[tid] : 0.f);
     __syncthreads();
     if (tid == 0) {
       float m = s_p[0];
@@ -510,34 +613,59 @@ __global__ __launch_bounds__(256) void gp_tail_kernel(GpArgs p) {
   }
   if (!TRAIN) return;
   if (tid == 0) {
-    // softmax-CE on log(clip(p)) with label smoothing (utils.py:100-108), as in the raw-waveform net's tail
     const float eps = 1e-7f;
     const float* yl = a.labels + (int64_t)b * NC;
-    float S = 0.f, ysum = 0.f;
-    for (int q = 0; q < NC; ++q) S += fminf(fmaxf(s_p[q], eps), 1.f - eps);
-    const float logS = logf(S);
-    float loss = 0.f;
     int am_p = 0, am_y = 0;
-    for (int q = 0; q < NC; ++q) {
-      const float ysm = yl[q] * (1.f - a.label_smoothing) + a.label_smoothing / (float)NC;
-      ysum += ysm;
-      const float pc = fminf(fmaxf(s_p[q], eps), 1.f - eps);
-      loss -= ysm * (logf(pc) - logS);
-      if (s_p[q] > s_p[am_p]) am_p = q;
-      if (yl[q] > yl[am_y]) am_y = q;
+    float loss = 0.f;
+    if (a.loss_kind == 0) {
+      // softmax-CE on log(clip(p)) with label smoothing (utils.py:100-108), as in the raw-waveform net's tail
+      float S = 0.f, ysum = 0.f;
+      for (int q = 0; q < NC; ++q) S += fminf(fmaxf(s_p[q], eps), 1.f - eps);
+      const float logS = logf(S);
+      for (int q = 0; q < NC; ++q) {
+        const float ysm = yl[q] * (1.f - a.label_smoothing) + a.label_smoothing / (float)NC;
+        ysum += ysm;
+        const float pc = fminf(fmaxf(s_p[q], eps), 1.f - eps);
+        loss -= ysm * (logf(pc) - logS);
+        if (s_p[q] > s_p[am_p]) am_p = q;
+        if (yl[q] > yl[am_y]) am_y = q;
+      }
+      float dot = 0.f;
+      for (int q = 0; q < NC; ++q) {
+        const float ysm = yl[q] * (1.f - a.label_smoothing) + a.label_smoothing / (float)NC;
+        const float pc = fminf(fmaxf(s_p[q], eps), 1.f - eps);
+        const float inside = (s_p[q] >= eps && s_p[q] <= 1.f - eps) ? 1.f : 0.f;
+        const float dp = (-ysm / pc + ysum / S) * p.inv_loss_batch * inside;
+        s_dl[q] = dp;
+        dot += dp * s_p[q];
+      }
+      for (int q = 0; q < NC; ++q) s_dl[q] = s_p[q] * (s_dl[q] - dot);
+    } else {
+      // keras categorical_crossentropy: p /= sum(p); clip(eps, 1-eps); -sum(y log p)   (as lm_tail_kernel)
+      float S = 0.f;
+      for (int q = 0; q < NC; ++q) S += s_p[q];
+      float dotp = 0.f;
+      for (int q = 0; q < NC; ++q) {
+        const float pn = s_p[q] / S;
+        const float pc = fminf(fmaxf(pn, eps), 1.f - eps);
+        loss -= yl[q] * logf(pc);
+        const float inside = (pn >= eps && pn <= 1.f - eps) ? 1.f : 0.f;
+        const float dpn = (-yl[q] / pc) * inside * p.inv_loss_batch;
+        s_dl[q] = dpn;
+        dotp += dpn * s_p[q];
+        if (s_p[q] > s_p[am_p]) am_p = q;
+        if (yl[q] > yl[am_y]) am_y = q;
+      }
+      float dot2 = 0.f;
+      for (int q = 0; q < NC; ++q) {
+        const float dp = s_dl[q] / S - dotp / (S * S);
+        s_dl[q] = dp;
+        dot2 += dp * s_p[q];
+      }
+      for (int q = 0; q < NC; ++q) s_dl[q] = s_p[q] * (s_dl[q] - dot2);
     }
     a.per_loss[b] = loss;
     a.per_correct[b] = (am_p == am_y) ? 1.f : 0.f;
-    float dot = 0.f;
-    for (int q = 0; q < NC; ++q) {
-      const float ysm = yl[q] * (1.f - a.label_smoothing) + a.label_smoothing / (float)NC;
-      const float pc = fminf(fmaxf(s_p[q], eps), 1.f - eps);
-      const float inside = (s_p[q] >= eps && s_p[q] <= 1.f - eps) ? 1.f : 0.f;
-      const float dp = (-ysm / pc + ysum / S) * p.inv_loss_batch * inside;
-      s_dl[q] = dp;
-      dot += dp * s_p[q];
-    }
-    for (int q = 0; q < NC; ++q) s_dl[q] = s_p[q] * (s_dl[q] - dot);
   }
   __syncthreads();
   if (tid < NC) a.dl[(int64_t)b * NC + tid] = s_dl[tid];
@@ -546,17 +674,22 @@ __global__ __launch_bounds__(256) void gp_tail_kernel(GpArgs p) {
   for (int c = tid; c < C; c += 256) {
     float d0 = 0.f, d1 = 0.f;
     for (int q = 0; q < NC; ++q) {
-      d0 = fmaf(a.Wd[(int64_t)c * NC + q], s_dl[q], d0);
-      d1 = fmaf(a.Wd[(int64_t)(C + c) * NC + q], s_dl[q], d1);
+      if (pmax) d0 = fmaf(a.Wd[(int64_t)c * NC + q], s_dl[q], d0);
+      d1 = fmaf(a.Wd[(int64_t)(avg0 + c) * NC + q], s_dl[q], d1);
     }
-    d0 = kws_keep(row * (uint32_t)(2 * C) + (uint32_t)c, p.key, p.thresh) ? d0 * p.inv_keep : 0.f;
-    d1 = kws_keep(row * (uint32_t)(2 * C) + (uint32_t)(C + c), p.key, p.thresh) ? d1 * p.inv_keep : 0.f;
-    float mx = xb[c];
-    for (int t = 1; t < T; ++t) mx = fmaxf(mx, xb[t * C + c]);
-    int ties = 0;
-    for (int t = 0; t < T; ++t) ties += xb[t * C + c] == mx ? 1 : 0;
-    const float share = d0 / (float)ties, avg = d1 / (float)T;
-    for (int t = 0; t < T; ++t) dxb[t * C + c] = (xb[t * C + c] == mx ? share : 0.f) + avg;
+    if (pmax) d0 = kws_keep(row * (uint32_t)F + (uint32_t)c, p.key, p.thresh) ? d0 * p.inv_keep : 0.f;
+    d1 = kws_keep(row * (uint32_t)F + (uint32_t)(avg0 + c), p.key, p.thresh) ? d1 * p.inv_keep : 0.f;
+    const float avg = d1 / (float)T;
+    if (pmax) {
+      float mx = xb[c];
+      for (int t = 1; t < T; ++t) mx = fmaxf(mx, xb[t * C + c]);
+      int ties = 0;
+      for (int t = 0; t < T; ++t) ties += xb[t * C + c] == mx ? 1 : 0;
+      const float share = d0 / (float)ties;
+      for (int t = 0; t < T; ++t) dxb[t * C + c] = (xb[t * C + c] == mx ? share : 0.f) + avg;
+    } else {
+      for (int t = 0; t < T; ++t) dxb[t * C + c] = avg;
+    }
   }
 }
 
@@ -618,6 +751,40 @@ int kws_block_out_bwd(const float* dO, const float* y, const float* bn, float* g
   else if (relu) hipLaunchKernelGGL((block_out_bwd_kernel<1, true>), gr, b, 0, st, dO, y, bn, g, part, B, Lo, C, ge.nchunks, ge.R, ge.Cb);
   else hipLaunchKernelGGL((block_out_bwd_kernel<1, false>), gr, b, 0, st, dO, y, bn, g, part, B, Lo, C, ge.nchunks, ge.R, ge.Cb);
   KWS_LAUNCH_CHECK("block_out_bwd_kernel");
+  return KWS_OK;
+}
+
+// 3-wide SAME max-pool join: L inputs -> Lo = ceil(L / stride) outputs, window of output t starts at t*stride - pad_l
+int kws_block_out3_fwd(const float* y, const float* bn, const float* res, const float* res_bn, float* o, int B, int L,
+                       int Lo, int C, int stride, int pad_l, hipStream_t st) {
+  KWS_REQUIRE(y && bn && res && o && B > 0 && L > 0 && Lo > 0 && C % 4 == 0 && (stride == 1 || stride == 2) &&
+                  pad_l >= 0 && pad_l <= 1 && (Lo - 1) * stride - pad_l < L,
+              "block_out3_fwd: bad arguments (L=%d Lo=%d C=%d stride=%d pad_l=%d)", L, Lo, C, stride, pad_l);
+  const int64_t n4 = (int64_t)B * Lo * C / 4;
+  KwsProfScope prof("block_join", 6.0 * B * L * C, 4.0 * ((double)B * L * C + 2.0 * B * Lo * C), st);
+  dim3 g((unsigned)ceil_div64(n4, 256)), b(256);
+  if (res_bn) hipLaunchKernelGGL((block_out3_fwd_kernel<true>), g, b, 0, st, y, bn, res, res_bn, o, n4, L, Lo, C, stride, pad_l);
+  else hipLaunchKernelGGL((block_out3_fwd_kernel<false>), g, b, 0, st, y, bn, res, res_bn, o, n4, L, Lo, C, stride, pad_l);
+  KWS_LAUNCH_CHECK("block_out3_fwd_kernel");
+  return KWS_OK;
+}
+
+int64_t kws_block_out3_bwd_part_floats(int B, int L, int C) {
+  if (B <= 0 || L <= 0 || !geom_ok(C)) return 0;
+  return geom(B, L, C).grid * 5 * C;
+}
+
+int kws_block_out3_bwd(const float* dO, const float* y, const float* bn, float* g, float* part, int B, int L, int Lo,
+                       int C, int stride, int pad_l, hipStream_t st) {
+  KWS_REQUIRE(dO && y && bn && g && part && B > 0 && L > 0 && Lo > 0 && geom_ok(C) && (stride == 1 || stride == 2) &&
+                  pad_l >= 0 && pad_l <= 1,
+              "block_out3_bwd: bad arguments (L=%d Lo=%d C=%d stride=%d pad_l=%d)", L, Lo, C, stride, pad_l);
+  const Geom ge = geom(B, L, C);
+  KwsProfScope prof("block_join", 12.0 * B * L * C, 4.0 * (2.0 * B * L * C + (double)B * Lo * C), st);
+  dim3 gr((unsigned)ge.grid, (unsigned)ge.ny), b((unsigned)ge.block);
+  hipLaunchKernelGGL(block_out3_bwd_kernel, gr, b, 0, st, dO, y, bn, g, part, B, L, Lo, C, stride, pad_l, ge.nchunks, ge.R,
+                     ge.Cb);
+  KWS_LAUNCH_CHECK("block_out3_bwd_kernel");
   return KWS_OK;
 }
 

@@ -6,7 +6,7 @@ from . import _lib
 from .keras_api import Model, RMSprop
 from .net import DeviceNet
 
-ACCELERATED = ('conv_1d_time_sliced_with_attention', 'conv_1d_log_mfcc', 'conv_1d_spectrogram', 'steffeNet')
+ACCELERATED = ('conv_1d_time_sliced_with_attention', 'conv_1d_log_mfcc', 'conv_1d_spectrogram', 'steffeNet', 'conv_1d_residual')
 REFERENCE_MODEL_TYPES = (
     'simple', 'snn', 'conv_1d_time_stacked', 'conv_1d_multi_time_sliced', 'conv_1d_time_sliced',
     'conv_1d_time_sliced_group', 'conv_1d_heavy', 'conv_1d_simple', 'conv_1d_gru', 'conv_2d', 'conv_2d_fast',
@@ -62,6 +62,14 @@ def steffeNet(input_size=16000, num_classes=11, *args, **kwargs):
     return Model(net, RMSprop(lr=1e-3), name='steffeNet')
 
 
+def conv_1d_residual_model(input_size=16000, num_classes=11, filter_mult=1):
+    """reference model.py:841-908: raw waveform -> time-slice stack -> Conv1D(64, 3, strides=2) -> 13 residual blocks
+    with 3-wide max-pool joins -> reduce block (1024) -> global average pooling -> Dropout(.5) -> Dense,
+    RMSprop(1e-4), categorical CE."""
+    net = DeviceNet(_lib.KWS_NET_RESIDUAL, num_classes, filter_mult=filter_mult, input_size=input_size)
+    return Model(net, RMSprop(lr=1e-4), name='conv_1d_residual', loss='cce')
+
+
 def speech_model(model_type, input_size, num_classes=11, *args, **kwargs):
     if model_type == 'conv_1d_time_sliced_with_attention':
         return conv_1d_time_sliced_with_attention_model(input_size, num_classes)
@@ -71,6 +79,8 @@ def speech_model(model_type, input_size, num_classes=11, *args, **kwargs):
         return conv_1d_spectrogram_model(input_size, num_classes, *args, **kwargs)
     if model_type == 'steffeNet':
         return steffeNet(input_size, num_classes, *args, **kwargs)
+    if model_type == 'conv_1d_residual':
+        return conv_1d_residual_model(input_size, num_classes)
     if model_type in REFERENCE_MODEL_TYPES:
         raise NotImplementedError(
             "model '%s' is outside the accelerated hot path (SURVEY.md 8: only %s are built natively)"
