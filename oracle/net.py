@@ -826,3 +826,181 @@ class Conv1dResidualNet(LogMfccNet):
         for k in self.l2_names:
             grads[k] = grads[k] + dt(2.0 * L.L2_COEF) * self._p(k)
         return loss, p, OrderedDict((k, grads[k]) for k in self.params), cache
+
+
+# ----------------------------------------------------------------------------------------------------------
+# conv_1d_mfcc_and_raw_model (reference model.py:1563-1660)
+# ----------------------------------------------------------------------------------------------------------
+MR_BLOCKS = [(160, 1), (160, 1), (192, 2), (192, 1), (256, 2), (256, 1), (320, 2), (320, 1), (384, 2), (384, 1)]
+
+
+class MfccAndRawNet(Conv1dResidualNet):
+    """Two inputs (the generator's 'mfcc_and_raw' output): log-mel features [T, F] -> Conv1D(64, 3) + BN + ReLU6 and raw
+    waveform -> overlapping_time_slice_stack(frame_length, frame_step, 'VALID') -> Conv1D(96, 3) + BN + ReLU6,
+    concatenated to 160 channels -> 10 residual blocks with MaxPool1D(3, strides, 'same') joins ->
+    GlobalAveragePooling1D -> Dropout(.3) -> Dense + softmax, categorical CE, RMSprop(5e-4).
+    Keras creation order: mfcc Conv1D + BN, raw Conv1D + BN, then the blocks (model.py:1611-1639)."""
+
+    def __init__(self, num_classes=12, spectrogram_length=98, num_features=60, raw_size=16000, frame_length=480,
+                 frame_step=160, blocks=MR_BLOCKS, c_mfcc=64, c_raw=96, seed=87654321, dtype=np.float64):
+        self.dtype = dtype
+        self.num_classes = num_classes
+        self.T0, self.F, self.L_in = spectrogram_length, num_features, raw_size
+        self.frame_length, self.frame_step = frame_length, frame_step
+        rng = np.random.RandomState(seed)
+        P, S = OrderedDict(), OrderedDict()
+        self.cnt = dict(conv=0, bn=0, dw=0)
+        self.l2_names = []
+
+        def conv(k, cin, cout, l2):
+            self.cnt['conv'] += 1
+            name = 'conv1d_%d/kernel' % self.cnt['conv']
+            P[name] = glorot_uniform(rng, (k, cin, cout), k * cin, k * cout)
+            if l2:
+                self.l2_names.append(name)
+            return name
+
+        def bn(c):
+            self.cnt['bn'] += 1
+            TimeSlicedAttentionNet._add_bn(P, S, self.cnt['bn'], c)
+            return self.cnt['bn']
+
+        def dw(c):
+            self.cnt['dw'] += 1
+            name = 'depthwise_conv2d_%d/depthwise_kernel' % self.cnt['dw']
+            P[name] = glorot_uniform(rng, (1, 3, c, 1), 3 * c, 3)
+            self.l2_names.append(name)
+            return name
+
+        n_frames = 1 + (raw_size - frame_length) // frame_step            # extract_image_patches VALID
+        assert n_frames == spectrogram_length, "both branches must have the same number of time steps"
+        self.L0 = spectrogram_length - 2
+        self.Cm, self.Cr = c_mfcc, c_raw
+        self.first_m = (conv(3, num_features, c_mfcc, True), bn(c_mfcc))  # model.py:1615-1618
+        self.first_r = (conv(3, frame_length, c_raw, True), bn(c_raw))    # model.py:1625-1628
+        self.blocks = []
+        cin, Lc = c_mfcc + c_raw, self.L0
+        for nf, stride in blocks:
+            Lout = L.same_pad(Lc, 3, stride)[0]
+            blk = dict(nf=nf, stride=stride, cin=cin, Lin=Lc, Lout=Lout)
+            if stride != 1:
+                blk['short'] = (conv(1, cin, nf, False), bn(nf))
+            blk['dw1'], blk['pw1'], blk['bn1'] = dw(cin), conv(1, cin, nf, True), bn(nf)
+            blk['dw2'], blk['pw2'], blk['bn2'] = dw(nf), conv(1, nf, nf, True), bn(nf)
+            self.blocks.append(blk)
+            cin, Lc = nf, Lout
+        self.red = []
+        self.T, self.C = Lc, cin
+        P['dense_1/kernel'] = glorot_uniform(rng, (cin, num_classes), cin, num_classes)
+        P['dense_1/bias'] = np.zeros((num_classes,), np.float32)
+        self.l2_names.append('dense_1/kernel')
+        self.params, self.state = P, S
+        self.drop_keep = 0.7                                              # Dropout(0.3), model.py:1648
+
+    def _stem(self, x, training, cache):
+        """x = [mfcc [B, T*F], raw [B, L]] -> concatenated, activated [B, T-2, 160]."""
+        dt = self.dtype
+        xm, xr = x
+        B = np.asarray(xm).shape[0]
+        hm = np.asarray(xm, dtype=dt).reshape(B, self.T0, self.F)
+        ym, cols_m = L.conv1d_fwd(hm, self._p(self.first_m[0]), stride=1)
+        xr = np.asarray(xr, dtype=dt)
+        idx = self.frame_step * np.arange(self.T0)[:, None] + np.arange(self.frame_length)[None, :]
+        frames = xr[:, idx]                                               # [B, T, frame_length], VALID
+        yr, cols_r = L.conv1d_fwd(frames, self._p(self.first_r[0]), stride=1)
+        cache['conv1_cols'] = (cols_m, cols_r)
+        am = self._bn(self.first_m[1], ym, training, cache)
+        ar = self._bn(self.first_r[1], yr, training, cache)
+        return np.concatenate([am, ar], axis=2)                           # Concatenate()([x_mfcc, x_raw])
+
+    def forward(self, x, training=False, seed=0, step=0, cache=None, drop_offset=0):
+        cache = {} if cache is None else cache
+        cache['stem'] = self._stem(x, training, cache)
+        return self._body(cache['stem'], training, seed, step, cache, drop_offset)
+
+    def _body(self, h, training, seed, step, cache, drop_offset):
+        dt = self.dtype
+        B = h.shape[0]
+        for i, blk in enumerate(self.blocks):
+            c = {'x': h}
+            if 'short' in blk:
+                xs = h[:, ::blk['stride'], :]
+                Ws = self._p(blk['short'][0]).reshape(blk['cin'], blk['nf'])
+                c['xs'], c['Ws'] = xs, Ws
+                res = self._bn(blk['short'][1], L.pw_fwd(xs, Ws), training, cache, relu=False)
+            else:
+                res = h
+            w1 = self._p(blk['dw1']).reshape(3, blk['cin'])
+            z1 = L.dwconv_fwd(h, w1, 1, (1, 1))
+            W1 = self._p(blk['pw1']).reshape(blk['cin'], blk['nf'])
+            a1 = self._bn(blk['bn1'], L.pw_fwd(z1, W1), training, cache)
+            w2 = self._p(blk['dw2']).reshape(3, blk['nf'])
+            z2 = L.dwconv_fwd(a1, w2, 1, (1, 1))
+            W2 = self._p(blk['pw2']).reshape(blk['nf'], blk['nf'])
+            a2 = self._bn(blk['bn2'], L.pw_fwd(z2, W2), training, cache)
+            pooled, arg = maxpool3_same_fwd(a2, blk['stride'])
+            c.update(w1=w1, z1=z1, W1=W1, a1=a1, w2=w2, z2=z2, W2=W2, arg=arg)
+            cache['blk%d' % i] = c
+            h = pooled + res
+        feat = h.mean(axis=1)
+        if training:
+            m = L.dropout_mask(L.dropout_key(seed, step, 1), B * self.C, self.drop_keep,
+                               drop_offset * self.C).reshape(B, self.C)
+            fd = feat * m / dt(self.drop_keep)
+        else:
+            m, fd = None, feat
+        Wd, bd = self._p('dense_1/kernel'), self._p('dense_1/bias')
+        p = L.softmax(fd @ Wd + bd, axis=1)
+        cache['tail'] = (m, fd, Wd, p)
+        return p
+
+    def loss_and_grads(self, x, y_onehot, seed=0, step=0, drop_offset=0, loss_scale_B=None, relu_masks=None,
+                       pool_args=None):
+        dt = self.dtype
+        cache = {'relu_masks': relu_masks}
+        p = self.forward(x, training=True, seed=seed, step=step, cache=cache, drop_offset=drop_offset)
+        y_onehot = np.asarray(y_onehot, dtype=dt)
+        loss, per, dp = L.cce_fwd_bwd(p, y_onehot)                        # model.py:1657
+        B = p.shape[0]
+        if loss_scale_B is not None:
+            dp = dp * dt(B) / dt(loss_scale_B)
+        grads = OrderedDict()
+        m, fd, Wd, p = cache['tail']
+        dl = L.softmax_bwd(dp, p, axis=1)
+        grads['dense_1/kernel'] = fd.T @ dl
+        grads['dense_1/bias'] = dl.sum(axis=0)
+        dfeat = (dl @ Wd.T) * m / dt(self.drop_keep)
+        dh = np.repeat(dfeat[:, None, :], self.T, axis=1) / dt(self.T)
+        for i in reversed(range(len(self.blocks))):
+            blk, c = self.blocks[i], cache['blk%d' % i]
+            arg = c['arg'] if pool_args is None or i not in pool_args else pool_args[i]
+            da2 = maxpool3_same_bwd(dh, arg, blk['stride'], blk['Lin'])
+            dy2 = self._bn_bwd(blk['bn2'], da2, cache, grads)
+            dz2, dW2 = L.pw_bwd(dy2, c['z2'], c['W2'])
+            grads[blk['pw2']] = dW2.reshape(1, blk['nf'], blk['nf'])
+            da1, dw2 = L.dwconv_bwd(dz2, c['a1'], c['w2'], 1, (1, 1))
+            grads[blk['dw2']] = dw2.reshape(1, 3, blk['nf'], 1)
+            dy1 = self._bn_bwd(blk['bn1'], da1, cache, grads)
+            dz1, dW1 = L.pw_bwd(dy1, c['z1'], c['W1'])
+            grads[blk['pw1']] = dW1.reshape(1, blk['cin'], blk['nf'])
+            dx, dw1 = L.dwconv_bwd(dz1, c['x'], c['w1'], 1, (1, 1))
+            grads[blk['dw1']] = dw1.reshape(1, 3, blk['cin'], 1)
+            if 'short' in blk:
+                dys = self._bn_bwd(blk['short'][1], dh, cache, grads, relu=False)
+                dxs, dWs = L.pw_bwd(dys, c['xs'], c['Ws'])
+                grads[blk['short'][0]] = dWs.reshape(1, blk['cin'], blk['nf'])
+                dx = dx.copy()
+                dx[:, ::blk['stride'], :] += dxs
+            else:
+                dx = dx + dh
+            dh = dx
+        cols_m, cols_r = cache['conv1_cols']
+        for (name, bidx), cols, sl in ((self.first_m, cols_m, slice(0, self.Cm)),
+                                       (self.first_r, cols_r, slice(self.Cm, self.Cm + self.Cr))):
+            dy = self._bn_bwd(bidx, dh[:, :, sl], cache, grads)
+            W0 = self._p(name)
+            B2, Lo, Co = dy.shape
+            grads[name] = (cols.T @ dy.reshape(B2 * Lo, Co)).reshape(W0.shape)
+        for k in self.l2_names:
+            grads[k] = grads[k] + dt(2.0 * L.L2_COEF) * self._p(k)
+        return loss, p, OrderedDict((k, grads[k]) for k in self.params), cache

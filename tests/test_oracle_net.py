@@ -303,3 +303,67 @@ def test_conv1d_residual_shapes_and_grads_match_torch_autograd():
     for k, g in grads.items():
         tg = tparams[k].grad.numpy().reshape(g.shape)
         assert np.abs(g - tg).max() / max(np.abs(tg).max(), 1e-12) < 1e-8, k
+
+
+# ---- conv_1d_mfcc_and_raw ---------------------------------------------------------------
+def test_mfcc_and_raw_shapes_and_grads_match_torch_autograd():
+    from oracle.net import MfccAndRawNet
+    full = MfccAndRawNet(num_classes=12)
+    assert full.L0 == 96 and [b['Lout'] for b in full.blocks] == [96, 96, 48, 48, 24, 24, 12, 12, 6, 6]
+    assert (full.T, full.C) == (6, 384)
+    assert list(full.params)[:6] == ['conv1d_1/kernel', 'batch_normalization_1/gamma', 'batch_normalization_1/beta',
+                                     'conv1d_2/kernel', 'batch_normalization_2/gamma', 'batch_normalization_2/beta']
+    assert full.params['conv1d_2/kernel'].shape == (3, 480, 96)
+    net = MfccAndRawNet(num_classes=12, spectrogram_length=23, num_features=8, raw_size=480 + 22 * 160,
+                        blocks=[(24, 1), (32, 2), (32, 1)], c_mfcc=8, c_raw=16, dtype=np.float64)
+    rng = np.random.RandomState(10)
+    for k in net.params:
+        if k.endswith('gamma'):
+            net.params[k] = (1.0 + 0.1 * rng.randn(*net.params[k].shape)).astype(np.float32)
+        if k.endswith('beta') or k.endswith('bias'):
+            net.params[k] = (0.1 * rng.randn(*net.params[k].shape)).astype(np.float32)
+    B = 3
+    xm = (rng.randn(B, 23 * 8) * 2.0).astype(np.float64)
+    xr = (rng.randn(B, net.L_in) * 0.3).astype(np.float64)
+    y = np.eye(12)[[3, 0, 11]]
+    loss, p, grads, _ = net.loss_and_grads([xm, xr], y, seed=9, step=2)
+    dt = torch.float64
+    params = {k: torch.tensor(v.astype(np.float64), requires_grad=True) for k, v in net.params.items()}
+
+    def bn(h, idx, relu=True):
+        h = F.batch_norm(h, None, None, params['batch_normalization_%d/gamma' % idx],
+                         params['batch_normalization_%d/beta' % idx], training=True, eps=1e-3)
+        return torch.clamp(h, 0, 6) if relu else h
+
+    def dwpw(h, dwn, pwn, cin, cout):
+        w = params[dwn].reshape(3, cin)
+        h = F.conv1d(F.pad(h, (1, 1)), w.t().unsqueeze(1), groups=cin)
+        return F.conv1d(h, params[pwn].reshape(cin, cout).t().unsqueeze(2))
+    hm = torch.from_numpy(xm).to(dt).reshape(B, 23, 8).permute(0, 2, 1)
+    am = bn(F.conv1d(hm, params[net.first_m[0]].permute(2, 1, 0)), net.first_m[1])
+    fr = torch.from_numpy(xr).to(dt).unfold(1, 480, 160).permute(0, 2, 1)          # [B, 480, 23]
+    ar = bn(F.conv1d(fr, params[net.first_r[0]].permute(2, 1, 0)), net.first_r[1])
+    h = torch.cat([am, ar], dim=1)
+    for blk in net.blocks:
+        if 'short' in blk:
+            res = bn(F.conv1d(h, params[blk['short'][0]].reshape(blk['cin'], blk['nf']).t().unsqueeze(2), stride=blk['stride']),
+                     blk['short'][1], relu=False)
+        else:
+            res = h
+        a = bn(dwpw(h, blk['dw1'], blk['pw1'], blk['cin'], blk['nf']), blk['bn1'])
+        a = bn(dwpw(a, blk['dw2'], blk['pw2'], blk['nf'], blk['nf']), blk['bn2'])
+        _, pl, pr = L.same_pad(blk['Lin'], 3, blk['stride'])
+        h = F.max_pool1d(F.pad(a, (pl, pr), value=float('-inf')), 3, blk['stride']) + res
+    feat = h.mean(dim=2)
+    m = torch.from_numpy(L.dropout_mask(L.dropout_key(9, 2, 1), B * net.C, 0.7).reshape(B, net.C)).to(dt)
+    pt = torch.softmax((feat * m / 0.7) @ params['dense_1/kernel'] + params['dense_1/bias'], dim=1)
+    yt = torch.from_numpy(y).to(dt)
+    pn = pt / pt.sum(dim=1, keepdim=True)
+    tloss = -(yt * torch.log(torch.clamp(pn, 1e-7, 1 - 1e-7))).sum(dim=1).mean()
+    treg = sum(1e-5 * (params[k] ** 2).sum() for k in net.l2_names)
+    (tloss + treg).backward()
+    np.testing.assert_allclose(p, pt.detach().numpy(), rtol=1e-9, atol=1e-12)
+    assert abs(loss - tloss.item()) < 1e-10
+    for k, g in grads.items():
+        tg = params[k].grad.numpy().reshape(g.shape)
+        assert np.abs(g - tg).max() / max(np.abs(tg).max(), 1e-12) < 1e-8, k
