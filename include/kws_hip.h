@@ -250,6 +250,8 @@ int kws_l2_loss(const float* p, const float* l2, int64_t n, float* out, void* st
  *                         model.py:1482-1561: num_features = 257)
  *   KWS_NET_STEFFE:       steffeNet, reference model.py:1663-1726 (raw input; input_size and num_classes only)
  *   KWS_NET_RESIDUAL:     conv_1d_residual_model, reference model.py:841-908 (raw input; filter_mult honoured)
+ *   KWS_NET_MFCC_AND_RAW: conv_1d_mfcc_and_raw_model, reference model.py:1563-1660; the two Keras inputs arrive as ONE
+ *                         row [mfcc spectrogram_length*num_features | raw samples], input_size = the row length
  * The net handle holds only the host-side layer table.  Parameters live in ONE flat f32 buffer
  * (trainable, Keras layer order) + one flat state buffer (BN moving mean/variance), both owned by
  * the caller; kws_net_tensor_info enumerates the Keras-named tensors inside them.
@@ -258,6 +260,7 @@ int kws_l2_loss(const float* p, const float* l2, int64_t n, float* out, void* st
 #define KWS_NET_LOG_MFCC 2
 #define KWS_NET_STEFFE 3
 #define KWS_NET_RESIDUAL 4
+#define KWS_NET_MFCC_AND_RAW 5
 typedef struct kws_net kws_net_t;
 typedef struct {
   int kind;

@@ -14,6 +14,7 @@ KWS_NET_TS_ATTENTION = 1
 KWS_NET_LOG_MFCC = 2
 KWS_NET_STEFFE = 3
 KWS_NET_RESIDUAL = 4
+KWS_NET_MFCC_AND_RAW = 5
 
 
 class KwsError(RuntimeError):

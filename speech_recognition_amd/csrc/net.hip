@@ -261,6 +261,8 @@ int kws_net_create(const kws_net_config_t* cfg, kws_net_t** out) {
     rc = steffe_build(n);
   } else if (cfg->kind == KWS_NET_RESIDUAL) {
     rc = residual_build(n);
+  } else if (cfg->kind == KWS_NET_MFCC_AND_RAW) {
+    rc = mfcc_raw_build(n);
   } else {
     kws_set_error("net_create: kind %d not supported", cfg->kind);
     rc = KWS_E_INVALID;
@@ -299,7 +301,8 @@ int kws_net_tensor_info(const kws_net_t* net, int idx, kws_tensor_info_t* info) 
 
 int64_t kws_net_workspace_bytes(const kws_net_t* net, int max_batch, int training) {
   if (!net || max_batch <= 0) return 0;
-  if ((net->cfg.kind == KWS_NET_LOG_MFCC || net->cfg.kind == KWS_NET_STEFFE || net->cfg.kind == KWS_NET_RESIDUAL)) return lm_workspace_bytes(net, max_batch, training);
+  if ((net->cfg.kind == KWS_NET_LOG_MFCC || net->cfg.kind == KWS_NET_STEFFE || net->cfg.kind == KWS_NET_RESIDUAL ||
+       net->cfg.kind == KWS_NET_MFCC_AND_RAW)) return lm_workspace_bytes(net, max_batch, training);
   Layout lo;
   make_layout(net, max_batch, training != 0, &lo);
   return lo.total;
@@ -308,7 +311,8 @@ int64_t kws_net_workspace_bytes(const kws_net_t* net, int max_batch, int trainin
 int kws_net_debug_view(const kws_net_t* net, int batch, int training, int what, int index, int64_t* offset_floats,
                        int64_t* count) {
   KWS_REQUIRE(net && offset_floats && count && batch > 0, "net_debug_view: bad arguments");
-  if ((net->cfg.kind == KWS_NET_LOG_MFCC || net->cfg.kind == KWS_NET_STEFFE || net->cfg.kind == KWS_NET_RESIDUAL)) return lm_debug_view(net, batch, training, what, index, offset_floats, count);
+  if ((net->cfg.kind == KWS_NET_LOG_MFCC || net->cfg.kind == KWS_NET_STEFFE || net->cfg.kind == KWS_NET_RESIDUAL ||
+       net->cfg.kind == KWS_NET_MFCC_AND_RAW)) return lm_debug_view(net, batch, training, what, index, offset_floats, count);
   Layout lo;
   make_layout(net, batch, training != 0, &lo);
   const int nb = (int)net->blocks.size();
@@ -339,7 +343,8 @@ int kws_net_debug_view(const kws_net_t* net, int batch, int training, int what, 
 int kws_net_predict(const kws_net_t* net, const float* params, const float* state, const float* x, int B,
                     float* probs, void* workspace, int64_t workspace_bytes, void* stream) {
   KWS_REQUIRE(net && params && state && x && probs && workspace && B > 0, "net_predict: bad arguments");
-  if ((net->cfg.kind == KWS_NET_LOG_MFCC || net->cfg.kind == KWS_NET_STEFFE || net->cfg.kind == KWS_NET_RESIDUAL))
+  if ((net->cfg.kind == KWS_NET_LOG_MFCC || net->cfg.kind == KWS_NET_STEFFE || net->cfg.kind == KWS_NET_RESIDUAL ||
+       net->cfg.kind == KWS_NET_MFCC_AND_RAW))
     return lm_predict(net, params, state, x, B, probs, (float*)workspace, workspace_bytes, (hipStream_t)stream);
   Layout lo;
   make_layout(net, B, false, &lo);
@@ -382,7 +387,8 @@ int kws_net_train_fwd_bwd(const kws_net_t* net, const float* params, float* stat
   KWS_REQUIRE(net && params && state && x && y_onehot && grads && probs && metrics && workspace && B > 0,
               "net_train_fwd_bwd: bad arguments");
   KWS_REQUIRE(loss_batch >= B, "net_train_fwd_bwd: loss_batch %d < B %d", loss_batch, B);
-  if ((net->cfg.kind == KWS_NET_LOG_MFCC || net->cfg.kind == KWS_NET_STEFFE || net->cfg.kind == KWS_NET_RESIDUAL))
+  if ((net->cfg.kind == KWS_NET_LOG_MFCC || net->cfg.kind == KWS_NET_STEFFE || net->cfg.kind == KWS_NET_RESIDUAL ||
+       net->cfg.kind == KWS_NET_MFCC_AND_RAW))
     return lm_train(net, params, state, x, y_onehot, B, grads, probs, metrics, seed, step, row_offset, loss_batch,
                     (float*)workspace, workspace_bytes, (hipStream_t)stream);
   Layout lo;

@@ -67,6 +67,7 @@ struct Bump {
 int lm_build(kws_net* n);
 int steffe_build(kws_net* n);
 int residual_build(kws_net* n);
+int mfcc_raw_build(kws_net* n);
 void lm_free(kws_net* n);
 int64_t lm_workspace_bytes(const kws_net* n, int B, int training);
 int lm_debug_view(const kws_net* n, int B, int training, int what, int index, int64_t* offset_floats, int64_t* count);

@@ -60,6 +60,13 @@ struct LmProgram {
   // conv_1d_residual (style 2): raw input through the time-slice gather, 3-wide max-pool joins, plain blocks after the
   // residual stack, global average pooling tail with bias and plain CE
   std::vector<LmPlain> plain;
+  // conv_1d_mfcc_and_raw (style 3): input rows are [mfcc T0*F | raw L_raw]; two first convolutions (Cm + Cr = C0
+  // channels, concatenated after BN + ReLU6), style-2 blocks, global-average tail
+  int Cm = 0, Cr = 0, Din = 0;
+  int64_t conv1r = 0;
+  BnRef bn0r;
+  kws_gather_t g0r;
+  float drop_keep = 0.5f;
   int64_t ctx_dw = 0, ctx_pw = 0;
   BnRef ctx_bn;
   int ctx_bn_idx = 0;
@@ -78,6 +85,7 @@ struct LmLayout {
   int64_t zc = 0, yc = 0, ac = 0;          // steffeNet context block
   std::vector<int64_t> pz, py;             // plain blocks (style 2)
   int64_t alast = 0;
+  int64_t a0m = 0, a0r = 0;                // style 3: activated branch outputs before the concatenation
 };
 
 void lm_layout(const kws_net* n, int B, LmLayout* lo) {
@@ -95,6 +103,11 @@ void lm_layout(const kws_net* n, int B, LmLayout* lo) {
     max_tn = std::max(max_tn, kws_gemm_tn_workspace_floats(M, K, N));
   };
   upd_gemm((int64_t)B * p.L0, p.style == 1 ? p.K0p : 3 * p.Fp, p.C0);
+  if (p.style == 3) {
+    upd_gemm((int64_t)B * p.L0, p.g0r.taps * p.g0r.cin, p.Cr);
+    lo->a0m = bp.take((int64_t)B * p.L0 * p.Cm);
+    lo->a0r = bp.take((int64_t)B * p.L0 * p.Cr);
+  }
   max_part = std::max(max_part, kws_block_out_bwd_part_floats(B, p.L0, p.C0, 1));
   if (p.style == 1) {
     lo->zc = bp.take((int64_t)B * p.L0 * p.C0);
@@ -195,6 +208,24 @@ int bn_table(const Ctx& c, const BnRef& r, int idx, int64_t M, int stat_rows) {
                               c.bn_at(idx), c.st);
 }
 
+// out[r, 0:cols] = in[r, 0:cols] for row pitches ld_in / ld_out (channel concatenation and its backward split)
+__global__ __launch_bounds__(256) void copy_cols_kernel(const float* __restrict__ in, int ld_in, float* __restrict__ out,
+                                                        int ld_out, int64_t rows, int cols4) {
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < rows * cols4; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / cols4;
+    const int c = (int)(i - r * cols4) * 4;
+    *reinterpret_cast<float4*>(out + r * ld_out + c) = *reinterpret_cast<const float4*>(in + r * ld_in + c);
+  }
+}
+int copy_cols(const float* in, int ld_in, float* out, int ld_out, int64_t rows, int cols, hipStream_t st) {
+  KWS_REQUIRE(cols % 4 == 0 && ld_in % 4 == 0 && ld_out % 4 == 0, "copy_cols: widths must be multiples of 4");
+  const int64_t n4 = rows * (cols / 4);
+  hipLaunchKernelGGL(copy_cols_kernel, dim3((unsigned)std::min<int64_t>(ceil_div64(n4, 256), 8192)), dim3(256), 0, st, in,
+                     ld_in, out, ld_out, rows, cols / 4);
+  KWS_LAUNCH_CHECK("copy_cols_kernel");
+  return KWS_OK;
+}
+
 // rows of F floats -> rows of Fp floats (Fp % 4 == 0), zero filled; one 16-byte store per thread
 __global__ __launch_bounds__(256) void repitch_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t rows,
                                                       int F, int Fp) {
@@ -248,11 +279,25 @@ int forward(const Ctx& c, const float* x, kws_lm_tail_args* t) {
   float* ws = c.ws;
   const int B = c.B;
   float* stats = c.training ? ws + lo.part : nullptr;
+  if (p.style == 3) {  // two stems on the packed [mfcc | raw] rows, concatenated after BN + ReLU6
+    const int64_t M = (int64_t)B * p.L0;
+    float* y0m = ws + lo.y0;
+    float* y0r = ws + lo.y0 + M * p.Cm;
+    KWS_TRY(kws_gemm_gather_f32(x, &p.g0, c.params + p.conv1, y0m, B, p.Cm, stats, c.st));
+    KWS_TRY(bn_table(c, p.bn0, 1, M, kws_gemm_gather_stats_rows(M)));
+    KWS_TRY(kws_gemm_gather_f32(x, &p.g0r, c.params + p.conv1r, y0r, B, p.Cr, stats, c.st));
+    KWS_TRY(bn_table(c, p.bn0r, 2, M, kws_gemm_gather_stats_rows(M)));
+    KWS_TRY(kws_bn_relu6_apply(y0m, c.bn_at(1), ws + lo.a0m, M, p.Cm, 1, c.st));
+    KWS_TRY(kws_bn_relu6_apply(y0r, c.bn_at(2), ws + lo.a0r, M, p.Cr, 1, c.st));
+    KWS_TRY(copy_cols(ws + lo.a0m, p.Cm, ws + lo.a0, p.C0, M, p.Cm, c.st));
+    KWS_TRY(copy_cols(ws + lo.a0r, p.Cr, ws + lo.a0 + p.Cm, p.C0, M, p.Cr, c.st));
+  } else {
   const float *x0, *w0;
   KWS_TRY(pad_first_conv(c, x, &x0, &w0));
   KWS_TRY(kws_gemm_gather_f32(x0, &p.g0, w0, ws + lo.y0, B, p.C0, stats, c.st));
   KWS_TRY(bn_table(c, p.bn0, 1, (int64_t)B * p.L0, kws_gemm_gather_stats_rows((int64_t)B * p.L0)));
   KWS_TRY(kws_bn_relu6_apply(ws + lo.y0, c.bn_at(1), ws + lo.a0, (int64_t)B * p.L0, p.C0, 1, c.st));
+  }
   const float* xin = ws + lo.a0;
   if (p.style == 1) {  // _context_conv(x, 256, 3, 'same'): depthwise -> pointwise -> BN -> ReLU6, materialised
     const int64_t M = (int64_t)B * p.L0;
@@ -396,6 +441,7 @@ int steffe_build(kws_net* n) {
   LmProgram* p = new LmProgram();
   n->lm = p;
   p->style = 1;
+  p->drop_keep = STEFFE_DROP_KEEP;
   int n_conv = 0, n_bn = 0, n_dw = 0;
   auto conv = [&](int k, int cin, int cout, bool l2) {
     ++n_conv;
@@ -480,6 +526,7 @@ int residual_build(kws_net* n) {
   LmProgram* p = new LmProgram();
   n->lm = p;
   p->style = 2;
+  p->drop_keep = 0.5f;                           // Dropout(0.5), model.py:899
   int n_conv = 0, n_bn = 0, n_dw = 0;
   auto conv = [&](int k, int cin, int cout, bool l2) {
     ++n_conv;
@@ -568,6 +615,93 @@ int residual_build(kws_net* n) {
   return KWS_OK;
 }
 
+// conv_1d_mfcc_and_raw_model, reference model.py:1563-1660.  Input rows: [mfcc T*F | raw L].
+int mfcc_raw_build(kws_net* n) {
+  const kws_net_config_t& c = n->cfg;
+  const int T = c.spectrogram_length, F = c.num_features;
+  KWS_REQUIRE(c.num_classes >= 2 && c.num_classes <= 64, "net: num_classes %d out of range", c.num_classes);
+  KWS_REQUIRE(T >= 19 && F >= 4 && F % 4 == 0 && c.input_size > T * F, "net: mfcc_and_raw input %d, features %d x %d",
+              c.input_size, T, F);
+  const int Lraw = c.input_size - T * F;
+  const int frame_len = 480, frame_step = 160;   // window_size_samples / window_stride_samples of prepare_model_settings
+  KWS_REQUIRE(1 + (Lraw - frame_len) / frame_step == T && (T * F) % 4 == 0 && Lraw % 2 == 0,
+              "net: mfcc_and_raw needs 1 + (raw %d - 480) / 160 == spectrogram_length %d", Lraw, T);
+  LmProgram* p = new LmProgram();
+  n->lm = p;
+  p->style = 3;
+  p->drop_keep = 0.7f;                           // Dropout(0.3), model.py:1648
+  int n_conv = 0, n_bn = 0, n_dw = 0;
+  auto conv = [&](int k, int cin, int cout, bool l2) {
+    ++n_conv;
+    return kws_net_add_tensor(n, "conv1d_" + std::to_string(n_conv) + "/kernel", {k, cin, cout}, false,
+                              l2 ? KWS_L2_COEF : 0.f, k * cin, k * cout, 0.f);
+  };
+  auto bn = [&](int C, int* idx) {
+    ++n_bn;
+    *idx = n_bn;
+    return kws_net_add_bn(n, n_bn, C);
+  };
+  auto dw = [&](int C) {
+    ++n_dw;
+    return kws_net_add_tensor(n, "depthwise_conv2d_" + std::to_string(n_dw) + "/depthwise_kernel", {1, 3, C, 1}, false,
+                              KWS_L2_COEF, 3 * C, 3, 0.f);
+  };
+  auto same = [](int L, int k, int stride, int* Lout, int* pad_l) {
+    *Lout = (L + stride - 1) / stride;
+    const int pad = std::max((*Lout - 1) * stride + k - L, 0);
+    *pad_l = pad / 2;
+  };
+  p->T0 = T; p->F = F; p->Fp = F; p->Cm = 64; p->Cr = 96; p->C0 = p->Cm + p->Cr; p->L0 = T - 2; p->Din = c.input_size;
+  int idx;
+  p->conv1 = conv(3, F, p->Cm, true);            // model.py:1615
+  p->bn0 = bn(p->Cm, &idx);
+  p->conv1r = conv(3, frame_len, p->Cr, true);   // model.py:1625
+  p->bn0r = bn(p->Cr, &idx);
+  kws_gather_t g;
+  g.L_out = p->L0; g.cin = F; g.taps = 3; g.stride_t = F; g.stride_j = F; g.base_off = 0;
+  g.x_len = T * F; g.x_batch_stride = p->Din;
+  p->g0 = g;
+  // overlapping_time_slice_stack(x, 480, 160, 'VALID') fused with Conv1D(96, 3): row t reads 3 frames 160 apart
+  g.cin = frame_len; g.stride_t = frame_step; g.stride_j = frame_step; g.base_off = T * F; g.x_len = p->Din;
+  p->g0r = g;
+  static const int spec[10][2] = {{160, 1}, {160, 1}, {192, 2}, {192, 1}, {256, 2}, {256, 1}, {320, 2}, {320, 1},
+                                  {384, 2}, {384, 1}};  // model.py:1632-1641
+  int cin = p->C0, L = p->L0;
+  p->maxC = p->C0;
+  for (int i = 0; i < 10; ++i) {
+    LmBlock b;
+    b.nf = spec[i][0]; b.stride = spec[i][1]; b.cin = cin; b.Lin = L;
+    b.s1 = 1; b.pool = b.stride; b.Lmid = L; b.pad1 = 1; b.pool3 = 1;
+    same(L, 3, b.stride, &b.Lout, &b.ppad);
+    b.has_short = b.stride != 1;
+    b.ws = 0; b.bns_idx = 0;
+    memset(&b.gs, 0, sizeof(b.gs));
+    if (b.has_short) {
+      b.ws = conv(1, cin, b.nf, false);
+      b.bns = bn(b.nf, &b.bns_idx);
+      b.gs.L_out = b.Lout; b.gs.cin = cin; b.gs.taps = 1; b.gs.stride_t = b.stride * cin; b.gs.stride_j = 0;
+      b.gs.base_off = 0; b.gs.x_len = L * cin; b.gs.x_batch_stride = (int64_t)L * cin;
+    } else {
+      KWS_REQUIRE(cin == b.nf, "net: identity shortcut needs cin == nf");
+    }
+    b.dw1 = dw(cin);
+    b.pw1 = conv(1, cin, b.nf, true);
+    b.bn1 = bn(b.nf, &b.bn1_idx);
+    b.dw2 = dw(b.nf);
+    b.pw2 = conv(1, b.nf, b.nf, true);
+    b.bn2 = bn(b.nf, &b.bn2_idx);
+    p->blocks.push_back(b);
+    cin = b.nf;
+    L = b.Lout;
+    p->maxC = std::max(p->maxC, b.nf);
+  }
+  p->T = L; p->C = cin; p->NC = c.num_classes;
+  p->dk = kws_net_add_tensor(n, "dense_1/kernel", {cin, p->NC}, false, KWS_L2_COEF, cin, p->NC, 0.f);
+  p->db = kws_net_add_tensor(n, "dense_1/bias", {p->NC}, false, 0.f, 0, 0, 0.f);
+  p->n_bn = n_bn;
+  return KWS_OK;
+}
+
 void lm_free(kws_net* n) {
   delete n->lm;
   n->lm = nullptr;
@@ -598,6 +732,11 @@ int lm_debug_view(const kws_net* n, int B, int training, int what, int index, in
   if (what == 4) { *offset_floats = lo.u; *count = (int64_t)B * p.T; return KWS_OK; }
   if (what == 5) { *offset_floats = lo.o[nb - 1]; *count = (int64_t)B * p.T * p.C; return KWS_OK; }
   if (what == 0) {
+    if (p.style == 3 && index <= 2) {
+      *offset_floats = lo.y0 + (index == 2 ? (int64_t)B * p.L0 * p.Cm : 0);
+      *count = (int64_t)B * p.L0 * (index == 2 ? p.Cr : p.Cm);
+      return KWS_OK;
+    }
     if (index == 1) { *offset_floats = lo.y0; *count = (int64_t)B * p.L0 * p.C0; return KWS_OK; }
     for (size_t j = 0; j < p.plain.size(); ++j)
       if (index == p.plain[j].bn_idx) { *offset_floats = lo.py[j]; *count = (int64_t)B * p.plain[j].Lout * p.plain[j].cout; return KWS_OK; }
@@ -631,7 +770,7 @@ int lm_predict(const kws_net* n, const float* params, const float* state, const 
     memset(&g, 0, sizeof(g));
     g.x = t.x; g.Wd = params + n->lm->dk; g.probs = probs; g.B = B; g.T = n->lm->T; g.C = n->lm->C; g.NC = n->lm->NC;
     g.keep_prob = 1.f; g.loss_batch = 1; g.pool_max = n->lm->style == 1;
-    g.bd = n->lm->style == 2 ? params + n->lm->db : nullptr;
+    g.bd = n->lm->style >= 2 ? params + n->lm->db : nullptr;
     return kws_gp_tail_launch(&g, 0, st);
   }
   t.probs = probs;
@@ -668,12 +807,12 @@ int lm_train(const kws_net* n, const float* params, float* state, const float* x
     g.x = t.x; g.Wd = params + p.dk; g.labels = y_onehot; g.probs = probs; g.dX = dO; g.fd = ws + lo.fd; g.dl = ws + lo.dl;
     g.per_loss = ws + lo.per_loss; g.per_correct = ws + lo.per_correct; g.B = B; g.T = p.T; g.C = p.C; g.NC = p.NC;
     g.pool_max = p.style == 1; g.loss_kind = p.style == 1 ? 0 : 1;
-    g.bd = p.style == 2 ? params + p.db : nullptr;
-    g.seed = seed; g.step = step; g.keep_prob = STEFFE_DROP_KEEP; g.label_smoothing = STEFFE_LABEL_SMOOTH;  // both Dropout(.5)
+    g.bd = p.style >= 2 ? params + p.db : nullptr;
+    g.seed = seed; g.step = step; g.keep_prob = p.drop_keep; g.label_smoothing = STEFFE_LABEL_SMOOTH;
     g.loss_batch = loss_batch; g.row_offset = row_offset;
     KWS_TRY(kws_gp_tail_launch(&g, 1, st));
     KWS_TRY(kws_metrics_launch(g.per_loss, g.per_correct, B, metrics, st));
-    KWS_TRY(kws_small_wgrad_launch(g.fd, g.dl, grads + p.dk, p.style == 2 ? grads + p.db : nullptr, B,
+    KWS_TRY(kws_small_wgrad_launch(g.fd, g.dl, grads + p.dk, p.style >= 2 ? grads + p.db : nullptr, B,
                                    p.style == 1 ? 2 * p.C : p.C, p.NC, ws + lo.swg, st));
     // ---- plain blocks after the residual stack, last to first: dO is the gradient wrt the materialised activation
     for (int j = (int)p.plain.size() - 1; j >= 0; --j) {
@@ -778,6 +917,24 @@ int lm_train(const kws_net* n, const float* params, float* state, const float* x
     np = (int)(kws_dwconv_bwd_part_floats(B, p.L0, p.C0) / (5 * p.C0));
     KWS_TRY(kws_dw_bwd_finalize(part, np, M, p.C0, grads + p.ctx_dw, nullptr, nullptr, nullptr, red, st));
     std::swap(dO, dX);
+  }
+  if (p.style == 3) {  // ---- the two stems: split the gradient of the concatenation, then each like a first convolution
+    const int64_t M = (int64_t)B * p.L0;
+    float* dOm = dX;
+    float* dOr = dX + M * p.Cm;
+    KWS_TRY(copy_cols(dO, p.C0, dOm, p.Cm, M, p.Cm, st));
+    KWS_TRY(copy_cols(dO + p.Cm, p.C0, dOr, p.Cr, M, p.Cr, st));
+    struct Stem { float* d; const float* y; int idx; int C; const BnRef* bn; const kws_gather_t* g; int64_t w; };
+    const Stem stems[2] = {{dOm, ws + lo.y0, 1, p.Cm, &p.bn0, &p.g0, p.conv1},
+                           {dOr, ws + lo.y0 + M * p.Cm, 2, p.Cr, &p.bn0r, &p.g0r, p.conv1r}};
+    for (const Stem& sm : stems) {
+      KWS_TRY(kws_block_out_bwd(sm.d, sm.y, c.bn_at(sm.idx), G, part, B, p.L0, sm.C, 1, 1, st));
+      const int np = (int)(kws_block_out_bwd_part_floats(B, p.L0, sm.C, 1) / (5 * sm.C));
+      KWS_TRY(kws_dw_bwd_finalize(part, np, M, sm.C, nullptr, grads + sm.bn->gamma, grads + sm.bn->beta, coef, red, st));
+      KWS_TRY(kws_bn_bwd_apply(G, sm.y, c.bn_at(sm.idx), params + sm.bn->gamma, coef, M, sm.C, st));
+      KWS_TRY(kws_gemm_tn_gather_f32(x, sm.g, G, grads + sm.w, B, sm.C, ws + lo.tn, st));
+    }
+    return KWS_OK;
   }
   // ---- first convolution ----
   {

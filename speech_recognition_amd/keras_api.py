@@ -22,6 +22,19 @@ import torch
 
 from . import _lib, parallel
 from .device_array import DeviceArray, as_device_f32
+
+
+def _inputs(x, device):
+    """One f32 device tensor per batch.  A multi-input Keras model (conv_1d_mfcc_and_raw: `[mfcc, raw]`, the
+    generator's 'mfcc_and_raw' output) reaches the network program as ONE row per clip, inputs side by side."""
+    if isinstance(x, (list, tuple)):
+        parts = [as_device_f32(v, device) for v in x]
+        return parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
+    return as_device_f32(x, device)
+
+
+def _batch_len(x):
+    return len(x[0]) if isinstance(x, (list, tuple)) else len(x)
 from .net import DeviceNet
 
 
@@ -364,7 +377,7 @@ class Model(object):
     def _train_step_async(self, x, y, metrics_row):
         """Enqueue forward+backward(+all-reduce)+optimizer for one batch; nothing is synchronised."""
         net = self.net
-        xd = as_device_f32(x, self.device)
+        xd = _inputs(x, self.device)
         yd = as_device_f32(y, self.device)
         world, rank = parallel.world_size(), parallel.rank()
         B = xd.shape[0]
@@ -379,7 +392,7 @@ class Model(object):
         self._train_step_async(x, y, row)
         reg = float(self.net.l2_loss().item())
         m = row.cpu().numpy()
-        B = len(x)
+        B = _batch_len(x)
         return [float(m[0]) / B + reg, float(m[1]) / B]
 
     def test_on_batch(self, x, y):
@@ -399,20 +412,20 @@ class Model(object):
         return [loss, acc]
 
     def predict_on_batch(self, x):
-        xd = as_device_f32(x, self.device)
+        xd = _inputs(x, self.device)
         return self.net.predict(xd).cpu().numpy()
 
     def predict(self, x, batch_size=32, verbose=0):
         """Keras default batch_size=32; results are independent of the chunking because
         inference uses moving statistics.  Device inputs are processed in large chunks."""
-        xd = as_device_f32(x, self.device)
+        xd = _inputs(x, self.device)
         n = xd.shape[0]
         chunk = max(int(batch_size), 1024)
         outs = [self.net.predict(xd[i:i + chunk].contiguous()) for i in range(0, n, chunk)]
         return torch.cat(outs, 0).cpu().numpy()
 
     def predict_device(self, x):
-        return self.net.predict(as_device_f32(x, self.device))
+        return self.net.predict(_inputs(x, self.device))
 
     # -- loops ---------------------------------------------------------------------------------------
     def fit_generator(self, generator, steps_per_epoch, epochs=1, verbose=1, callbacks=None,
@@ -443,9 +456,9 @@ class Model(object):
                 for step in range(steps_per_epoch):
                     x, y = enq.get()
                     for cb in cbs:
-                        cb.on_batch_begin(step, {'batch': step, 'size': len(x)})
+                        cb.on_batch_begin(step, {'batch': step, 'size': _batch_len(x)})
                     self._train_step_async(x, y, self._ring[step])
-                    sizes.append(len(x))
+                    sizes.append(_batch_len(x))
                     if step % self._reg_every == 0:
                         reg_sum += float(self.net.l2_loss().item())   # also a natural sync point
                         reg_n += 1
@@ -453,7 +466,7 @@ class Model(object):
                         print("\rEpoch %d/%d  step %d/%d" % (epoch + 1, epochs, step + 1, steps_per_epoch), end='')
                         sys.stdout.flush()
                     for cb in cbs:
-                        cb.on_batch_end(step, {'batch': step, 'size': len(x)})
+                        cb.on_batch_end(step, {'batch': step, 'size': _batch_len(x)})
                 m = self._ring[:steps_per_epoch].cpu().numpy().astype(np.float64)
                 n = float(sum(sizes))
                 logs = {'loss': m[:, 0].sum() / n + reg_sum / max(reg_n, 1),
@@ -476,8 +489,8 @@ class Model(object):
         for _ in range(steps):
             x, y = next(generator)
             l, a = self.test_on_batch(x, y)
-            tot += np.array([l, a]) * len(x)
-            n += len(x)
+            tot += np.array([l, a]) * _batch_len(x)
+            n += _batch_len(x)
         return list(tot / max(n, 1))
 
     def predict_generator(self, generator, steps, **_):

@@ -6,7 +6,7 @@ from . import _lib
 from .keras_api import Model, RMSprop
 from .net import DeviceNet
 
-ACCELERATED = ('conv_1d_time_sliced_with_attention', 'conv_1d_log_mfcc', 'conv_1d_spectrogram', 'steffeNet', 'conv_1d_residual')
+ACCELERATED = ('conv_1d_time_sliced_with_attention', 'conv_1d_log_mfcc', 'conv_1d_spectrogram', 'steffeNet', 'conv_1d_residual', 'conv_1d_mfcc_and_raw')
 REFERENCE_MODEL_TYPES = (
     'simple', 'snn', 'conv_1d_time_stacked', 'conv_1d_multi_time_sliced', 'conv_1d_time_sliced',
     'conv_1d_time_sliced_group', 'conv_1d_heavy', 'conv_1d_simple', 'conv_1d_gru', 'conv_2d', 'conv_2d_fast',
@@ -70,6 +70,21 @@ def conv_1d_residual_model(input_size=16000, num_classes=11, filter_mult=1):
     return Model(net, RMSprop(lr=1e-4), name='conv_1d_residual', loss='cce')
 
 
+def conv_1d_mfcc_and_raw_model(input_size=16000, num_classes=11, *args, **kwargs):
+    """reference model.py:1563-1660: the two-input model fed by the generator's 'mfcc_and_raw' output - log-mel
+    features -> Conv1D(64, 3) and raw frames (480 / 160, VALID) -> Conv1D(96, 3), concatenated, 10 residual blocks
+    with 3-wide max-pool joins, global average pooling, Dropout(.3), Dense; RMSprop(5e-4), categorical CE.
+    `input_size` is the feature input's size (as the reference passes it); batches are `[mfcc, raw]`."""
+    time_size = kwargs.get('spectrogram_length', 65)
+    frequency_size = kwargs.get('num_log_mel_features', 40)
+    raw_size = kwargs.get('desired_samples', 16000)
+    if kwargs.get('window_size_samples', 480) != 480 or kwargs.get('window_stride_samples', 160) != 160:
+        raise NotImplementedError("conv_1d_mfcc_and_raw: only the 30 ms / 10 ms framing (480 / 160 samples) is built")
+    net = DeviceNet(_lib.KWS_NET_MFCC_AND_RAW, num_classes, input_size=time_size * frequency_size + raw_size,
+                    spectrogram_length=time_size, num_features=frequency_size)
+    return Model(net, RMSprop(lr=5e-4), name='conv_1d_mfcc_and_raw', loss='cce')
+
+
 def speech_model(model_type, input_size, num_classes=11, *args, **kwargs):
     if model_type == 'conv_1d_time_sliced_with_attention':
         return conv_1d_time_sliced_with_attention_model(input_size, num_classes)
@@ -81,6 +96,8 @@ def speech_model(model_type, input_size, num_classes=11, *args, **kwargs):
         return steffeNet(input_size, num_classes, *args, **kwargs)
     if model_type == 'conv_1d_residual':
         return conv_1d_residual_model(input_size, num_classes)
+    if model_type == 'conv_1d_mfcc_and_raw':
+        return conv_1d_mfcc_and_raw_model(input_size, num_classes, *args, **kwargs)
     if model_type in REFERENCE_MODEL_TYPES:
         raise NotImplementedError(
             "model '%s' is outside the accelerated hot path (SURVEY.md 8: only %s are built natively)"
