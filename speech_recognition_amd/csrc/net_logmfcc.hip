@@ -1,3 +1,12 @@
+// Residual-block network programs.  One layer table (LmProgram) drives five reference models:
+//   style 0  conv_1d_log_mfcc_model (model.py:1400-1479) and conv_1d_spectrogram_model
+//            (model.py:1482-1561: the same program on 257-bin input, first convolution on re-pitched copies)
+//   style 1  steffeNet (model.py:1663-1726): stride in the block's first depthwise convolution, context block,
+//            global max ++ average pooling tail
+//   style 2  conv_1d_residual_model (model.py:841-908): 3-wide SAME max-pool joins, plain blocks after the stack,
+//            global-average tail
+//   style 3  conv_1d_mfcc_and_raw_model (model.py:1563-1660): two stems on packed [mfcc | raw] rows, concatenated
+// The original description of style 0 follows.
 // Network program of conv_1d_log_mfcc_model (reference model.py:1400-1479; SURVEY 8a row a19, layer
 // table Appendix B.2): Conv1D(64,3)+BN+ReLU6 on [98,40] features, 10 residual blocks of
 // 2 x [depthwise k3 SAME -> pointwise -> BN -> ReLU6] + MaxPool1D(pool=stride) + Add (1x1 stride-2
