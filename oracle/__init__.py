@@ -29,4 +29,11 @@ Pinning status (see DESIGN.md "Oracle"):
     PARITY UNPINNED by reference outputs - the reference holds no tests, no
     golden tensors and TF cannot run here.  They are cross-checked against
     independent implementations (scipy.fft, torch CPU autograd) in tests/.
+  * "next" rows of SURVEY 8f: the time stretch (stretch.py: librosa's published
+    algorithm, librosa itself not pinned by the reference nor installed) and the
+    four further model families in net.py (SteffeNet, Conv1dResidualNet,
+    MfccAndRawNet; conv_1d_spectrogram = LogMfccNet at 257 features) are PARITY
+    UNPINNED the same way and cross-checked against scipy / torch autograd; the
+    export tools (product module speech_recognition_amd/export.py) are pinned by
+    outputs of the reference's own scripts (fixtures K7) and need no oracle.
 """
