@@ -1,0 +1,278 @@
+// First convolution of the raw-waveform net as a Toeplitz GEMM (reference model.py:805-807: overlapping_time_slice_stack
+// (40, 20) + Conv1D(128, 3, strides=2); net.hip folds the three overlapping taps into ONE tap of KF = 80 samples).
+//
+// A[(b, t), k] = x[b, 40 t - 10 + k] is not a matrix in memory: consecutive rows overlap by half and the first row of
+// every clip hangs over its start.  The generic gathered GEMMs (gemm.hip) pay for that with per-element address
+// arithmetic inside a K loop that is only 2.5 slabs long (forward 160 us = 52 TFLOP/s, weight gradient 212 us = 40 TFLOP/s
+// at batch 1024).  These two kernels are shaped for this one operand instead:
+//   * the whole K extent (80) of a row tile is staged at once, two threads per row reading 8-byte pairs (the rows are
+//     8-byte aligned: stride 40, offset -10), zero filled outside the clip; no K loop, no per-slab barrier;
+//   * forward: persistent workgroups keep the folded [80, 128] kernel in LDS for all their tiles, 4 waves x (32 rows x
+//     128 columns), next tile's rows in flight in registers while the current one is multiplied; BN column sums per tile
+//     like the generic gathered kernel (one statistics row per 128-row tile);
+//   * weight gradient: dW[80, 128] = A^T G split over M into one slab per workgroup (fixed-order slab sum afterwards),
+//     64-row units of A and G double-buffered in LDS, wave w owns output columns [32 w, 32 w + 32) x 96 rows (3 MFMA blocks,
+//     rows 80..95 multiply LDS zeros).
+#include "internal.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int NOUT = 128;   // output channels (filter_mult 1)
+constexpr int BM = 128;     // forward row tile
+constexpr int UM = 64;      // weight-gradient row unit
+
+struct Conv1Args {
+  const float* x;
+  const float* W;      // forward: folded kernel [KF, 128]
+  float* y;            // forward: [M, 128]
+  float* stats;        // forward: [m_tiles][2][128] or NULL
+  const float* G;      // wgrad: dy [M, 128]
+  float* ws;           // wgrad: [S][KF][128]
+  kws_gather_t g;
+  int B, m_tiles, S;
+  int64_t M, chunk;
+};
+
+__device__ __forceinline__ float2 load2_or_zero(const float* xb, int pos, int x_len) {
+  if (pos >= 0 && pos + 1 < x_len) return *reinterpret_cast<const float2*>(xb + pos);
+  float2 v = make_float2(0.f, 0.f);
+  if (pos >= 0 && pos < x_len) v.x = xb[pos];
+  if (pos + 1 >= 0 && pos + 1 < x_len) v.y = xb[pos + 1];
+  return v;
+}
+
+template <int KF, bool STATS>
+__global__ __launch_bounds__(256) void conv1_fwd_kernel(Conv1Args p) {
+  constexpr int PA = KF + 4;        // LDS row pitch of the staged rows (16-byte aligned fragments)
+  constexpr int HALF = KF / 2;      // floats per staging thread
+  constexpr int NL = HALF / 2;      // 8-byte loads per staging thread
+  __shared__ float sW[KF * NOUT];
+  __shared__ float sA[2][BM * PA];
+  __shared__ float sRed[2][4][NOUT];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  for (int i = tid; i < KF * NOUT / 4; i += 256)
+    reinterpret_cast<float4*>(sW)[i] = reinterpret_cast<const float4*>(p.W)[i];
+  const int srow = tid >> 1, shalf = tid & 1;
+  float2 ra[NL];
+  auto load_rows = [&](int tile) {
+    const int64_t m = (int64_t)tile * BM + srow;
+    if (m < p.M) {
+      const int64_t b = m / p.g.L_out;
+      const int t = (int)(m - b * p.g.L_out);
+      const float* xb = p.x + b * p.g.x_batch_stride;
+      const int e0 = t * p.g.stride_t + p.g.base_off + shalf * HALF;
+#pragma unroll
+      for (int i = 0; i < NL; ++i) ra[i] = load2_or_zero(xb, e0 + 2 * i, p.g.x_len);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NL; ++i) ra[i] = make_float2(0.f, 0.f);
+    }
+  };
+  auto store_rows = [&](int buf) {
+    float* dst = &sA[buf][srow * PA + shalf * HALF];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) *reinterpret_cast<float2*>(dst + 2 * i) = ra[i];
+  };
+  int tile = blockIdx.x;
+  if (tile >= p.m_tiles) return;
+  load_rows(tile);
+  store_rows(0);
+  __syncthreads();
+  int buf = 0;
+  for (; tile < p.m_tiles; tile += gridDim.x) {
+    const int next = tile + gridDim.x;
+    const bool has_next = next < p.m_tiles;
+    if (has_next) load_rows(next);
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[j][v] = 0.f;
+    const float* cA = &sA[buf][(wave * 32 + li) * PA + lh * 4];
+    const float* cB = sW + (lh * 4) * NOUT + li;
+#pragma unroll
+    for (int q = 0; q < KF / 8; ++q) {
+      const float4 a = *reinterpret_cast<const float4*>(cA + q * 8);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float av = r == 0 ? a.x : (r == 1 ? a.y : (r == 2 ? a.z : a.w));
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, cB[(q * 8 + r) * NOUT + j * 32], acc[j], 0, 0, 0);
+      }
+    }
+    // epilogue: a store instruction covers 2 rows x 32 consecutive columns (two 128-byte segments)
+    const int64_t m0 = (int64_t)tile * BM + wave * 32 + 4 * lh;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int64_t m = m0 + (v & 3) + 8 * (v >> 2);
+      if (m < p.M) {
+        float* yr = p.y + m * NOUT + li;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) yr[j * 32] = acc[j][v];
+      }
+    }
+    if (STATS) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float s = 0.f, ss = 0.f;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          s += acc[j][v];
+          ss = fmaf(acc[j][v], acc[j][v], ss);
+        }
+        s += __shfl_xor(s, 32);
+        ss += __shfl_xor(ss, 32);
+        if (lh == 0) {
+          sRed[0][wave][j * 32 + li] = s;
+          sRed[1][wave][j * 32 + li] = ss;
+        }
+      }
+    }
+    if (has_next) store_rows(buf ^ 1);
+    __syncthreads();
+    if (STATS) {
+      const int q = tid >> 7, c = tid & 127;
+      p.stats[((int64_t)tile * 2 + q) * NOUT + c] = ((sRed[q][0][c] + sRed[q][1][c]) + sRed[q][2][c]) + sRed[q][3][c];
+      __syncthreads();   // sRed is rewritten by the next tile
+    }
+    buf ^= 1;
+  }
+}
+
+template <int KF>
+__global__ __launch_bounds__(256) void conv1_wgrad_kernel(Conv1Args p) {
+  constexpr int PA = 100;           // 96 columns (3 MFMA row blocks of dW) + 4; columns KF..95 stay zero
+  constexpr int QF = KF / 4;        // floats per A-staging thread (4 threads per row)
+  constexpr int NL = QF / 2;
+  __shared__ float sA[2][UM * PA];
+  __shared__ float sG[2][UM * NOUT];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  for (int i = tid; i < 2 * UM * PA; i += 256) (&sA[0][0])[i] = 0.f;
+  const int64_t m_begin = (int64_t)blockIdx.x * p.chunk;
+  const int64_t m_end = m_begin + p.chunk < p.M ? m_begin + p.chunk : p.M;
+  const int arow = tid >> 2, aq = tid & 3;
+  float2 ra[NL];
+  float4 rg[8];
+  auto load_unit = [&](int64_t mb) {
+    const int64_t m = mb + arow;
+    if (m < m_end) {
+      const int64_t b = m / p.g.L_out;
+      const int t = (int)(m - b * p.g.L_out);
+      const float* xb = p.x + b * p.g.x_batch_stride;
+      const int e0 = t * p.g.stride_t + p.g.base_off + aq * QF;
+#pragma unroll
+      for (int i = 0; i < NL; ++i) ra[i] = load2_or_zero(xb, e0 + 2 * i, p.g.x_len);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NL; ++i) ra[i] = make_float2(0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = tid + i * 256;
+      const int64_t gm = mb + (idx >> 5);
+      rg[i] = gm < m_end ? *reinterpret_cast<const float4*>(p.G + gm * NOUT + (idx & 31) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_unit = [&](int buf) {
+    float* dst = &sA[buf][arow * PA + aq * QF];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) *reinterpret_cast<float2*>(dst + 2 * i) = ra[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = tid + i * 256;
+      *reinterpret_cast<float4*>(&sG[buf][(idx >> 5) * NOUT + (idx & 31) * 4]) = rg[i];
+    }
+  };
+  f32x16 acc[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[j][v] = 0.f;
+  __syncthreads();   // zero fill done before the first rows land
+  if (m_begin < m_end) {
+    load_unit(m_begin);
+    store_unit(0);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (int64_t mb = m_begin; mb < m_end; mb += UM) {
+    const bool has_next = mb + UM < m_end;
+    if (has_next) load_unit(mb + UM);
+    const float* cA = &sA[buf][(lh * 4) * PA + li];
+    const float* cG = &sG[buf][(lh * 4) * NOUT + wave * 32 + li];
+#pragma unroll
+    for (int q = 0; q < UM / 8; ++q) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float gv = cG[(q * 8 + r) * NOUT];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(cA[(q * 8 + r) * PA + j * 32], gv, acc[j], 0, 0, 0);
+      }
+    }
+    if (has_next) store_unit(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  float* slab = p.ws + (int64_t)blockIdx.x * KF * NOUT;
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int k = j * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh;
+      if (k < KF) slab[k * NOUT + wave * 32 + li] = acc[j][v];
+    }
+}
+
+struct WgradPlan {
+  int S;
+  int64_t chunk;
+};
+WgradPlan wgrad_plan(int64_t M) {
+  WgradPlan pl;
+  int64_t chunk = ceil_div64(ceil_div64(M, 256), UM) * UM;   // one 116 KB workgroup per CU, one round
+  if (chunk < UM) chunk = UM;
+  pl.chunk = chunk;
+  pl.S = (int)ceil_div64(M, chunk);
+  return pl;
+}
+
+}  // namespace
+
+bool kws_conv1_supported(const kws_gather_t* g, int N) {
+  static const bool off = getenv("KWS_CONV1_GENERIC") != nullptr;   // A/B: the generic gathered GEMMs of gemm.hip
+  return !off && g && g->taps == 1 && g->cin == 80 && N == NOUT && g->stride_t % 2 == 0 && g->base_off % 2 == 0 &&
+         g->x_batch_stride % 2 == 0 && g->L_out > 0;
+}
+
+int kws_conv1_fwd(const float* x, const kws_gather_t* g, const float* Weff, float* y, int B, int N, float* stats,
+                  hipStream_t st) {
+  KWS_REQUIRE(x && g && Weff && y && B > 0 && kws_conv1_supported(g, N), "conv1_fwd: unsupported shape");
+  Conv1Args a{};
+  a.x = x; a.W = Weff; a.y = y; a.stats = stats; a.g = *g; a.B = B; a.M = (int64_t)B * g->L_out;
+  a.m_tiles = (int)ceil_div64(a.M, BM);
+  KwsProfScope prof("gemm_nn", 2.0 * a.M * 80 * N, 4.0 * ((double)B * g->x_len + (double)a.M * N + 80.0 * N), st);
+  const int grid = a.m_tiles < 256 ? a.m_tiles : 256;   // 131 KB of LDS: one persistent workgroup per CU
+  if (stats) hipLaunchKernelGGL((conv1_fwd_kernel<80, true>), dim3(grid), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((conv1_fwd_kernel<80, false>), dim3(grid), dim3(256), 0, st, a);
+  KWS_LAUNCH_CHECK("conv1_fwd_kernel");
+  return KWS_OK;
+}
+
+int64_t kws_conv1_wgrad_workspace_floats(int64_t M) { return (int64_t)wgrad_plan(M).S * 80 * NOUT; }
+
+int kws_conv1_wgrad(const float* x, const kws_gather_t* g, const float* G, float* dWeff, int B, int N, float* workspace,
+                    hipStream_t st) {
+  KWS_REQUIRE(x && g && G && dWeff && workspace && B > 0 && kws_conv1_supported(g, N), "conv1_wgrad: unsupported shape");
+  Conv1Args a{};
+  a.x = x; a.G = G; a.ws = workspace; a.g = *g; a.B = B; a.M = (int64_t)B * g->L_out;
+  const WgradPlan pl = wgrad_plan(a.M);
+  a.S = pl.S; a.chunk = pl.chunk;
+  KwsProfScope prof("gemm_tn", 2.0 * a.M * 80 * N, 4.0 * ((double)B * g->x_len + (double)a.M * N + 80.0 * N), st);
+  hipLaunchKernelGGL((conv1_wgrad_kernel<80>), dim3(pl.S), dim3(256), 0, st, a);
+  KWS_LAUNCH_CHECK("conv1_wgrad_kernel");
+  return kws_reduce_slabs_f32(workspace, dWeff, (int64_t)80 * N, pl.S, st);
+}

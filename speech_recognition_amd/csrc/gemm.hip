@@ -1377,6 +1377,14 @@ int kws_transpose_f32(const float* in, float* out, int rows, int cols, void* str
   return KWS_OK;
 }
 
+int kws_reduce_slabs_f32(const float* ws, float* out, int64_t n, int S, hipStream_t st) {
+  KWS_REQUIRE(ws && out && n > 0 && n % 4 == 0 && S > 0, "reduce_slabs: bad arguments");
+  const int64_t n4 = n / 4;
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)ceil_div64(n4, 64)), dim3(256), 0, st, ws, out, n4, S);
+  KWS_LAUNCH_CHECK("reduce_slabs_kernel");
+  return KWS_OK;
+}
+
 // internal (net.hip): n <= KWS_TRANSPOSE_BATCH row-major [rows[i], cols[i]] matrices -> their transposes, one launch
 int kws_transpose_batch_f32(const float* const* in, float* const* out, const int* rows, const int* cols, int n,
                             hipStream_t stream) {

@@ -13,6 +13,16 @@ constexpr int KWS_SMALL_WGRAD_SLICES = 32;  // scratch: KWS_SMALL_WGRAD_SLICES *
 int kws_small_wgrad_launch(const float* X, const float* D, float* out, float* out_bias, int B, int K, int N,
                            float* scratch, hipStream_t st);
 int kws_metrics_launch(const float* per_loss, const float* per_correct, int B, float* metrics, hipStream_t st);
+// conv1.hip: the raw-waveform net's folded first convolution as a Toeplitz GEMM (forward with BN statistics rows, weight
+// gradient with its own slab workspace); kws_conv1_supported() says whether a gather descriptor / width qualifies
+bool kws_conv1_supported(const kws_gather_t* g, int N);
+int kws_conv1_fwd(const float* x, const kws_gather_t* g, const float* Weff, float* y, int B, int N, float* stats,
+                  hipStream_t st);
+int64_t kws_conv1_wgrad_workspace_floats(int64_t M);
+int kws_conv1_wgrad(const float* x, const kws_gather_t* g, const float* G, float* dWeff, int B, int N, float* workspace,
+                    hipStream_t st);
+// gemm.hip: out[i] = sum over S slabs of ws[s][i], fixed order (n % 4 == 0)
+extern "C" int kws_reduce_slabs_f32(const float* ws, float* out, int64_t n, int S, hipStream_t st);
 constexpr int KWS_TRANSPOSE_BATCH = 16;
 extern "C" int kws_transpose_batch_f32(const float* const* in, float* const* out, const int* rows, const int* cols, int n,
                                        hipStream_t stream);

@@ -187,7 +187,8 @@ void make_layout(const kws_net* n, int B, bool training, Layout* lo) {
   int64_t max_y = (int64_t)B * n->L1 * n->C1, max_z = 0, max_part = 0, max_dwpart = 0, max_tn = 0;
   int maxC = n->C1;
   max_part = (int64_t)kws_gemm_num_row_tiles((int64_t)B * n->L1) * 2 * n->C1;
-  max_tn = kws_gemm_tn_workspace_floats((int64_t)B * n->L1, n->K1f, n->C1);
+  max_tn = std::max(kws_gemm_tn_workspace_floats((int64_t)B * n->L1, n->K1f, n->C1),
+                    kws_conv1_wgrad_workspace_floats((int64_t)B * n->L1));
   for (int i = 0; i < nb; ++i) {
     const Block& b = n->blocks[i];
     const int64_t M = (int64_t)B * b.Lout;
@@ -364,7 +365,10 @@ int kws_net_predict(const kws_net_t* net, const float* params, const float* stat
   KWS_TRY(prep(net->bn1, 0));
   for (int i = 0; i < nb; ++i) KWS_TRY(prep(net->blocks[i].bn, i + 1));
   KWS_TRY(fold_conv1(net, params, ws + lo.w1f, st));
-  KWS_TRY(kws_gemm_gather_f32(x, &net->gather1f, ws + lo.w1f, ws + lo.y[0], B, net->C1, nullptr, st));
+  if (kws_conv1_supported(&net->gather1f, net->C1))
+    KWS_TRY(kws_conv1_fwd(x, &net->gather1f, ws + lo.w1f, ws + lo.y[0], B, net->C1, nullptr, st));
+  else
+    KWS_TRY(kws_gemm_gather_f32(x, &net->gather1f, ws + lo.w1f, ws + lo.y[0], B, net->C1, nullptr, st));
   for (int i = 0; i < nb; ++i) {
     const Block& b = net->blocks[i];
     KWS_TRY(kws_dwconv_fwd_f32(ws + lo.y[i], bn_at(i), params + b.dw, ws + lo.z[i], B, b.Lin, b.Lout, b.cin, b.stride,
@@ -412,7 +416,10 @@ int kws_net_train_fwd_bwd(const kws_net_t* net, const float* params, float* stat
   {
     const int64_t M = (int64_t)B * net->L1;
     KWS_TRY(fold_conv1(net, params, ws + lo.w1f, st));
-    KWS_TRY(kws_gemm_gather_f32(x, &net->gather1f, ws + lo.w1f, ws + lo.y[0], B, net->C1, part, st));
+    if (kws_conv1_supported(&net->gather1f, net->C1))
+      KWS_TRY(kws_conv1_fwd(x, &net->gather1f, ws + lo.w1f, ws + lo.y[0], B, net->C1, part, st));
+    else
+      KWS_TRY(kws_gemm_gather_f32(x, &net->gather1f, ws + lo.w1f, ws + lo.y[0], B, net->C1, part, st));
     KWS_TRY(kws_bn_stats_finalize(part, kws_gemm_gather_stats_rows(M), M, net->C1, params + net->bn1.gamma,
                                   params + net->bn1.beta, BN_EPS, BN_MOMENTUM, state + net->bn1.mm, state + net->bn1.mv,
                                   bn_at(0), red, st));
@@ -522,7 +529,10 @@ int kws_net_train_fwd_bwd(const kws_net_t* net, const float* params, float* stat
       KWS_HIP(hipEventRecord(net->ev_join, net->side));
       KWS_HIP(hipStreamWaitEvent(st, net->ev_join, 0));
     }
-    KWS_TRY(kws_gemm_tn_gather_f32(x, &net->gather1f, Gb[0], ws + lo.g1f, B, net->C1, ws + lo.tn, st));
+    if (kws_conv1_supported(&net->gather1f, net->C1))
+      KWS_TRY(kws_conv1_wgrad(x, &net->gather1f, Gb[0], ws + lo.g1f, B, net->C1, ws + lo.tn, st));
+    else
+      KWS_TRY(kws_gemm_tn_gather_f32(x, &net->gather1f, Gb[0], ws + lo.g1f, B, net->C1, ws + lo.tn, st));
     KWS_TRY(unfold_conv1(net, ws + lo.g1f, grads, st));
   }
   return KWS_OK;

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("env", [
-    {"KWS_GEMM_PERSIST": "1", "KWS_GEMM_TN_V1": "1", "KWS_TAIL_GENERIC": "1"},
+    {"KWS_GEMM_PERSIST": "1", "KWS_GEMM_TN_V1": "1", "KWS_TAIL_GENERIC": "1", "KWS_CONV1_GENERIC": "1"},
     {"KWS_OVERLAP": "1"},
     {"KWS_STFT_V2": "1"},
 ])
