@@ -9,7 +9,7 @@ for r in csv.DictReader(open(sys.argv[1])):
     name = r["Kernel_Name"].replace("void ", "")
     m = re.search(r"(?:\(anonymous namespace\)::)?(\w+)(?:<[^(]*>)?\(", name)
     k = m.group(1) if m else name[:60]
-    if "gemm" not in k:
+    if "gemm" not in k and "conv1" not in k:
         continue
     if r["Counter_Name"] == "SQ_VALU_MFMA_BUSY_CYCLES":
         busy[k] += float(r["Counter_Value"])
