@@ -11,8 +11,14 @@
 //     128 columns), next tile's rows in flight in registers while the current one is multiplied; BN column sums per tile
 //     like the generic gathered kernel (one statistics row per 128-row tile);
 //   * weight gradient: dW[80, 128] = A^T G split over M into one slab per workgroup (fixed-order slab sum afterwards),
-//     64-row units of A and G double-buffered in LDS, wave w owns output columns [32 w, 32 w + 32) x 96 rows (3 MFMA blocks,
-//     rows 80..95 multiply LDS zeros).
+//     32-row units of A and G double-buffered in LDS (58 KB: two workgroups per CU hide each other's load latency; 64-row
+//     units with one workgroup per CU took 157 us instead of 127), wave w owns output columns [32 w, 32 w + 32) x 96 rows
+//     (3 MFMA blocks, rows 80..95 multiply LDS zeros).
+// Three things the compiler had to be told (each visible in the ISA): selecting between a row pointer and a `const`
+// zero buffer makes the loads FLAT loads (the zero buffer is a plain __device__ array); the next tile's global loads
+// sink below the MFMA loop unless a memory clobber pins them; the LDS operand reads are issued one pair at a time with
+// lgkmcnt(0) in front of every two MFMAs unless the next K group's reads are written out and fenced with
+// __builtin_amdgcn_sched_barrier (168 -> 157 us).
 #include "internal.h"
 
 namespace {
@@ -21,7 +27,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int NOUT = 128;   // output channels (filter_mult 1)
 constexpr int BM = 128;     // forward row tile
-constexpr int UM = 64;      // weight-gradient row unit
+constexpr int UM = 32;      // weight-gradient row unit (58 KB of LDS per workgroup: two workgroups per CU hide each other's loads)
 
 struct Conv1Args {
   const float* x;
@@ -34,6 +40,11 @@ struct Conv1Args {
   int B, m_tiles, S;
   int64_t M, chunk;
 };
+
+// Rows that lie fully inside their clip (all but the first row of a clip) are read with unconditional 8-byte loads; the
+// others - and the rows past M - read this zero buffer instead, and only a row that straddles the clip start is patched
+// element by element.  (A per-load `inside ? load : 0` compiles to a branch and a vmcnt(0) per load.)
+__device__ __attribute__((aligned(16))) float g_zero64[64] = {0.f};   // not const: a constant-address-space operand turns the selected loads into flat loads
 
 __device__ __forceinline__ float2 load2_or_zero(const float* xb, int pos, int x_len) {
   if (pos >= 0 && pos + 1 < x_len) return *reinterpret_cast<const float2*>(xb + pos);
@@ -58,16 +69,18 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(Conv1Args p) {
   float2 ra[NL];
   auto load_rows = [&](int tile) {
     const int64_t m = (int64_t)tile * BM + srow;
-    if (m < p.M) {
-      const int64_t b = m / p.g.L_out;
-      const int t = (int)(m - b * p.g.L_out);
-      const float* xb = p.x + b * p.g.x_batch_stride;
-      const int e0 = t * p.g.stride_t + p.g.base_off + shalf * HALF;
+    const bool row_ok = m < p.M;
+    const int64_t b = row_ok ? m / p.g.L_out : 0;
+    const int t = row_ok ? (int)(m - b * p.g.L_out) : 0;
+    const float* xb = p.x + b * p.g.x_batch_stride;
+    const int e0 = t * p.g.stride_t + p.g.base_off + shalf * HALF;
+    const bool inside = row_ok && e0 >= 0 && e0 + HALF <= p.g.x_len;
+    const float* src = inside ? xb + e0 : g_zero64;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) ra[i] = *reinterpret_cast<const float2*>(src + 2 * i);
+    if (row_ok && !inside) {
 #pragma unroll
       for (int i = 0; i < NL; ++i) ra[i] = load2_or_zero(xb, e0 + 2 * i, p.g.x_len);
-    } else {
-#pragma unroll
-      for (int i = 0; i < NL; ++i) ra[i] = make_float2(0.f, 0.f);
     }
   };
   auto store_rows = [&](int buf) {
@@ -85,6 +98,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(Conv1Args p) {
     const int next = tile + gridDim.x;
     const bool has_next = next < p.m_tiles;
     if (has_next) load_rows(next);
+    asm volatile("" ::: "memory");   // the loads are issued HERE (the scheduler otherwise sinks them below the MFMA loop)
     f32x16 acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -92,26 +106,53 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(Conv1Args p) {
       for (int v = 0; v < 16; ++v) acc[j][v] = 0.f;
     const float* cA = &sA[buf][(wave * 32 + li) * PA + lh * 4];
     const float* cB = sW + (lh * 4) * NOUT + li;
+    // operands of K group q+1 are read from LDS while the 16 MFMAs of group q issue (written out: left to itself the
+    // compiler reads one operand pair, waits for it, issues two MFMAs, reads the next pair ...)
+    float4 a_cur = *reinterpret_cast<const float4*>(cA), a_nxt = a_cur;
+    float b_cur[4][4], b_nxt[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b_cur[r][j] = cB[r * NOUT + j * 32];
 #pragma unroll
     for (int q = 0; q < KF / 8; ++q) {
-      const float4 a = *reinterpret_cast<const float4*>(cA + q * 8);
+      if (q + 1 < KF / 8) {
+        a_nxt = *reinterpret_cast<const float4*>(cA + (q + 1) * 8);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) b_nxt[r][j] = cB[((q + 1) * 8 + r) * NOUT + j * 32];
+      }
+      __builtin_amdgcn_sched_barrier(0);   // the reads above stay above the MFMAs below
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float av = r == 0 ? a.x : (r == 1 ? a.y : (r == 2 ? a.z : a.w));
+        const float av = r == 0 ? a_cur.x : (r == 1 ? a_cur.y : (r == 2 ? a_cur.z : a_cur.w));
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, cB[(q * 8 + r) * NOUT + j * 32], acc[j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b_cur[r][j], acc[j], 0, 0, 0);
       }
+      a_cur = a_nxt;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b_cur[r][j] = b_nxt[r][j];
     }
     // epilogue: a store instruction covers 2 rows x 32 consecutive columns (two 128-byte segments)
     const int64_t m0 = (int64_t)tile * BM + wave * 32 + 4 * lh;
+    if ((int64_t)(tile + 1) * BM <= p.M) {   // whole tile inside: no per-row test
+      float* y0 = p.y + m0 * NOUT + li;
 #pragma unroll
-    for (int v = 0; v < 16; ++v) {
-      const int64_t m = m0 + (v & 3) + 8 * (v >> 2);
-      if (m < p.M) {
-        float* yr = p.y + m * NOUT + li;
+      for (int v = 0; v < 16; ++v)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) yr[j * 32] = acc[j][v];
+        for (int j = 0; j < 4; ++j) y0[((v & 3) + 8 * (v >> 2)) * NOUT + j * 32] = acc[j][v];
+    } else {
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int64_t m = m0 + (v & 3) + 8 * (v >> 2);
+        if (m < p.M) {
+          float* yr = p.y + m * NOUT + li;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) yr[j * 32] = acc[j][v];
+        }
       }
     }
     if (STATS) {
@@ -145,7 +186,10 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(Conv1Args p) {
 template <int KF>
 __global__ __launch_bounds__(256) void conv1_wgrad_kernel(Conv1Args p) {
   constexpr int PA = 100;           // 96 columns (3 MFMA row blocks of dW) + 4; columns KF..95 stay zero
-  constexpr int QF = KF / 4;        // floats per A-staging thread (4 threads per row)
+  constexpr int TPR = 256 / UM;     // A-staging threads per row
+  constexpr int QF = KF / TPR;      // floats per A-staging thread
+  constexpr int NG = UM / 8;        // 16-byte loads of dy per thread
+  static_assert(KF % (2 * TPR) == 0, "8-byte staging loads");
   constexpr int NL = QF / 2;
   __shared__ float sA[2][UM * PA];
   __shared__ float sG[2][UM * NOUT];
@@ -153,27 +197,30 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(Conv1Args p) {
   for (int i = tid; i < 2 * UM * PA; i += 256) (&sA[0][0])[i] = 0.f;
   const int64_t m_begin = (int64_t)blockIdx.x * p.chunk;
   const int64_t m_end = m_begin + p.chunk < p.M ? m_begin + p.chunk : p.M;
-  const int arow = tid >> 2, aq = tid & 3;
+  const int arow = tid / TPR, aq = tid % TPR;
   float2 ra[NL];
-  float4 rg[8];
+  float4 rg[NG];
   auto load_unit = [&](int64_t mb) {
     const int64_t m = mb + arow;
-    if (m < m_end) {
-      const int64_t b = m / p.g.L_out;
-      const int t = (int)(m - b * p.g.L_out);
-      const float* xb = p.x + b * p.g.x_batch_stride;
-      const int e0 = t * p.g.stride_t + p.g.base_off + aq * QF;
+    const bool row_ok = m < m_end;
+    const int64_t b = row_ok ? m / p.g.L_out : 0;
+    const int t = row_ok ? (int)(m - b * p.g.L_out) : 0;
+    const float* xb = p.x + b * p.g.x_batch_stride;
+    const int e0 = t * p.g.stride_t + p.g.base_off + aq * QF;
+    const bool inside = row_ok && e0 >= 0 && e0 + QF <= p.g.x_len;
+    const float* src = inside ? xb + e0 : g_zero64;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) ra[i] = *reinterpret_cast<const float2*>(src + 2 * i);
+    if (row_ok && !inside) {
 #pragma unroll
       for (int i = 0; i < NL; ++i) ra[i] = load2_or_zero(xb, e0 + 2 * i, p.g.x_len);
-    } else {
-#pragma unroll
-      for (int i = 0; i < NL; ++i) ra[i] = make_float2(0.f, 0.f);
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NG; ++i) {
       const int idx = tid + i * 256;
       const int64_t gm = mb + (idx >> 5);
-      rg[i] = gm < m_end ? *reinterpret_cast<const float4*>(p.G + gm * NOUT + (idx & 31) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float* gsrc = gm < m_end ? p.G + gm * NOUT + (idx & 31) * 4 : g_zero64;   // address select, not a branch
+      rg[i] = *reinterpret_cast<const float4*>(gsrc);
     }
   };
   auto store_unit = [&](int buf) {
@@ -181,7 +228,7 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(Conv1Args p) {
 #pragma unroll
     for (int i = 0; i < NL; ++i) *reinterpret_cast<float2*>(dst + 2 * i) = ra[i];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NG; ++i) {
       const int idx = tid + i * 256;
       *reinterpret_cast<float4*>(&sG[buf][(idx >> 5) * NOUT + (idx & 31) * 4]) = rg[i];
     }
@@ -201,16 +248,36 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(Conv1Args p) {
   for (int64_t mb = m_begin; mb < m_end; mb += UM) {
     const bool has_next = mb + UM < m_end;
     if (has_next) load_unit(mb + UM);
+    asm volatile("" ::: "memory");   // keep the next unit's loads above the MFMA loop
     const float* cA = &sA[buf][(lh * 4) * PA + li];
     const float* cG = &sG[buf][(lh * 4) * NOUT + wave * 32 + li];
+    float a_cur[4][3], g_cur[4], a_nxt[4][3], g_nxt[4];   // software-pipelined LDS reads, as in the forward kernel
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      g_cur[r] = cG[r * NOUT];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) a_cur[r][j] = cA[r * PA + j * 32];
+    }
 #pragma unroll
     for (int q = 0; q < UM / 8; ++q) {
+      if (q + 1 < UM / 8) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          g_nxt[r] = cG[((q + 1) * 8 + r) * NOUT];
+#pragma unroll
+          for (int j = 0; j < 3; ++j) a_nxt[r][j] = cA[((q + 1) * 8 + r) * PA + j * 32];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);   // the reads above stay above the MFMAs below
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[r][j], g_cur[r], acc[j], 0, 0, 0);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float gv = cG[(q * 8 + r) * NOUT];
+        g_cur[r] = g_nxt[r];
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(cA[(q * 8 + r) * PA + j * 32], gv, acc[j], 0, 0, 0);
+        for (int j = 0; j < 3; ++j) a_cur[r][j] = a_nxt[r][j];
       }
     }
     if (has_next) store_unit(buf ^ 1);
@@ -233,7 +300,7 @@ struct WgradPlan {
 };
 WgradPlan wgrad_plan(int64_t M) {
   WgradPlan pl;
-  int64_t chunk = ceil_div64(ceil_div64(M, 256), UM) * UM;   // one 116 KB workgroup per CU, one round
+  int64_t chunk = ceil_div64(ceil_div64(M, 512), UM) * UM;   // two workgroups per CU, one round
   if (chunk < UM) chunk = UM;
   pl.chunk = chunk;
   pl.S = (int)ceil_div64(M, chunk);
