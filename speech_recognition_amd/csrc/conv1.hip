@@ -7,9 +7,8 @@
 // at batch 1024).  These two kernels are shaped for this one operand instead:
 //   * the whole K extent (80) of a row tile is staged at once, two threads per row reading 8-byte pairs (the rows are
 //     8-byte aligned: stride 40, offset -10), zero filled outside the clip; no K loop, no per-slab barrier;
-//   * forward: persistent workgroups keep the folded [80, 128] kernel in LDS for all their tiles, 4 waves x (32 rows x
-//     128 columns), next tile's rows in flight in registers while the current one is multiplied; BN column sums per tile
-//     like the generic gathered kernel (one statistics row per 128-row tile);
+//   * forward: persistent workgroups hold the folded [80, 128] kernel in REGISTERS for all their tiles (see the kernel),
+//     next tile's rows in flight in registers while the current one is multiplied; one BN statistics row per workgroup;
 //   * weight gradient: dW[80, 128] = A^T G split over M into one slab per workgroup (fixed-order slab sum afterwards),
 //     32-row units of A and G double-buffered in LDS (58 KB: two workgroups per CU hide each other's load latency; 64-row
 //     units with one workgroup per CU took 157 us instead of 127), wave w owns output columns [32 w, 32 w + 32) x 96 rows
@@ -26,7 +25,7 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int NOUT = 128;   // output channels (filter_mult 1)
-constexpr int BM = 128;     // forward row tile
+constexpr int FM = 64;      // forward row tile
 constexpr int UM = 32;      // weight-gradient row unit (58 KB of LDS per workgroup: two workgroups per CU hide each other's loads)
 
 struct Conv1Args {
@@ -54,27 +53,38 @@ __device__ __forceinline__ float2 load2_or_zero(const float* xb, int pos, int x_
   return v;
 }
 
+// Forward.  64-row tiles, wave (wr, wc) = (wave / 2, wave % 2) computes rows [32 wr, 32 wr + 32) x columns [64 wc, 64 wc + 64).
+// The folded kernel never touches LDS: lane (li, lh) needs W[8 q + 4 lh + r][64 wc + 32 jj + li] for every K group q -
+// 80 values that stay in registers for all tiles of the persistent workgroup, so the MFMA loop reads ONE 16-byte LDS
+// operand per 8 MFMAs.  43 KB of LDS (double-buffered rows) -> three workgroups per CU hide each other's epilogues and
+// loads.  BN statistics: every wave keeps running column sums over all its tiles; ONE row per workgroup at the end.
 template <int KF, bool STATS>
-__global__ __launch_bounds__(256) void conv1_fwd_kernel(Conv1Args p) {
+__global__ __launch_bounds__(256, 3) void conv1_fwd_kernel(Conv1Args p) {
   constexpr int PA = KF + 4;        // LDS row pitch of the staged rows (16-byte aligned fragments)
-  constexpr int HALF = KF / 2;      // floats per staging thread
-  constexpr int NL = HALF / 2;      // 8-byte loads per staging thread
-  __shared__ float sW[KF * NOUT];
-  __shared__ float sA[2][BM * PA];
-  __shared__ float sRed[2][4][NOUT];
+  constexpr int QF = KF / 4;        // floats per staging thread (4 threads per row)
+  constexpr int NL = QF / 2;        // 8-byte loads per staging thread
+  constexpr int NQ = KF / 8;
+  __shared__ float sA[2][FM * PA];
+  __shared__ float sRed[2][2][NOUT];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
-  for (int i = tid; i < KF * NOUT / 4; i += 256)
-    reinterpret_cast<float4*>(sW)[i] = reinterpret_cast<const float4*>(p.W)[i];
-  const int srow = tid >> 1, shalf = tid & 1;
+  const int wr = wave >> 1, wc = wave & 1;
+  float wreg[NQ][4][2];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) wreg[q][r][jj] = p.W[(q * 8 + lh * 4 + r) * NOUT + wc * 64 + jj * 32 + li];
+  const int srow = tid >> 2, sq = tid & 3;
   float2 ra[NL];
   auto load_rows = [&](int tile) {
-    const int64_t m = (int64_t)tile * BM + srow;
+    const int64_t m = (int64_t)tile * FM + srow;
     const bool row_ok = m < p.M;
     const int64_t b = row_ok ? m / p.g.L_out : 0;
     const int t = row_ok ? (int)(m - b * p.g.L_out) : 0;
     const float* xb = p.x + b * p.g.x_batch_stride;
-    const int e0 = t * p.g.stride_t + p.g.base_off + shalf * HALF;
-    const bool inside = row_ok && e0 >= 0 && e0 + HALF <= p.g.x_len;
+    const int e0 = t * p.g.stride_t + p.g.base_off + sq * QF;
+    const bool inside = row_ok && e0 >= 0 && e0 + QF <= p.g.x_len;
     const float* src = inside ? xb + e0 : g_zero64;
 #pragma unroll
     for (int i = 0; i < NL; ++i) ra[i] = *reinterpret_cast<const float2*>(src + 2 * i);
@@ -84,14 +94,16 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(Conv1Args p) {
     }
   };
   auto store_rows = [&](int buf) {
-    float* dst = &sA[buf][srow * PA + shalf * HALF];
+    float* dst = &sA[buf][srow * PA + sq * QF];
 #pragma unroll
     for (int i = 0; i < NL; ++i) *reinterpret_cast<float2*>(dst + 2 * i) = ra[i];
   };
+  float st_s[2] = {0.f, 0.f}, st_ss[2] = {0.f, 0.f};
   int tile = blockIdx.x;
-  if (tile >= p.m_tiles) return;
-  load_rows(tile);
-  store_rows(0);
+  if (tile < p.m_tiles) {
+    load_rows(tile);
+    store_rows(0);
+  }
   __syncthreads();
   int buf = 0;
   for (; tile < p.m_tiles; tile += gridDim.x) {
@@ -99,87 +111,73 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(Conv1Args p) {
     const bool has_next = next < p.m_tiles;
     if (has_next) load_rows(next);
     asm volatile("" ::: "memory");   // the loads are issued HERE (the scheduler otherwise sinks them below the MFMA loop)
-    f32x16 acc[4];
+    f32x16 acc[2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-      for (int v = 0; v < 16; ++v) acc[j][v] = 0.f;
-    const float* cA = &sA[buf][(wave * 32 + li) * PA + lh * 4];
-    const float* cB = sW + (lh * 4) * NOUT + li;
-    // operands of K group q+1 are read from LDS while the 16 MFMAs of group q issue (written out: left to itself the
-    // compiler reads one operand pair, waits for it, issues two MFMAs, reads the next pair ...)
-    float4 a_cur = *reinterpret_cast<const float4*>(cA), a_nxt = a_cur;
-    float b_cur[4][4], b_nxt[4][4];
+      for (int v = 0; v < 16; ++v) acc[jj][v] = 0.f;
+    const float* cA = &sA[buf][(wr * 32 + li) * PA + lh * 4];
+    // operand reads run two K groups ahead of the MFMAs (pinned: left alone the compiler reads one operand, waits, issues)
+    float4 av[3];
+    av[0] = *reinterpret_cast<const float4*>(cA);
+    av[1] = *reinterpret_cast<const float4*>(cA + 8);
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) b_cur[r][j] = cB[r * NOUT + j * 32];
-#pragma unroll
-    for (int q = 0; q < KF / 8; ++q) {
-      if (q + 1 < KF / 8) {
-        a_nxt = *reinterpret_cast<const float4*>(cA + (q + 1) * 8);
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) b_nxt[r][j] = cB[((q + 1) * 8 + r) * NOUT + j * 32];
-      }
-      __builtin_amdgcn_sched_barrier(0);   // the reads above stay above the MFMAs below
+    for (int q = 0; q < NQ; ++q) {
+      if (q + 2 < NQ) av[(q + 2) % 3] = *reinterpret_cast<const float4*>(cA + (q + 2) * 8);
+      __builtin_amdgcn_sched_barrier(0);
+      const float4 ac = av[q % 3];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float av = r == 0 ? a_cur.x : (r == 1 ? a_cur.y : (r == 2 ? a_cur.z : a_cur.w));
+        const float a = r == 0 ? ac.x : (r == 1 ? ac.y : (r == 2 ? ac.z : ac.w));
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b_cur[r][j], acc[j], 0, 0, 0);
+        for (int jj = 0; jj < 2; ++jj) acc[jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wreg[q][r][jj], acc[jj], 0, 0, 0);
       }
-      a_cur = a_nxt;
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) b_cur[r][j] = b_nxt[r][j];
+      __builtin_amdgcn_sched_barrier(0);
     }
     // epilogue: a store instruction covers 2 rows x 32 consecutive columns (two 128-byte segments)
-    const int64_t m0 = (int64_t)tile * BM + wave * 32 + 4 * lh;
-    if ((int64_t)(tile + 1) * BM <= p.M) {   // whole tile inside: no per-row test
-      float* y0 = p.y + m0 * NOUT + li;
+    const int64_t m0 = (int64_t)tile * FM + wr * 32 + 4 * lh;
+    if ((int64_t)(tile + 1) * FM <= p.M) {   // whole tile inside: no per-row test
+      float* y0 = p.y + m0 * NOUT + wc * 64 + li;
 #pragma unroll
       for (int v = 0; v < 16; ++v)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) y0[((v & 3) + 8 * (v >> 2)) * NOUT + j * 32] = acc[j][v];
+        for (int jj = 0; jj < 2; ++jj) y0[((v & 3) + 8 * (v >> 2)) * NOUT + jj * 32] = acc[jj][v];
     } else {
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
         const int64_t m = m0 + (v & 3) + 8 * (v >> 2);
         if (m < p.M) {
-          float* yr = p.y + m * NOUT + li;
+          float* yr = p.y + m * NOUT + wc * 64 + li;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) yr[j * 32] = acc[j][v];
+          for (int jj = 0; jj < 2; ++jj) yr[jj * 32] = acc[jj][v];
         }
       }
     }
-    if (STATS) {
+    if (STATS) {   // rows past M were staged as zeros: they add nothing
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float s = 0.f, ss = 0.f;
+      for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
-          s += acc[j][v];
-          ss = fmaf(acc[j][v], acc[j][v], ss);
+          st_s[jj] += acc[jj][v];
+          st_ss[jj] = fmaf(acc[jj][v], acc[jj][v], st_ss[jj]);
         }
-        s += __shfl_xor(s, 32);
-        ss += __shfl_xor(ss, 32);
-        if (lh == 0) {
-          sRed[0][wave][j * 32 + li] = s;
-          sRed[1][wave][j * 32 + li] = ss;
-        }
-      }
     }
     if (has_next) store_rows(buf ^ 1);
     __syncthreads();
-    if (STATS) {
-      const int q = tid >> 7, c = tid & 127;
-      p.stats[((int64_t)tile * 2 + q) * NOUT + c] = ((sRed[q][0][c] + sRed[q][1][c]) + sRed[q][2][c]) + sRed[q][3][c];
-      __syncthreads();   // sRed is rewritten by the next tile
-    }
     buf ^= 1;
+  }
+  if (STATS) {
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const float s = st_s[jj] + __shfl_xor(st_s[jj], 32), ss = st_ss[jj] + __shfl_xor(st_ss[jj], 32);
+      if (lh == 0) {
+        sRed[0][wr][wc * 64 + jj * 32 + li] = s;
+        sRed[1][wr][wc * 64 + jj * 32 + li] = ss;
+      }
+    }
+    __syncthreads();
+    const int q = tid >> 7, c = tid & 127;
+    p.stats[((int64_t)blockIdx.x * 2 + q) * NOUT + c] = sRed[q][0][c] + sRed[q][1][c];
   }
 }
 
@@ -309,6 +307,12 @@ WgradPlan wgrad_plan(int64_t M) {
 
 }  // namespace
 
+// statistics rows the forward kernel writes = its grid: three persistent 43 KB workgroups per CU
+int kws_conv1_stats_rows(int64_t M) {
+  const int64_t tiles = ceil_div64(M, FM);
+  return (int)(tiles < 768 ? tiles : 768);
+}
+
 bool kws_conv1_supported(const kws_gather_t* g, int N) {
   static const bool off = getenv("KWS_CONV1_GENERIC") != nullptr;   // A/B: the generic gathered GEMMs of gemm.hip
   return !off && g && g->taps == 1 && g->cin == 80 && N == NOUT && g->stride_t % 2 == 0 && g->base_off % 2 == 0 &&
@@ -320,9 +324,9 @@ int kws_conv1_fwd(const float* x, const kws_gather_t* g, const float* Weff, floa
   KWS_REQUIRE(x && g && Weff && y && B > 0 && kws_conv1_supported(g, N), "conv1_fwd: unsupported shape");
   Conv1Args a{};
   a.x = x; a.W = Weff; a.y = y; a.stats = stats; a.g = *g; a.B = B; a.M = (int64_t)B * g->L_out;
-  a.m_tiles = (int)ceil_div64(a.M, BM);
+  a.m_tiles = (int)ceil_div64(a.M, FM);
   KwsProfScope prof("gemm_nn", 2.0 * a.M * 80 * N, 4.0 * ((double)B * g->x_len + (double)a.M * N + 80.0 * N), st);
-  const int grid = a.m_tiles < 256 ? a.m_tiles : 256;   // 131 KB of LDS: one persistent workgroup per CU
+  const int grid = kws_conv1_stats_rows(a.M);
   if (stats) hipLaunchKernelGGL((conv1_fwd_kernel<80, true>), dim3(grid), dim3(256), 0, st, a);
   else hipLaunchKernelGGL((conv1_fwd_kernel<80, false>), dim3(grid), dim3(256), 0, st, a);
   KWS_LAUNCH_CHECK("conv1_fwd_kernel");

@@ -16,6 +16,7 @@ int kws_metrics_launch(const float* per_loss, const float* per_correct, int B, f
 // conv1.hip: the raw-waveform net's folded first convolution as a Toeplitz GEMM (forward with BN statistics rows, weight
 // gradient with its own slab workspace); kws_conv1_supported() says whether a gather descriptor / width qualifies
 bool kws_conv1_supported(const kws_gather_t* g, int N);
+int kws_conv1_stats_rows(int64_t M);
 int kws_conv1_fwd(const float* x, const kws_gather_t* g, const float* Weff, float* y, int B, int N, float* stats,
                   hipStream_t st);
 int64_t kws_conv1_wgrad_workspace_floats(int64_t M);

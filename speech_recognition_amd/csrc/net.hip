@@ -420,7 +420,8 @@ int kws_net_train_fwd_bwd(const kws_net_t* net, const float* params, float* stat
       KWS_TRY(kws_conv1_fwd(x, &net->gather1f, ws + lo.w1f, ws + lo.y[0], B, net->C1, part, st));
     else
       KWS_TRY(kws_gemm_gather_f32(x, &net->gather1f, ws + lo.w1f, ws + lo.y[0], B, net->C1, part, st));
-    KWS_TRY(kws_bn_stats_finalize(part, kws_gemm_gather_stats_rows(M), M, net->C1, params + net->bn1.gamma,
+    const int rows1 = kws_conv1_supported(&net->gather1f, net->C1) ? kws_conv1_stats_rows(M) : kws_gemm_gather_stats_rows(M);
+    KWS_TRY(kws_bn_stats_finalize(part, rows1, M, net->C1, params + net->bn1.gamma,
                                   params + net->bn1.beta, BN_EPS, BN_MOMENTUM, state + net->bn1.mm, state + net->bn1.mv,
                                   bn_at(0), red, st));
   }
