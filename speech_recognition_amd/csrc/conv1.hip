@@ -10,9 +10,9 @@
 //   * forward: persistent workgroups hold the folded [80, 128] kernel in REGISTERS for all their tiles (see the kernel),
 //     next tile's rows in flight in registers while the current one is multiplied; one BN statistics row per workgroup;
 //   * weight gradient: dW[80, 128] = A^T G split over M into one slab per workgroup (fixed-order slab sum afterwards),
-//     32-row units of A and G double-buffered in LDS (58 KB: two workgroups per CU hide each other's load latency; 64-row
-//     units with one workgroup per CU took 157 us instead of 127), wave w owns output columns [32 w, 32 w + 32) x 96 rows
-//     (3 MFMA blocks, rows 80..95 multiply LDS zeros).
+//     32-row units; wave w owns output columns [32 w, 32 w + 32) x 96 rows (3 MFMA blocks, rows 80..95 multiply LDS zeros).
+//     Measured alone at batch 1024: 64-row units with A and G in LDS and one workgroup per CU 157 us, 32-row units two
+//     per CU 127 us, G straight into registers and three per CU 111 us (the generic gathered kernel: 156 us).
 // Three things the compiler had to be told (each visible in the ISA): selecting between a row pointer and a `const`
 // zero buffer makes the loads FLAT loads (the zero buffer is a plain __device__ array); the next tile's global loads
 // sink below the MFMA loop unless a memory clobber pins them; the LDS operand reads are issued one pair at a time with
@@ -26,7 +26,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int NOUT = 128;   // output channels (filter_mult 1)
 constexpr int FM = 64;      // forward row tile
-constexpr int UM = 32;      // weight-gradient row unit (58 KB of LDS per workgroup: two workgroups per CU hide each other's loads)
+constexpr int UM = 32;      // weight-gradient row unit
 
 struct Conv1Args {
   const float* x;
@@ -181,23 +181,26 @@ __global__ __launch_bounds__(256, 3) void conv1_fwd_kernel(Conv1Args p) {
   }
 }
 
+// Weight gradient.  dy goes from global memory STRAIGHT into the MFMA operand registers: lane (li, lh) of wave w needs
+// dy[m][32 w + li] for the 16 rows m = 8 q + 4 lh + r of a 32-row unit - per (q, r) the wave reads two rows x 32 consecutive
+// floats, and every dy element is read by exactly one wave.  Only the Toeplitz rows of x pass through LDS (25.6 KB double
+// buffered -> three workgroups per CU).
 template <int KF>
-__global__ __launch_bounds__(256) void conv1_wgrad_kernel(Conv1Args p) {
+__global__ __launch_bounds__(256, 3) void conv1_wgrad_kernel(Conv1Args p) {
   constexpr int PA = 100;           // 96 columns (3 MFMA row blocks of dW) + 4; columns KF..95 stay zero
   constexpr int TPR = 256 / UM;     // A-staging threads per row
   constexpr int QF = KF / TPR;      // floats per A-staging thread
-  constexpr int NG = UM / 8;        // 16-byte loads of dy per thread
+  constexpr int NQ = UM / 8;
   static_assert(KF % (2 * TPR) == 0, "8-byte staging loads");
   constexpr int NL = QF / 2;
   __shared__ float sA[2][UM * PA];
-  __shared__ float sG[2][UM * NOUT];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
   for (int i = tid; i < 2 * UM * PA; i += 256) (&sA[0][0])[i] = 0.f;
   const int64_t m_begin = (int64_t)blockIdx.x * p.chunk;
   const int64_t m_end = m_begin + p.chunk < p.M ? m_begin + p.chunk : p.M;
   const int arow = tid / TPR, aq = tid % TPR;
   float2 ra[NL];
-  float4 rg[NG];
+  float g_cur[NQ][4], g_nxt[NQ][4];
   auto load_unit = [&](int64_t mb) {
     const int64_t m = mb + arow;
     const bool row_ok = m < m_end;
@@ -214,22 +217,24 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(Conv1Args p) {
       for (int i = 0; i < NL; ++i) ra[i] = load2_or_zero(xb, e0 + 2 * i, p.g.x_len);
     }
 #pragma unroll
-    for (int i = 0; i < NG; ++i) {
-      const int idx = tid + i * 256;
-      const int64_t gm = mb + (idx >> 5);
-      const float* gsrc = gm < m_end ? p.G + gm * NOUT + (idx & 31) * 4 : g_zero64;   // address select, not a branch
-      rg[i] = *reinterpret_cast<const float4*>(gsrc);
-    }
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t gm = mb + q * 8 + lh * 4 + r;
+        const float* gsrc = gm < m_end ? p.G + gm * NOUT + wave * 32 + li : g_zero64;   // address select, not a branch
+        g_nxt[q][r] = *gsrc;
+      }
   };
   auto store_unit = [&](int buf) {
     float* dst = &sA[buf][arow * PA + aq * QF];
 #pragma unroll
     for (int i = 0; i < NL; ++i) *reinterpret_cast<float2*>(dst + 2 * i) = ra[i];
+  };
+  auto take_g = [&]() {
 #pragma unroll
-    for (int i = 0; i < NG; ++i) {
-      const int idx = tid + i * 256;
-      *reinterpret_cast<float4*>(&sG[buf][(idx >> 5) * NOUT + (idx & 31) * 4]) = rg[i];
-    }
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) g_cur[q][r] = g_nxt[q][r];
   };
   f32x16 acc[3];
 #pragma unroll
@@ -241,6 +246,7 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(Conv1Args p) {
     load_unit(m_begin);
     store_unit(0);
   }
+  take_g();
   __syncthreads();
   int buf = 0;
   for (int64_t mb = m_begin; mb < m_end; mb += UM) {
@@ -248,37 +254,33 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(Conv1Args p) {
     if (has_next) load_unit(mb + UM);
     asm volatile("" ::: "memory");   // keep the next unit's loads above the MFMA loop
     const float* cA = &sA[buf][(lh * 4) * PA + li];
-    const float* cG = &sG[buf][(lh * 4) * NOUT + wave * 32 + li];
-    float a_cur[4][3], g_cur[4], a_nxt[4][3], g_nxt[4];   // software-pipelined LDS reads, as in the forward kernel
+    float a_cur[4][3], a_nxt[4][3];   // software-pipelined LDS reads, as in the forward kernel
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      g_cur[r] = cG[r * NOUT];
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
       for (int j = 0; j < 3; ++j) a_cur[r][j] = cA[r * PA + j * 32];
-    }
 #pragma unroll
-    for (int q = 0; q < UM / 8; ++q) {
-      if (q + 1 < UM / 8) {
+    for (int q = 0; q < NQ; ++q) {
+      if (q + 1 < NQ) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          g_nxt[r] = cG[((q + 1) * 8 + r) * NOUT];
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
           for (int j = 0; j < 3; ++j) a_nxt[r][j] = cA[((q + 1) * 8 + r) * PA + j * 32];
-        }
       }
       __builtin_amdgcn_sched_barrier(0);   // the reads above stay above the MFMAs below
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[r][j], g_cur[r], acc[j], 0, 0, 0);
+        for (int j = 0; j < 3; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[r][j], g_cur[q][r], acc[j], 0, 0, 0);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        g_cur[r] = g_nxt[r];
+      for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int j = 0; j < 3; ++j) a_cur[r][j] = a_nxt[r][j];
-      }
     }
-    if (has_next) store_unit(buf ^ 1);
+    if (has_next) {
+      store_unit(buf ^ 1);
+      take_g();
+    }
     __syncthreads();
     buf ^= 1;
   }
@@ -298,7 +300,7 @@ struct WgradPlan {
 };
 WgradPlan wgrad_plan(int64_t M) {
   WgradPlan pl;
-  int64_t chunk = ceil_div64(ceil_div64(M, 512), UM) * UM;   // two workgroups per CU, one round
+  int64_t chunk = ceil_div64(ceil_div64(M, 768), UM) * UM;   // three workgroups per CU, one round
   if (chunk < UM) chunk = UM;
   pl.chunk = chunk;
   pl.S = (int)ceil_div64(M, chunk);
