@@ -1063,22 +1063,34 @@ __global__ __launch_bounds__((4 + ((128 / BKO) * (128 / BNO) > 2 ? 4 : 2)) * 64,
 // out[i] = sum_k ws[k][i], k ascending within 4 interleaved groups that are combined in a fixed order
 // (bit-reproducible).  64 float4 columns x 4 slab groups per workgroup so that the S slabs of the small
 // K x N outputs are read by S/4-deep loops on many workgroups instead of S-deep loops on a few.
-__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* ws, float* out, int64_t n4, int S) {
+// Sums S slabs that lie `stride4` float4 apart (the plain case: stride4 = n4).  blockIdx.y selects a GROUP of `per_group`
+// slabs and the sum goes to out + blockIdx.y * out_stride4: the first stage of a two-stage sum writes every group's
+// result over the group's own first slab (each thread reads its column of all slabs before it writes it).
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* ws, float* out, int64_t n4, int S,
+                                                           int64_t stride4 = -1, int per_group = 0,
+                                                           int64_t out_stride4 = 0) {
   __shared__ float4 red[4][64];
   const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int64_t i = (int64_t)blockIdx.x * 64 + col;
+  if (stride4 < 0) stride4 = n4;
   const float4* w = reinterpret_cast<const float4*>(ws);
+  if (per_group > 0) {
+    const int first = blockIdx.y * per_group;
+    w += (int64_t)first * stride4;
+    out += (int64_t)blockIdx.y * out_stride4 * 4;
+    S = S - first < per_group ? S - first : per_group;
+  }
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s;
   if (i < n4) {
     int k = grp;
     for (; k + 4 < S; k += 8) {
-      const float4 v = w[(int64_t)k * n4 + i];
-      const float4 u = w[(int64_t)(k + 4) * n4 + i];
+      const float4 v = w[(int64_t)k * stride4 + i];
+      const float4 u = w[(int64_t)(k + 4) * stride4 + i];
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
       s2.x += u.x; s2.y += u.y; s2.z += u.z; s2.w += u.w;
     }
     if (k < S) {
-      const float4 v = w[(int64_t)k * n4 + i];
+      const float4 v = w[(int64_t)k * stride4 + i];
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
     s.x += s2.x; s.y += s2.y; s.z += s2.z; s.w += s2.w;
@@ -1286,7 +1298,8 @@ int launch_tn(TNArgs a, float* dW, hipStream_t st) {
   }
   KWS_LAUNCH_CHECK("gemm_tn_kernel");
   const int64_t n4 = (int64_t)a.K * a.N / 4;
-  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)ceil_div64(n4, 64)), dim3(256), 0, st, a.ws, dW, n4, pl.S);
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)ceil_div64(n4, 64)), dim3(256), 0, st, a.ws, dW, n4, pl.S,
+                     (int64_t)-1, 0, (int64_t)0);
   KWS_LAUNCH_CHECK("reduce_slabs_kernel");
   return KWS_OK;
 }
@@ -1380,7 +1393,19 @@ int kws_transpose_f32(const float* in, float* out, int rows, int cols, void* str
 int kws_reduce_slabs_f32(const float* ws, float* out, int64_t n, int S, hipStream_t st) {
   KWS_REQUIRE(ws && out && n > 0 && n % 4 == 0 && S > 0, "reduce_slabs: bad arguments");
   const int64_t n4 = n / 4;
-  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)ceil_div64(n4, 64)), dim3(256), 0, st, ws, out, n4, S);
+  const unsigned gx = (unsigned)ceil_div64(n4, 64);
+  if (S > 128 && gx < 256) {
+    // few columns, many slabs (the first convolution: 40 column groups x 768 slabs): one workgroup per column group cannot
+    // stream them - sum groups of slabs in place first (each group's result over its first slab), then the group sums
+    const int per_group = 32, groups = ceil_div(S, per_group);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(gx, (unsigned)groups), dim3(256), 0, st, ws, const_cast<float*>(ws), n4, S,
+                       n4, per_group, (int64_t)per_group * n4);
+    KWS_LAUNCH_CHECK("reduce_slabs_kernel");
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(gx), dim3(256), 0, st, ws, out, n4, groups, (int64_t)per_group * n4, 0,
+                       (int64_t)0);
+  } else {
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(gx), dim3(256), 0, st, ws, out, n4, S, (int64_t)-1, 0, (int64_t)0);
+  }
   KWS_LAUNCH_CHECK("reduce_slabs_kernel");
   return KWS_OK;
 }
