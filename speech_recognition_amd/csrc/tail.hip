@@ -384,6 +384,45 @@ __global__ __launch_bounds__(256) void small_wgrad_kernel(const float* __restric
   for (int b = b0; b < b1; ++b) s = fmaf(X[(int64_t)b * K + i], D[(int64_t)b * N + k], s);
   out[(int64_t)blockIdx.y * K * N + id] = s;
 }
+// N <= NMAX: one thread per input feature i keeps its N outputs in registers and walks its batch slice once - X is read
+// coalesced and exactly once (the generic kernel reads every X element N times, N threads apart), D rows are uniform
+// across the workgroup.  Same summation order per output as the generic kernel (ascending b inside a slice).
+constexpr int KWS_SMALL_WGRAD_ROWS = 64;   // most rows a slice may hold (B / KWS_SMALL_WGRAD_SLICES, checked by the launcher)
+template <int NMAX>
+__global__ __launch_bounds__(256) void small_wgrad_rows_kernel(const float* __restrict__ X, const float* __restrict__ D,
+                                                               float* __restrict__ out, int B, int K, int N,
+                                                               int rows_per) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int b0 = blockIdx.y * rows_per;
+  int b1 = b0 + rows_per;
+  if (b1 > B) b1 = B;
+  __shared__ float sD[KWS_SMALL_WGRAD_ROWS * NMAX];   // this slice's D rows, zero padded to NMAX columns
+  for (int j = threadIdx.x; j < KWS_SMALL_WGRAD_ROWS * NMAX; j += 256) {
+    const int r = j / NMAX, k = j - r * NMAX;
+    sD[j] = (b0 + r < b1 && k < N) ? D[(int64_t)(b0 + r) * N + k] : 0.f;
+  }
+  __syncthreads();
+  float acc[NMAX];
+#pragma unroll
+  for (int k = 0; k < NMAX; ++k) acc[k] = 0.f;
+  if (i < K) {
+    const float* xp = X + (int64_t)b0 * K + i;
+    const int nb = b1 - b0;
+    for (int r0 = 0; r0 < nb; r0 += 8) {       // eight independent loads in flight, then their FMAs in row order
+      float x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = r0 + u < nb ? xp[(int64_t)(r0 + u) * K] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int k = 0; k < NMAX; ++k) acc[k] = fmaf(x[u], sD[(r0 + u) * NMAX + k], acc[k]);
+    }
+    float* o = out + (int64_t)blockIdx.y * K * N + (int64_t)i * N;
+#pragma unroll
+    for (int k = 0; k < NMAX; ++k)
+      if (k < N) o[k] = acc[k];
+  }
+}
 __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t n,
                                                        int S) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -497,12 +536,20 @@ int kws_small_wgrad_launch(const float* X, const float* D, float* out, float* ou
   const int rows_per = ceil_div(B, S);
   S = ceil_div(B, rows_per);
   float* dst = S > 1 ? scratch : out;
-  hipLaunchKernelGGL(small_wgrad_kernel, dim3((unsigned)ceil_div64(n, 256), (unsigned)S), dim3(256), 0, st, X, D, dst, B,
-                     K, N, rows_per);
+  if (N <= 16 && rows_per <= KWS_SMALL_WGRAD_ROWS)
+    hipLaunchKernelGGL(small_wgrad_rows_kernel<16>, dim3((unsigned)ceil_div(K, 256), (unsigned)S), dim3(256), 0, st, X, D, dst,
+                       B, K, N, rows_per);
+  else
+    hipLaunchKernelGGL(small_wgrad_kernel, dim3((unsigned)ceil_div64(n, 256), (unsigned)S), dim3(256), 0, st, X, D, dst, B,
+                       K, N, rows_per);
   KWS_LAUNCH_CHECK("small_wgrad_kernel");
   if (S > 1) {
-    hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, st, scratch, out, n, S);
-    KWS_LAUNCH_CHECK("slab_sum_kernel");
+    if (n % 4 == 0) {   // four slab groups per column in parallel (fixed order), 16-byte loads
+      KWS_TRY(kws_reduce_slabs_f32(scratch, out, n, S, st));
+    } else {
+      hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, st, scratch, out, n, S);
+      KWS_LAUNCH_CHECK("slab_sum_kernel");
+    }
   }
   if (out_bias) {
     KWS_REQUIRE(N <= 64, "small_wgrad: N=%d > 64", N);
