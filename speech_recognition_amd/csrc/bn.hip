@@ -10,6 +10,8 @@ namespace {
 // directly (<= 16 per thread; more rows with only C/16 workgroups is latency-bound: 2048 rows took 35 us), row group r takes rows r, r+FIN_RG, ... and the groups are combined in order
 constexpr int FIN_CG = 16, FIN_RG = 16;
 
+__device__ float g_zero_fin[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
 // part[n_tiles][2][C] -> bn[4C] = scale | shift | mean | rstd ; moving stats update in place.
 __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ part, int n_tiles,
                                                                 double inv_count, int C,
@@ -22,9 +24,22 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __r
   const int c = blockIdx.x * FIN_CG + cg;
   double s = 0.0, ss = 0.0;
   if (c < C) {
-    for (int t = rg; t < n_tiles; t += FIN_RG) {
-      s += (double)part[((int64_t)t * 2 + 0) * C + c];
-      ss += (double)part[((int64_t)t * 2 + 1) * C + c];
+    // four rows' loads in flight per trip (rows past the end read a zero buffer: address select, not a branch); the
+    // additions stay in ascending row order
+    for (int t = rg; t < n_tiles; t += 4 * FIN_RG) {
+      float a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int tt = t + u * FIN_RG;
+        const float* src = tt < n_tiles ? part + (int64_t)tt * 2 * C + c : g_zero_fin;
+        a[u] = src[0];
+        b[u] = src[tt < n_tiles ? C : 1];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        s += (double)a[u];
+        ss += (double)b[u];
+      }
     }
   }
   red[0][rg][cg] = s;
@@ -114,9 +129,20 @@ __global__ __launch_bounds__(256) void dw_bwd_finalize_kernel(const float* __res
   const int c = blockIdx.x * FIN_CG + cg;
   double s[5] = {0, 0, 0, 0, 0};
   if (c < C) {
-    for (int t = rg; t < n_parts; t += FIN_RG) {
+    for (int t = rg; t < n_parts; t += 4 * FIN_RG) {   // as in bn_stats_finalize_kernel: 20 loads in flight per trip
+      float a[4][5];
 #pragma unroll
-      for (int q = 0; q < 5; ++q) s[q] += (double)part[((int64_t)t * 5 + q) * C + c];
+      for (int u = 0; u < 4; ++u) {
+        const int tt = t + u * FIN_RG;
+        const bool ok = tt < n_parts;
+        const float* src = ok ? part + (int64_t)tt * 5 * C + c : g_zero_fin;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) a[u][q] = src[ok ? q * C : q];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int q = 0; q < 5; ++q) s[q] += (double)a[u][q];
     }
   }
 #pragma unroll
