@@ -226,8 +226,8 @@ def main():
                         traffic = json.load(f)["kernels"]["gemm_nn_ws_kernel"]["hbm_bytes_per_launch"]
                 except Exception:
                     pass
-                roof = {"kernel": "gemm_nn_ws_kernel (f32 MFMA: pointwise fwd + dgrad; the gathered first conv "
-                                  "runs gemm_nn_persist_kernel and is counted in the same family)",
+                roof = {"kernel": "gemm_nn_ws_kernel (f32 MFMA: pointwise fwd + dgrad; the first convolution's forward "
+                                  "runs conv1_fwd_kernel and is counted in the same family)",
                         "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                         "algorithmic_bytes_per_launch": k["bytes"] / max(k["count"], 1),
