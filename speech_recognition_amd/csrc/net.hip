@@ -186,7 +186,8 @@ void make_layout(const kws_net* n, int B, bool training, Layout* lo) {
   lo->z.assign(nb, 0);
   int64_t max_y = (int64_t)B * n->L1 * n->C1, max_z = 0, max_part = 0, max_dwpart = 0, max_tn = 0;
   int maxC = n->C1;
-  max_part = (int64_t)kws_gemm_num_row_tiles((int64_t)B * n->L1) * 2 * n->C1;
+  max_part = std::max((int64_t)kws_gemm_num_row_tiles((int64_t)B * n->L1), (int64_t)kws_conv1_stats_rows((int64_t)B * n->L1)) *
+             2 * n->C1;   // statistics rows of either first-convolution kernel
   max_tn = std::max(kws_gemm_tn_workspace_floats((int64_t)B * n->L1, n->K1f, n->C1),
                     kws_conv1_wgrad_workspace_floats((int64_t)B * n->L1));
   for (int i = 0; i < nb; ++i) {
