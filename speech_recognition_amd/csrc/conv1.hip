@@ -36,6 +36,7 @@ struct Conv1Args {
   const float* G;      // wgrad: dy [M, 128]
   float* ws;           // wgrad: [S][KF][128]
   kws_gather_t g;
+  int taps, cin, hop;  // the unfolded kernel W[taps][cin][128]: Weff[s] = sum_j W[j][s - hop j] (taps = 1: W is folded)
   int B, m_tiles, S;
   int64_t M, chunk;
 };
@@ -74,7 +75,16 @@ __global__ __launch_bounds__(256, 3) void conv1_fwd_kernel(Conv1Args p) {
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int jj = 0; jj < 2; ++jj) wreg[q][r][jj] = p.W[(q * 8 + lh * 4 + r) * NOUT + wc * 64 + jj * 32 + li];
+      for (int jj = 0; jj < 2; ++jj) {
+        // the kernel rows that hit sample s, added in tap order (what net.hip's fold_taps_kernel computes)
+        const int sidx = q * 8 + lh * 4 + r, n = wc * 64 + jj * 32 + li;
+        float w = 0.f;
+        for (int j = 0; j < p.taps; ++j) {
+          const int c = sidx - p.hop * j;
+          if (c >= 0 && c < p.cin) w += p.W[((int64_t)j * p.cin + c) * NOUT + n];
+        }
+        wreg[q][r][jj] = w;
+      }
   const int srow = tid >> 2, sq = tid & 3;
   float2 ra[NL];
   auto load_rows = [&](int tile) {
@@ -294,6 +304,23 @@ __global__ __launch_bounds__(256, 3) void conv1_wgrad_kernel(Conv1Args p) {
     }
 }
 
+// dW[j][c][n] = sum over slab groups of ws[group][hop j + c][n]: the second stage of the slab sum writes the three taps
+// directly (every tap row reads the gradient of the sample it multiplies)
+__global__ __launch_bounds__(256) void conv1_unfold_sum_kernel(const float* __restrict__ ws, float* __restrict__ dW,
+                                                               int groups, int64_t group_stride, int taps, int cin, int hop) {
+  const int i = blockIdx.x * 256 + threadIdx.x;   // float4 index into dW[taps][cin][128]
+  if (i >= taps * cin * (NOUT / 4)) return;
+  const int n4 = i % (NOUT / 4), jc = i / (NOUT / 4);
+  const int j = jc / cin, c = jc - j * cin;
+  const float4* src = reinterpret_cast<const float4*>(ws) + (int64_t)(hop * j + c) * (NOUT / 4) + n4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int g = 0; g < groups; ++g) {
+    const float4 v = src[(int64_t)g * group_stride];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  reinterpret_cast<float4*>(dW)[i] = s;
+}
+
 struct WgradPlan {
   int S;
   int64_t chunk;
@@ -321,11 +348,12 @@ bool kws_conv1_supported(const kws_gather_t* g, int N) {
          g->x_batch_stride % 2 == 0 && g->L_out > 0;
 }
 
-int kws_conv1_fwd(const float* x, const kws_gather_t* g, const float* Weff, float* y, int B, int N, float* stats,
-                  hipStream_t st) {
-  KWS_REQUIRE(x && g && Weff && y && B > 0 && kws_conv1_supported(g, N), "conv1_fwd: unsupported shape");
+int kws_conv1_fwd(const float* x, const kws_gather_t* g, const kws_gather_t* unfolded, const float* W, float* y, int B, int N,
+                  float* stats, hipStream_t st) {
+  KWS_REQUIRE(x && g && unfolded && W && y && B > 0 && kws_conv1_supported(g, N), "conv1_fwd: unsupported shape");
   Conv1Args a{};
-  a.x = x; a.W = Weff; a.y = y; a.stats = stats; a.g = *g; a.B = B; a.M = (int64_t)B * g->L_out;
+  a.x = x; a.W = W; a.y = y; a.stats = stats; a.g = *g; a.B = B; a.M = (int64_t)B * g->L_out;
+  a.taps = unfolded->taps; a.cin = unfolded->cin; a.hop = unfolded->stride_j;
   a.m_tiles = (int)ceil_div64(a.M, FM);
   KwsProfScope prof("gemm_nn", 2.0 * a.M * 80 * N, 4.0 * ((double)B * g->x_len + (double)a.M * N + 80.0 * N), st);
   const int grid = kws_conv1_stats_rows(a.M);
@@ -337,9 +365,10 @@ int kws_conv1_fwd(const float* x, const kws_gather_t* g, const float* Weff, floa
 
 int64_t kws_conv1_wgrad_workspace_floats(int64_t M) { return (int64_t)wgrad_plan(M).S * 80 * NOUT; }
 
-int kws_conv1_wgrad(const float* x, const kws_gather_t* g, const float* G, float* dWeff, int B, int N, float* workspace,
-                    hipStream_t st) {
-  KWS_REQUIRE(x && g && G && dWeff && workspace && B > 0 && kws_conv1_supported(g, N), "conv1_wgrad: unsupported shape");
+int kws_conv1_wgrad(const float* x, const kws_gather_t* g, const kws_gather_t* unfolded, const float* G, float* dW, int B,
+                    int N, float* workspace, hipStream_t st) {
+  KWS_REQUIRE(x && g && unfolded && G && dW && workspace && B > 0 && kws_conv1_supported(g, N),
+              "conv1_wgrad: unsupported shape");
   Conv1Args a{};
   a.x = x; a.G = G; a.ws = workspace; a.g = *g; a.B = B; a.M = (int64_t)B * g->L_out;
   const WgradPlan pl = wgrad_plan(a.M);
@@ -347,5 +376,13 @@ int kws_conv1_wgrad(const float* x, const kws_gather_t* g, const float* G, float
   KwsProfScope prof("gemm_tn", 2.0 * a.M * 80 * N, 4.0 * ((double)B * g->x_len + (double)a.M * N + 80.0 * N), st);
   hipLaunchKernelGGL((conv1_wgrad_kernel<80>), dim3(pl.S), dim3(256), 0, st, a);
   KWS_LAUNCH_CHECK("conv1_wgrad_kernel");
-  return kws_reduce_slabs_f32(workspace, dWeff, (int64_t)80 * N, pl.S, st);
+  // slab sum in two stages: groups of 32 slabs in place (over each group's first slab), then the group sums straight into
+  // the three taps of dW
+  const int per_group = 32, groups = ceil_div(pl.S, per_group);
+  KWS_TRY(kws_reduce_slab_groups_f32(workspace, (int64_t)80 * N, pl.S, per_group, st));
+  const int n4 = unfolded->taps * unfolded->cin * (NOUT / 4);
+  hipLaunchKernelGGL(conv1_unfold_sum_kernel, dim3(ceil_div(n4, 256)), dim3(256), 0, st, workspace, dW, groups,
+                     (int64_t)per_group * 80 * (NOUT / 4), unfolded->taps, unfolded->cin, unfolded->stride_j);
+  KWS_LAUNCH_CHECK("conv1_unfold_sum_kernel");
+  return KWS_OK;
 }

@@ -1390,6 +1390,15 @@ int kws_transpose_f32(const float* in, float* out, int rows, int cols, void* str
   return KWS_OK;
 }
 
+int kws_reduce_slab_groups_f32(float* ws, int64_t n, int S, int per_group, hipStream_t st) {
+  KWS_REQUIRE(ws && n > 0 && n % 4 == 0 && S > 0 && per_group > 0, "reduce_slab_groups: bad arguments");
+  const int64_t n4 = n / 4;
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)ceil_div64(n4, 64), (unsigned)ceil_div(S, per_group)), dim3(256), 0, st,
+                     ws, ws, n4, S, n4, per_group, (int64_t)per_group * n4);
+  KWS_LAUNCH_CHECK("reduce_slabs_kernel");
+  return KWS_OK;
+}
+
 int kws_reduce_slabs_f32(const float* ws, float* out, int64_t n, int S, hipStream_t st) {
   KWS_REQUIRE(ws && out && n > 0 && n % 4 == 0 && S > 0, "reduce_slabs: bad arguments");
   const int64_t n4 = n / 4;

@@ -17,11 +17,16 @@ int kws_metrics_launch(const float* per_loss, const float* per_correct, int B, f
 // gradient with its own slab workspace); kws_conv1_supported() says whether a gather descriptor / width qualifies
 bool kws_conv1_supported(const kws_gather_t* g, int N);
 int kws_conv1_stats_rows(int64_t M);
-int kws_conv1_fwd(const float* x, const kws_gather_t* g, const float* Weff, float* y, int B, int N, float* stats,
-                  hipStream_t st);
+// g = the folded view (one tap of 80 samples), unfolded = the reference's view (taps x cin, taps `stride_j` apart); W and
+// dW are the UNFOLDED kernel / gradient [taps][cin][128]: the forward kernel folds W while loading it into registers, the
+// weight gradient's slab sum writes the taps directly
+int kws_conv1_fwd(const float* x, const kws_gather_t* g, const kws_gather_t* unfolded, const float* W, float* y, int B, int N,
+                  float* stats, hipStream_t st);
 int64_t kws_conv1_wgrad_workspace_floats(int64_t M);
-int kws_conv1_wgrad(const float* x, const kws_gather_t* g, const float* G, float* dWeff, int B, int N, float* workspace,
-                    hipStream_t st);
+int kws_conv1_wgrad(const float* x, const kws_gather_t* g, const kws_gather_t* unfolded, const float* G, float* dW, int B,
+                    int N, float* workspace, hipStream_t st);
+// gemm.hip: first stage of a two-stage slab sum: every group of `per_group` slabs is summed over the group's first slab
+extern "C" int kws_reduce_slab_groups_f32(float* ws, int64_t n, int S, int per_group, hipStream_t st);
 // gemm.hip: out[i] = sum over S slabs of ws[s][i], fixed order (n % 4 == 0)
 extern "C" int kws_reduce_slabs_f32(const float* ws, float* out, int64_t n, int S, hipStream_t st);
 constexpr int KWS_TRANSPOSE_BATCH = 16;
