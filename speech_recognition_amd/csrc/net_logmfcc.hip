@@ -95,6 +95,8 @@ struct LmLayout {
   std::vector<int64_t> pz, py;             // plain blocks (style 2)
   int64_t alast = 0;
   int64_t a0m = 0, a0r = 0;                // style 3: activated branch outputs before the concatenation
+  std::vector<int64_t> wt_pw1, wt_pw2, wt_ws, wt_plain;   // transposed pointwise kernels for the dgrad GEMMs
+  int64_t wt_ctx = 0;
 };
 
 void lm_layout(const kws_net* n, int B, LmLayout* lo) {
@@ -168,6 +170,15 @@ void lm_layout(const kws_net* n, int B, LmLayout* lo) {
   lo->red = bp.take((int64_t)KWS_REDUCE_SLICES * 5 * p.maxC);
   lo->coef = bp.take(2 * p.maxC);
   lo->WT = bp.take(max_wt);
+  lo->wt_pw1.assign(nb, 0); lo->wt_pw2.assign(nb, 0); lo->wt_ws.assign(nb, 0); lo->wt_plain.assign(p.plain.size(), 0);
+  for (int i = 0; i < nb; ++i) {
+    const LmBlock& b = p.blocks[i];
+    lo->wt_pw1[i] = bp.take((int64_t)b.cin * b.nf);
+    lo->wt_pw2[i] = bp.take((int64_t)b.nf * b.nf);
+    if (b.has_short) lo->wt_ws[i] = bp.take((int64_t)b.cin * b.nf);
+  }
+  for (size_t j = 0; j < p.plain.size(); ++j) lo->wt_plain[j] = bp.take((int64_t)p.plain[j].cin * p.plain[j].cout);
+  if (p.style == 1) lo->wt_ctx = bp.take((int64_t)p.C0 * p.C0);
   lo->tn = bp.take(max_tn);
   lo->swg = bp.take((int64_t)KWS_SMALL_WGRAD_SLICES * feat * p.NC);
   lo->dOa = bp.take(max_o);
@@ -802,6 +813,26 @@ int lm_train(const kws_net* n, const float* params, float* state, const float* x
   KWS_HIP(hipMemsetAsync(grads, 0, (size_t)n->n_params * 4, st));
   kws_lm_tail_args t;
   KWS_TRY(forward(c, x, &t));
+  {  // every pointwise kernel transposed for its dgrad GEMM, KWS_TRANSPOSE_BATCH matrices per launch
+    std::vector<const float*> tin;
+    std::vector<float*> tout;
+    std::vector<int> trows, tcols;
+    auto add = [&](int64_t src, int64_t dst, int rows, int cols) {
+      tin.push_back(params + src); tout.push_back(ws + dst); trows.push_back(rows); tcols.push_back(cols);
+    };
+    for (size_t i = 0; i < p.blocks.size(); ++i) {
+      const LmBlock& b = p.blocks[i];
+      add(b.pw1, lo.wt_pw1[i], b.cin, b.nf);
+      add(b.pw2, lo.wt_pw2[i], b.nf, b.nf);
+      if (b.has_short) add(b.ws, lo.wt_ws[i], b.cin, b.nf);
+    }
+    for (size_t j = 0; j < p.plain.size(); ++j) add(p.plain[j].pw, lo.wt_plain[j], p.plain[j].cin, p.plain[j].cout);
+    if (p.style == 1) add(p.ctx_pw, lo.wt_ctx, p.C0, p.C0);
+    for (size_t o = 0; o < tin.size(); o += KWS_TRANSPOSE_BATCH) {
+      const int nbat = (int)std::min<size_t>(KWS_TRANSPOSE_BATCH, tin.size() - o);
+      KWS_TRY(kws_transpose_batch_f32(tin.data() + o, tout.data() + o, trows.data() + o, tcols.data() + o, nbat, st));
+    }
+  }
   float* part = ws + lo.part;
   float* red = ws + lo.red;
   float* coef = ws + lo.coef;
@@ -833,8 +864,7 @@ int lm_train(const kws_net* n, const float* params, float* state, const float* x
         KWS_TRY(kws_dw_bwd_finalize(part, np, M, q.cout, nullptr, grads + q.bn.gamma, grads + q.bn.beta, coef, red, st));
         KWS_TRY(kws_bn_bwd_apply(G, ws + lo.py[j], c.bn_at(q.bn_idx), params + q.bn.gamma, coef, M, q.cout, st));
       }  // else: G already holds dy of this block (pass 2 of the next block's depthwise backward)
-      KWS_TRY(kws_transpose_f32(params + q.pw, ws + lo.WT, q.cin, q.cout, st));
-      KWS_TRY(kws_gemm_nn_f32(G, ws + lo.WT, DZ, M, q.cout, q.cin, nullptr, st));
+      KWS_TRY(kws_gemm_nn_f32(G, ws + lo.wt_plain[j], DZ, M, q.cout, q.cin, nullptr, st));
       KWS_TRY(kws_gemm_tn_f32(ws + lo.pz[j], G, grads + q.pw, M, q.cin, q.cout, ws + lo.tn, st));
       const int np = (int)(kws_dwconv_bwd_part_floats(B, q.Lin, q.cin) / (5 * q.cin));
       if (j > 0) {
@@ -879,8 +909,7 @@ int lm_train(const kws_net* n, const float* params, float* state, const float* x
     }
     KWS_TRY(kws_dw_bwd_finalize(part, np, M, b.nf, nullptr, grads + b.bn2.gamma, grads + b.bn2.beta, coef, red, st));
     KWS_TRY(kws_bn_bwd_apply(G, ws + lo.y2[i], c.bn_at(b.bn2_idx), params + b.bn2.gamma, coef, M, b.nf, st));
-    KWS_TRY(kws_transpose_f32(params + b.pw2, ws + lo.WT, b.nf, b.nf, st));
-    KWS_TRY(kws_gemm_nn_f32(G, ws + lo.WT, DZ, M, b.nf, b.nf, nullptr, st));
+    KWS_TRY(kws_gemm_nn_f32(G, ws + lo.wt_pw2[i], DZ, M, b.nf, b.nf, nullptr, st));
     KWS_TRY(kws_gemm_tn_f32(ws + lo.z2[i], G, grads + b.pw2, M, b.nf, b.nf, ws + lo.tn, st));
     // depthwise 2 -> BN1 -> pointwise 1
     // (two passes over dz and y1 instead of "store g, then kws_bn_bwd_apply": the masked gradient is never stored)
@@ -890,8 +919,7 @@ int lm_train(const kws_net* n, const float* params, float* state, const float* x
     KWS_TRY(kws_dw_bwd_finalize(part, np, M, b.nf, grads + b.dw2, grads + b.bn1.gamma, grads + b.bn1.beta, coef, red, st));
     KWS_TRY(kws_dwconv_bwd_bn_f32(DZ, ws + lo.y1[i], c.bn_at(b.bn1_idx), params + b.dw2, coef, G, nullptr, 2, B, b.Lmid,
                                   b.Lmid, b.nf, 1, 1, st));
-    KWS_TRY(kws_transpose_f32(params + b.pw1, ws + lo.WT, b.cin, b.nf, st));
-    KWS_TRY(kws_gemm_nn_f32(G, ws + lo.WT, DZ, M, b.nf, b.cin, nullptr, st));
+    KWS_TRY(kws_gemm_nn_f32(G, ws + lo.wt_pw1[i], DZ, M, b.nf, b.cin, nullptr, st));
     KWS_TRY(kws_gemm_tn_f32(ws + lo.z1[i], G, grads + b.pw1, M, b.cin, b.nf, ws + lo.tn, st));
     // depthwise 1 on the (materialised) block input
     KWS_TRY(kws_dwconv_bwd_f32(DZ, xin, nullptr, params + b.dw1, dX, part, B, b.Lin, b.Lmid, b.cin, b.s1, b.pad1, st));
@@ -907,8 +935,7 @@ int lm_train(const kws_net* n, const float* params, float* state, const float* x
       KWS_TRY(kws_dw_bwd_finalize(part, np, Mo, b.nf, nullptr, grads + b.bns.gamma, grads + b.bns.beta, coef, red, st));
       KWS_TRY(kws_bn_bwd_apply(dO, ws + lo.ys[i], c.bn_at(b.bns_idx), params + b.bns.gamma, coef, Mo, b.nf, st));
       KWS_TRY(kws_gemm_tn_gather_f32(xin, &b.gs, dO, grads + b.ws, B, b.nf, ws + lo.tn, st));
-      KWS_TRY(kws_transpose_f32(params + b.ws, ws + lo.WT, b.cin, b.nf, st));
-      KWS_TRY(kws_gemm_nn_f32(dO, ws + lo.WT, ws + lo.DXS, Mo, b.nf, b.cin, nullptr, st));
+      KWS_TRY(kws_gemm_nn_f32(dO, ws + lo.wt_ws[i], ws + lo.DXS, Mo, b.nf, b.cin, nullptr, st));
       KWS_TRY(kws_add_strided_f32(dX, ws + lo.DXS, B, b.Lin, b.Lout, b.cin, b.stride, st));
     }
     std::swap(dO, dX);
@@ -919,8 +946,7 @@ int lm_train(const kws_net* n, const float* params, float* state, const float* x
     int np = (int)(kws_block_out_bwd_part_floats(B, p.L0, p.C0, 1) / (5 * p.C0));
     KWS_TRY(kws_dw_bwd_finalize(part, np, M, p.C0, nullptr, grads + p.ctx_bn.gamma, grads + p.ctx_bn.beta, coef, red, st));
     KWS_TRY(kws_bn_bwd_apply(G, ws + lo.yc, c.bn_at(p.ctx_bn_idx), params + p.ctx_bn.gamma, coef, M, p.C0, st));
-    KWS_TRY(kws_transpose_f32(params + p.ctx_pw, ws + lo.WT, p.C0, p.C0, st));
-    KWS_TRY(kws_gemm_nn_f32(G, ws + lo.WT, DZ, M, p.C0, p.C0, nullptr, st));
+    KWS_TRY(kws_gemm_nn_f32(G, ws + lo.wt_ctx, DZ, M, p.C0, p.C0, nullptr, st));
     KWS_TRY(kws_gemm_tn_f32(ws + lo.zc, G, grads + p.ctx_pw, M, p.C0, p.C0, ws + lo.tn, st));
     KWS_TRY(kws_dwconv_bwd_f32(DZ, ws + lo.a0, nullptr, params + p.ctx_dw, dX, part, B, p.L0, p.L0, p.C0, 1, 1, st));
     np = (int)(kws_dwconv_bwd_part_floats(B, p.L0, p.C0) / (5 * p.C0));
