@@ -188,7 +188,14 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const float* __restrict
         *reinterpret_cast<float4*>(gb + (int64_t)u * C) = o;
         continue;
       }
-      if (MODE == 0) *reinterpret_cast<float4*>(gb + (int64_t)u * C) = gv;
+      if (MODE == 0) {
+        float4 o = gv;
+        if (coef != nullptr) {   // MODE 0 reuses `coef` as an optional tensor added to the input gradient (residual join)
+          const float4 ad = *reinterpret_cast<const float4*>(coef + (b * (int64_t)Lin + u) * C + c);
+          o = make_float4(o.x + ad.x, o.y + ad.y, o.z + ad.z, o.w + ad.w);
+        }
+        *reinterpret_cast<float4*>(gb + (int64_t)u * C) = o;
+      }
       sg.x += gv.x; sg.y += gv.y; sg.z += gv.z; sg.w += gv.w;
       sgx = f4_fma(gv, xh, sgx);
       sw0 = f4_fma(d0, a, sw0);
@@ -297,6 +304,16 @@ int kws_dwconv_bwd_f32(const float* dz, const float* y, const float* bn, const f
   hipStream_t st = (hipStream_t)stream;
   KwsProfScope prof("dwconv_bwd", 12.0 * B * L_in * C, 4.0 * (2.0 * B * L_in * C + (double)B * L_out * C), st);
   return launch_dw_bwd<0>(dz, y, bn, w, nullptr, g, part, B, L_in, L_out, C, stride, pad_l, st);
+}
+
+// internal (residual-family programs): as kws_dwconv_bwd_f32 without a BatchNorm on the input, g = dgrad + add
+int kws_dwconv_bwd_acc_f32(const float* dz, const float* y, const float* w, const float* add, float* g, float* part, int B,
+                           int L_in, int L_out, int C, int stride, int pad_l, hipStream_t st) {
+  KWS_REQUIRE(dz && y && w && add && g && part && add != g, "dwconv_bwd_acc: bad pointers");
+  KWS_REQUIRE(B > 0 && L_in > 0 && L_out > 0 && bwd_geom_ok(C) && (stride == 1 || stride == 2),
+              "dwconv_bwd_acc: bad shape B=%d L=%d->%d C=%d stride=%d", B, L_in, L_out, C, stride);
+  KwsProfScope prof("dwconv_bwd", 13.0 * B * L_in * C, 4.0 * (3.0 * B * L_in * C + (double)B * L_out * C), st);
+  return launch_dw_bwd<0>(dz, y, nullptr, w, add, g, part, B, L_in, L_out, C, stride, pad_l, st);
 }
 
 int kws_dwconv_bwd_bn_f32(const float* dz, const float* y, const float* bn, const float* w, const float* coef,

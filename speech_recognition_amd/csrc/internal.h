@@ -29,6 +29,8 @@ int kws_conv1_wgrad(const float* x, const kws_gather_t* g, const kws_gather_t* u
 extern "C" int kws_reduce_slab_groups_f32(float* ws, int64_t n, int S, int per_group, hipStream_t st);
 // gemm.hip: out[i] = sum over S slabs of ws[s][i], fixed order (n % 4 == 0)
 extern "C" int kws_reduce_slabs_f32(const float* ws, float* out, int64_t n, int S, hipStream_t st);
+extern "C" int kws_dwconv_bwd_acc_f32(const float* dz, const float* y, const float* w, const float* add, float* g, float* part,
+                                      int B, int L_in, int L_out, int C, int stride, int pad_l, hipStream_t st);
 constexpr int KWS_TRANSPOSE_BATCH = 16;
 extern "C" int kws_transpose_batch_f32(const float* const* in, float* const* out, const int* rows, const int* cols, int n,
                                        hipStream_t stream);

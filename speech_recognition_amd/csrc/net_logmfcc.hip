@@ -922,13 +922,14 @@ int lm_train(const kws_net* n, const float* params, float* state, const float* x
     KWS_TRY(kws_gemm_nn_f32(G, ws + lo.wt_pw1[i], DZ, M, b.nf, b.cin, nullptr, st));
     KWS_TRY(kws_gemm_tn_f32(ws + lo.z1[i], G, grads + b.pw1, M, b.cin, b.nf, ws + lo.tn, st));
     // depthwise 1 on the (materialised) block input
-    KWS_TRY(kws_dwconv_bwd_f32(DZ, xin, nullptr, params + b.dw1, dX, part, B, b.Lin, b.Lmid, b.cin, b.s1, b.pad1, st));
+    if (!b.has_short)   // identity shortcut: the join's other gradient is added while the depthwise input gradient is written
+      KWS_TRY(kws_dwconv_bwd_acc_f32(DZ, xin, params + b.dw1, dO, dX, part, B, b.Lin, b.Lmid, b.cin, b.s1, b.pad1, st));
+    else
+      KWS_TRY(kws_dwconv_bwd_f32(DZ, xin, nullptr, params + b.dw1, dX, part, B, b.Lin, b.Lmid, b.cin, b.s1, b.pad1, st));
     np = (int)(kws_dwconv_bwd_part_floats(B, b.Lin, b.cin) / (5 * b.cin));
     KWS_TRY(kws_dw_bwd_finalize(part, np, (int64_t)B * b.Lin, b.cin, grads + b.dw1, nullptr, nullptr, nullptr, red, st));
     // residual branch
-    if (!b.has_short) {
-      KWS_TRY(kws_add_f32(dX, dO, dX, (int64_t)B * b.Lin * b.cin, st));
-    } else {
+    if (b.has_short) {
       const int64_t Mo = (int64_t)B * b.Lout;
       KWS_TRY(kws_block_out_bwd(dO, ws + lo.ys[i], c.bn_at(b.bns_idx), dO, part, B, b.Lout, b.nf, 1, 0, st));
       np = (int)(kws_block_out_bwd_part_floats(B, b.Lout, b.nf, 1) / (5 * b.nf));
