@@ -295,7 +295,6 @@ __global__ __launch_bounds__(NW3 * 64, 1) void stft3_kernel(Stft2Args a) {
   const int64_t wave_global = (int64_t)blockIdx.x * NW3 + wave;
   const int64_t wave_stride = (int64_t)gridDim.x * NW3;
   const int nb_mel = (n_mel + 15) >> 4;   // mel bands per lane
-  const int n_blk = (n_out + 15) >> 4;    // 16-column output blocks
   for (int64_t sq = wave_global; sq < n_super; sq += wave_stride) {
 #pragma unroll 1
     for (int qq = 0; qq < 4; ++qq) {
@@ -395,11 +394,27 @@ __global__ __launch_bounds__(NW3 * 64, 1) void stft3_kernel(Stft2Args a) {
     for (int nb = 0; nb < 4; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float* pa = s_lm16 + l16 * LMS + fq;
     const float* pb = s_dct + fq * DSTR + l16;
-    for (int ks = 0; ks < n_mel; ks += 4) {
-      const float av = pa[ks];
+    // All four 16-column blocks every step (the table is zero padded to 64 columns: no per-block branch), operands of
+    // step s+1 read while the MFMAs of step s issue.  (Written as `if (nb < n_blk) mfma(pa[ks], pb[...])` the loop
+    // compiled to a read, an lgkmcnt(0) and a branch in front of every single MFMA.)
+    {
+      float av = pa[0], bv[4], an = 0.f, bn[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int nb = 0; nb < 4; ++nb)
-        if (nb < n_blk) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, pb[ks * DSTR + 16 * nb], acc[nb], 0, 0, 0);
+      for (int nb = 0; nb < 4; ++nb) bv[nb] = pb[16 * nb];
+      for (int ks = 0; ks < n_mel; ks += 4) {
+        if (ks + 4 < n_mel) {
+          an = pa[ks + 4];
+#pragma unroll
+          for (int nb = 0; nb < 4; ++nb) bn[nb] = pb[(ks + 4) * DSTR + 16 * nb];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[nb], acc[nb], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        av = an;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) bv[nb] = bn[nb];
+      }
     }
     {
       const int64_t quad = sq * 4 + fq;               // lane group fq holds the frames of quad fq
