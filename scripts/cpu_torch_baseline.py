@@ -7,12 +7,44 @@ import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.nn.functional as F  # noqa: E402
 
-from oracle.net import TimeSlicedAttentionNet  # noqa: E402  (layer table and initial weights only)
+
+
+class Net(object):
+    """Layer table of conv_1d_time_sliced_with_attention (reference model.py:775-838) and Glorot-uniform weights."""
+
+    def __init__(self, num_classes=12):
+        spec = [(1, 128), (2, 192), (1, 192), (2, 256), (1, 256), (2, 320), (1, 320), (2, 384), (1, 384), (2, 512), (1, 512)]
+        rng = np.random.RandomState(0)
+
+        def glorot(shape, fi, fo):
+            lim = np.sqrt(6.0 / (fi + fo))
+            return rng.uniform(-lim, lim, shape).astype(np.float32)
+        self.params = {'conv1d_1/kernel': glorot((3, 40, 128), 120, 384)}
+        self.blocks = []
+        cin, L = 128, 399
+        for i, (stride, cout) in enumerate(spec):
+            if stride == 1:
+                pad, Lout = (0, 0), L - 2
+            else:
+                Lout = -(-L // 2)
+                p = max((Lout - 1) * 2 + 3 - L, 0)
+                pad = (p // 2, p - p // 2)
+            self.blocks.append(dict(cin=cin, cout=cout, stride=stride, pad=pad))
+            self.params['depthwise_conv2d_%d/depthwise_kernel' % (i + 1)] = glorot((1, 3, cin, 1), 3 * cin, 3)
+            self.params['conv1d_%d/kernel' % (i + 2)] = glorot((1, cin, cout), cin, cout)
+            cin, L = cout, Lout
+        for i in range(1, 13):
+            c = 128 if i == 1 else spec[i - 2][1]
+            self.params['batch_normalization_%d/gamma' % i] = np.ones(c, np.float32)
+            self.params['batch_normalization_%d/beta' % i] = np.zeros(c, np.float32)
+        self.T, self.C = L, cin
+        self.params['dense_1/kernel'] = glorot((L * cin, L), L * cin, L)
+        self.params['dense_1/bias'] = np.zeros(L, np.float32)
+        self.params['dense_2/kernel'] = glorot((2 * cin, num_classes), 2 * cin, num_classes)
 
 
 def forward(net, P, x, y):
@@ -42,7 +74,7 @@ def forward(net, P, x, y):
 def main():
     if len(sys.argv) > 1:
         torch.set_num_threads(int(sys.argv[1]))
-    net = TimeSlicedAttentionNet(dtype=np.float32)
+    net = Net()
     P = {k: torch.tensor(v, requires_grad=True) for k, v in net.params.items()}
     opt = torch.optim.RMSprop(P.values(), lr=1e-3, alpha=0.9, eps=1e-8)
     out = {"threads": torch.get_num_threads()}
