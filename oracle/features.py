@@ -213,12 +213,15 @@ def features(x, tables, frame_step=160, dtype=np.float64, return_all=False):
     path A (audio.py:15-23):        log(max(sqrt(|X|^2) @ W, 1e-12)) @ D
     """
     mag = stft_magnitude(x, tables, frame_step, dtype)
-    mel = mag @ np.asarray(tables['mel'], dtype=dtype)
+    lead = mag.shape[:-1]
+    # the two products run on [frames, bins] matrices (one GEMM each; a stacked matmul loops over the batch)
+    mel = mag.reshape(-1, mag.shape[-1]) @ np.asarray(tables['mel'], dtype=dtype)
     mel = mel + dtype(tables['log_offset'])
     if tables['log_floor'] > 0.0:
         mel = np.maximum(mel, dtype(tables['log_floor']))
     logmel = np.log(mel)
-    out = logmel @ np.asarray(tables['dct'], dtype=dtype)
+    out = (logmel @ np.asarray(tables['dct'], dtype=dtype)).reshape(lead + (-1,))
+    logmel = logmel.reshape(lead + (-1,))
     if return_all:
         return mag, logmel, out
     return out

@@ -2,7 +2,15 @@
 usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
 Units/corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE/WRITE_SIZE are in
 KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request for wide coalesced streaming reads -> doubled."""
-import collections, csv, json, re, sys
+import collections, csv, hashlib, json, os, re, sys
+
+CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "speech_recognition_amd", "csrc")
+# kernel -> the source file that defines it: bench.py drops a traffic figure once that file has changed
+SOURCE_OF = {"gemm_nn_ws_kernel": "gemm.hip", "gemm_tn_ws_kernel": "gemm.hip", "gemm_nn_persist_kernel": "gemm.hip",
+             "gemm_tn_kernel": "gemm.hip", "reduce_slabs_kernel": "gemm.hip", "conv1_fwd_kernel": "conv1.hip",
+             "conv1_wgrad_kernel": "conv1.hip", "stft3_kernel": "stft2.hip", "stft2_kernel": "stft2.hip",
+             "stft4_kernel": "stft4.hip", "augment_kernel": "augment.hip", "dwconv_fwd_kernel": "dwconv.hip",
+             "dwconv_bwd_kernel": "dwconv.hip", "dwconv_bwd_bn_kernel": "dwconv.hip", "ts_tail_kernel": "tail.hip"}
 
 
 def load(path, counter):
@@ -22,9 +30,14 @@ for k in sorted(set(f) | set(w)):
     fk = sum(f.get(k, [0])) / max(len(f.get(k, [])), 1)
     wk = sum(w.get(k, [0])) / max(len(w.get(k, [])), 1)
     out[k] = {"launches_seen": len(f.get(k, [])), "fetch_kib_avg_raw": fk, "write_kib_avg": wk,
-              "hbm_bytes_per_launch": (2.0 * fk + wk) * 1024.0}
+              "hbm_bytes_per_launch": (2.0 * fk + wk) * 1024.0, "source": SOURCE_OF.get(k)}
+sources = {}
+for src in sorted(set(v for v in SOURCE_OF.values())):
+    path = os.path.join(CSRC, src)
+    if os.path.exists(path):
+        sources[src] = hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
 json.dump({"note": "FETCH_SIZE doubled (gfx950 correction), separate --pmc passes, bench.py --batch 1024",
-           "kernels": out}, open(sys.argv[3], "w"), indent=1, sort_keys=True)
+           "sources": sources, "kernels": out}, open(sys.argv[3], "w"), indent=1, sort_keys=True)
 for k, v in out.items():
     if v["hbm_bytes_per_launch"] > 1e6:
         print("%-60s n=%4d  %.1f MB/launch" % (k[:60], v["launches_seen"], v["hbm_bytes_per_launch"] / 1e6))

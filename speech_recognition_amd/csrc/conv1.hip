@@ -355,7 +355,7 @@ int kws_conv1_fwd(const float* x, const kws_gather_t* g, const kws_gather_t* unf
   a.x = x; a.W = W; a.y = y; a.stats = stats; a.g = *g; a.B = B; a.M = (int64_t)B * g->L_out;
   a.taps = unfolded->taps; a.cin = unfolded->cin; a.hop = unfolded->stride_j;
   a.m_tiles = (int)ceil_div64(a.M, FM);
-  KwsProfScope prof("gemm_nn", 2.0 * a.M * 80 * N, 4.0 * ((double)B * g->x_len + (double)a.M * N + 80.0 * N), st);
+  KwsProfScope prof("conv1_fwd", 2.0 * a.M * 80 * N, 4.0 * ((double)B * g->x_len + (double)a.M * N + 80.0 * N), st);
   const int grid = kws_conv1_stats_rows(a.M);
   if (stats) hipLaunchKernelGGL((conv1_fwd_kernel<80, true>), dim3(grid), dim3(256), 0, st, a);
   else hipLaunchKernelGGL((conv1_fwd_kernel<80, false>), dim3(grid), dim3(256), 0, st, a);
@@ -373,7 +373,7 @@ int kws_conv1_wgrad(const float* x, const kws_gather_t* g, const kws_gather_t* u
   a.x = x; a.G = G; a.ws = workspace; a.g = *g; a.B = B; a.M = (int64_t)B * g->L_out;
   const WgradPlan pl = wgrad_plan(a.M);
   a.S = pl.S; a.chunk = pl.chunk;
-  KwsProfScope prof("gemm_tn", 2.0 * a.M * 80 * N, 4.0 * ((double)B * g->x_len + (double)a.M * N + 80.0 * N), st);
+  KwsProfScope prof("conv1_wgrad", 2.0 * a.M * 80 * N, 4.0 * ((double)B * g->x_len + (double)a.M * N + 80.0 * N), st);
   hipLaunchKernelGGL((conv1_wgrad_kernel<80>), dim3(pl.S), dim3(256), 0, st, a);
   KWS_LAUNCH_CHECK("conv1_wgrad_kernel");
   // slab sum in two stages: groups of 32 slabs in place (over each group's first slab), then the group sums straight into

@@ -30,6 +30,35 @@ def test_bench_two_ranks_print_one_json_line():
     out = json.loads(json_lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 6 and out["warmup"] == 2 and out["scaling"] == "weak"
     assert out["config"]["global_batch"] == 512 and out["config"]["parallelism"] == "dp2"
-    assert out["value"] > 0 and out["roofline"] is not None and out["cpu_baseline"] is None
+    assert out["value"] > 0 and out["roofline"] is not None and out["rccl_ranks"] == 2
+    assert out["cpu_baseline"]["value"] > 0 and out["cpu_baseline"]["kind"] == "port"      # N>1 lines carry it too
     assert out["train_loss_first_last"][0] == out["train_loss_first_last"][0]      # finite
     print("non-JSON stdout lines of the launcher:", other)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (how the driver may call it): bench.py starts the two
+    ranks itself as child processes BEFORE touching the GPU, relays rank 0's line and reports n_gpus 2 - never a
+    silent 1-GPU run.  (--no-cpu-baseline: the other test covers that leg.)"""
+    env = dict(os.environ, KWS_BENCH_ONE_DEVICE="1", KWS_BENCH_TRACE="240", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--bank", "8192",
+           "--batch", "256", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=400)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    lines = [l for l in res.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["config"]["global_batch"] == 512
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """--gpus 64 on this box must fail, not degrade to the devices that exist."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "KWS_BENCH_ONE_DEVICE"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1", "--warmup", "0"],
+                         cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert res.returncode != 0 and not res.stdout.strip()
+    assert b"GPU(s) visible" in res.stderr

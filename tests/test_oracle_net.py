@@ -10,44 +10,35 @@ from oracle.net import TimeSlicedAttentionNet
 
 
 def torch_forward(net, params, x, y, seed, step):
-    """Same network written with torch.nn.functional (channels-first inside)."""
-    B = x.shape[0]
-    dt = torch.float64
-    xt = torch.from_numpy(x).to(dt)
-    xp = F.pad(xt, (10, 10))
-    frames = xp.unfold(1, 40, 20)                     # [B, 800, 40]
-    h = frames.permute(0, 2, 1)                       # [B, 40, 800]
-    W = params['conv1d_1/kernel']                     # [3, 40, 128]
-    h = F.conv1d(h, W.permute(2, 1, 0), stride=2)
+    """The same network through torch.nn.functional (oracle/torch_net.py, float64 here)."""
+    from oracle.torch_net import forward
+    return forward(net, params, torch.from_numpy(x).to(torch.float64), torch.from_numpy(y).to(torch.float64), seed, step)
 
-    def bn_relu6(h, idx):
-        g = params['batch_normalization_%d/gamma' % idx]
-        b = params['batch_normalization_%d/beta' % idx]
-        h = F.batch_norm(h, None, None, g, b, training=True, eps=1e-3)
-        return torch.clamp(h, 0, 6)
-    h = bn_relu6(h, 1)
-    for i, blk in enumerate(net.blocks):
-        w = params['depthwise_conv2d_%d/depthwise_kernel' % (i + 1)].reshape(3, blk['cin'])
-        hp = F.pad(h, blk['pad'])
-        h = F.conv1d(hp, w.t().unsqueeze(1), stride=blk['stride'], groups=blk['cin'])
-        Wp = params['conv1d_%d/kernel' % (i + 2)].reshape(blk['cin'], blk['cout'])
-        h = F.conv1d(h, Wp.t().unsqueeze(2))
-        h = bn_relu6(h, i + 2)
-    a = h.permute(0, 2, 1)                            # [B, T, C]
-    T, C = net.T, net.C
-    m1 = torch.from_numpy(L.dropout_mask(L.dropout_key(seed, step, 1), B * T * C, 0.6).reshape(B, T * C)).to(dt)
-    m2 = torch.from_numpy(L.dropout_mask(L.dropout_key(seed, step, 2), B * 2 * C, 0.6).reshape(B, 2 * C)).to(dt)
-    fd = a.reshape(B, T * C) * m1 / 0.6
-    att = torch.softmax(fd @ params['dense_1/kernel'] + params['dense_1/bias'], dim=1)
-    xa = a * att[:, :, None]
-    feat = torch.cat([xa.max(dim=1).values, a.mean(dim=1)], dim=1) * m2 / 0.6
-    p = torch.softmax(feat @ params['dense_2/kernel'], dim=1)
-    yt = torch.from_numpy(y).to(dt)
-    ysm = yt * 0.9 + 0.1 / y.shape[1]
-    logits = torch.log(torch.clamp(p, 1e-7, 1 - 1e-7))
-    loss = -(ysm * torch.log_softmax(logits, dim=1)).sum(dim=1).mean()
-    reg = sum(1e-5 * (v ** 2).sum() for k, v in params.items() if k.endswith('kernel'))
-    return p, loss, reg
+
+def test_torch_twin_train_steps_follow_numpy_oracle():
+    """oracle/torch_net.py:TorchTimeSlicedNet (the CPU trainer of the val-acc parity run and of bench.py's cpu_baseline)
+    against the NumPy oracle's train_step: losses, parameters, BN moving statistics after 3 RMSprop / SGD steps, and the
+    inference-mode probabilities that validation reads."""
+    from oracle.torch_net import TorchTimeSlicedNet
+    for kind, lr in (('rmsprop', 1e-3), ('sgd', 1e-2)):
+        ora = TimeSlicedAttentionNet(dtype=np.float64)
+        ora.init_optimizer(kind)
+        twin = TorchTimeSlicedNet(dtype=torch.float64, numpy_net=TimeSlicedAttentionNet(dtype=np.float64))
+        twin.init_optimizer(kind)
+        rng = np.random.RandomState(5)
+        for step in range(3):
+            x = rng.randn(4, 16000) * 0.0774
+            y = np.eye(12)[rng.randint(0, 12, 4)]
+            l0, a0 = ora.train_step(x, y, lr, seed=3, step=step)
+            l1, a1 = twin.train_step(x, y, lr, seed=3, step=step)
+            assert abs(l0 - l1) < 1e-9 * max(1.0, abs(l0)) and a0 == a1, (kind, step, l0, l1)
+        for k, v in ora.master.items():
+            # RMSprop divides by sqrt(a): elements whose gradient is ~0 amplify rounding, hence the absolute floor
+            np.testing.assert_allclose(twin.params[k].detach().numpy().reshape(v.shape), v, rtol=1e-6, atol=1e-7, err_msg=k)
+        for k, v in ora.state.items():
+            np.testing.assert_allclose(twin.state[k].numpy(), v, rtol=1e-9, atol=1e-12, err_msg=k)
+        xv = rng.randn(3, 16000) * 0.0774
+        np.testing.assert_allclose(twin.predict(xv), ora.forward(xv, training=False), rtol=1e-5, atol=1e-8)
 
 
 def test_param_count_matches_reference_readme_and_survey():
