@@ -305,6 +305,11 @@ class LogMfccNet(object):
         self.first = (conv(3, num_features, 64, True), bn(64))
         self.blocks = []
         cin, L = 64, spectrogram_length - 2
+        if L % 8 != 0:
+            # Keras' MaxPool1D(2, 2, 'same') / Conv1D(strides=2, 'same') give ceil(L/2) for an odd length (e.g. the
+            # function default spectrogram_length=65, model.py:1410 -> 63 frames); this restatement (and the device
+            # program, net_logmfcc.hip:lm_build) covers the lengths that halve evenly three times (98 -> 96) only
+            raise ValueError("LogMfccNet: spectrogram_length - 2 = %d must be a multiple of 8" % L)
         for nf, stride in LM_BLOCKS:
             blk = dict(nf=nf, stride=stride, cin=cin, Lin=L, Lout=L // stride)
             if stride != 1:

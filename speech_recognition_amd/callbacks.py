@@ -4,6 +4,7 @@ which is what drives ReduceLROnPlateau and ModelCheckpoint (train.py:56-68).  pa
 by a NumPy confusion matrix with the same label ordering (sorted union of seen labels)."""
 import numpy as np
 
+from . import parallel
 from .keras_api import Callback
 
 
@@ -39,9 +40,11 @@ class ConfusionMatrixCallback(Callback):
         self.all_words = all_words
         self.label2int = label2int
         self.int2label = {v: k for k, v in label2int.items()}
+        self._writes = parallel.rank() == 0      # data-parallel: rank 0 owns the two text files
         for fn in ('confusion_matrix.txt', 'wanted_confusion_matrix.txt'):
-            with open(fn, 'w'):
-                pass
+            if self._writes:
+                with open(fn, 'w'):
+                    pass
 
     @staticmethod
     def accuracies(confusion_val):
@@ -73,12 +76,13 @@ class ConfusionMatrixCallback(Callback):
         wanted_accs = self.accuracies(wconf)
         acc_line = "\n[%03d]: val_categorical_accuracy: %.2f, val_mean_categorical_accuracy_wanted: %.2f" % (
             epoch, acc, wanted_accs.mean())
-        with open('confusion_matrix.txt', 'a') as f:
-            f.write('%s\n' % acc_line)
-            f.write(_format(labels, conf))
-        with open('wanted_confusion_matrix.txt', 'a') as f:
-            f.write('%s\n' % acc_line)
-            f.write(_format(wlabels, wconf))
+        if self._writes:
+            with open('confusion_matrix.txt', 'a') as f:
+                f.write('%s\n' % acc_line)
+                f.write(_format(labels, conf))
+            with open('wanted_confusion_matrix.txt', 'a') as f:
+                f.write('%s\n' % acc_line)
+                f.write(_format(wlabels, wconf))
         logs['val_loss'] = val_loss
         logs['val_categorical_accuracy'] = acc
         logs['val_mean_categorical_accuracy_all'] = accs.mean()

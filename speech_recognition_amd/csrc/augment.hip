@@ -167,15 +167,20 @@ int launch_augment(const BankT* bank, int64_t n_clips, int L, const int32_t* cli
                    const int32_t* shift, const float* noise, int64_t noise_len, const int64_t* noise_off,
                    const float* bg_vol, float* out, int B, void* stream) {
   KWS_REQUIRE(bank && clip_idx && fg_vol && shift && bg_vol && out, "augment: NULL pointer");
-  KWS_REQUIRE(n_clips > 0 && L > 0 && B > 0 && B <= 65535, "augment: bad sizes n_clips=%lld L=%d B=%d",
-              (long long)n_clips, L, B);
+  KWS_REQUIRE(n_clips > 0 && L > 0 && B > 0, "augment: bad sizes n_clips=%lld L=%d B=%d", (long long)n_clips, L, B);
   KWS_REQUIRE(noise == nullptr || (noise_off != nullptr && noise_len > 0), "augment: noise given without offsets");
   const int L4 = ceil_div(L, 4);
-  dim3 g((unsigned)ceil_div(L4, 256), (unsigned)B), b(256);
   KwsProfScope prof("augment", 3.0 * B * L, (double)B * L * (sizeof(BankT) + 8.0), (hipStream_t)stream);
-  hipLaunchKernelGGL((augment_kernel<BankT>), g, b, 0, (hipStream_t)stream, bank, n_clips, L, clip_idx, fg_vol, shift,
-                     noise, noise_len, noise_off, bg_vol, out, L4);
-  KWS_LAUNCH_CHECK("augment_kernel");
+  // grid.y carries the clip and is capped at 65535: a whole partition at once (get_data(how_many=-1),
+  // get_unprocessed_data(-1); input_data.py:404-407,553) goes out as several launches
+  for (int b0 = 0; b0 < B; b0 += 65535) {
+    const int nb = B - b0 < 65535 ? B - b0 : 65535;
+    dim3 g((unsigned)ceil_div(L4, 256), (unsigned)nb), b(256);
+    hipLaunchKernelGGL((augment_kernel<BankT>), g, b, 0, (hipStream_t)stream, bank, n_clips, L, clip_idx + b0, fg_vol + b0,
+                       shift + b0, noise, noise_len, noise_off ? noise_off + b0 : nullptr, bg_vol + b0,
+                       out + (int64_t)b0 * L, L4);
+    KWS_LAUNCH_CHECK("augment_kernel");
+  }
   return KWS_OK;
 }
 
@@ -198,11 +203,14 @@ int kws_augment_i16(const int16_t* bank, int64_t n_clips, int L, const int32_t* 
 }
 
 int kws_tta_transform(const float* x, float* out, int B, int L, int kind, void* stream) {
-  KWS_REQUIRE(x && out && B > 0 && B <= 65535 && L > 0, "tta_transform: bad arguments");
+  KWS_REQUIRE(x && out && B > 0 && L > 0, "tta_transform: bad arguments");
   KWS_REQUIRE(kind >= 0 && kind <= 4, "tta_transform: kind %d unknown", kind);
-  dim3 g((unsigned)ceil_div(L, 256), (unsigned)B), b(256);
-  hipLaunchKernelGGL(tta_kernel, g, b, 0, (hipStream_t)stream, x, out, L, kind);
-  KWS_LAUNCH_CHECK("tta_kernel");
+  for (int b0 = 0; b0 < B; b0 += 65535) {      // grid.y cap, as in launch_augment
+    const int nb = B - b0 < 65535 ? B - b0 : 65535;
+    dim3 g((unsigned)ceil_div(L, 256), (unsigned)nb), b(256);
+    hipLaunchKernelGGL(tta_kernel, g, b, 0, (hipStream_t)stream, x + (int64_t)b0 * L, out + (int64_t)b0 * L, L, kind);
+    KWS_LAUNCH_CHECK("tta_kernel");
+  }
   return KWS_OK;
 }
 

@@ -104,11 +104,26 @@ extern "C" int kws_sampler_draw(uint32_t* mt_key, int* mt_pos, const kws_sampler
       row = cand->rows[j]; lab = cand->labels[j]; sil = cand->silence[j] != 0;
     }
     int32_t shift = 0;
-    if (mt.uniform(0.0, 1.0) < a->time_shift_frequency) shift = (int32_t)mt.randint(a->shift_lo, (int64_t)a->shift_hi + 1);
+    if (mt.uniform(0.0, 1.0) < a->time_shift_frequency) {
+      if (a->shift_lo > a->shift_hi) {
+        kws_set_error("sampler_draw: low >= high (time_shift_range [%d, %d])", a->shift_lo, a->shift_hi);
+        *mt_pos = mt.pos;
+        return KWS_E_INVALID;
+      }
+      shift = (int32_t)mt.randint(a->shift_lo, (int64_t)a->shift_hi + 1);
+    }
     int64_t bg_off = 0;
     double bg_vol = 0.0;
     if (a->use_background) {
       const int64_t bi = mt.randint(0, a->n_bg);
+      if (a->bg_len[bi] <= (int64_t)a->desired_samples) {
+        // np.random.randint(0, n <= 0) raises ValueError("low >= high") in the reference (input_data.py:485);
+        // the unsigned range below would wrap and index outside the recording
+        kws_set_error("sampler_draw: low >= high (background recording %lld has %lld samples, desired_samples %d)",
+                      (long long)bi, (long long)a->bg_len[bi], a->desired_samples);
+        *mt_pos = mt.pos;
+        return KWS_E_INVALID;
+      }
       const int64_t bo = mt.randint(0, a->bg_len[bi] - a->desired_samples);
       bg_off = a->bg_start[bi] + bo;
       if (mt.uniform(0, 1) < a->background_frequency) {

@@ -75,6 +75,17 @@ def save_wav_file(filename, wav_data, sample_rate):
                 b'data' + struct.pack('<I', len(pcm)) + pcm)
 
 
+def bank_from_files(file_row, desired_samples):
+    """Host image of the int16 clip bank: row r = the first `desired_samples` samples of file r's first channel,
+    zero padded (DecodeWav with desired_channels=1, desired_samples; reference input_data.py:335-336)."""
+    bank = np.zeros((max(len(file_row), 1), desired_samples), dtype=np.int16)
+    for fn, r in file_row.items():
+        a, _ = _read_wav_int16(fn)
+        n = min(len(a), desired_samples)
+        bank[r, :n] = a[:n]
+    return bank
+
+
 class _Placeholder(object):
     """Opaque feed key standing in for a tf.placeholder of the reference's processing graph."""
 
@@ -184,13 +195,7 @@ class AudioProcessor(object):
 
     def _build_bank(self):
         """Decode every distinct file of the index once into the int16 HBM clip bank."""
-        L = self.model_settings['desired_samples']
-        rows = self._file_row
-        bank = np.zeros((max(len(rows), 1), L), dtype=np.int16)
-        for fn, r in rows.items():
-            a, _ = _read_wav_int16(fn)
-            n = min(len(a), L)
-            bank[r, :n] = a[:n]
+        bank = bank_from_files(self._file_row, self.model_settings['desired_samples'])
         self.bank = ClipBank(torch.from_numpy(bank).to(self.device), self.background_data, self.device)
 
     def _init_synthetic(self, spec, wanted_words):

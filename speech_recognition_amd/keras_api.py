@@ -224,6 +224,8 @@ class ModelCheckpoint(Callback):
                 print('\nEpoch %05d: %s improved from %0.5f to %0.5f, saving model to %s'
                       % (epoch + 1, self.monitor, self.best, current, filepath))
             self.best = current
+        if parallel.rank() != 0:      # data-parallel: replicas are identical, rank 0 owns the files
+            return
         d = os.path.dirname(filepath)
         if d and not os.path.isdir(d):
             os.makedirs(d)
@@ -240,11 +242,15 @@ class TensorBoard(Callback):
         self._f = None
 
     def on_train_begin(self, logs=None):
+        if parallel.rank() != 0:
+            return
         if not os.path.isdir(self.log_dir):
             os.makedirs(self.log_dir)
         self._f = open(os.path.join(self.log_dir, 'scalars.jsonl'), 'a')
 
     def on_epoch_end(self, epoch, logs=None):
+        if self._f is None:
+            return
         rec = OrderedDict(step=epoch, wall_time=time.time())
         for k, v in sorted((logs or {}).items()):
             rec[k] = float(v)
@@ -366,6 +372,22 @@ class Model(object):
                 self.net.slots.copy_(torch.from_numpy(z['__optimizer_slots__']))
                 self.optimizer.lr.value = np.float32(z['__lr__'])
                 self._step = int(z['__step__'])
+        self.sync_replicas()
+
+    def sync_replicas(self):
+        """Data-parallel runs: every replica takes rank 0's parameters, BN moving statistics, optimizer slots, lr and
+        step counter (no-op on one GPU).  Called at fit start, after load_weights and at every epoch end, so replicas
+        cannot drift apart through a one-rank load or through their rank-local BN statistics."""
+        if not parallel.active():
+            return
+        for buf in (self.net.params, self.net.state, self.net.slots):
+            parallel.broadcast_params(buf)
+        t = torch.tensor([float(self.optimizer.lr.value), float(self._step), float(self.stop_training)],
+                         dtype=torch.float64, device=self.device if parallel.dist.get_backend() == 'nccl' else 'cpu')
+        parallel.dist.broadcast(t, src=0)
+        self.optimizer.lr.value = np.float32(t[0].item())
+        self._step = int(t[1].item())
+        self.stop_training = bool(t[2].item())
 
     def summary(self):
         print("Model: %s" % self.name)
@@ -445,6 +467,7 @@ class Model(object):
         enq.start()
         self.stop_training = False
         try:
+            self.sync_replicas()
             for cb in cbs:
                 cb.on_train_begin()
             for epoch in range(initial_epoch, epochs):
@@ -471,8 +494,14 @@ class Model(object):
                 n = float(sum(sizes))
                 logs = {'loss': m[:, 0].sum() / n + reg_sum / max(reg_n, 1),
                         'categorical_accuracy': m[:, 1].sum() / n}
+                if parallel.active():
+                    # rank 0's moving statistics become everyone's BEFORE validation: every rank then computes the
+                    # same val_* logs, so ReduceLROnPlateau / early stopping decide alike on all replicas
+                    parallel.broadcast_params(self.net.state)
                 for cb in cbs:
                     cb.on_epoch_end(epoch, logs)
+                if parallel.active():
+                    self.sync_replicas()          # lr / stop flag as rank 0 decided them; also the barrier after file writes
                 if verbose:
                     print("\rEpoch %d/%d - %.1fs - %s" % (epoch + 1, epochs, time.time() - t0,
                           " - ".join("%s: %.4f" % kv for kv in sorted(logs.items()))))

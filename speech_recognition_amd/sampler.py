@@ -13,6 +13,7 @@ import math
 import os.path
 import random
 import re
+import threading
 
 import numpy as np
 
@@ -48,6 +49,9 @@ def which_set(filename, validation_percentage, testing_percentage):
     if percentage_hash < (testing_percentage + validation_percentage):
         return 'testing'
     return 'training'
+
+
+_RNG_LOCK = threading.Lock()     # serialises every read-modify-write of np.random's global state (DataIndex.draw)
 
 
 class DataIndex(object):
@@ -148,6 +152,20 @@ class DataIndex(object):
         import ctypes
         from . import _lib
         lib = _lib.load()
+        with _RNG_LOCK:
+            return self._draw_locked(lib, ctypes, _lib, mode, offset, sample_count, how_many, desired_samples,
+                                     background_lengths, background_starts, background_frequency, background_volume_range,
+                                     foreground_frequency, foreground_volume_range, time_shift_frequency, time_shift_range,
+                                     pseudo_frequency, flip_frequency, silence_volume_range)
+
+    def _draw_locked(self, lib, ctypes, _lib, mode, offset, sample_count, how_many, desired_samples, background_lengths,
+                     background_starts, background_frequency, background_volume_range, foreground_frequency,
+                     foreground_volume_range, time_shift_frequency, time_shift_range, pseudo_frequency, flip_frequency,
+                     silence_volume_range):
+        # get_state -> C (GIL released) -> set_state is a read-modify-write of the GLOBAL generator: fit_generator's
+        # enqueuer thread draws training batches while the validation callback draws on the main thread, and an
+        # interleaving would replay a stretch of the stream.  The reference consumes the generator call by call under
+        # the GIL and never rewinds; _RNG_LOCK gives the same guarantee here.
         st = np.random.get_state()
         if st[0] != 'MT19937':
             raise _lib.KwsError("np.random global state is not MT19937")
@@ -181,11 +199,15 @@ class DataIndex(object):
         bg_off = np.empty(sample_count, np.int64)
         bg_vol = np.empty(sample_count, np.float32)
         fg_vol = np.empty(sample_count, np.float32)
-        _lib.check(lib.kws_sampler_draw(key.ctypes.data, ctypes.byref(pos), ctypes.byref(cand), ctypes.byref(pseudo),
-                                        ctypes.byref(a), rows.ctypes.data, labels.ctypes.data, shift.ctypes.data,
-                                        bg_off.ctypes.data, bg_vol.ctypes.data, fg_vol.ctypes.data),
-                   "kws_sampler_draw")
-        np.random.set_state((st[0], key, pos.value, st[3], st[4]))
+        rc = lib.kws_sampler_draw(key.ctypes.data, ctypes.byref(pos), ctypes.byref(cand), ctypes.byref(pseudo),
+                                  ctypes.byref(a), rows.ctypes.data, labels.ctypes.data, shift.ctypes.data,
+                                  bg_off.ctypes.data, bg_vol.ctypes.data, fg_vol.ctypes.data)
+        np.random.set_state((st[0], key, pos.value, st[3], st[4]))     # draws made before an error stay consumed
+        if rc != 0:
+            msg = (lib.kws_last_error() or b"").decode()
+            if "low >= high" in msg:          # what np.random.randint raises at input_data.py:474,485
+                raise ValueError(msg)
+            _lib.check(rc, "kws_sampler_draw")
         return rows, labels, shift, bg_off, bg_vol, fg_vol
 
     def draw_python(self, mode, offset, sample_count, how_many, desired_samples, background_lengths,
