@@ -117,6 +117,50 @@ int kws_time_stretch_f32(const kws_stretch_plan_t* plan, const float* x, float i
 int kws_time_stretch_i16(const kws_stretch_plan_t* plan, const int16_t* x, float* out, int B, int keep,
                          int quantize, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Stand-alone forms of the classifier-tail ops (the network programs below run them fused in one
+ * kernel; these bind ONE reference call site each).
+ *
+ * keras Dropout, reference model.py:819,828 (mask = floor(keep_prob + U[0,1)), x / keep_prob).
+ * Counter-based: element i of row r keeps its value iff fmix32(((row_offset + r) * n + i) * 0x9E3779B1 + key) <
+ * keep_prob * 2^32, key = f(seed, step, layer_id) - the masks the network programs and the oracle use
+ * (layer_id 1 = dropout_1, 2 = dropout_2).  bwd = the same mask applied to the incoming gradient.
+ * ---------------------------------------------------------------------------------------- */
+int kws_dropout_fwd(const float* x, float* out, int B, int n, float keep_prob, uint64_t seed,
+                    uint32_t step, uint32_t layer_id, int64_t row_offset, void* stream);
+int kws_dropout_bwd(const float* dy, float* dx, int B, int n, float keep_prob, uint64_t seed,
+                    uint32_t step, uint32_t layer_id, int64_t row_offset, void* stream);
+
+/* a12 attention pooling, reference model.py:824-827:
+ *   feat[b] = [ max_t(x[b,t,:] * att[b,t]) ; mean_t x[b,t,:] ]        x [B,T,C], att [B,T], feat [B,2C]
+ * bwd: dfeat [B,2C] -> dx [B,T,C] (gradient wrt x through both branches) and datt [B,T]; reduce_max
+ * splits its gradient equally among ties (TF _MinOrMaxGrad).  workspace: kws_attn_pool_bwd_workspace_floats. */
+int kws_attn_pool_fwd(const float* x, const float* att, float* feat, int B, int T, int C, void* stream);
+int64_t kws_attn_pool_bwd_workspace_floats(int B, int T, int C);
+int kws_attn_pool_bwd(const float* x, const float* att, const float* dfeat, float* dx, float* datt,
+                      float* workspace, int B, int T, int C, void* stream);
+
+/* a13 smooth_categorical_crossentropy, reference utils.py:87-108 as used at model.py:835-836:
+ *   loss[b] = softmax_cross_entropy(labels = y (1 - s) + s / NC, logits = log(clip(p, 1e-7, 1 - 1e-7)))
+ * probs/labels [B,NC] (NC <= 64); per_correct (may be NULL) = 1 where argmax p == argmax y.
+ * bwd: dprobs = dL/dp * inv_loss_batch (zero where the clip is active), dlogits = that gradient carried
+ * through the softmax that produced p; either output may be NULL. */
+int kws_softmax_xent_smooth_fwd(const float* probs, const float* labels, float* per_loss,
+                                float* per_correct, int B, int NC, float label_smoothing, void* stream);
+int kws_softmax_xent_smooth_bwd(const float* probs, const float* labels, float* dprobs, float* dlogits,
+                                int B, int NC, float label_smoothing, float inv_loss_batch, void* stream);
+
+/* Gradient exchange of the data-parallel step (the reference is single-session, train.py:24-26):
+ * an RCCL communicator from a (rank, world, 128-byte unique id) triple - rank 0 calls kws_comm_unique_id and
+ * hands the bytes to the other ranks by any side channel - and the in-place sum of the flat gradient buffer
+ * over xGMI, enqueued on `stream`.  librccl is resolved at run time (dlopen); a process that never creates a
+ * communicator never loads it. */
+typedef struct kws_comm kws_comm_t;
+int kws_comm_unique_id(void* id128);
+int kws_comm_create(int rank, int world, const void* id128, kws_comm_t** comm);
+int kws_comm_destroy(kws_comm_t* comm);
+int kws_allreduce_grads(kws_comm_t* comm, float* grads, int64_t n, void* stream);
+
 /* a18 32->12 head, reference freeze_graph_32_classes.py:55-69.
  * map[i] in [0,12): output slot of input class i (slot 1 = max over all classes mapped to 1). */
 int kws_head32to12(const float* p_in, int C_in, const int32_t* map, int C_out, float* p_out,

@@ -77,6 +77,17 @@ SIGNATURES = {
     "kws_tta_transform": (_I, [_P, _P, _I, _I, _I, _P]),
     "kws_tta_combine": (_I, [ctypes.POINTER(_P), _I, _F, _P, _P, _I, _I, _P]),
     "kws_head32to12": (_I, [_P, _I, _P, _I, _P, _I, _P]),
+    "kws_dropout_fwd": (_I, [_P, _P, _I, _I, _F, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, _I64, _P]),
+    "kws_dropout_bwd": (_I, [_P, _P, _I, _I, _F, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, _I64, _P]),
+    "kws_attn_pool_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "kws_attn_pool_bwd_workspace_floats": (_I64, [_I, _I, _I]),
+    "kws_attn_pool_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "kws_softmax_xent_smooth_fwd": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
+    "kws_softmax_xent_smooth_bwd": (_I, [_P, _P, _P, _P, _I, _I, _F, _F, _P]),
+    "kws_comm_unique_id": (_I, [_P]),
+    "kws_comm_create": (_I, [_I, _I, _P, ctypes.POINTER(_P)]),
+    "kws_comm_destroy": (_I, [_P]),
+    "kws_allreduce_grads": (_I, [_P, _P, _I64, _P]),
     "kws_stretch_plan_create": (_I, [_I, ctypes.c_double, ctypes.POINTER(_P)]),
     "kws_stretch_plan_destroy": (_I, [_P]),
     "kws_stretch_out_samples": (_I, [_P]),

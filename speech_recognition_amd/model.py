@@ -27,6 +27,53 @@ def overlapping_time_slice_stack(x, ksize, stride, padding='SAME'):
     raise _lib.KwsError("overlapping_time_slice_stack is fused into kws_gemm_gather_f32 on the device")
 
 
+def class_map_32_to_12(all_classes=None, wanted_classes=None):
+    """int32 map [len(all_classes) + 2] -> slot of the 12-class head, as freeze_graph_32_classes.py:55-69 walks it:
+    silence -> 0, the unknown-unknown class and every word outside `wanted_classes` -> 1 (their MAXIMUM becomes the
+    unknown probability), wanted words -> 2.. in the order they appear in `all_classes`."""
+    import numpy as np
+    from .classes import get_classes
+    all_classes = get_classes(wanted_only=False) if all_classes is None else list(all_classes)
+    wanted_classes = get_classes(wanted_only=True) if wanted_classes is None else list(wanted_classes)
+    mp = np.zeros(len(all_classes) + 2, np.int32)
+    mp[1], slot = 1, 2
+    for i, c in enumerate(all_classes):
+        if c in wanted_classes:
+            mp[i + 2] = slot
+            slot += 1
+        else:
+            mp[i + 2] = 1
+    return mp, slot
+
+
+_HEAD_MAPS = {}
+
+
+def head32to12(all_probs, all_classes=None, wanted_classes=None, out=None):
+    """The 32 -> 12 class head of the reference's frozen graph (freeze_graph_32_classes.py:55-69, BASELINE config C3)
+    on the device: `all_probs` [B, 32] softmax outputs of a 32-class model (CUDA tensor / DeviceArray / array) ->
+    [B, 12] = softmax over (silence, max over the unknown words, the wanted words).  One `kws_head32to12` launch."""
+    import torch
+    from .device_array import as_device_f32
+    dev = all_probs.device if isinstance(all_probs, torch.Tensor) and all_probs.is_cuda else \
+        torch.device("cuda", torch.cuda.current_device())
+    p = as_device_f32(all_probs, dev)
+    key = (tuple(all_classes) if all_classes is not None else None,
+           tuple(wanted_classes) if wanted_classes is not None else None, str(dev))
+    if key not in _HEAD_MAPS:
+        mp, n_out = class_map_32_to_12(all_classes, wanted_classes)
+        _HEAD_MAPS[key] = (torch.from_numpy(mp).to(dev), n_out)
+    dmap, n_out = _HEAD_MAPS[key]
+    if p.dim() != 2 or p.shape[1] != dmap.numel():
+        raise ValueError("head32to12: expected [B, %d] probabilities, got %s" % (dmap.numel(), tuple(p.shape)))
+    B = p.shape[0]
+    if out is None:
+        out = torch.empty((B, n_out), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.call("kws_head32to12", _lib.ptr(p), p.shape[1], _lib.ptr(dmap), n_out, _lib.ptr(out), B, _lib.stream_ptr())
+    return out
+
+
 def conv_1d_time_sliced_with_attention_model(input_size=16000, num_classes=11, filter_mult=1):
     """reference model.py:775-838: 12-block depthwise/pointwise 1-D CNN on raw waveform, attention-pooled
     head, RMSprop(1e-3), label-smoothed CE (0.1), categorical accuracy."""
