@@ -295,9 +295,9 @@ def parse_args(argv=None):
     ap.add_argument("--bank", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=5)
-    ap.add_argument("--val-acc", action="store_true",
-                    help="also train/validate a short run on the tone dataset and report val_acc (device) next to "
-                         "val_acc_cpu (oracle) - see scripts/val_acc_parity.py")
+    ap.add_argument("--no-val-acc", action="store_true",
+                    help="skip the short val-acc parity run (scripts/val_acc_parity.py: the same batches trained on the "
+                         "device and on the oracle's torch-CPU twin, val_acc next to val_acc_cpu); N=1 only")
     return ap.parse_args(argv)
 
 
@@ -475,7 +475,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        if args.val_acc:
+        if not args.no_val_acc and world == 1:
             try:
                 sys.path.insert(0, os.path.join(ROOT, "scripts"))
                 import val_acc_parity

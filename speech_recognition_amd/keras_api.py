@@ -456,7 +456,8 @@ class Model(object):
         if workers != 1 or use_multiprocessing:
             raise NotImplementedError("the reference uses the Keras defaults workers=1, threads (SURVEY D.7)")
         self.history = History()
-        cbs = [self.history] + list(callbacks or [])
+        cbs = list(callbacks or []) + [self.history]     # Keras 2.1.2 order: History last, so it records the val_* / lr
+                                                         # entries the user callbacks inject into `logs`
         for cb in cbs:
             cb.set_model(self)
             cb.set_params({'epochs': epochs, 'steps': steps_per_epoch, 'verbose': verbose,

@@ -1,0 +1,21 @@
+"""Val-acc parity (BASELINE.json metric: "...; val-acc parity"): the reference's train/validate loop (train.py:56-75,
+callbacks.py:45-83) on the device and on the oracle's CPU twin over the same batches - scripts/val_acc_parity.py."""
+import os
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_val_acc_parity_device_vs_cpu_oracle(repo_root):
+    sys.path.insert(0, os.path.join(repo_root, "scripts"))
+    import val_acc_parity
+    res = val_acc_parity.run(epochs=3, steps=40, batch=64, val_batches=8, quiet=True)
+    par = res["val_acc_parity"]
+    print(par["device"], par["cpu"])
+    assert abs(res["val_acc"] - res["val_acc_cpu"]) <= par["tolerance"] == 0.05
+    # both learned the 12-class tone task (chance = the largest class share, ~0.3 with 60 % 'unknown' draws folded in)
+    assert res["val_acc"] > 0.6 and res["val_acc_cpu"] > 0.6
+    # the training-side accuracies (same batches, same dropout masks) track each other as well
+    assert abs(par["device"]["train_acc"][-1] - par["cpu"]["train_acc"][-1]) < 0.08
