@@ -37,6 +37,12 @@ const char* kws_last_error(void);
 /* name of the device the calling thread is bound to; "" if no HIP device is usable */
 int kws_device_name(char* buf, int cap);
 
+/* A HIP stream in a scheduling class (cls: -1 lowest, 0 normal, +1 highest priority of the device's range).  The
+ * batch generator runs on a LOW-priority stream so that its kernels fill the CUs the training stream leaves idle
+ * instead of co-running with its MFMA kernels (PyTorch itself can only create normal / high priority streams). */
+int kws_stream_create(int cls, void** stream);
+int kws_stream_destroy(void* stream);
+
 /* Optional per-kernel-family profiler (measurement only, off by default).  While enabled every
  * launcher brackets its launch with a hipEvent pair on the launch stream and books the algorithmic
  * FLOPs/bytes of the call; kws_profile_collect() waits for the events and returns the number of

@@ -66,6 +66,8 @@ SIGNATURES = {
     "kws_abi_version": (_I, []),
     "kws_last_error": (ctypes.c_char_p, []),
     "kws_device_name": (_I, [ctypes.c_char_p, _I]),
+    "kws_stream_create": (_I, [_I, ctypes.POINTER(_P)]),
+    "kws_stream_destroy": (_I, [_P]),
     "kws_profile_enable": (_I, [_I]),
     "kws_profile_collect": (_I, []),
     "kws_profile_get": (_I, [_I, ctypes.c_char_p, _I, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I64),
@@ -172,6 +174,15 @@ def stream_ptr(stream=None):
     import torch
     s = stream if stream is not None else torch.cuda.current_stream()
     return ctypes.c_void_p(s.cuda_stream)
+
+
+def make_stream(device, cls):
+    """torch stream object around a HIP stream of scheduling class `cls` (-1 low, 0 normal, +1 high)."""
+    import torch
+    with torch.cuda.device(device):
+        h = ctypes.c_void_p()
+        check(load().kws_stream_create(int(cls), ctypes.byref(h)), "kws_stream_create")
+        return torch.cuda.ExternalStream(h.value, device=device)
 
 
 def profile_collect():

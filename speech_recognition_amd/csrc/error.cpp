@@ -38,6 +38,38 @@ int kws_device_name(char* buf, int cap) {
   return KWS_OK;
 }
 
+// Streams with a scheduling class.  PyTorch can only make normal / high priority streams; the batch generator wants
+// a LOW one, so that its augment / STFT kernels take the CUs the training stream leaves idle instead of competing
+// with its MFMA kernels (they co-ran with conv1_* and lost both ways).  cls: -1 low, 0 normal, +1 high.
+int kws_stream_create(int cls, void** stream) {
+  if (!stream) {
+    kws_set_error("kws_stream_create: NULL output");
+    return KWS_E_INVALID;
+  }
+  int least = 0, greatest = 0;   // numerically: least priority is the LARGER number
+  if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) {
+    kws_set_error("hipDeviceGetStreamPriorityRange failed");
+    return KWS_E_HIP;
+  }
+  const int prio = cls < 0 ? least : (cls > 0 ? greatest : (least + greatest) / 2);
+  hipStream_t s = nullptr;
+  hipError_t e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio);
+  if (e != hipSuccess) {
+    kws_set_error("hipStreamCreateWithPriority(%d) failed: %s", prio, hipGetErrorString(e));
+    return KWS_E_HIP;
+  }
+  *stream = s;
+  return KWS_OK;
+}
+
+int kws_stream_destroy(void* stream) {
+  if (stream && hipStreamDestroy((hipStream_t)stream) != hipSuccess) {
+    kws_set_error("hipStreamDestroy failed");
+    return KWS_E_HIP;
+  }
+  return KWS_OK;
+}
+
 }  // extern "C"
 
 // ---- profiler ----------------------------------------------------------------------------------------

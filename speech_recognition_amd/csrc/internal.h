@@ -50,7 +50,13 @@ struct kws_stft_plan {
   float* dct;         // [n_mel * n_out]
   float2* tw16;       // [16][16] W256^(n2*k1)
   float* dct64;       // [n_mel][64] zero padded
+  // stft4 (first radix-16 pass on the matrix pipe): per-lane constants, columns in the order KPERM = 0..7, 9..15, 8
+  float* b4;          // [64 lanes][8 k-chunks][2 column tiles] 0.5 * DFT16 entries of the MFMA B operand
+  float2* tw4;        // [16 c][16 n2] W256^(n2 * KPERM[c])
+  float2* w512p;      // [16 c][8 k2]  W512^(KPERM[c] + 16 k2)
 };
 int kws_stft2_launch(const kws_stft_plan* pl, const float* x, int B, int L, int F, float* out, hipStream_t st);
 int kws_stft3_lds_bytes(const kws_stft_plan* pl);
 int kws_stft3_launch(const kws_stft_plan* pl, const float* x, int B, int L, int F, float* out, hipStream_t st);
+int kws_stft4_lds_bytes(const kws_stft_plan* pl);
+int kws_stft4_launch(const kws_stft_plan* pl, const float* x, int B, int L, int F, float* out, hipStream_t st);

@@ -258,6 +258,33 @@ int kws_stft_plan_create(int frame_len, int frame_step, int fft_len, int n_mel, 
   std::vector<float> d64((size_t)n_mel * 64, 0.f);
   for (int m = 0; m < n_mel; ++m)
     for (int q = 0; q < n_out && q < 64; ++q) d64[(size_t)m * 64 + q] = dct[(size_t)m * n_out + q];
+  // v4 kernel tables (stft4.hip; index algebra replayed in scripts/emulate_stft4.py)
+  static const int KPERM[16] = {0, 1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15, 8};
+  std::vector<float> b4(64 * 16);
+  for (int lane = 0; lane < 64; ++lane)
+    for (int j = 0; j < 8; ++j)
+      for (int ct = 0; ct < 2; ++ct) {
+        const int s4 = lane >> 4, c = lane & 15, jp = j >> 1, part = j & 1;
+        const int n1 = 4 * jp + s4;
+        // W16^(n1 k1) needs only the angle mod 2 pi: reduce the integer first so cos / sin see an exact multiple of pi/8
+        const int e = (n1 * KPERM[c]) & 15;
+        const double th = 2.0 * M_PI * e / 16.0;
+        double v;
+        if (ct == 0) v = part == 0 ? cos(th) : sin(th);
+        else v = part == 0 ? -sin(th) : cos(th);
+        b4[lane * 16 + j * 2 + ct] = (float)(0.5 * v);
+      }
+  std::vector<float2> tw4(256), w512p(128);
+  for (int c = 0; c < 16; ++c) {
+    for (int n2 = 0; n2 < 16; ++n2) {
+      const double ang = -2.0 * M_PI * (n2 * KPERM[c]) / 256.0;
+      tw4[c * 16 + n2] = make_float2((float)cos(ang), (float)sin(ang));
+    }
+    for (int k2 = 0; k2 < 8; ++k2) {
+      const double ang = -2.0 * M_PI * (KPERM[c] + 16 * k2) / 512.0;
+      w512p[c * 8 + k2] = make_float2((float)cos(ang), (float)sin(ang));
+    }
+  }
   int rc = upload(&p->window, win);
   if (rc == KWS_OK) rc = upload(&p->w256, w256);
   if (rc == KWS_OK) rc = upload(&p->w512, w512);
@@ -268,6 +295,9 @@ int kws_stft_plan_create(int frame_len, int frame_step, int fft_len, int n_mel, 
   if (rc == KWS_OK) rc = upload(&p->dct, d);
   if (rc == KWS_OK) rc = upload(&p->tw16, tw16);
   if (rc == KWS_OK) rc = upload(&p->dct64, d64);
+  if (rc == KWS_OK) rc = upload(&p->b4, b4);
+  if (rc == KWS_OK) rc = upload(&p->tw4, tw4);
+  if (rc == KWS_OK) rc = upload(&p->w512p, w512p);
   if (rc != KWS_OK) {
     kws_stft_plan_destroy(p);
     return rc;
@@ -278,8 +308,8 @@ int kws_stft_plan_create(int frame_len, int frame_step, int fft_len, int n_mel, 
 
 int kws_stft_plan_destroy(kws_stft_plan_t* p) {
   if (!p) return KWS_OK;
-  void* bufs[10] = {p->window, p->w256, p->w512, p->band_start, p->band_cnt, p->band_ofs, p->band_w, p->dct,
-                    p->tw16, p->dct64};
+  void* bufs[13] = {p->window, p->w256, p->w512, p->band_start, p->band_cnt, p->band_ofs, p->band_w, p->dct,
+                    p->tw16, p->dct64, p->b4, p->tw4, p->w512p};
   for (void* q : bufs)
     if (q) (void)hipFree(q);
   delete p;
@@ -307,7 +337,10 @@ int kws_stft_mel_f32(const kws_stft_plan_t* plan, const float* x, int B, int L, 
   KwsProfScope prof("stft_mel", fl, 4.0 * ((double)B * L + (double)B * a.F * width), st);
   static const bool force_v1 = getenv("KWS_STFT_V1") != nullptr;
   static const bool force_v2 = getenv("KWS_STFT_V2") != nullptr;
+  static const bool force_v3 = getenv("KWS_STFT_V3") != nullptr;
   if (out_kind == 0 && plan->n_out <= 64 && plan->n_mel <= 128 && plan->frame_len % 2 == 0 && !force_v1) {
+    if (!force_v2 && !force_v3 && plan->n_mel % 4 == 0 && kws_stft4_lds_bytes(plan) <= 160 * 1024)
+      return kws_stft4_launch(plan, x, B, L, a.F, out, st);   // first radix-16 pass + DCT on the matrix pipe
     if (!force_v2 && plan->n_mel % 4 == 0 && kws_stft3_lds_bytes(plan) <= 160 * 1024)
       return kws_stft3_launch(plan, x, B, L, a.F, out, st);   // tables in registers, DCT on the matrix pipe
     return kws_stft2_launch(plan, x, B, L, a.F, out, st);

@@ -1,0 +1,270 @@
+// STFT -> |X| -> mel -> log -> DCT feature kernel, fourth generation (reference
+// input_data.py:361-381, audio.py:15-23).
+//
+// The third kernel (stft2.hip: stft3_kernel) is bound by vector-instruction issue at 2 waves per SIMD: both radix-16
+// passes of the 16 x 16 Cooley-Tukey split run on the vector pipe, the passes are joined by a transpose through LDS,
+// and 94 registers per lane hold FFT constants.  Here the FIRST pass is a matrix product on the matrix pipe:
+//
+//   z[m] = w x[2m] + i w x[2m+1],  m = 16 n1 + n2,  Z[k1 + 16 k2] = sum_n2 W256^(n2 k1) W16^(n2 k2) Y[k1][n2]
+//   Y[k1][n2] = sum_n1 z[16 n1 + n2] W16^(n1 k1)                      <- 16-point DFTs over n1 = [rows x 32] x [32 x 32]
+//
+// as v_mfma_f32_16x16x4_f32 products D = A B (exact f32 fma chains):
+//   A  (data)      row r = 4 u + i  <->  frame u of the wave's four frames, n2 = 4 t + i of row tile t = 0..3;
+//                  K index (8 chunks of 4) <-> (n1, re/im): one 8-byte load per lane feeds two chunks;
+//   B  (constant)  [K][col]: col c <-> k1 = KPERM[c]; column tile 0 = Re Y, 1 = Im Y; entries 0.5 cos / 0.5 sin
+//                  (the 0.5 of the real-input split is folded in: a power of two, so the products stay exact);
+//   D  layout      lane (g = lane / 16, c = lane % 16), register i of tile t: row 4 g + i = (frame g, n2 = 4 t + i)
+// so after 64 MFMAs lane (g, c) holds Y[k1][n2 = 0..15] of frame g in registers - exactly what the SECOND pass (a
+// 16-point FFT in registers, twiddles W256^(n2 k1) first) wants.  The matrix layouts do the transpose: no LDS round
+// trip between the passes, no window / twiddle constants in registers (32 instead of 94: they are LDS tables), and the column
+// order KPERM = 0..7, 9..15, 8 puts the real-input split's partner bin Z[256 - k] in the MIRRORED lane of the 16-lane
+// row, so the partner exchange is a DPP row_mirror operand instead of a ds_bpermute.
+// Everything after the split (magnitudes to LDS, CSR mel bands, log, DCT of 16 frames on the matrix pipe, one
+// 16-lane x 16-byte store per feature row) is the third kernel's, with 12 waves per workgroup (3 per SIMD) so that one
+// wave's matrix work runs beside another's vector work.
+// scripts/emulate_stft4.py replays this index algebra in NumPy against numpy.fft.rfft.
+#include "stft_common.h"
+
+using namespace kws_fft;
+
+namespace {
+
+constexpr int NW4 = 12;             // waves per workgroup: 3 per SIMD
+constexpr int DSTR4 = 80;           // DCT table row stride (floats), as in stft3
+constexpr int MAGF = 260;           // floats of one frame's magnitude row
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float row_mirror(float v) {   // value of lane 15 - (lane % 16) of the same 16-lane row
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));
+}
+
+__global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const kws_stft_plan& pl = a.pl;
+  const int n_mel = pl.n_mel, n_out = pl.n_out;
+  const int LMS = n_mel + 1;                                       // log-mel row stride (odd: conflict-free columns)
+  float* s_win = lds;                                              // [512] zero padded window
+  float2* s_tw = reinterpret_cast<float2*>(s_win + 512);           // [16 n2][16 c] second-pass twiddles W256^(n2 k1)
+  float* s_dct = s_win + 512 + 512;                                // [n_mel][DSTR4]
+  float* s_bw = s_dct + n_mel * DSTR4;                             // [n_w]
+  int* s_csr = reinterpret_cast<int*>(s_bw + ((pl.n_w + 3) & ~3)); // [3][128] start | cnt | ofs
+  float* s_wave = reinterpret_cast<float*>(s_csr + 3 * 128);
+  const int wave_floats = 4 * MAGF + ((16 * LMS + 3) & ~3);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l16 = lane & 15, fq = lane >> 4;                       // D role: column c = l16, frame g = fq
+  const int ar_u = l16 >> 2, ar_i = l16 & 3;                       // A role: row l16 = (frame u, n2 % 4), k slot fq
+  float* s_mag = s_wave + wave * wave_floats + fq * MAGF;          // this lane row's frame
+  float* s_lm16 = s_wave + wave * wave_floats + 4 * MAGF;          // [16][LMS] log-mel rows of the super-quad
+
+  for (int i = tid; i < 512; i += NW4 * 64) s_win[i] = pl.window[i];
+  for (int i = tid; i < 256; i += NW4 * 64) s_tw[i] = pl.tw4[(i & 15) * 16 + (i >> 4)];   // [c][n2] -> [n2][c]: a row's
+                                                   // 16 lanes read 16 consecutive 8-byte entries (conflict-free)
+  for (int i = tid; i < n_mel * DSTR4; i += NW4 * 64) {
+    const int m = i / DSTR4, q = i - m * DSTR4;
+    s_dct[i] = q < 64 ? pl.dct64[m * 64 + q] : 0.f;
+  }
+  for (int i = tid; i < pl.n_w; i += NW4 * 64) s_bw[i] = pl.band_w[i];
+  for (int i = tid; i < 128; i += NW4 * 64) {
+    s_csr[i] = i < n_mel ? pl.band_start[i] : 0;
+    s_csr[128 + i] = i < n_mel ? pl.band_cnt[i] : 0;
+    s_csr[256 + i] = i < n_mel ? pl.band_ofs[i] : 0;
+  }
+  // per-lane constants: B operand of the 16 (k-chunk, column tile) products, second-pass twiddles, split factors
+  float r_b[16];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 v = *reinterpret_cast<const float4*>(pl.b4 + lane * 16 + 4 * q);
+    r_b[4 * q] = v.x; r_b[4 * q + 1] = v.y; r_b[4 * q + 2] = v.z; r_b[4 * q + 3] = v.w;
+  }
+  float2 r_w512[8];
+#pragma unroll
+  for (int k2 = 0; k2 < 8; ++k2) r_w512[k2] = pl.w512p[l16 * 8 + k2];
+  const int k1 = l16 < 8 ? l16 : (l16 < 15 ? l16 + 1 : 8);         // KPERM[l16]
+  // sample offsets of this lane's A-operand loads: 2 (16 (4 j' + s) + 4 t + i), s = fq, i = ar_i
+  const int a_off0 = 2 * (16 * fq + ar_i);                         // + 128 j' + 8 t
+  __syncthreads();
+
+  const int64_t n_super = (a.total_quads + 3) / 4;
+  const int64_t wave_global = (int64_t)blockIdx.x * NW4 + wave;
+  const int64_t wave_stride = (int64_t)gridDim.x * NW4;
+  const int nb_mel = (n_mel + 15) >> 4;   // mel bands per lane
+  for (int64_t sq = wave_global; sq < n_super; sq += wave_stride) {
+#pragma unroll 1
+    for (int qq = 0; qq < 4; ++qq) {
+      const int64_t quad = sq * 4 + qq;
+      const bool quad_ok = quad < a.total_quads;
+      const int64_t b = quad_ok ? quad / a.quads_per_clip : 0;
+      const int f0 = quad_ok ? (int)(quad - b * a.quads_per_clip) * 4 : 0;
+      // ---- first pass on the matrix pipe ----------------------------------------------------------------
+      // A role: this lane loads for frame u = ar_u (frames past the clip's last one re-read frame 0: discarded below)
+      const int fu = f0 + ar_u < a.F ? f0 + ar_u : 0;
+      const float* fx = a.x + b * (int64_t)a.L + (int64_t)fu * pl.frame_step;
+      float2 xv[4][4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int jp = 0; jp < 4; ++jp) {
+          const int sidx = a_off0 + 128 * jp + 8 * t;
+          const int sc = sidx < pl.frame_len ? sidx : pl.frame_len - 2;   // clamped; the padded window zeroes the tail
+          xv[t][jp] = *reinterpret_cast<const float2*>(fx + sc);
+        }
+      f32x4 acc[4][2];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int jp = 0; jp < 4; ++jp) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float2 wv = *reinterpret_cast<const float2*>(s_win + a_off0 + 128 * jp + 8 * t);
+          const float ar = xv[t][jp].x * wv.x, ai = xv[t][jp].y * wv.y;
+          acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar, r_b[4 * jp + 0], acc[t][0], 0, 0, 0);
+          acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar, r_b[4 * jp + 1], acc[t][1], 0, 0, 0);
+          acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai, r_b[4 * jp + 2], acc[t][0], 0, 0, 0);
+          acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai, r_b[4 * jp + 3], acc[t][1], 0, 0, 0);
+        }
+      }
+      // ---- second pass in registers: lane (g, c) holds Y[k1][n2] of frame g ------------------------------
+      float2 z[16];
+#pragma unroll
+      for (int n2 = 0; n2 < 16; ++n2) z[n2] = make_float2(acc[n2 >> 2][0][n2 & 3], acc[n2 >> 2][1][n2 & 3]);
+#pragma unroll
+      for (int n2 = 1; n2 < 16; ++n2) z[n2] = cmul(z[n2], s_tw[n2 * 16 + l16]);
+      fft16(z);                                       // z[k2] = Z[k1 + 16 k2] / 2
+      // ---- real-input split + magnitude -------------------------------------------------------------
+      // X[k] = E + T and X[256-k] = conj(E - T) with E = (Z[k] + conj Z[256-k]) / 2, T = W512^k (Z[k] - conj Z[256-k]) / 2i
+      // (the halves are in z already).  Z[256-k] sits in the mirrored lane's register 15-k2; k1 = 0 (lane 0) and k1 = 8
+      // (lane 15) are their own partners, with registers (16-k2)&15 and 15-k2.
+#pragma unroll
+      for (int k2 = 0; k2 < 8; ++k2) {
+        const float2 pa = z[15 - k2], pb = z[(16 - k2) & 15];
+        const float mx = row_mirror(pa.x), my = row_mirror(pa.y);
+        const float2 zn0 = (l16 == 0) ? pb : (l16 == 15 ? pa : make_float2(mx, my));
+        const float2 zk = z[k2];
+        const float2 zn = make_float2(zn0.x, -zn0.y);
+        const float2 E = cadd(zk, zn);
+        const float2 dd = csub(zk, zn);
+        const float2 O = make_float2(dd.y, -dd.x);
+        const float2 T = cmul(r_w512[k2], O);
+        const float2 Xp = cadd(E, T), Xm = csub(E, T);
+        const int kk = k1 + 16 * k2;
+        s_mag[kk] = __builtin_amdgcn_sqrtf(Xp.x * Xp.x + Xp.y * Xp.y);
+        s_mag[256 - kk] = __builtin_amdgcn_sqrtf(Xm.x * Xm.x + Xm.y * Xm.y);
+      }
+      if (l16 == 0) {                                 // bin 128: Z[128] pairs with itself, |X[128]| = |Z[128]|
+        const float2 zk = z[8];
+        s_mag[128] = 2.0f * __builtin_amdgcn_sqrtf(zk.x * zk.x + zk.y * zk.y);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // ---- sparse mel bands + log -> row 4 qq + fq of the super-quad's log-mel block ----------------------
+      float* lm_row = s_lm16 + (4 * qq + fq) * LMS;
+      for (int i = 0; i < nb_mel; ++i) {
+        const int m = l16 + 16 * i;
+        if (m < n_mel) {
+          const int st0 = s_csr[m], cnt = s_csr[128 + m], ofs = s_csr[256 + m];
+          float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+          for (int j = 0; j < cnt; j += 4) {
+            const int j1 = j + 1 < cnt ? j + 1 : j, j2 = j + 2 < cnt ? j + 2 : j, j3 = j + 3 < cnt ? j + 3 : j;
+            const float m0 = s_mag[st0 + j], m1 = s_mag[st0 + j1], m2 = s_mag[st0 + j2], m3 = s_mag[st0 + j3];
+            const float w0 = s_bw[ofs + j];
+            const float w1 = j + 1 < cnt ? s_bw[ofs + j1] : 0.f;
+            const float w2 = j + 2 < cnt ? s_bw[ofs + j2] : 0.f;
+            const float w3 = j + 3 < cnt ? s_bw[ofs + j3] : 0.f;
+            s0 = fmaf(m0, w0, s0);
+            s1 = fmaf(m1, w1, s1);
+            s2 = fmaf(m2, w2, s2);
+            s3 = fmaf(m3, w3, s3);
+          }
+          float sm = ((s0 + s1) + (s2 + s3)) + pl.log_offset;
+          if (pl.log_floor > 0.f) sm = fmaxf(sm, pl.log_floor);
+          lm_row[m] = __logf(sm);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();                // s_mag reads done before the next quad overwrites the rows
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    // ---- DCT of the 16 frames on the matrix pipe: D[frame][q] = sum_m logmel[frame][m] dct[m][q] ----------
+    // A: lane -> (frame = lane % 16, k = lane / 16); B: lane -> (k = lane / 16, q = 16 nb + lane % 16);
+    // D: lane -> q = 16 nb + lane % 16, frames 4 (lane / 16) + v, i.e. quad lane/16, frame-in-quad v
+    f32x4 dacc[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) dacc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* pa = s_lm16 + l16 * LMS + fq;
+    const float* pb = s_dct + fq * DSTR4 + l16;
+    {
+      float av = pa[0], bv[4], an = 0.f, bn[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) bv[nb] = pb[16 * nb];
+      for (int ks = 0; ks < n_mel; ks += 4) {
+        if (ks + 4 < n_mel) {
+          an = pa[ks + 4];
+#pragma unroll
+          for (int nb = 0; nb < 4; ++nb) bn[nb] = pb[(ks + 4) * DSTR4 + 16 * nb];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) dacc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[nb], dacc[nb], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        av = an;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) bv[nb] = bn[nb];
+      }
+    }
+    {
+      const int64_t quad = sq * 4 + fq;               // lane group fq holds the frames of quad fq
+      if (quad < a.total_quads) {
+        const int64_t b = quad / a.quads_per_clip;
+        const int f0 = (int)(quad - b * a.quads_per_clip) * 4;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          if (f0 + v < a.F) {
+            float* orow = a.out + (b * a.F + f0 + v) * (int64_t)n_out + l16;
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+              if (16 * nb + l16 < n_out) orow[16 * nb] = dacc[nb][v];
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();                  // log-mel reads done before the next super-quad's writes
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
+}  // namespace
+
+int kws_stft4_lds_bytes(const kws_stft_plan* pl) {
+  const size_t floats = 512 + 512 + (size_t)pl->n_mel * DSTR4 + ((pl->n_w + 3) & ~3) + 3 * 128 +
+                        (size_t)NW4 * (4 * MAGF + ((16 * (pl->n_mel + 1) + 3) & ~3));
+  return (int)(floats * 4);
+}
+
+int kws_stft4_launch(const kws_stft_plan* pl, const float* x, int B, int L, int F, float* out, hipStream_t st) {
+  KWS_REQUIRE(pl->n_out <= 64 && pl->n_mel % 4 == 0 && pl->n_mel <= 128, "stft4: n_mel=%d n_out=%d unsupported",
+              pl->n_mel, pl->n_out);
+  KWS_REQUIRE(F > 0 && (pl->frame_step % 2) == 0 && (L % 2) == 0 && (pl->frame_len % 2) == 0, "stft4: bad geometry");
+  Stft2Args a;
+  a.pl = *pl;
+  a.x = x; a.out = out; a.B = B; a.L = L; a.F = F;
+  a.quads_per_clip = (F + 3) / 4;
+  a.total_quads = (int64_t)B * a.quads_per_clip;
+  const int bytes = kws_stft4_lds_bytes(pl);
+  KWS_REQUIRE(bytes <= 160 * 1024, "stft4: LDS need %d B exceeds 160 KiB", bytes);
+  static bool attr_done = false;
+  if (!attr_done) {
+    KWS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&stft4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024));
+    attr_done = true;
+  }
+  int64_t wgs = ((a.total_quads + 3) / 4 + NW4 - 1) / NW4;
+  if (wgs > 256) wgs = 256;   // persistent: one workgroup per CU, tables staged once
+  hipLaunchKernelGGL(stft4_kernel, dim3((unsigned)wgs), dim3(NW4 * 64), (size_t)bytes, st, a);
+  KWS_LAUNCH_CHECK("stft4_kernel");
+  return KWS_OK;
+}

@@ -17,6 +17,7 @@ import ctypes
 import glob
 import hashlib
 import math
+import os
 import os.path
 import random
 import re
@@ -139,7 +140,9 @@ class AudioProcessor(object):
         assert output_representation in {'raw', 'spec', 'mfcc', 'mfcc_and_raw'}
         self.output_representation = output_representation
         self.model_settings = model_settings
-        self._stream = torch.cuda.Stream(device=self.device)
+        # the generator's own stream, LOW priority by default (KWS_GEN_STREAM_PRIORITY = -1 low / 0 normal / 1 high):
+        # augment + STFT fill the CUs the training stream leaves idle instead of co-running with its MFMA kernels
+        self._stream = _lib.make_stream(self.device, int(os.environ.get("KWS_GEN_STREAM_PRIORITY", "-1")))
         self._plan = None
         self._synthetic = isinstance(data_dirs, dict)
         if self._synthetic:

@@ -26,12 +26,14 @@ def test_dropout_masks_are_the_oracles(B, n, keep, row_offset):
     rng = np.random.RandomState(B * 31 + n)
     x = rng.randn(B, n).astype(np.float32)
     out = torch.full((B, n), float("nan"), device="cuda")
-    _lib.call("kws_dropout_fwd", _lib.ptr(dev(x)), _lib.ptr(out), B, n, keep, ctypes.c_uint64(0x1234567890), 17, 2, row_offset, S())
+    dx_in = dev(x)          # device inputs stay referenced until the synchronising read below (a temporary's block could
+                            # be handed to the next allocation while the kernel is still queued)
+    _lib.call("kws_dropout_fwd", _lib.ptr(dx_in), _lib.ptr(out), B, n, keep, ctypes.c_uint64(0x1234567890), 17, 2, row_offset, S())
     mask = OL.dropout_mask(OL.dropout_key(0x1234567890, 17, 2), B * n, keep, row_offset * n).reshape(B, n)
     ref = np.where(mask, x * np.float32(1.0 / np.float32(keep)), np.float32(0)).astype(np.float32)
     assert np.array_equal(out.cpu().numpy(), ref)                    # bit-exact: integer hash + one f32 multiply
     dx = torch.empty((B, n), device="cuda")
-    _lib.call("kws_dropout_bwd", _lib.ptr(dev(x)), _lib.ptr(dx), B, n, keep, ctypes.c_uint64(0x1234567890), 17, 2, row_offset, S())
+    _lib.call("kws_dropout_bwd", _lib.ptr(dx_in), _lib.ptr(dx), B, n, keep, ctypes.c_uint64(0x1234567890), 17, 2, row_offset, S())
     assert torch.equal(dx, out)
     if keep < 1.0 and B * n > 1000:
         assert abs(mask.mean() - keep) < 0.03
@@ -48,18 +50,20 @@ def test_attn_pool_fwd_bwd_matches_oracle(B, T, C):
         att[:, 1] = att[:, 0]
         x[:, 1, ::3] = x[:, 0, ::3]
     feat = torch.full((B, 2 * C), float("nan"), device="cuda")
-    _lib.call("kws_attn_pool_fwd", _lib.ptr(dev(x)), _lib.ptr(dev(att)), _lib.ptr(feat), B, T, C, S())
+    d_x, d_att = dev(x), dev(att)
+    _lib.call("kws_attn_pool_fwd", _lib.ptr(d_x), _lib.ptr(d_att), _lib.ptr(feat), B, T, C, S())
     xa = x * att[:, :, None]                                                      # f32 product, as on the device
     ref = np.concatenate([xa.max(axis=1), x.astype(np.float64).mean(axis=1)], axis=1)
     got = feat.cpu().numpy()
     assert np.array_equal(got[:, :C], xa.max(axis=1))                              # max of f32 products: bit-exact
     np.testing.assert_allclose(got[:, C:], ref[:, C:], rtol=2e-6, atol=1e-7)
     dfeat = rng.randn(B, 2 * C).astype(np.float32)
+    d_dfeat = dev(dfeat)
     lib = _lib.load()
     ws = torch.empty(int(lib.kws_attn_pool_bwd_workspace_floats(B, T, C)), device="cuda")
     dx = torch.full((B, T, C), float("nan"), device="cuda")
     datt = torch.full((B, T), float("nan"), device="cuda")
-    _lib.call("kws_attn_pool_bwd", _lib.ptr(dev(x)), _lib.ptr(dev(att)), _lib.ptr(dev(dfeat)), _lib.ptr(dx), _lib.ptr(datt),
+    _lib.call("kws_attn_pool_bwd", _lib.ptr(d_x), _lib.ptr(d_att), _lib.ptr(d_dfeat), _lib.ptr(dx), _lib.ptr(datt),
               _lib.ptr(ws), B, T, C, S())
     # oracle (oracle/net.py:loss_and_grads tail): ties share the max gradient equally
     ind = (xa == xa.max(axis=1, keepdims=True)).astype(np.float64)
@@ -83,14 +87,15 @@ def test_softmax_xent_smooth_fwd_bwd_matches_oracle(B, NC, s):
     y = np.eye(NC, dtype=np.float32)[lab]
     per = torch.full((B,), float("nan"), device="cuda")
     cor = torch.full((B,), float("nan"), device="cuda")
-    _lib.call("kws_softmax_xent_smooth_fwd", _lib.ptr(dev(p)), _lib.ptr(dev(y)), _lib.ptr(per), _lib.ptr(cor), B, NC, s, S())
+    d_p, d_y = dev(p), dev(y)
+    _lib.call("kws_softmax_xent_smooth_fwd", _lib.ptr(d_p), _lib.ptr(d_y), _lib.ptr(per), _lib.ptr(cor), B, NC, s, S())
     loss, per_ref, dp_ref = OL.smooth_cce_fwd_bwd(p.astype(np.float64), y.astype(np.float64), s)
     np.testing.assert_allclose(per.cpu().numpy(), per_ref, rtol=2e-6, atol=2e-6)
     assert np.array_equal(cor.cpu().numpy(), (p.argmax(1) == lab).astype(np.float32))
     dp = torch.full((B, NC), float("nan"), device="cuda")
     dl = torch.full((B, NC), float("nan"), device="cuda")
     inv = 1.0 / (2 * B)                                                            # a data-parallel world of 2
-    _lib.call("kws_softmax_xent_smooth_bwd", _lib.ptr(dev(p)), _lib.ptr(dev(y)), _lib.ptr(dp), _lib.ptr(dl), B, NC, s, inv, S())
+    _lib.call("kws_softmax_xent_smooth_bwd", _lib.ptr(d_p), _lib.ptr(d_y), _lib.ptr(dp), _lib.ptr(dl), B, NC, s, inv, S())
     ref_dp = dp_ref * 0.5                                                          # oracle scales by 1/B
     scale = np.abs(ref_dp).max()
     assert np.abs(dp.cpu().numpy() - ref_dp).max() < 2e-6 * scale
@@ -98,10 +103,10 @@ def test_softmax_xent_smooth_fwd_bwd_matches_oracle(B, NC, s):
     assert np.abs(dl.cpu().numpy() - ref_dl).max() < 2e-6 * max(np.abs(ref_dl).max(), 1e-12)
     assert (dp[0].cpu().numpy() == 0).all()                                        # clipped entries pass no gradient
     # either output may be omitted
-    _lib.call("kws_softmax_xent_smooth_bwd", _lib.ptr(dev(p)), _lib.ptr(dev(y)), None, _lib.ptr(dl), B, NC, s, inv, S())
+    _lib.call("kws_softmax_xent_smooth_bwd", _lib.ptr(d_p), _lib.ptr(d_y), None, _lib.ptr(dl), B, NC, s, inv, S())
     lib = _lib.load()
-    assert lib.kws_softmax_xent_smooth_bwd(_lib.ptr(dev(p)), _lib.ptr(dev(y)), None, None, B, NC, s, inv, S()) != 0
-    assert lib.kws_softmax_xent_smooth_fwd(_lib.ptr(dev(p)), _lib.ptr(dev(y)), _lib.ptr(per), None, B, 65, s, S()) != 0
+    assert lib.kws_softmax_xent_smooth_bwd(_lib.ptr(d_p), _lib.ptr(d_y), None, None, B, NC, s, inv, S()) != 0
+    assert lib.kws_softmax_xent_smooth_fwd(_lib.ptr(d_p), _lib.ptr(d_y), _lib.ptr(per), None, B, 65, s, S()) != 0
 
 
 def test_standalone_ops_reproduce_the_fused_tail():
@@ -118,21 +123,24 @@ def test_standalone_ops_reproduce_the_fused_tail():
     x = (rng.randn(B, 16000) * 0.0774).astype(np.float32)
     lab = rng.randint(0, 12, B)
     y = np.eye(12, dtype=np.float32)[lab]
-    probs = net.train_fwd_bwd(dev(x), dev(y), seed=5, step=1).cpu().numpy()
+    d_x0, d_y0 = dev(x), dev(y)
+    probs = net.train_fwd_bwd(d_x0, d_y0, seed=5, step=1).cpu().numpy()
     torch.cuda.synchronize()
     y12 = net.debug_view(B, 0, 11).reshape(B, 9, 512)
     bn = net.debug_view(B, 2, 11)
     a = np.clip((y12.astype(np.float64) * bn[:512] + bn[512:1024]).astype(np.float32), 0, 6)
     att = net.debug_view(B, 3, 0).reshape(B, 9)
     feat = torch.empty((B, 1024), device="cuda")
-    _lib.call("kws_attn_pool_fwd", _lib.ptr(dev(a)), _lib.ptr(dev(att)), _lib.ptr(feat), B, 9, 512, S())
+    d_a, d_att = dev(a), dev(att)
+    _lib.call("kws_attn_pool_fwd", _lib.ptr(d_a), _lib.ptr(d_att), _lib.ptr(feat), B, 9, 512, S())
     fd = torch.empty_like(feat)
     _lib.call("kws_dropout_fwd", _lib.ptr(feat), _lib.ptr(fd), B, 1024, 0.6, ctypes.c_uint64(5), 1, 2, 0, S())
     W2 = ora.params['dense_2/kernel'].astype(np.float64)
     p = OL.softmax(fd.cpu().numpy().astype(np.float64) @ W2, axis=1)
     assert np.abs(p - probs).max() < 2e-6
     per = torch.empty(B, device="cuda")
-    _lib.call("kws_softmax_xent_smooth_fwd", _lib.ptr(dev(probs)), _lib.ptr(dev(y)), _lib.ptr(per), None, B, 12, 0.1, S())
+    d_probs, d_y = dev(probs), dev(y)
+    _lib.call("kws_softmax_xent_smooth_fwd", _lib.ptr(d_probs), _lib.ptr(d_y), _lib.ptr(per), None, B, 12, 0.1, S())
     assert abs(float(per.sum().item()) - float(net.metrics[0].item())) < 1e-5 * B
 
 

@@ -14,12 +14,15 @@ pytestmark = pytest.mark.gpu
     {"KWS_GEMM_PERSIST": "1", "KWS_GEMM_TN_V1": "1", "KWS_TAIL_GENERIC": "1", "KWS_CONV1_GENERIC": "1"},
     {"KWS_OVERLAP": "1"},
     {"KWS_STFT_V2": "1"},
+    {"KWS_STFT_V3": "1"},
 ])
 def test_alternative_paths_pass_the_parity_suites(repo_root, env):
     e = dict(os.environ)
     e.update(env)
-    files = ["tests/test_kernels_gpu.py", "tests/test_net_gpu.py"] if "KWS_STFT_V2" not in env else \
-        ["tests/test_kernels_gpu.py", "tests/test_logmfcc_gpu.py", "-k", "stft or c3"]
+    stft_variant = "KWS_STFT_V2" in env or "KWS_STFT_V3" in env
+    files = ["tests/test_kernels_gpu.py", "tests/test_net_gpu.py"] if not stft_variant else \
+        ["tests/test_kernels_gpu.py", "tests/test_logmfcc_gpu.py", "tests/test_fullsize_gpu.py",
+         "tests/test_processor_features_gpu.py", "-k", "stft or c3 or audio"]
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider"] + files, cwd=repo_root,
                        env=e, capture_output=True, text=True, timeout=900)
     tail = "\n".join(r.stdout.splitlines()[-15:])
