@@ -17,7 +17,9 @@ expected to agree weight by weight after hundreds of steps; what must agree is t
 (tolerance TOL_VAL_ACC) - and both must have learned the task.  Validation runs in inference mode on the BatchNorm
 MOVING statistics (momentum 0.99): for the first ~300 steps they lag the batch statistics so far that
 both runs validate at chance (measured: val_loss 2.487 = ln 12 on both sides after 120 steps while the training
-accuracy is already 0.94), hence the default of 5 x 100 steps.
+accuracy is already 0.94; over 500 steps val_loss climbs in step on both sides - 2.49 / 2.51 / 2.59 / 2.83 device,
+2.49 / 2.52 / 2.60 / 2.87 CPU - and then collapses to 0.55 within one epoch, which the two chaotic trajectories reach
+an epoch apart), hence the default of 10 x 100 steps, by which both have converged.
 
 The oracle is used here as the CHECKER (this script is measurement / test infrastructure, like bench.cpu_baseline).
 usage:  python scripts/val_acc_parity.py [--epochs 3] [--steps 40] [--batch 64] [--json out.json]
@@ -58,7 +60,7 @@ class Recorder(object):
     next = __next__
 
 
-def run(device=None, epochs=5, steps=100, batch=64, val_batches=8, bank=4096, quiet=False, cpu_threads=None):
+def run(device=None, epochs=10, steps=100, batch=64, val_batches=8, bank=4096, quiet=False, cpu_threads=None):
     import bench
     from oracle.net import TimeSlicedAttentionNet
     from oracle.torch_net import TorchTimeSlicedNet
@@ -132,7 +134,7 @@ def run(device=None, epochs=5, steps=100, batch=64, val_batches=8, bank=4096, qu
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--epochs", type=int, default=5)
+    ap.add_argument("--epochs", type=int, default=10)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--val-batches", type=int, default=8)

@@ -27,6 +27,23 @@
 
 using namespace kws_fft;
 
+// -DKWS_STFT_STAMP builds (scripts/build_variant.sh, scripts/stamps_stft.py): wave 0 of every workgroup accumulates
+// s_memtime deltas per phase: [0] loads issued -> first-pass MFMAs done, [1] twiddle + second pass, [2] split + magnitudes,
+// [3] mel + log, [4] DCT + store, [5] passes, [6] total cycles, [7] total in 100 MHz ticks
+#ifdef KWS_STFT_STAMP
+__device__ unsigned long long g_stft_stamps[256][8];
+extern "C" int kws_debug_read_stft_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stft_stamps), sizeof(g_stft_stamps));
+}
+#define ST_DECL unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_mark = __builtin_amdgcn_s_memtime(); \
+  const unsigned long long st_t0 = st_mark, st_r0 = __builtin_amdgcn_s_memrealtime();
+#define ST(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long n_ = __builtin_amdgcn_s_memtime(); \
+  st_acc[i] += n_ - st_mark; st_mark = n_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define ST_DECL
+#define ST(i)
+#endif
+
 namespace {
 
 constexpr int NW4 = 12;             // waves per workgroup: 3 per SIMD
@@ -36,6 +53,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float row_mirror(float v) {   // value of lane 15 - (lane % 16) of the same 16-lane row
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));
+}
+
+__device__ __forceinline__ float blend(unsigned m, float a, float b) {   // m all ones: a, m zero: b
+  return __uint_as_float((__float_as_uint(a) & m) | (__float_as_uint(b) & ~m));
 }
 
 __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
@@ -80,6 +101,7 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
 #pragma unroll
   for (int k2 = 0; k2 < 8; ++k2) r_w512[k2] = pl.w512p[l16 * 8 + k2];
   const int k1 = l16 < 8 ? l16 : (l16 < 15 ? l16 + 1 : 8);         // KPERM[l16]
+  const unsigned m0 = l16 == 0 ? 0xFFFFFFFFu : 0u, m15 = l16 == 15 ? 0xFFFFFFFFu : 0u;
   // sample offsets of this lane's A-operand loads: 2 (16 (4 j' + s) + 4 t + i), s = fq, i = ar_i
   const int a_off0 = 2 * (16 * fq + ar_i);                         // + 128 j' + 8 t
   __syncthreads();
@@ -88,9 +110,14 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
   const int64_t wave_global = (int64_t)blockIdx.x * NW4 + wave;
   const int64_t wave_stride = (int64_t)gridDim.x * NW4;
   const int nb_mel = (n_mel + 15) >> 4;   // mel bands per lane
+  ST_DECL
   for (int64_t sq = wave_global; sq < n_super; sq += wave_stride) {
 #pragma unroll 1
     for (int qq = 0; qq < 4; ++qq) {
+#ifdef KWS_STFT_STAMP
+      st_acc[5] += 1;
+      st_mark = __builtin_amdgcn_s_memtime();
+#endif
       const int64_t quad = sq * 4 + qq;
       const bool quad_ok = quad < a.total_quads;
       const int64_t b = quad_ok ? quad / a.quads_per_clip : 0;
@@ -130,9 +157,17 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
       float2 z[16];
 #pragma unroll
       for (int n2 = 0; n2 < 16; ++n2) z[n2] = make_float2(acc[n2 >> 2][0][n2 & 3], acc[n2 >> 2][1][n2 & 3]);
+#ifdef KWS_STFT_STAMP
+      asm volatile("" :: "v"(z[0].x), "v"(z[15].y));   // the MFMA results have landed
+#endif
+      ST(0);
 #pragma unroll
       for (int n2 = 1; n2 < 16; ++n2) z[n2] = cmul(z[n2], s_tw[n2 * 16 + l16]);
       fft16(z);                                       // z[k2] = Z[k1 + 16 k2] / 2
+#ifdef KWS_STFT_STAMP
+      asm volatile("" :: "v"(z[0].x), "v"(z[15].y));
+#endif
+      ST(1);
       // ---- real-input split + magnitude -------------------------------------------------------------
       // X[k] = E + T and X[256-k] = conj(E - T) with E = (Z[k] + conj Z[256-k]) / 2, T = W512^k (Z[k] - conj Z[256-k]) / 2i
       // (the halves are in z already).  Z[256-k] sits in the mirrored lane's register 15-k2; k1 = 0 (lane 0) and k1 = 8
@@ -141,7 +176,9 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
       for (int k2 = 0; k2 < 8; ++k2) {
         const float2 pa = z[15 - k2], pb = z[(16 - k2) & 15];
         const float mx = row_mirror(pa.x), my = row_mirror(pa.y);
-        const float2 zn0 = (l16 == 0) ? pb : (l16 == 15 ? pa : make_float2(mx, my));
+        // lane-dependent source picked by bit masks (v_bfi): written as `l16 == 0 ? pb : ...` it compiled to two
+        // EXEC-masked branches per bin pair
+        const float2 zn0 = make_float2(blend(m0, pb.x, blend(m15, pa.x, mx)), blend(m0, pb.y, blend(m15, pa.y, my)));
         const float2 zk = z[k2];
         const float2 zn = make_float2(zn0.x, -zn0.y);
         const float2 E = cadd(zk, zn);
@@ -160,6 +197,7 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      ST(2);
       // ---- sparse mel bands + log -> row 4 qq + fq of the super-quad's log-mel block ----------------------
       float* lm_row = s_lm16 + (4 * qq + fq) * LMS;
       for (int i = 0; i < nb_mel; ++i) {
@@ -187,6 +225,7 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();                // s_mag reads done before the next quad overwrites the rows
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      ST(3);
     }
     // ---- DCT of the 16 frames on the matrix pipe: D[frame][q] = sum_m logmel[frame][m] dct[m][q] ----------
     // A: lane -> (frame = lane % 16, k = lane / 16); B: lane -> (k = lane / 16, q = 16 nb + lane % 16);
@@ -234,7 +273,18 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();                  // log-mel reads done before the next super-quad's writes
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#ifdef KWS_STFT_STAMP
+    st_mark = __builtin_amdgcn_s_memtime() - st_mark;   // (not a phase of the quad loop: the DCT + store of this super-quad)
+    st_acc[4] += st_mark;
+#endif
   }
+#ifdef KWS_STFT_STAMP
+  if (tid == 0 && blockIdx.x < 256) {
+    for (int i = 0; i < 6; ++i) g_stft_stamps[blockIdx.x][i] = st_acc[i];
+    g_stft_stamps[blockIdx.x][6] = __builtin_amdgcn_s_memtime() - st_t0;
+    g_stft_stamps[blockIdx.x][7] = __builtin_amdgcn_s_memrealtime() - st_r0;
+  }
+#endif
 }
 
 }  // namespace

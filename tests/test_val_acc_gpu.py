@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 def test_val_acc_parity_device_vs_cpu_oracle(repo_root):
     sys.path.insert(0, os.path.join(repo_root, "scripts"))
     import val_acc_parity
-    res = val_acc_parity.run(epochs=5, steps=100, batch=64, val_batches=8, quiet=True)
+    res = val_acc_parity.run(epochs=10, steps=100, batch=64, val_batches=8, quiet=True)
     par = res["val_acc_parity"]
     print(par["device"], par["cpu"])
     assert abs(res["val_acc"] - res["val_acc_cpu"]) <= par["tolerance"] == 0.05
