@@ -358,6 +358,22 @@ int kws_net_train_fwd_bwd(const kws_net_t* net, const float* params, float* stat
                           uint64_t seed, uint32_t step, int64_t row_offset, int loss_batch,
                           void* workspace, int64_t workspace_bytes, void* stream);
 
+/* The same step in two calls, so that the caller can start the gradient all-reduce of the LATE layers while the early
+ * layers' backward still runs ("one fused buffer, overlapped with the tail of backward"; raw-waveform
+ * attention net only):
+ *   part 1  forward, classifier tail, backward of blocks n_blocks-1 .. split_block;
+ *   part 2  backward of blocks split_block-1 .. 0 and of the first convolution.
+ * After part 1 every gradient from float offset kws_net_grad_ready_offset(net, split_block) to the end of the flat
+ * buffer is final.  Parts 1 + 2 enqueue exactly the launches of kws_net_train_fwd_bwd in the same order: the result is
+ * bit-identical.  1 <= split_block < kws_net_num_blocks(net). */
+int kws_net_num_blocks(const kws_net_t* net);
+int64_t kws_net_grad_ready_offset(const kws_net_t* net, int split_block);
+int kws_net_train_fwd_bwd_part(const kws_net_t* net, const float* params, float* state, const float* x,
+                               const float* y_onehot, int B, float* grads, float* probs, float* metrics,
+                               uint64_t seed, uint32_t step, int64_t row_offset, int loss_batch,
+                               void* workspace, int64_t workspace_bytes, int part, int split_block,
+                               void* stream);
+
 #ifdef __cplusplus
 }
 #endif

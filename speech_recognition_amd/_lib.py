@@ -131,6 +131,10 @@ SIGNATURES = {
     "kws_net_predict": (_I, [_P, _P, _P, _P, _I, _P, _P, _I64, _P]),
     "kws_net_train_fwd_bwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, ctypes.c_uint64, ctypes.c_uint32,
                                    _I64, _I, _P, _I64, _P]),
+    "kws_net_num_blocks": (_I, [_P]),
+    "kws_net_grad_ready_offset": (_I64, [_P, _I]),
+    "kws_net_train_fwd_bwd_part": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, ctypes.c_uint64, ctypes.c_uint32,
+                                        _I64, _I, _P, _I64, _I, _I, _P]),
 }
 
 _lib = None

@@ -386,17 +386,12 @@ int kws_net_predict(const kws_net_t* net, const float* params, const float* stat
   return kws_ts_tail_launch(&t, st);
 }
 
-int kws_net_train_fwd_bwd(const kws_net_t* net, const float* params, float* state, const float* x,
-                          const float* y_onehot, int B, float* grads, float* probs, float* metrics, uint64_t seed,
-                          uint32_t step, int64_t row_offset, int loss_batch, void* workspace, int64_t workspace_bytes,
-                          void* stream) {
-  KWS_REQUIRE(net && params && state && x && y_onehot && grads && probs && metrics && workspace && B > 0,
-              "net_train_fwd_bwd: bad arguments");
-  KWS_REQUIRE(loss_batch >= B, "net_train_fwd_bwd: loss_batch %d < B %d", loss_batch, B);
-  if ((net->cfg.kind == KWS_NET_LOG_MFCC || net->cfg.kind == KWS_NET_STEFFE || net->cfg.kind == KWS_NET_RESIDUAL ||
-       net->cfg.kind == KWS_NET_MFCC_AND_RAW))
-    return lm_train(net, params, state, x, y_onehot, B, grads, probs, metrics, seed, step, row_offset, loss_batch,
-                    (float*)workspace, workspace_bytes, (hipStream_t)stream);
+// part 0: the whole step.  part 1: forward, tail and the backward pass down to block `split` (inclusive); part 2: the rest
+// of the backward pass (blocks split-1 .. 0 and the first convolution).  Parts 1 + 2 enqueue exactly the launches of
+// part 0 in the same order - every intermediate lives in the caller's workspace - so the gradients are bit-identical.
+static int ts_train(const kws_net_t* net, const float* params, float* state, const float* x, const float* y_onehot, int B,
+                    float* grads, float* probs, float* metrics, uint64_t seed, uint32_t step, int64_t row_offset,
+                    int loss_batch, void* workspace, int64_t workspace_bytes, void* stream, int phase, int split) {
   Layout lo;
   make_layout(net, B, true, &lo);
   if (lo.total > workspace_bytes) {
@@ -413,6 +408,10 @@ int kws_net_train_fwd_bwd(const kws_net_t* net, const float* params, float* stat
   float* coef = ws + lo.coef;
   float* red = ws + lo.red;
 
+  const bool run_head = phase != 2;                   // forward + tail + the late blocks' backward
+  kws_ts_tail_args t;
+  memset(&t, 0, sizeof(t));
+  if (run_head) {
   KWS_HIP(hipMemsetAsync(grads, 0, (size_t)net->n_params * 4, st));
   // ---------------- forward ----------------
   {
@@ -438,8 +437,6 @@ int kws_net_train_fwd_bwd(const kws_net_t* net, const float* params, float* stat
                                   BN_EPS, BN_MOMENTUM, state + b.bn.mm, state + b.bn.mv, bn_at(i + 1), red, st));
   }
   // ---------------- tail forward + backward ----------------
-  kws_ts_tail_args t;
-  memset(&t, 0, sizeof(t));
   t.y = ws + lo.y[nb]; t.bn = bn_at(nb); t.W1 = params + net->d1k; t.b1 = params + net->d1b;
   t.W2 = params + net->d2k; t.labels = y_onehot; t.probs = probs; t.g = ws + ((nb % 2) ? lo.G2 : lo.G); t.part = part; t.xd = ws + lo.xd;
   t.fd = ws + lo.fd; t.dl1 = ws + lo.dl1; t.dl2 = ws + lo.dl2; t.per_loss = ws + lo.per_loss;
@@ -456,6 +453,7 @@ int kws_net_train_fwd_bwd(const kws_net_t* net, const float* params, float* stat
     KWS_TRY(kws_dw_bwd_finalize(part, B, (int64_t)B * net->T, r.C, nullptr, grads + r.gamma,
                                 grads + r.beta, coef, red, st));
   }
+  }  // run_head
   // ---------------- backward through the blocks ----------------
   // One stream by default.  The weight-gradient GEMM of a block depends only on dy and z, so it CAN run on a side
   // stream beside the HBM-bound depthwise / BN kernels of the main chain (KWS_OVERLAP=1; the masked gradient then
@@ -464,7 +462,8 @@ int kws_net_train_fwd_bwd(const kws_net_t* net, const float* params, float* stat
   // orders take the same 5.14 - 5.20 ms: the early-layer GEMMs (32 FLOP/B) draw 3.7 TB/s themselves, so each side
   // slows the other by what the overlap gains.  Moving only the small off-chain kernels (transposes, slab sums,
   // the tail's weight gradients) to a helper stream was measured too: the event traffic costs what it hides.
-  static const bool overlap = getenv("KWS_OVERLAP") != nullptr;
+  static const bool overlap_env = getenv("KWS_OVERLAP") != nullptr;
+  const bool overlap = overlap_env && phase == 0;     // the side-stream program is a whole-step program
   if (overlap && net->side == nullptr) {
     KWS_HIP(hipStreamCreateWithFlags(&net->side, hipStreamNonBlocking));
     KWS_HIP(hipEventCreateWithFlags(&net->ev_fork, hipEventDisableTiming));
@@ -473,7 +472,7 @@ int kws_net_train_fwd_bwd(const kws_net_t* net, const float* params, float* stat
     KWS_HIP(hipEventCreateWithFlags(&net->ev_join, hipEventDisableTiming));
   }
   static const int overlap_from = getenv("KWS_OVERLAP_FROM") ? atoi(getenv("KWS_OVERLAP_FROM")) : 0;  // experiment knob
-  {  // the dgrad GEMMs read the pointwise kernels transposed: all of them in one launch
+  if (run_head) {  // the dgrad GEMMs read the pointwise kernels transposed: all of them in one launch
     static_assert(KWS_TRANSPOSE_BATCH >= 11, "one batch holds every block");
     const float* tin[KWS_TRANSPOSE_BATCH];
     float* tout[KWS_TRANSPOSE_BATCH];
@@ -487,7 +486,8 @@ int kws_net_train_fwd_bwd(const kws_net_t* net, const float* params, float* stat
   }
   float* Gb[2] = {ws + lo.G, ws + lo.G2};          // gradient wrt y[l] lives in Gb[l % 2]; the tail wrote Gb[nb % 2]
   bool wgrad_pending[2] = {false, false};
-  for (int i = nb - 1; i >= 0; --i) {
+  const int i_hi = phase == 2 ? split - 1 : nb - 1, i_lo = phase == 1 ? split : 0;
+  for (int i = i_hi; i >= i_lo; --i) {
     const Block& b = net->blocks[i];
     const int64_t M = (int64_t)B * b.Lout;
     float* Gcur = Gb[(i + 1) % 2];
@@ -526,7 +526,7 @@ int kws_net_train_fwd_bwd(const kws_net_t* net, const float* params, float* stat
     KWS_TRY(kws_dwconv_bwd_bn_f32(DZ, ws + lo.y[i], bn_at(i), params + b.dw, coef, Gnext, nullptr, 2, B, b.Lin, b.Lout,
                                   b.cin, b.stride, b.pad_l, st));
   }
-  {
+  if (phase != 1) {
     const int64_t M = (int64_t)B * net->L1;
     (void)M;                                        // Gb[0] already holds dy of the first convolution
     if (overlap) {                                  // the side stream's TN workspace is free once its queue drains
@@ -541,6 +541,46 @@ int kws_net_train_fwd_bwd(const kws_net_t* net, const float* params, float* stat
     }
   }
   return KWS_OK;
+}
+
+int kws_net_train_fwd_bwd(const kws_net_t* net, const float* params, float* state, const float* x,
+                          const float* y_onehot, int B, float* grads, float* probs, float* metrics, uint64_t seed,
+                          uint32_t step, int64_t row_offset, int loss_batch, void* workspace, int64_t workspace_bytes,
+                          void* stream) {
+  KWS_REQUIRE(net && params && state && x && y_onehot && grads && probs && metrics && workspace && B > 0,
+              "net_train_fwd_bwd: bad arguments");
+  KWS_REQUIRE(loss_batch >= B, "net_train_fwd_bwd: loss_batch %d < B %d", loss_batch, B);
+  if ((net->cfg.kind == KWS_NET_LOG_MFCC || net->cfg.kind == KWS_NET_STEFFE || net->cfg.kind == KWS_NET_RESIDUAL ||
+       net->cfg.kind == KWS_NET_MFCC_AND_RAW))
+    return lm_train(net, params, state, x, y_onehot, B, grads, probs, metrics, seed, step, row_offset, loss_batch,
+                    (float*)workspace, workspace_bytes, (hipStream_t)stream);
+  return ts_train(net, params, state, x, y_onehot, B, grads, probs, metrics, seed, step, row_offset, loss_batch, workspace,
+                  workspace_bytes, stream, 0, 0);
+}
+
+int kws_net_num_blocks(const kws_net_t* net) {
+  return (net && net->cfg.kind == KWS_NET_TS_ATTENTION) ? (int)net->blocks.size() : 0;
+}
+
+int64_t kws_net_grad_ready_offset(const kws_net_t* net, int split_block) {
+  if (!net || net->cfg.kind != KWS_NET_TS_ATTENTION || split_block < 1 || split_block >= (int)net->blocks.size()) return -1;
+  // block `split_block`'s backward writes the gradients of the BatchNorm in front of it; everything from there to the end
+  // of the flat buffer (Keras layer order) is final once part 1 has run
+  return net->blocks[split_block - 1].bn.gamma;
+}
+
+int kws_net_train_fwd_bwd_part(const kws_net_t* net, const float* params, float* state, const float* x,
+                               const float* y_onehot, int B, float* grads, float* probs, float* metrics, uint64_t seed,
+                               uint32_t step, int64_t row_offset, int loss_batch, void* workspace,
+                               int64_t workspace_bytes, int part, int split_block, void* stream) {
+  KWS_REQUIRE(net && params && state && x && y_onehot && grads && probs && metrics && workspace && B > 0,
+              "net_train_fwd_bwd_part: bad arguments");
+  KWS_REQUIRE(loss_batch >= B, "net_train_fwd_bwd_part: loss_batch %d < B %d", loss_batch, B);
+  KWS_REQUIRE(net->cfg.kind == KWS_NET_TS_ATTENTION, "net_train_fwd_bwd_part: only the raw-waveform attention net is split");
+  KWS_REQUIRE((part == 1 || part == 2) && split_block >= 1 && split_block < (int)net->blocks.size(),
+              "net_train_fwd_bwd_part: part %d split_block %d", part, split_block);
+  return ts_train(net, params, state, x, y_onehot, B, grads, probs, metrics, seed, step, row_offset, loss_batch, workspace,
+                  workspace_bytes, stream, part, split_block);
 }
 
 }  // extern "C"

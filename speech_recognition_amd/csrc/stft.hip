@@ -285,6 +285,35 @@ int kws_stft_plan_create(int frame_len, int frame_step, int fft_len, int n_mel, 
       w512p[c * 8 + k2] = make_float2((float)cos(ang), (float)sin(ang));
     }
   }
+  // mel tap windows of the v4 kernel: band m of lane group i = m / 16 reads 4 * mc[i] taps from bin ws[m]
+  std::vector<int> mws(n_mel, 0);
+  std::vector<float> wpad(1, 0.f);
+  {
+    const int MAGF4 = 260;                                   // floats of a magnitude row in the kernel's LDS
+    int mcmax = 0;
+    for (int i = 0; i < 8; ++i) p->mel_mc[i] = 0;
+    for (int m = 0; m < n_mel; ++m) {
+      const int g = m >> 4, need = (bc[m] + 3) / 4;
+      if (need > p->mel_mc[g]) p->mel_mc[g] = need;
+    }
+    for (int i = 0; i < 8; ++i) {
+      if (i < (n_mel + 15) / 16 && p->mel_mc[i] == 0) p->mel_mc[i] = 1;
+      if (p->mel_mc[i] > mcmax) mcmax = p->mel_mc[i];
+    }
+    p->mel_maxw = 4 * mcmax;
+    if (p->mel_maxw > MAGF4) {
+      p->mel_maxw = 0;                                       // stft4 declines (kws_stft4_lds_bytes / launch check it)
+    } else {
+      wpad.assign((size_t)n_mel * p->mel_maxw, 0.f);
+      for (int m = 0; m < n_mel; ++m) {
+        const int taps = 4 * p->mel_mc[m >> 4];
+        int ws0 = bs[m];
+        if (ws0 + taps > MAGF4) ws0 = MAGF4 - taps;          // keep the window inside the row: the band sits later in it
+        mws[m] = ws0;
+        for (int k = 0; k < bc[m]; ++k) wpad[(size_t)m * p->mel_maxw + (bs[m] - ws0) + k] = bw[bo[m] + k];
+      }
+    }
+  }
   int rc = upload(&p->window, win);
   if (rc == KWS_OK) rc = upload(&p->w256, w256);
   if (rc == KWS_OK) rc = upload(&p->w512, w512);
@@ -298,6 +327,8 @@ int kws_stft_plan_create(int frame_len, int frame_step, int fft_len, int n_mel, 
   if (rc == KWS_OK) rc = upload(&p->b4, b4);
   if (rc == KWS_OK) rc = upload(&p->tw4, tw4);
   if (rc == KWS_OK) rc = upload(&p->w512p, w512p);
+  if (rc == KWS_OK) rc = upload(&p->mel_ws, mws);
+  if (rc == KWS_OK) rc = upload(&p->mel_wpad, wpad);
   if (rc != KWS_OK) {
     kws_stft_plan_destroy(p);
     return rc;
@@ -308,8 +339,8 @@ int kws_stft_plan_create(int frame_len, int frame_step, int fft_len, int n_mel, 
 
 int kws_stft_plan_destroy(kws_stft_plan_t* p) {
   if (!p) return KWS_OK;
-  void* bufs[13] = {p->window, p->w256, p->w512, p->band_start, p->band_cnt, p->band_ofs, p->band_w, p->dct,
-                    p->tw16, p->dct64, p->b4, p->tw4, p->w512p};
+  void* bufs[15] = {p->window, p->w256, p->w512, p->band_start, p->band_cnt, p->band_ofs, p->band_w, p->dct,
+                    p->tw16, p->dct64, p->b4, p->tw4, p->w512p, p->mel_ws, p->mel_wpad};
   for (void* q : bufs)
     if (q) (void)hipFree(q);
   delete p;
@@ -339,7 +370,7 @@ int kws_stft_mel_f32(const kws_stft_plan_t* plan, const float* x, int B, int L, 
   static const bool force_v2 = getenv("KWS_STFT_V2") != nullptr;
   static const bool force_v3 = getenv("KWS_STFT_V3") != nullptr;
   if (out_kind == 0 && plan->n_out <= 64 && plan->n_mel <= 128 && plan->frame_len % 2 == 0 && !force_v1) {
-    if (!force_v2 && !force_v3 && plan->n_mel % 4 == 0 && kws_stft4_lds_bytes(plan) <= 160 * 1024)
+    if (!force_v2 && !force_v3 && plan->n_mel % 4 == 0 && plan->mel_maxw > 0 && kws_stft4_lds_bytes(plan) <= 160 * 1024)
       return kws_stft4_launch(plan, x, B, L, a.F, out, st);   // first radix-16 pass + DCT on the matrix pipe
     if (!force_v2 && plan->n_mel % 4 == 0 && kws_stft3_lds_bytes(plan) <= 160 * 1024)
       return kws_stft3_launch(plan, x, B, L, a.F, out, st);   // tables in registers, DCT on the matrix pipe

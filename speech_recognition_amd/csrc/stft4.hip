@@ -50,6 +50,7 @@ constexpr int NW4 = 12;             // waves per workgroup: 3 per SIMD
 constexpr int DSTR4 = 80;           // DCT table row stride (floats), as in stft3
 constexpr int MAGF = 260;           // floats of one frame's magnitude row
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float row_mirror(float v) {   // value of lane 15 - (lane % 16) of the same 16-lane row
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));
@@ -64,77 +65,86 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
   const kws_stft_plan& pl = a.pl;
   const int n_mel = pl.n_mel, n_out = pl.n_out;
   const int LMS = n_mel + 1;                                       // log-mel row stride (odd: conflict-free columns)
+  const int MAXW = pl.mel_maxw;                                    // padded taps per mel band (multiple of 4)
   float* s_win = lds;                                              // [512] zero padded window
   float2* s_tw = reinterpret_cast<float2*>(s_win + 512);           // [16 n2][16 c] second-pass twiddles W256^(n2 k1)
-  float* s_dct = s_win + 512 + 512;                                // [n_mel][DSTR4]
-  float* s_bw = s_dct + n_mel * DSTR4;                             // [n_w]
-  int* s_csr = reinterpret_cast<int*>(s_bw + ((pl.n_w + 3) & ~3)); // [3][128] start | cnt | ofs
-  float* s_wave = reinterpret_cast<float*>(s_csr + 3 * 128);
+  float2* s_w5 = s_tw + 256;                                       // [8 k2][16 c] split factors W512^(k1 + 16 k2)
+  float* s_dct = s_win + 512 + 512 + 256;                          // [n_mel][DSTR4]
+  float* s_wpad = s_dct + n_mel * DSTR4;                           // [n_mel][MAXW] band weights over the band's tap window
+  int* s_mws = reinterpret_cast<int*>(s_wpad + n_mel * MAXW);      // [128] first bin of every band's tap window
+  float* s_wave = reinterpret_cast<float*>(s_mws + 128);
   const int wave_floats = 4 * MAGF + ((16 * LMS + 3) & ~3);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l16 = lane & 15, fq = lane >> 4;                       // D role: column c = l16, frame g = fq
   const int ar_u = l16 >> 2, ar_i = l16 & 3;                       // A role: row l16 = (frame u, n2 % 4), k slot fq
   float* s_mag = s_wave + wave * wave_floats + fq * MAGF;          // this lane row's frame
-  float* s_lm16 = s_wave + wave * wave_floats + 4 * MAGF;          // [16][LMS] log-mel rows of the super-quad
+  float* s_lm16 = s_wave + wave * wave_floats + 4 * MAGF;          // [16][LMS] log-mel rows of a group of four quads
 
   for (int i = tid; i < 512; i += NW4 * 64) s_win[i] = pl.window[i];
   for (int i = tid; i < 256; i += NW4 * 64) s_tw[i] = pl.tw4[(i & 15) * 16 + (i >> 4)];   // [c][n2] -> [n2][c]: a row's
                                                    // 16 lanes read 16 consecutive 8-byte entries (conflict-free)
+  for (int i = tid; i < 128; i += NW4 * 64) s_w5[i] = pl.w512p[(i & 15) * 8 + (i >> 4)];  // [c][k2] -> [k2][c]
   for (int i = tid; i < n_mel * DSTR4; i += NW4 * 64) {
     const int m = i / DSTR4, q = i - m * DSTR4;
     s_dct[i] = q < 64 ? pl.dct64[m * 64 + q] : 0.f;
   }
-  for (int i = tid; i < pl.n_w; i += NW4 * 64) s_bw[i] = pl.band_w[i];
-  for (int i = tid; i < 128; i += NW4 * 64) {
-    s_csr[i] = i < n_mel ? pl.band_start[i] : 0;
-    s_csr[128 + i] = i < n_mel ? pl.band_cnt[i] : 0;
-    s_csr[256 + i] = i < n_mel ? pl.band_ofs[i] : 0;
-  }
-  // per-lane constants: B operand of the 16 (k-chunk, column tile) products, second-pass twiddles, split factors
+  for (int i = tid; i < n_mel * MAXW; i += NW4 * 64) s_wpad[i] = pl.mel_wpad[i];
+  for (int i = tid; i < 128; i += NW4 * 64) s_mws[i] = i < n_mel ? pl.mel_ws[i] : 0;
+  if (l16 < MAGF - 257) s_mag[257 + l16] = 0.f;    // the tap windows may reach past the Nyquist bin: finite zeros there
+  // log-mel rows start finite too: a partial last group multiplies rows it never wrote (their outputs are not stored)
+  for (int i = lane; i < 16 * LMS; i += 64) s_lm16[i] = 0.f;
+  // per-lane constants: B operand of the 16 (k-chunk, column tile) products
   float r_b[16];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const float4 v = *reinterpret_cast<const float4*>(pl.b4 + lane * 16 + 4 * q);
     r_b[4 * q] = v.x; r_b[4 * q + 1] = v.y; r_b[4 * q + 2] = v.z; r_b[4 * q + 3] = v.w;
   }
-  float2 r_w512[8];
-#pragma unroll
-  for (int k2 = 0; k2 < 8; ++k2) r_w512[k2] = pl.w512p[l16 * 8 + k2];
   const int k1 = l16 < 8 ? l16 : (l16 < 15 ? l16 + 1 : 8);         // KPERM[l16]
   const unsigned m0 = l16 == 0 ? 0xFFFFFFFFu : 0u, m15 = l16 == 15 ? 0xFFFFFFFFu : 0u;
   // sample offsets of this lane's A-operand loads: 2 (16 (4 j' + s) + 4 t + i), s = fq, i = ar_i
   const int a_off0 = 2 * (16 * fq + ar_i);                         // + 128 j' + 8 t
   __syncthreads();
 
-  const int64_t n_super = (a.total_quads + 3) / 4;
+  // Work items are QUADS of frames, strided over all waves of the grid (25,600 quads over 3,072 waves at batch 1024: 8 or
+  // 9 per wave - whole groups of four per wave left a third of the waves with 12 instead of 8).  A wave takes its quads
+  // in groups of up to four and hands every group's 16 log-mel rows to one DCT product.
   const int64_t wave_global = (int64_t)blockIdx.x * NW4 + wave;
   const int64_t wave_stride = (int64_t)gridDim.x * NW4;
   const int nb_mel = (n_mel + 15) >> 4;   // mel bands per lane
+  // A role: PCM of one quad into registers (frames past the clip's last one re-read frame 0: their rows are never stored)
+  float2 xv[4][4];
+  // Buffer loads: the descriptor spans ONE clip, so a frame's zero-padded tail (samples 480..511 of the last frames run
+  // past the clip) reads as zeros through the range check instead of needing a clamped address per load - the 16 clamped
+  // 64-bit offsets were loop invariants that cost 32 registers - and a lane addresses all 16 loads with one register plus
+  // immediates.
+  auto issue_loads = [&](int64_t quad) {
+    const int64_t b = quad / a.quads_per_clip;
+    const int f0 = (int)(quad - b * a.quads_per_clip) * 4;
+    const int fu = f0 + ar_u < a.F ? f0 + ar_u : 0;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + b * (int64_t)a.L), 0,
+                                                                        a.L * 4, 0x00020000);
+    const int voff = (fu * pl.frame_step + a_off0) * 4;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int jp = 0; jp < 4; ++jp) {
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff + 512 * jp + 32 * t, 0, 0);
+        xv[t][jp] = make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+      }
+  };
   ST_DECL
-  for (int64_t sq = wave_global; sq < n_super; sq += wave_stride) {
+  if (wave_global < a.total_quads) issue_loads(wave_global);
+  for (int64_t q0 = wave_global; q0 < a.total_quads; q0 += 4 * wave_stride) {
 #pragma unroll 1
     for (int qq = 0; qq < 4; ++qq) {
+      const int64_t quad = q0 + qq * wave_stride;
+      if (quad >= a.total_quads) break;             // wave-uniform: the group is partial
 #ifdef KWS_STFT_STAMP
       st_acc[5] += 1;
       st_mark = __builtin_amdgcn_s_memtime();
 #endif
-      const int64_t quad = sq * 4 + qq;
-      const bool quad_ok = quad < a.total_quads;
-      const int64_t b = quad_ok ? quad / a.quads_per_clip : 0;
-      const int f0 = quad_ok ? (int)(quad - b * a.quads_per_clip) * 4 : 0;
       // ---- first pass on the matrix pipe ----------------------------------------------------------------
-      // A role: this lane loads for frame u = ar_u (frames past the clip's last one re-read frame 0: discarded below)
-      const int fu = f0 + ar_u < a.F ? f0 + ar_u : 0;
-      const float* fx = a.x + b * (int64_t)a.L + (int64_t)fu * pl.frame_step;
-      float2 xv[4][4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int jp = 0; jp < 4; ++jp) {
-          const int sidx = a_off0 + 128 * jp + 8 * t;
-          const int sc = sidx < pl.frame_len ? sidx : pl.frame_len - 2;   // clamped; the padded window zeroes the tail
-          xv[t][jp] = *reinterpret_cast<const float2*>(fx + sc);
-        }
       f32x4 acc[4][2];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
@@ -153,6 +163,11 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
           acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai, r_b[4 * jp + 3], acc[t][1], 0, 0, 0);
         }
       }
+      // the PCM of this wave's NEXT quad is requested as soon as the MFMAs have consumed this quad's: it lands while
+      // the vector work of this quad runs
+      __builtin_amdgcn_sched_barrier(0);
+      if (quad + wave_stride < a.total_quads) issue_loads(quad + wave_stride);
+      __builtin_amdgcn_sched_barrier(0);
       // ---- second pass in registers: lane (g, c) holds Y[k1][n2] of frame g ------------------------------
       float2 z[16];
 #pragma unroll
@@ -176,15 +191,15 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
       for (int k2 = 0; k2 < 8; ++k2) {
         const float2 pa = z[15 - k2], pb = z[(16 - k2) & 15];
         const float mx = row_mirror(pa.x), my = row_mirror(pa.y);
-        // lane-dependent source picked by bit masks (v_bfi): written as `l16 == 0 ? pb : ...` it compiled to two
-        // EXEC-masked branches per bin pair
+        // lane-dependent source picked by bit masks: written as `l16 == 0 ? pb : ...` it compiled to two EXEC-masked
+        // branches per bin pair
         const float2 zn0 = make_float2(blend(m0, pb.x, blend(m15, pa.x, mx)), blend(m0, pb.y, blend(m15, pa.y, my)));
         const float2 zk = z[k2];
         const float2 zn = make_float2(zn0.x, -zn0.y);
         const float2 E = cadd(zk, zn);
         const float2 dd = csub(zk, zn);
         const float2 O = make_float2(dd.y, -dd.x);
-        const float2 T = cmul(r_w512[k2], O);
+        const float2 T = cmul(s_w5[k2 * 16 + l16], O);
         const float2 Xp = cadd(E, T), Xm = csub(E, T);
         const int kk = k1 + 16 * k2;
         s_mag[kk] = __builtin_amdgcn_sqrtf(Xp.x * Xp.x + Xp.y * Xp.y);
@@ -198,29 +213,41 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       ST(2);
-      // ---- sparse mel bands + log -> row 4 qq + fq of the super-quad's log-mel block ----------------------
+      // ---- mel bands + log -> row 4 qq + fq of the group's log-mel block ------------------------------------------
+      // Lane l16 takes bands l16 + 16 i.  Every band reads a window of 4 mel_mc[i] taps (mel_mc[i] = the widest band of
+      // the 16 that share i, so the trip count is wave-uniform) that starts at mel_ws[m] and carries zero weights outside
+      // the band: all of a band's LDS reads are in flight before its first multiply-add - the CSR walk of the third
+      // kernel (a dependent wait per four taps, trip counts that differ lane by lane) took 40 % of a pass.
       float* lm_row = s_lm16 + (4 * qq + fq) * LMS;
       for (int i = 0; i < nb_mel; ++i) {
         const int m = l16 + 16 * i;
-        if (m < n_mel) {
-          const int st0 = s_csr[m], cnt = s_csr[128 + m], ofs = s_csr[256 + m];
-          float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-          for (int j = 0; j < cnt; j += 4) {
-            const int j1 = j + 1 < cnt ? j + 1 : j, j2 = j + 2 < cnt ? j + 2 : j, j3 = j + 3 < cnt ? j + 3 : j;
-            const float m0 = s_mag[st0 + j], m1 = s_mag[st0 + j1], m2 = s_mag[st0 + j2], m3 = s_mag[st0 + j3];
-            const float w0 = s_bw[ofs + j];
-            const float w1 = j + 1 < cnt ? s_bw[ofs + j1] : 0.f;
-            const float w2 = j + 2 < cnt ? s_bw[ofs + j2] : 0.f;
-            const float w3 = j + 3 < cnt ? s_bw[ofs + j3] : 0.f;
-            s0 = fmaf(m0, w0, s0);
-            s1 = fmaf(m1, w1, s1);
-            s2 = fmaf(m2, w2, s2);
-            s3 = fmaf(m3, w3, s3);
-          }
-          float sm = ((s0 + s1) + (s2 + s3)) + pl.log_offset;
-          if (pl.log_floor > 0.f) sm = fmaxf(sm, pl.log_floor);
-          lm_row[m] = __logf(sm);
+        const int mm = m < n_mel ? m : 0;
+        const int mcl = pl.mel_mc[i];
+        const float* mp = s_mag + s_mws[mm];
+        const float* wp = s_wpad + mm * MAXW;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        for (int t0 = 0; t0 < mcl; t0 += 4) {
+          float4 wv[4];
+          float mv[4][4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            if (t0 + t < mcl) {
+              wv[t] = *reinterpret_cast<const float4*>(wp + 4 * (t0 + t));
+#pragma unroll
+              for (int r = 0; r < 4; ++r) mv[t][r] = mp[4 * (t0 + t) + r];
+            }
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            if (t0 + t < mcl) {
+              s0 = fmaf(mv[t][0], wv[t].x, s0);
+              s1 = fmaf(mv[t][1], wv[t].y, s1);
+              s2 = fmaf(mv[t][2], wv[t].z, s2);
+              s3 = fmaf(mv[t][3], wv[t].w, s3);
+            }
         }
+        float sm = ((s0 + s1) + (s2 + s3)) + pl.log_offset;
+        if (pl.log_floor > 0.f) sm = fmaxf(sm, pl.log_floor);
+        if (m < n_mel) lm_row[m] = __logf(sm);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();                // s_mag reads done before the next quad overwrites the rows
@@ -255,7 +282,7 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
       }
     }
     {
-      const int64_t quad = sq * 4 + fq;               // lane group fq holds the frames of quad fq
+      const int64_t quad = q0 + fq * wave_stride;     // lane group fq holds the frames of the group's quad fq
       if (quad < a.total_quads) {
         const int64_t b = quad / a.quads_per_clip;
         const int f0 = (int)(quad - b * a.quads_per_clip) * 4;
@@ -271,10 +298,10 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();                  // log-mel reads done before the next super-quad's writes
+    __builtin_amdgcn_wave_barrier();                  // log-mel reads done before the next group's writes
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #ifdef KWS_STFT_STAMP
-    st_mark = __builtin_amdgcn_s_memtime() - st_mark;   // (not a phase of the quad loop: the DCT + store of this super-quad)
+    st_mark = __builtin_amdgcn_s_memtime() - st_mark;   // (not a phase of the quad loop: the DCT + store of this group)
     st_acc[4] += st_mark;
 #endif
   }
@@ -290,7 +317,7 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
 }  // namespace
 
 int kws_stft4_lds_bytes(const kws_stft_plan* pl) {
-  const size_t floats = 512 + 512 + (size_t)pl->n_mel * DSTR4 + ((pl->n_w + 3) & ~3) + 3 * 128 +
+  const size_t floats = 512 + 512 + 256 + (size_t)pl->n_mel * DSTR4 + (size_t)pl->n_mel * pl->mel_maxw + 128 +
                         (size_t)NW4 * (4 * MAGF + ((16 * (pl->n_mel + 1) + 3) & ~3));
   return (int)(floats * 4);
 }
@@ -299,6 +326,7 @@ int kws_stft4_launch(const kws_stft_plan* pl, const float* x, int B, int L, int 
   KWS_REQUIRE(pl->n_out <= 64 && pl->n_mel % 4 == 0 && pl->n_mel <= 128, "stft4: n_mel=%d n_out=%d unsupported",
               pl->n_mel, pl->n_out);
   KWS_REQUIRE(F > 0 && (pl->frame_step % 2) == 0 && (L % 2) == 0 && (pl->frame_len % 2) == 0, "stft4: bad geometry");
+  KWS_REQUIRE(pl->mel_maxw > 0 && pl->mel_maxw <= MAGF, "stft4: mel bands of up to %d taps unsupported", pl->mel_maxw);
   Stft2Args a;
   a.pl = *pl;
   a.x = x; a.out = out; a.B = B; a.L = L; a.F = F;
@@ -312,7 +340,7 @@ int kws_stft4_launch(const kws_stft_plan* pl, const float* x, int B, int L, int 
                                 160 * 1024));
     attr_done = true;
   }
-  int64_t wgs = ((a.total_quads + 3) / 4 + NW4 - 1) / NW4;
+  int64_t wgs = (a.total_quads + NW4 - 1) / NW4;
   if (wgs > 256) wgs = 256;   // persistent: one workgroup per CU, tables staged once
   hipLaunchKernelGGL(stft4_kernel, dim3((unsigned)wgs), dim3(NW4 * 64), (size_t)bytes, st, a);
   KWS_LAUNCH_CHECK("stft4_kernel");

@@ -404,8 +404,19 @@ class Model(object):
         world, rank = parallel.world_size(), parallel.rank()
         B = xd.shape[0]
         net.metrics = metrics_row
-        net.train_fwd_bwd(xd, yd, seed=self.seed, step=self._step, row_offset=rank * B, loss_batch=B * world)
-        parallel.allreduce_grads(net.grads)   # RCCL sum over xGMI; grads are already scaled by 1/(B*world)
+        split = parallel.split_block_from_env() if world > 1 and net.kind == _lib.KWS_NET_TS_ATTENTION else 0
+        if split > 0:
+            # the late layers' gradients (a contiguous tail of the flat buffer) are summed over the ranks while the early
+            # layers' backward still runs; the two slices together are the one-buffer all-reduce, element for element
+            off = net.grad_ready_offset(split)
+            net.train_fwd_bwd_part(1, split, xd, yd, seed=self.seed, step=self._step, row_offset=rank * B, loss_batch=B * world)
+            h = parallel.allreduce_begin(net.grads[off:])
+            net.train_fwd_bwd_part(2, split, xd, yd, seed=self.seed, step=self._step, row_offset=rank * B, loss_batch=B * world)
+            parallel.allreduce_grads(net.grads[:off])
+            parallel.allreduce_wait(h)
+        else:
+            net.train_fwd_bwd(xd, yd, seed=self.seed, step=self._step, row_offset=rank * B, loss_batch=B * world)
+            parallel.allreduce_grads(net.grads)   # RCCL sum over xGMI; grads are already scaled by 1/(B*world)
         self.optimizer.apply(net, 1.0)
         self._step += 1
 

@@ -160,6 +160,30 @@ class DeviceNet(object):
                   _lib.stream_ptr(stream))
         return probs
 
+    def train_fwd_bwd_part(self, part, split_block, x, y, seed, step, row_offset=0, loss_batch=None, probs=None, stream=None):
+        """Half of train_fwd_bwd (kws_net_train_fwd_bwd_part): part 1 = forward + backward down to `split_block`, part 2 =
+        the rest.  After part 1, self.grads[self.grad_ready_offset(split_block):] is final."""
+        B = x.shape[0]
+        ws = self._workspace(B, True)
+        if probs is None:
+            probs = self._probs_part if part == 2 and getattr(self, "_probs_part", None) is not None else \
+                torch.empty((B, self.num_classes), dtype=torch.float32, device=self.device)
+        self._probs_part = probs if part == 1 else None
+        _lib.call("kws_net_train_fwd_bwd_part", self.handle, _lib.ptr(self.params), _lib.ptr(self.state), _lib.ptr(x),
+                  _lib.ptr(y), B, _lib.ptr(self.grads), _lib.ptr(probs), _lib.ptr(self.metrics), ctypes.c_uint64(seed),
+                  ctypes.c_uint32(step), row_offset, B if loss_batch is None else loss_batch, _lib.ptr(ws), ws.numel() * 4,
+                  int(part), int(split_block), _lib.stream_ptr(stream))
+        return probs
+
+    def num_blocks(self):
+        return int(self.lib.kws_net_num_blocks(self.handle))
+
+    def grad_ready_offset(self, split_block):
+        off = int(self.lib.kws_net_grad_ready_offset(self.handle, int(split_block)))
+        if off < 0:
+            raise _lib.KwsError("grad_ready_offset: split_block %d is not valid for this network" % split_block)
+        return off
+
     def debug_view(self, B, what, index, training=True):
         """Copy of one intermediate tensor of the LAST call with this (B, training) (parity tests)."""
         off, cnt = ctypes.c_int64(), ctypes.c_int64()

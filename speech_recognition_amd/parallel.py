@@ -52,6 +52,30 @@ def allreduce_grads(flat_grads):
     return flat_grads
 
 
+def allreduce_begin(flat_slice):
+    """Start the sum of one contiguous slice of the gradient buffer (async); returns the handle for allreduce_wait.
+    The collective is ordered after everything enqueued on the current stream so far, and runs on the communicator's own
+    stream beside whatever the caller enqueues next."""
+    if not active():
+        return None
+    return dist.all_reduce(flat_slice, op=dist.ReduceOp.SUM, async_op=True)
+
+
+def allreduce_wait(handle):
+    if handle is not None:
+        handle.wait()           # NCCL/RCCL: the current stream waits for the collective; gloo: the host does
+
+
+def split_block_from_env():
+    """KWS_ALLREDUCE_SPLIT=<block>: all-reduce the gradients of blocks >= <block> (+ tail) while the earlier blocks'
+    backward still runs.  Unset / 0 = one buffer after the backward pass (the default until an N-GPU run shows which
+    wins: the 4.8 MB message is latency-bound either way)."""
+    try:
+        return int(os.environ.get("KWS_ALLREDUCE_SPLIT", "0"))
+    except ValueError:
+        return 0
+
+
 def shard_rows(global_batch):
     """[start, stop) rows of the global batch owned by this rank (dropout counter offset = start)."""
     w, r = world_size(), rank()

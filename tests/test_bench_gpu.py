@@ -40,7 +40,9 @@ def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher around it (how the driver may call it): bench.py starts the two
     ranks itself as child processes BEFORE touching the GPU, relays rank 0's line and reports n_gpus 2 - never a
     silent 1-GPU run.  (--no-cpu-baseline: the other test covers that leg.)"""
-    env = dict(os.environ, KWS_BENCH_ONE_DEVICE="1", KWS_BENCH_TRACE="240", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # KWS_ALLREDUCE_SPLIT: this run also takes the two-part step with the late layers' all-reduce started early
+    env = dict(os.environ, KWS_BENCH_ONE_DEVICE="1", KWS_BENCH_TRACE="240", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               KWS_ALLREDUCE_SPLIT="6")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--bank", "8192",

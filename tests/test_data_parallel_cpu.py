@@ -39,6 +39,14 @@ def _worker(rank, world, port, out_dir):
     flat = torch.from_numpy(np.concatenate([g.reshape(-1) for g in grads.values()]))
     local = flat.clone()
     parallel.allreduce_grads(flat)
+    # the split form (KWS_ALLREDUCE_SPLIT: late layers' slice started early, early layers' slice afterwards) must give the
+    # bits of the one-buffer all-reduce
+    flat2 = local.clone()
+    off = 12345
+    h = parallel.allreduce_begin(flat2[off:])
+    parallel.allreduce_grads(flat2[:off])
+    parallel.allreduce_wait(h)
+    assert torch.equal(flat2, flat)
     # optimizer step on the reduced gradient: replicas stay identical
     p0 = np.concatenate([v.reshape(-1).astype(np.float64) for v in net.params.values()])
     new_p, _ = OL.rmsprop_step(p0, flat.numpy(), np.zeros_like(p0), 1e-3)

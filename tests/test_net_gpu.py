@@ -264,3 +264,32 @@ def test_first_convolution_kernels_at_awkward_batch_sizes(B):
     # move by up to a gradient term, everything else agrees to f32 rounding
     assert d.max() < 5e-2 * scale
     assert np.percentile(d, 99.9) < 2e-3 * scale and np.median(d) < 1e-6 * scale
+
+
+@pytest.mark.parametrize("split", [1, 6, 10])
+def test_split_step_is_bit_identical_to_the_whole_step(split):
+    """kws_net_train_fwd_bwd_part (the two-call form that lets the data-parallel step all-reduce the late layers'
+    gradients during the early layers' backward): parts 1 + 2 give the bits of the one-call step, and after part 1 the
+    gradient buffer from kws_net_grad_ready_offset onward is already final."""
+    ora, net = _pair()
+    B = 6
+    x, y = _batch(B, 12, 41)
+    dx, dy = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    p0 = net.train_fwd_bwd(dx, dy, seed=9, step=2, row_offset=3, loss_batch=2 * B).clone()
+    g0, m0, st0 = net.grads.clone(), net.metrics.clone(), net.state.clone()
+    net.set_weights(dict(ora.params, **ora.state))               # BN moving statistics back to the start
+    assert net.num_blocks() == 11
+    off = net.grad_ready_offset(split)
+    assert 0 < off < net.n_params
+    assert off == net.tensors['batch_normalization_%d/gamma' % split].offset   # the BatchNorm in front of block `split`
+    p1 = net.train_fwd_bwd_part(1, split, dx, dy, seed=9, step=2, row_offset=3, loss_batch=2 * B)
+    torch.cuda.synchronize()
+    assert torch.equal(net.grads[off:], g0[off:])                # final before part 2 has run
+    assert torch.equal(p1, p0) and torch.equal(net.metrics, m0)
+    net.train_fwd_bwd_part(2, split, dx, dy, seed=9, step=2, row_offset=3, loss_batch=2 * B)
+    torch.cuda.synchronize()
+    assert torch.equal(net.grads, g0) and torch.equal(net.state, st0)
+    with pytest.raises(_lib.KwsError):
+        net.train_fwd_bwd_part(1, 11, dx, dy, seed=9, step=2)
+    with pytest.raises(_lib.KwsError):
+        net.grad_ready_offset(0)
