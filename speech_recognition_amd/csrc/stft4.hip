@@ -71,10 +71,12 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
   float2* s_w5 = s_tw + 256;                                       // [8 k2][16 c] split factors W512^(k1 + 16 k2)
   float* s_dct = s_win + 512 + 512 + 256;                          // [n_mel][DSTR4]
   float* s_wpad = s_dct + n_mel * DSTR4;                           // [n_mel][MAXW] band weights over the band's tap window
-  int* s_mws = reinterpret_cast<int*>(s_wpad + n_mel * MAXW);      // [128] first bin of every band's tap window
-  float* s_wave = reinterpret_cast<float*>(s_mws + 128);
+  float* s_wave = s_wpad + n_mel * MAXW;
   const int wave_floats = 4 * MAGF + ((16 * LMS + 3) & ~3);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform by construction; SAYING so keeps the quad
+                                                                   // arithmetic and the buffer descriptors in scalar registers
+                                                                   // (left to itself the compiler built a waterfall loop per load)
   const int l16 = lane & 15, fq = lane >> 4;                       // D role: column c = l16, frame g = fq
   const int ar_u = l16 >> 2, ar_i = l16 & 3;                       // A role: row l16 = (frame u, n2 % 4), k slot fq
   float* s_mag = s_wave + wave * wave_floats + fq * MAGF;          // this lane row's frame
@@ -89,7 +91,6 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
     s_dct[i] = q < 64 ? pl.dct64[m * 64 + q] : 0.f;
   }
   for (int i = tid; i < n_mel * MAXW; i += NW4 * 64) s_wpad[i] = pl.mel_wpad[i];
-  for (int i = tid; i < 128; i += NW4 * 64) s_mws[i] = i < n_mel ? pl.mel_ws[i] : 0;
   if (l16 < MAGF - 257) s_mag[257 + l16] = 0.f;    // the tap windows may reach past the Nyquist bin: finite zeros there
   // log-mel rows start finite too: a partial last group multiplies rows it never wrote (their outputs are not stored)
   for (int i = lane; i < 16 * LMS; i += 64) s_lm16[i] = 0.f;
@@ -99,6 +100,15 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
   for (int q = 0; q < 4; ++q) {
     const float4 v = *reinterpret_cast<const float4*>(pl.b4 + lane * 16 + 4 * q);
     r_b[4 * q] = v.x; r_b[4 * q + 1] = v.y; r_b[4 * q + 2] = v.z; r_b[4 * q + 3] = v.w;
+  }
+  // mel stage: first bin of the tap window and offset of the weight row of this lane's band l16 + 16 i (band 0's for
+  // lanes past n_mel: they compute and do not store)
+  int r_mws[8], r_wofs[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m = l16 + 16 * i < n_mel ? l16 + 16 * i : 0;
+    r_mws[i] = pl.mel_ws[m];
+    r_wofs[i] = m * MAXW;
   }
   const int k1 = l16 < 8 ? l16 : (l16 < 15 ? l16 + 1 : 8);         // KPERM[l16]
   const unsigned m0 = l16 == 0 ? 0xFFFFFFFFu : 0u, m15 = l16 == 15 ? 0xFFFFFFFFu : 0u;
@@ -119,8 +129,9 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
   // 64-bit offsets were loop invariants that cost 32 registers - and a lane addresses all 16 loads with one register plus
   // immediates.
   auto issue_loads = [&](int64_t quad) {
-    const int64_t b = quad / a.quads_per_clip;
-    const int f0 = (int)(quad - b * a.quads_per_clip) * 4;
+    const unsigned qu = (unsigned)quad, qpc = (unsigned)a.quads_per_clip;   // < 2^31 quads (host-checked): 32-bit division
+    const int64_t b = qu / qpc;
+    const int f0 = (int)(qu - (unsigned)b * qpc) * 4;
     const int fu = f0 + ar_u < a.F ? f0 + ar_u : 0;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + b * (int64_t)a.L), 0,
                                                                         a.L * 4, 0x00020000);
@@ -187,6 +198,9 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
       // X[k] = E + T and X[256-k] = conj(E - T) with E = (Z[k] + conj Z[256-k]) / 2, T = W512^k (Z[k] - conj Z[256-k]) / 2i
       // (the halves are in z already).  Z[256-k] sits in the mirrored lane's register 15-k2; k1 = 0 (lane 0) and k1 = 8
       // (lane 15) are their own partners, with registers (16-k2)&15 and 15-k2.
+      float2 w5[8];                                   // all eight split factors requested before the first use
+#pragma unroll
+      for (int k2 = 0; k2 < 8; ++k2) w5[k2] = s_w5[k2 * 16 + l16];
 #pragma unroll
       for (int k2 = 0; k2 < 8; ++k2) {
         const float2 pa = z[15 - k2], pb = z[(16 - k2) & 15];
@@ -199,7 +213,7 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
         const float2 E = cadd(zk, zn);
         const float2 dd = csub(zk, zn);
         const float2 O = make_float2(dd.y, -dd.x);
-        const float2 T = cmul(s_w5[k2 * 16 + l16], O);
+        const float2 T = cmul(w5[k2], O);
         const float2 Xp = cadd(E, T), Xm = csub(E, T);
         const int kk = k1 + 16 * k2;
         s_mag[kk] = __builtin_amdgcn_sqrtf(Xp.x * Xp.x + Xp.y * Xp.y);
@@ -219,35 +233,36 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
       // the band: all of a band's LDS reads are in flight before its first multiply-add - the CSR walk of the third
       // kernel (a dependent wait per four taps, trip counts that differ lane by lane) took 40 % of a pass.
       float* lm_row = s_lm16 + (4 * qq + fq) * LMS;
-      for (int i = 0; i < nb_mel; ++i) {
-        const int m = l16 + 16 * i;
-        const int mm = m < n_mel ? m : 0;
-        const int mcl = pl.mel_mc[i];
-        const float* mp = s_mag + s_mws[mm];
-        const float* wp = s_wpad + mm * MAXW;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        for (int t0 = 0; t0 < mcl; t0 += 4) {
-          float4 wv[4];
-          float mv[4][4];
 #pragma unroll
-          for (int t = 0; t < 4; ++t)
-            if (t0 + t < mcl) {
-              wv[t] = *reinterpret_cast<const float4*>(wp + 4 * (t0 + t));
+      for (int i = 0; i < 8; ++i) {
+        if (i < nb_mel) {                             // wave-uniform
+          const int mcl = pl.mel_mc[i];
+          const float* mp = s_mag + r_mws[i];
+          const float* wp = s_wpad + r_wofs[i];
+          float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+          for (int t0 = 0; t0 < mcl; t0 += 4) {
+            float4 wv[4];
+            float mv[4][4];
 #pragma unroll
-              for (int r = 0; r < 4; ++r) mv[t][r] = mp[4 * (t0 + t) + r];
-            }
+            for (int t = 0; t < 4; ++t)
+              if (t0 + t < mcl) {
+                wv[t] = *reinterpret_cast<const float4*>(wp + 4 * (t0 + t));
 #pragma unroll
-          for (int t = 0; t < 4; ++t)
-            if (t0 + t < mcl) {
-              s0 = fmaf(mv[t][0], wv[t].x, s0);
-              s1 = fmaf(mv[t][1], wv[t].y, s1);
-              s2 = fmaf(mv[t][2], wv[t].z, s2);
-              s3 = fmaf(mv[t][3], wv[t].w, s3);
-            }
+                for (int r = 0; r < 4; ++r) mv[t][r] = mp[4 * (t0 + t) + r];
+              }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+              if (t0 + t < mcl) {
+                s0 = fmaf(mv[t][0], wv[t].x, s0);
+                s1 = fmaf(mv[t][1], wv[t].y, s1);
+                s2 = fmaf(mv[t][2], wv[t].z, s2);
+                s3 = fmaf(mv[t][3], wv[t].w, s3);
+              }
+          }
+          float sm = ((s0 + s1) + (s2 + s3)) + pl.log_offset;
+          if (pl.log_floor > 0.f) sm = fmaxf(sm, pl.log_floor);
+          if (l16 + 16 * i < n_mel) lm_row[l16 + 16 * i] = __logf(sm);
         }
-        float sm = ((s0 + s1) + (s2 + s3)) + pl.log_offset;
-        if (pl.log_floor > 0.f) sm = fmaxf(sm, pl.log_floor);
-        if (m < n_mel) lm_row[m] = __logf(sm);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();                // s_mag reads done before the next quad overwrites the rows
@@ -263,29 +278,38 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
     const float* pa = s_lm16 + l16 * LMS + fq;
     const float* pb = s_dct + fq * DSTR4 + l16;
     {
-      float av = pa[0], bv[4], an = 0.f, bn[4] = {0.f, 0.f, 0.f, 0.f};
+      // operands two steps ahead of the MFMAs that use them (one step = 4 MFMAs = 128 cycles of cover, an LDS round trip
+      // under 12 waves takes longer)
+      float av[3], bv[3][4];
 #pragma unroll
-      for (int nb = 0; nb < 4; ++nb) bv[nb] = pb[16 * nb];
+      for (int d = 0; d < 2; ++d) {
+        av[d] = pa[4 * d];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) bv[d][nb] = pb[(4 * d) * DSTR4 + 16 * nb];
+      }
       for (int ks = 0; ks < n_mel; ks += 4) {
-        if (ks + 4 < n_mel) {
-          an = pa[ks + 4];
+        const int kn = ks + 8 < n_mel ? ks + 8 : ks;              // clamped: the last two requests are not used
+        av[2] = pa[kn];
 #pragma unroll
-          for (int nb = 0; nb < 4; ++nb) bn[nb] = pb[(ks + 4) * DSTR4 + 16 * nb];
+        for (int nb = 0; nb < 4; ++nb) bv[2][nb] = pb[kn * DSTR4 + 16 * nb];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) dacc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv[0][nb], dacc[nb], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        av[0] = av[1]; av[1] = av[2];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+          bv[0][nb] = bv[1][nb];
+          bv[1][nb] = bv[2][nb];
         }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) dacc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[nb], dacc[nb], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        av = an;
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) bv[nb] = bn[nb];
       }
     }
     {
       const int64_t quad = q0 + fq * wave_stride;     // lane group fq holds the frames of the group's quad fq
       if (quad < a.total_quads) {
-        const int64_t b = quad / a.quads_per_clip;
-        const int f0 = (int)(quad - b * a.quads_per_clip) * 4;
+        const unsigned qu = (unsigned)quad, qpc = (unsigned)a.quads_per_clip;
+        const int64_t b = qu / qpc;
+        const int f0 = (int)(qu - (unsigned)b * qpc) * 4;
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           if (f0 + v < a.F) {
@@ -317,7 +341,7 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
 }  // namespace
 
 int kws_stft4_lds_bytes(const kws_stft_plan* pl) {
-  const size_t floats = 512 + 512 + 256 + (size_t)pl->n_mel * DSTR4 + (size_t)pl->n_mel * pl->mel_maxw + 128 +
+  const size_t floats = 512 + 512 + 256 + (size_t)pl->n_mel * DSTR4 + (size_t)pl->n_mel * pl->mel_maxw +
                         (size_t)NW4 * (4 * MAGF + ((16 * (pl->n_mel + 1) + 3) & ~3));
   return (int)(floats * 4);
 }
@@ -327,6 +351,7 @@ int kws_stft4_launch(const kws_stft_plan* pl, const float* x, int B, int L, int 
               pl->n_mel, pl->n_out);
   KWS_REQUIRE(F > 0 && (pl->frame_step % 2) == 0 && (L % 2) == 0 && (pl->frame_len % 2) == 0, "stft4: bad geometry");
   KWS_REQUIRE(pl->mel_maxw > 0 && pl->mel_maxw <= MAGF, "stft4: mel bands of up to %d taps unsupported", pl->mel_maxw);
+  KWS_REQUIRE((int64_t)B * ((F + 3) / 4) < (1ll << 31), "stft4: %d clips x %d frames exceed 2^31 frame quads", B, F);
   Stft2Args a;
   a.pl = *pl;
   a.x = x; a.out = out; a.B = B; a.L = L; a.F = F;

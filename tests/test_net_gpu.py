@@ -281,7 +281,8 @@ def test_split_step_is_bit_identical_to_the_whole_step(split):
     assert net.num_blocks() == 11
     off = net.grad_ready_offset(split)
     assert 0 < off < net.n_params
-    assert off == net.tensors['batch_normalization_%d/gamma' % split].offset   # the BatchNorm in front of block `split`
+    # the BatchNorm in front of block `split` (blocks count from 0: block i owns conv1d_{i+2} / batch_normalization_{i+2})
+    assert off == net.tensors['batch_normalization_%d/gamma' % (split + 1)].offset
     p1 = net.train_fwd_bwd_part(1, split, dx, dy, seed=9, step=2, row_offset=3, loss_batch=2 * B)
     torch.cuda.synchronize()
     assert torch.equal(net.grads[off:], g0[off:])                # final before part 2 has run
