@@ -54,8 +54,9 @@ struct kws_stft_plan {
   float* b4;          // [64 lanes][8 k-chunks][2 column tiles] 0.5 * DFT16 entries of the MFMA B operand
   float2* tw4;        // [16 c][16 n2] W256^(n2 * KPERM[c])
   float2* w512p;      // [16 c][8 k2]  W512^(KPERM[c] + 16 k2)
-  // stft4 mel stage: band m reads the 4 * mel_mc[m / 16] taps starting at bin mel_ws[m] with weights mel_wpad[m][.]
-  // (zero outside the band); mel_maxw = 4 * max(mel_mc) = row stride of mel_wpad, 0 when the windows do not fit
+  // stft4 mel stage: band m reads the mel_maxw taps starting at bin mel_ws[m] with weights mel_wpad[m][.] (zero outside
+  // the band); mel_maxw = 4 * max(mel_mc) = row stride of mel_wpad (mel_mc[i] = four-tap blocks of the widest band of
+  // bands 16 i .. 16 i + 15), 0 when the windows do not fit
   int mel_mc[8];
   int mel_maxw;
   int* mel_ws;        // [n_mel]

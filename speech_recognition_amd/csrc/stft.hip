@@ -285,7 +285,7 @@ int kws_stft_plan_create(int frame_len, int frame_step, int fft_len, int n_mel, 
       w512p[c * 8 + k2] = make_float2((float)cos(ang), (float)sin(ang));
     }
   }
-  // mel tap windows of the v4 kernel: band m of lane group i = m / 16 reads 4 * mc[i] taps from bin ws[m]
+  // mel tap windows of the v4 kernel: band m reads mel_maxw taps from bin ws[m] (weights zero outside the band)
   std::vector<int> mws(n_mel, 0);
   std::vector<float> wpad(1, 0.f);
   {
@@ -301,12 +301,12 @@ int kws_stft_plan_create(int frame_len, int frame_step, int fft_len, int n_mel, 
       if (p->mel_mc[i] > mcmax) mcmax = p->mel_mc[i];
     }
     p->mel_maxw = 4 * mcmax;
-    if (p->mel_maxw > MAGF4) {
+    if (p->mel_maxw > 64) {
       p->mel_maxw = 0;                                       // stft4 declines (kws_stft4_lds_bytes / launch check it)
     } else {
       wpad.assign((size_t)n_mel * p->mel_maxw, 0.f);
       for (int m = 0; m < n_mel; ++m) {
-        const int taps = 4 * p->mel_mc[m >> 4];
+        const int taps = p->mel_maxw;                        // one window width for every band
         int ws0 = bs[m];
         if (ws0 + taps > MAGF4) ws0 = MAGF4 - taps;          // keep the window inside the row: the band sits later in it
         mws[m] = ws0;

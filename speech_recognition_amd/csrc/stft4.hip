@@ -60,19 +60,23 @@ __device__ __forceinline__ float blend(unsigned m, float a, float b) {   // m al
   return __uint_as_float((__float_as_uint(a) & m) | (__float_as_uint(b) & ~m));
 }
 
+// NB = mel bands per lane (ceil(n_mel / 16)), MC = four-tap blocks per band window (mel_maxw = 4 MC): compile-time, so
+// the mel stage and the DCT are straight-line code whose LDS reads the compiler can put in flight together.
+template <int NB, int MC>
 __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const kws_stft_plan& pl = a.pl;
   const int n_mel = pl.n_mel, n_out = pl.n_out;
-  const int LMS = n_mel + 1;                                       // log-mel row stride (odd: conflict-free columns)
-  const int MAXW = pl.mel_maxw;                                    // padded taps per mel band (multiple of 4)
+  constexpr int LMS = 16 * NB + 1;                                 // log-mel row stride (odd: conflict-free columns); the
+                                                                   // columns n_mel .. 16 NB - 1 stay zero
+  constexpr int MAXW = 4 * MC;                                     // taps of a mel band's window
   float* s_win = lds;                                              // [512] zero padded window
   float2* s_tw = reinterpret_cast<float2*>(s_win + 512);           // [16 n2][16 c] second-pass twiddles W256^(n2 k1)
   float2* s_w5 = s_tw + 256;                                       // [8 k2][16 c] split factors W512^(k1 + 16 k2)
   float* s_dct = s_win + 512 + 512 + 256;                          // [n_mel][DSTR4]
-  float* s_wpad = s_dct + n_mel * DSTR4;                           // [n_mel][MAXW] band weights over the band's tap window
+  float* s_wpad = s_dct + 16 * NB * DSTR4;                         // [n_mel][MAXW] band weights over the band's tap window
   float* s_wave = s_wpad + n_mel * MAXW;
-  const int wave_floats = 4 * MAGF + ((16 * LMS + 3) & ~3);
+  constexpr int wave_floats = 4 * MAGF + ((16 * LMS + 3) & ~3);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform by construction; SAYING so keeps the quad
                                                                    // arithmetic and the buffer descriptors in scalar registers
@@ -86,11 +90,19 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
   for (int i = tid; i < 256; i += NW4 * 64) s_tw[i] = pl.tw4[(i & 15) * 16 + (i >> 4)];   // [c][n2] -> [n2][c]: a row's
                                                    // 16 lanes read 16 consecutive 8-byte entries (conflict-free)
   for (int i = tid; i < 128; i += NW4 * 64) s_w5[i] = pl.w512p[(i & 15) * 8 + (i >> 4)];  // [c][k2] -> [k2][c]
-  for (int i = tid; i < n_mel * DSTR4; i += NW4 * 64) {
+  for (int i = tid; i < 16 * NB * DSTR4; i += NW4 * 64) {          // rows n_mel .. 16 NB - 1 are zero
     const int m = i / DSTR4, q = i - m * DSTR4;
-    s_dct[i] = q < 64 ? pl.dct64[m * 64 + q] : 0.f;
+    s_dct[i] = (q < 64 && m < n_mel) ? pl.dct64[m * 64 + q] : 0.f;
   }
-  for (int i = tid; i < n_mel * MAXW; i += NW4 * 64) s_wpad[i] = pl.mel_wpad[i];
+  for (int i = tid; i < n_mel * MAXW; i += NW4 * 64) {
+    // row m = the weights of bins win_m .. win_m + MAXW - 1, win_m = min(plan window start, MAGF - MAXW): the plan's
+    // window (mel_maxw <= MAXW taps from mel_ws[m]) shifted right inside the row where the kernel's starts earlier
+    const int m = i / MAXW, q = i - m * MAXW;
+    const int ws0 = pl.mel_ws[m];
+    const int win = ws0 + MAXW <= MAGF ? ws0 : MAGF - MAXW;
+    const int j = q - (ws0 - win);
+    s_wpad[i] = (j >= 0 && j < pl.mel_maxw) ? pl.mel_wpad[m * pl.mel_maxw + j] : 0.f;
+  }
   if (l16 < MAGF - 257) s_mag[257 + l16] = 0.f;    // the tap windows may reach past the Nyquist bin: finite zeros there
   // log-mel rows start finite too: a partial last group multiplies rows it never wrote (their outputs are not stored)
   for (int i = lane; i < 16 * LMS; i += 64) s_lm16[i] = 0.f;
@@ -103,11 +115,12 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
   }
   // mel stage: first bin of the tap window and offset of the weight row of this lane's band l16 + 16 i (band 0's for
   // lanes past n_mel: they compute and do not store)
-  int r_mws[8], r_wofs[8];
+  int r_mws[NB], r_wofs[NB];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < NB; ++i) {
     const int m = l16 + 16 * i < n_mel ? l16 + 16 * i : 0;
-    r_mws[i] = pl.mel_ws[m];
+    const int ws0 = pl.mel_ws[m];
+    r_mws[i] = ws0 + MAXW <= MAGF ? ws0 : MAGF - MAXW;   // as in the staging loop above
     r_wofs[i] = m * MAXW;
   }
   const int k1 = l16 < 8 ? l16 : (l16 < 15 ? l16 + 1 : 8);         // KPERM[l16]
@@ -121,7 +134,6 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
   // in groups of up to four and hands every group's 16 log-mel rows to one DCT product.
   const int64_t wave_global = (int64_t)blockIdx.x * NW4 + wave;
   const int64_t wave_stride = (int64_t)gridDim.x * NW4;
-  const int nb_mel = (n_mel + 15) >> 4;   // mel bands per lane
   // A role: PCM of one quad into registers (frames past the clip's last one re-read frame 0: their rows are never stored)
   float2 xv[4][4];
   // Buffer loads: the descriptor spans ONE clip, so a frame's zero-padded tail (samples 480..511 of the last frames run
@@ -234,35 +246,32 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
       // kernel (a dependent wait per four taps, trip counts that differ lane by lane) took 40 % of a pass.
       float* lm_row = s_lm16 + (4 * qq + fq) * LMS;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        if (i < nb_mel) {                             // wave-uniform
-          const int mcl = pl.mel_mc[i];
-          const float* mp = s_mag + r_mws[i];
-          const float* wp = s_wpad + r_wofs[i];
-          float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-          for (int t0 = 0; t0 < mcl; t0 += 4) {
-            float4 wv[4];
-            float mv[4][4];
+      for (int i = 0; i < NB; ++i) {
+        const float* mp = s_mag + r_mws[i];
+        const float* wp = s_wpad + r_wofs[i];
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        constexpr int CH = MC < 8 ? MC : 8;           // blocks in flight per request burst
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-              if (t0 + t < mcl) {
-                wv[t] = *reinterpret_cast<const float4*>(wp + 4 * (t0 + t));
+        for (int t0 = 0; t0 < MC; t0 += CH) {
+          float4 wv[CH];
+          float mv[CH][4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) mv[t][r] = mp[4 * (t0 + t) + r];
-              }
+          for (int t = 0; t < CH; ++t) {
+            wv[t] = *reinterpret_cast<const float4*>(wp + 4 * (t0 + t));
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-              if (t0 + t < mcl) {
-                s0 = fmaf(mv[t][0], wv[t].x, s0);
-                s1 = fmaf(mv[t][1], wv[t].y, s1);
-                s2 = fmaf(mv[t][2], wv[t].z, s2);
-                s3 = fmaf(mv[t][3], wv[t].w, s3);
-              }
+            for (int r = 0; r < 4; ++r) mv[t][r] = mp[4 * (t0 + t) + r];
           }
-          float sm = ((s0 + s1) + (s2 + s3)) + pl.log_offset;
-          if (pl.log_floor > 0.f) sm = fmaxf(sm, pl.log_floor);
-          if (l16 + 16 * i < n_mel) lm_row[l16 + 16 * i] = __logf(sm);
+#pragma unroll
+          for (int t = 0; t < CH; ++t) {
+            s0 = fmaf(mv[t][0], wv[t].x, s0);
+            s1 = fmaf(mv[t][1], wv[t].y, s1);
+            s2 = fmaf(mv[t][2], wv[t].z, s2);
+            s3 = fmaf(mv[t][3], wv[t].w, s3);
+          }
         }
+        float sm = ((s0 + s1) + (s2 + s3)) + pl.log_offset;
+        if (pl.log_floor > 0.f) sm = fmaxf(sm, pl.log_floor);
+        if (l16 + 16 * i < n_mel) lm_row[l16 + 16 * i] = __logf(sm);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();                // s_mag reads done before the next quad overwrites the rows
@@ -287,15 +296,15 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) bv[d][nb] = pb[(4 * d) * DSTR4 + 16 * nb];
       }
-      for (int ks = 0; ks < n_mel; ks += 4) {
-        const int kn = ks + 8 < n_mel ? ks + 8 : ks;              // clamped: the last two requests are not used
+#pragma unroll
+      for (int ks = 0; ks < 16 * NB; ks += 4) {
+        constexpr int KLAST = 16 * NB - 4;
+        const int kn = ks + 8 <= KLAST ? ks + 8 : KLAST;          // clamped: the last two requests are not used
         av[2] = pa[kn];
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) bv[2][nb] = pb[kn * DSTR4 + 16 * nb];
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) dacc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv[0][nb], dacc[nb], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
         av[0] = av[1]; av[1] = av[2];
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
@@ -340,17 +349,43 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
 
 }  // namespace
 
+static void stft4_shape(const kws_stft_plan* pl, int* nb, int* mc) {
+  *nb = (pl->n_mel + 15) / 16;
+  const int need = (pl->mel_maxw + 3) / 4;
+  // instantiated shapes: (5, 4) = 80 mel bins at 16 kHz / 512 (input_data.py:366-373 as train.py sets it), (3, 8) = 40 mel
+  // bins; everything else takes the generic (8, 16)
+  if (*nb == 5 && need <= 4) *mc = 4;
+  else if (*nb == 3 && need <= 8) *mc = 8;
+  else { *nb = 8; *mc = 16; }
+}
+
 int kws_stft4_lds_bytes(const kws_stft_plan* pl) {
-  const size_t floats = 512 + 512 + 256 + (size_t)pl->n_mel * DSTR4 + (size_t)pl->n_mel * pl->mel_maxw +
-                        (size_t)NW4 * (4 * MAGF + ((16 * (pl->n_mel + 1) + 3) & ~3));
+  if (pl->mel_maxw <= 0 || pl->mel_maxw > 64) return 1 << 30;       // declines: the caller falls back to stft3
+  int nb, mc;
+  stft4_shape(pl, &nb, &mc);
+  const size_t floats = 512 + 512 + 256 + (size_t)16 * nb * DSTR4 + (size_t)pl->n_mel * 4 * mc +
+                        (size_t)NW4 * (4 * MAGF + ((16 * (16 * nb + 1) + 3) & ~3));
   return (int)(floats * 4);
+}
+
+template <int NB, int MC>
+static int stft4_launch_t(const Stft2Args& a, int bytes, int64_t wgs, hipStream_t st) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    KWS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&stft4_kernel<NB, MC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((stft4_kernel<NB, MC>), dim3((unsigned)wgs), dim3(NW4 * 64), (size_t)bytes, st, a);
+  KWS_LAUNCH_CHECK("stft4_kernel");
+  return KWS_OK;
 }
 
 int kws_stft4_launch(const kws_stft_plan* pl, const float* x, int B, int L, int F, float* out, hipStream_t st) {
   KWS_REQUIRE(pl->n_out <= 64 && pl->n_mel % 4 == 0 && pl->n_mel <= 128, "stft4: n_mel=%d n_out=%d unsupported",
               pl->n_mel, pl->n_out);
   KWS_REQUIRE(F > 0 && (pl->frame_step % 2) == 0 && (L % 2) == 0 && (pl->frame_len % 2) == 0, "stft4: bad geometry");
-  KWS_REQUIRE(pl->mel_maxw > 0 && pl->mel_maxw <= MAGF, "stft4: mel bands of up to %d taps unsupported", pl->mel_maxw);
+  KWS_REQUIRE(pl->mel_maxw > 0 && pl->mel_maxw <= 64, "stft4: mel bands of up to %d taps unsupported", pl->mel_maxw);
   KWS_REQUIRE((int64_t)B * ((F + 3) / 4) < (1ll << 31), "stft4: %d clips x %d frames exceed 2^31 frame quads", B, F);
   Stft2Args a;
   a.pl = *pl;
@@ -359,15 +394,11 @@ int kws_stft4_launch(const kws_stft_plan* pl, const float* x, int B, int L, int 
   a.total_quads = (int64_t)B * a.quads_per_clip;
   const int bytes = kws_stft4_lds_bytes(pl);
   KWS_REQUIRE(bytes <= 160 * 1024, "stft4: LDS need %d B exceeds 160 KiB", bytes);
-  static bool attr_done = false;
-  if (!attr_done) {
-    KWS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&stft4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024));
-    attr_done = true;
-  }
   int64_t wgs = (a.total_quads + NW4 - 1) / NW4;
   if (wgs > 256) wgs = 256;   // persistent: one workgroup per CU, tables staged once
-  hipLaunchKernelGGL(stft4_kernel, dim3((unsigned)wgs), dim3(NW4 * 64), (size_t)bytes, st, a);
-  KWS_LAUNCH_CHECK("stft4_kernel");
-  return KWS_OK;
+  int nb, mc;
+  stft4_shape(pl, &nb, &mc);
+  if (nb == 5 && mc == 4) return stft4_launch_t<5, 4>(a, bytes, wgs, st);
+  if (nb == 3 && mc == 8) return stft4_launch_t<3, 8>(a, bytes, wgs, st);
+  return stft4_launch_t<8, 16>(a, bytes, wgs, st);
 }
