@@ -17,7 +17,7 @@ out = torch.empty(B, 98 * n_out, device='cuda')
 for _ in range(5):
     _lib.call("kws_stft_mel_f32", plan, _lib.ptr(x), B, 16000, _lib.ptr(out), 0, S)
 torch.cuda.synchronize()
-buf = np.zeros((256, 8), dtype=np.uint64)
+buf = np.zeros((256, 12), dtype=np.uint64)
 raw = ctypes.CDLL(_lib.LIB_PATH)
 raw.kws_debug_read_stft_stamps(buf.ctypes.data_as(ctypes.c_void_p))
 t = buf.astype(np.float64)
@@ -29,3 +29,6 @@ print("workgroups %d, passes/wave %.1f, total %.0f cycles = %.1f us, clock %.2f 
 for nm, v in zip(names, per):
     print("  %-24s %8.0f cycles per pass" % (nm, v))
 print("  sum %.0f of %.0f cycles per pass" % (per.sum(), np.median(t[:, 6] / n[:, 0])))
+e, l0, l1, lw = t[:, 8], t[:, 9], t[:, 10], t[:, 11]
+print("absolute (100 MHz ticks -> us): first entry 0, last entry %.1f, median prologue %.1f, wave-0 loop ends %.1f .. %.1f, last wave of any workgroup ends %.1f"
+      % ((e.max() - e.min()) / 100.0, np.median(l0 - e) / 100.0, (l1.min() - e.min()) / 100.0, (l1.max() - e.min()) / 100.0, (lw.max() - e.min()) / 100.0))

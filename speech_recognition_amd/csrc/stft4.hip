@@ -31,7 +31,7 @@ using namespace kws_fft;
 // s_memtime deltas per phase: [0] loads issued -> first-pass MFMAs done, [1] twiddle + second pass, [2] split + magnitudes,
 // [3] mel + log, [4] DCT + store, [5] passes, [6] total cycles, [7] total in 100 MHz ticks
 #ifdef KWS_STFT_STAMP
-__device__ unsigned long long g_stft_stamps[256][8];
+__device__ unsigned long long g_stft_stamps[256][12];
 extern "C" int kws_debug_read_stft_stamps(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stft_stamps), sizeof(g_stft_stamps));
 }
@@ -65,17 +65,22 @@ __device__ __forceinline__ float blend(unsigned m, float a, float b) {   // m al
 template <int NB, int MC>
 __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+#ifdef KWS_STFT_STAMP
+  const unsigned long long st_entry = __builtin_amdgcn_s_memrealtime();
+#endif
   const kws_stft_plan& pl = a.pl;
   const int n_mel = pl.n_mel, n_out = pl.n_out;
   constexpr int LMS = 16 * NB + 1;                                 // log-mel row stride (odd: conflict-free columns); the
                                                                    // columns n_mel .. 16 NB - 1 stay zero
   constexpr int MAXW = 4 * MC;                                     // taps of a mel band's window
+  constexpr int WSTR = MAXW + 4;                                   // row stride of the weight table: 16-byte reads of 16
+                                                                   // consecutive rows fall on disjoint banks
   float* s_win = lds;                                              // [512] zero padded window
   float2* s_tw = reinterpret_cast<float2*>(s_win + 512);           // [16 n2][16 c] second-pass twiddles W256^(n2 k1)
   float2* s_w5 = s_tw + 256;                                       // [8 k2][16 c] split factors W512^(k1 + 16 k2)
   float* s_dct = s_win + 512 + 512 + 256;                          // [n_mel][DSTR4]
-  float* s_wpad = s_dct + 16 * NB * DSTR4;                         // [n_mel][MAXW] band weights over the band's tap window
-  float* s_wave = s_wpad + n_mel * MAXW;
+  float* s_wpad = s_dct + 16 * NB * DSTR4;                         // [n_mel][WSTR] band weights over the band's tap window
+  float* s_wave = s_wpad + n_mel * WSTR;
   constexpr int wave_floats = 4 * MAGF + ((16 * LMS + 3) & ~3);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform by construction; SAYING so keeps the quad
@@ -94,14 +99,14 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
     const int m = i / DSTR4, q = i - m * DSTR4;
     s_dct[i] = (q < 64 && m < n_mel) ? pl.dct64[m * 64 + q] : 0.f;
   }
-  for (int i = tid; i < n_mel * MAXW; i += NW4 * 64) {
+  for (int i = tid; i < n_mel * WSTR; i += NW4 * 64) {
     // row m = the weights of bins win_m .. win_m + MAXW - 1, win_m = min(plan window start, MAGF - MAXW): the plan's
     // window (mel_maxw <= MAXW taps from mel_ws[m]) shifted right inside the row where the kernel's starts earlier
-    const int m = i / MAXW, q = i - m * MAXW;
+    const int m = i / WSTR, q = i - m * WSTR;
     const int ws0 = pl.mel_ws[m];
     const int win = ws0 + MAXW <= MAGF ? ws0 : MAGF - MAXW;
     const int j = q - (ws0 - win);
-    s_wpad[i] = (j >= 0 && j < pl.mel_maxw) ? pl.mel_wpad[m * pl.mel_maxw + j] : 0.f;
+    s_wpad[i] = (q < MAXW && j >= 0 && j < pl.mel_maxw) ? pl.mel_wpad[m * pl.mel_maxw + j] : 0.f;
   }
   if (l16 < MAGF - 257) s_mag[257 + l16] = 0.f;    // the tap windows may reach past the Nyquist bin: finite zeros there
   // log-mel rows start finite too: a partial last group multiplies rows it never wrote (their outputs are not stored)
@@ -121,7 +126,7 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
     const int m = l16 + 16 * i < n_mel ? l16 + 16 * i : 0;
     const int ws0 = pl.mel_ws[m];
     r_mws[i] = ws0 + MAXW <= MAGF ? ws0 : MAGF - MAXW;   // as in the staging loop above
-    r_wofs[i] = m * MAXW;
+    r_wofs[i] = m * WSTR;
   }
   const int k1 = l16 < 8 ? l16 : (l16 < 15 ? l16 + 1 : 8);         // KPERM[l16]
   const unsigned m0 = l16 == 0 ? 0xFFFFFFFFu : 0u, m15 = l16 == 15 ? 0xFFFFFFFFu : 0u;
@@ -343,6 +348,12 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
     for (int i = 0; i < 6; ++i) g_stft_stamps[blockIdx.x][i] = st_acc[i];
     g_stft_stamps[blockIdx.x][6] = __builtin_amdgcn_s_memtime() - st_t0;
     g_stft_stamps[blockIdx.x][7] = __builtin_amdgcn_s_memrealtime() - st_r0;
+    g_stft_stamps[blockIdx.x][8] = st_entry;            // absolute 100 MHz ticks: kernel entry, loop start, loop end
+    g_stft_stamps[blockIdx.x][9] = st_r0;
+    g_stft_stamps[blockIdx.x][10] = __builtin_amdgcn_s_memrealtime();
+  }
+  if (lane == 0 && blockIdx.x < 256) {                  // latest wave of the workgroup to finish
+    atomicMax(&g_stft_stamps[blockIdx.x][11], (unsigned long long)__builtin_amdgcn_s_memrealtime());
   }
 #endif
 }
@@ -363,7 +374,7 @@ int kws_stft4_lds_bytes(const kws_stft_plan* pl) {
   if (pl->mel_maxw <= 0 || pl->mel_maxw > 64) return 1 << 30;       // declines: the caller falls back to stft3
   int nb, mc;
   stft4_shape(pl, &nb, &mc);
-  const size_t floats = 512 + 512 + 256 + (size_t)16 * nb * DSTR4 + (size_t)pl->n_mel * 4 * mc +
+  const size_t floats = 512 + 512 + 256 + (size_t)16 * nb * DSTR4 + (size_t)pl->n_mel * (4 * mc + 4) +
                         (size_t)NW4 * (4 * MAGF + ((16 * (16 * nb + 1) + 3) & ~3));
   return (int)(floats * 4);
 }
