@@ -1183,7 +1183,8 @@ TNPlan tn_plan(int64_t M, int K, int N, bool ws) {
   } else {
     S = ceil_div64(768, tiles);         // 4-wave kernel: ~3 workgroups per CU in flight
   }
-  if (S > 256) S = 256;                 // bounds the partial-slab traffic (S * K * N floats)
+  static const int max_s = getenv("KWS_GEMM_TN_MAXS") ? atoi(getenv("KWS_GEMM_TN_MAXS")) : 256;   // A/B knob
+  if (S > max_s) S = max_s;             // bounds the partial-slab traffic (S * K * N floats)
   const int64_t maxS = M / 256 > 1 ? M / 256 : 1;
   if (S > maxS) S = maxS;
   if (S < 1) S = 1;

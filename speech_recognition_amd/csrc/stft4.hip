@@ -78,7 +78,8 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
   float* s_win = lds;                                              // [512] zero padded window
   float2* s_tw = reinterpret_cast<float2*>(s_win + 512);           // [16 n2][16 c] second-pass twiddles W256^(n2 k1)
   float2* s_w5 = s_tw + 256;                                       // [8 k2][16 c] split factors W512^(k1 + 16 k2)
-  float* s_dct = s_win + 512 + 512 + 256;                          // [n_mel][DSTR4]
+  int* s_ctr = reinterpret_cast<int*>(s_win + 512 + 512 + 256);    // [4] the workgroup's quad counter
+  float* s_dct = s_win + 512 + 512 + 256 + 4;                      // [n_mel][DSTR4]
   float* s_wpad = s_dct + 16 * NB * DSTR4;                         // [n_mel][WSTR] band weights over the band's tap window
   float* s_wave = s_wpad + n_mel * WSTR;
   constexpr int wave_floats = 4 * MAGF + ((16 * LMS + 3) & ~3);
@@ -108,6 +109,7 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
     const int j = q - (ws0 - win);
     s_wpad[i] = (q < MAXW && j >= 0 && j < pl.mel_maxw) ? pl.mel_wpad[m * pl.mel_maxw + j] : 0.f;
   }
+  if (tid == 0) s_ctr[0] = 0;
   if (l16 < MAGF - 257) s_mag[257 + l16] = 0.f;    // the tap windows may reach past the Nyquist bin: finite zeros there
   // log-mel rows start finite too: a partial last group multiplies rows it never wrote (their outputs are not stored)
   for (int i = lane; i < 16 * LMS; i += 64) s_lm16[i] = 0.f;
@@ -134,11 +136,16 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
   const int a_off0 = 2 * (16 * fq + ar_i);                         // + 128 j' + 8 t
   __syncthreads();
 
-  // Work items are QUADS of frames, strided over all waves of the grid (25,600 quads over 3,072 waves at batch 1024: 8 or
-  // 9 per wave - whole groups of four per wave left a third of the waves with 12 instead of 8).  A wave takes its quads
-  // in groups of up to four and hands every group's 16 log-mel rows to one DCT product.
-  const int64_t wave_global = (int64_t)blockIdx.x * NW4 + wave;
-  const int64_t wave_stride = (int64_t)gridDim.x * NW4;
+  // Work items are QUADS of frames.  Every workgroup owns a contiguous range of them (neighbouring frames share samples
+  // in L1 / L2) and its waves draw quads from a counter in LDS: the waves of a SIMD do not run at the same speed - the
+  // oldest wave wins the issue arbitration and, with a fixed 8 or 9 quads per wave, finished at 56 us while the youngest
+  // ran alone, latency-bound, until 94 us.  A wave collects up to four quads and hands their 16 log-mel rows to one DCT.
+  const int64_t q_lo = a.total_quads * blockIdx.x / gridDim.x, q_hi = a.total_quads * (blockIdx.x + 1) / gridDim.x;
+  auto grab = [&]() -> int64_t {
+    int v = 0;
+    if (lane == 0) v = atomicAdd(s_ctr, 1);
+    return q_lo + __builtin_amdgcn_readfirstlane(v);
+  };
   // A role: PCM of one quad into registers (frames past the clip's last one re-read frame 0: their rows are never stored)
   float2 xv[4][4];
   // Buffer loads: the descriptor spans ONE clip, so a frame's zero-padded tail (samples 480..511 of the last frames run
@@ -162,12 +169,15 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
       }
   };
   ST_DECL
-  if (wave_global < a.total_quads) issue_loads(wave_global);
-  for (int64_t q0 = wave_global; q0 < a.total_quads; q0 += 4 * wave_stride) {
+  int64_t cur = grab();
+  if (cur < q_hi) issue_loads(cur);
+  while (cur < q_hi) {
+    int gq[4] = {-1, -1, -1, -1};                   // the quads of this group (scalar registers)
 #pragma unroll 1
     for (int qq = 0; qq < 4; ++qq) {
-      const int64_t quad = q0 + qq * wave_stride;
-      if (quad >= a.total_quads) break;             // wave-uniform: the group is partial
+      if (cur >= q_hi) break;                       // wave-uniform: the group is partial
+      const int64_t quad = cur;
+      if (qq == 0) gq[0] = (int)quad; else if (qq == 1) gq[1] = (int)quad; else if (qq == 2) gq[2] = (int)quad; else gq[3] = (int)quad;
 #ifdef KWS_STFT_STAMP
       st_acc[5] += 1;
       st_mark = __builtin_amdgcn_s_memtime();
@@ -194,7 +204,8 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
       // the PCM of this wave's NEXT quad is requested as soon as the MFMAs have consumed this quad's: it lands while
       // the vector work of this quad runs
       __builtin_amdgcn_sched_barrier(0);
-      if (quad + wave_stride < a.total_quads) issue_loads(quad + wave_stride);
+      cur = grab();
+      if (cur < q_hi) issue_loads(cur);
       __builtin_amdgcn_sched_barrier(0);
       // ---- second pass in registers: lane (g, c) holds Y[k1][n2] of frame g ------------------------------
       float2 z[16];
@@ -319,8 +330,8 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
       }
     }
     {
-      const int64_t quad = q0 + fq * wave_stride;     // lane group fq holds the frames of the group's quad fq
-      if (quad < a.total_quads) {
+      const int quad = fq == 0 ? gq[0] : (fq == 1 ? gq[1] : (fq == 2 ? gq[2] : gq[3]));   // lane group fq: the group's quad fq
+      if (quad >= 0) {
         const unsigned qu = (unsigned)quad, qpc = (unsigned)a.quads_per_clip;
         const int64_t b = qu / qpc;
         const int f0 = (int)(qu - (unsigned)b * qpc) * 4;
@@ -374,7 +385,7 @@ int kws_stft4_lds_bytes(const kws_stft_plan* pl) {
   if (pl->mel_maxw <= 0 || pl->mel_maxw > 64) return 1 << 30;       // declines: the caller falls back to stft3
   int nb, mc;
   stft4_shape(pl, &nb, &mc);
-  const size_t floats = 512 + 512 + 256 + (size_t)16 * nb * DSTR4 + (size_t)pl->n_mel * (4 * mc + 4) +
+  const size_t floats = 512 + 512 + 256 + 4 + (size_t)16 * nb * DSTR4 + (size_t)pl->n_mel * (4 * mc + 4) +
                         (size_t)NW4 * (4 * MAGF + ((16 * (16 * nb + 1) + 3) & ~3));
   return (int)(floats * 4);
 }
