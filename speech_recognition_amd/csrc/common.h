@@ -77,15 +77,26 @@ __device__ static inline float relu6f(float v) { return fminf(fmaxf(v, 0.0f), 6.
 bool kws_prof_on();
 void* kws_prof_begin(hipStream_t st);
 void kws_prof_end(void* token, const char* name, double flops, double bytes, hipStream_t st);
+// KWS_ROCTX=1: every launcher also opens a roctx range under its family name, so the host side of each C-ABI call shows
+// up in rocprofv3 --marker-trace timelines (librocprofiler-sdk-roctx / libroctx64 resolved at run time; a no-op otherwise)
+bool kws_roctx_on();
+void kws_roctx_push(const char* name);
+void kws_roctx_pop();
 struct KwsProfScope {
   void* tok;
   const char* name;
   double flops, bytes;
   hipStream_t st;
-  KwsProfScope(const char* n, double f, double b, hipStream_t s) : tok(nullptr), name(n), flops(f), bytes(b), st(s) {
+  bool tx;
+  KwsProfScope(const char* n, double f, double b, hipStream_t s) : tok(nullptr), name(n), flops(f), bytes(b), st(s), tx(false) {
     if (kws_prof_on()) tok = kws_prof_begin(s);
+    if (kws_roctx_on()) {
+      kws_roctx_push(n);
+      tx = true;
+    }
   }
   ~KwsProfScope() {
     if (tok) kws_prof_end(tok, name, flops, bytes, st);
+    if (tx) kws_roctx_pop();
   }
 };

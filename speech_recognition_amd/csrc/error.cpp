@@ -105,6 +105,42 @@ void prof_clear_locked() {
 
 bool kws_prof_on() { return g_prof_enabled; }
 
+// ---- roctx ranges (KWS_ROCTX=1) -----------------------------------------------------------------------------
+#include <dlfcn.h>
+#include <stdlib.h>
+namespace {
+int (*g_roctx_push)(const char*) = nullptr;
+int (*g_roctx_pop)() = nullptr;
+int g_roctx_state = -1;   // -1 unknown, 0 off, 1 on
+}  // namespace
+
+bool kws_roctx_on() {
+  if (g_roctx_state < 0) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (g_roctx_state < 0) {
+      int st = 0;
+      const char* e = getenv("KWS_ROCTX");
+      if (e && e[0] && e[0] != '0') {
+        const char* names[] = {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"};
+        for (const char* n : names) {
+          void* h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+          if (!h) continue;
+          g_roctx_push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+          g_roctx_pop = (int (*)())dlsym(h, "roctxRangePop");
+          if (g_roctx_push && g_roctx_pop) {
+            st = 1;
+            break;
+          }
+        }
+      }
+      g_roctx_state = st;
+    }
+  }
+  return g_roctx_state == 1;
+}
+void kws_roctx_push(const char* name) { (void)g_roctx_push(name); }
+void kws_roctx_pop() { (void)g_roctx_pop(); }
+
 void* kws_prof_begin(hipStream_t st) {
   ProfRec* r = new ProfRec();
   if (hipEventCreate(&r->a) != hipSuccess || hipEventCreate(&r->b) != hipSuccess) {
