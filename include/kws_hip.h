@@ -191,6 +191,11 @@ int kws_stft_num_frames(const kws_stft_plan_t* plan, int L);
 int kws_stft_mel_f32(const kws_stft_plan_t* plan, const float* x, int B, int L, float* out,
                      int out_kind, void* stream);
 
+/* EXPERIMENT (A/B measurement, not called by the network programs): the same product with every f32 operand split
+ * into three bf16 parts and six bf16 MFMA products accumulated in f32 - as accurate as the f32 matrix pipe, not
+ * bit-identical to it.  C[M,N] = A[M,K] . Bt[N,K]^T (Bt = the kernel stored [out][in]).  K % 32 == 0. */
+int kws_gemm_nn_bf16x3_f32(const float* A, const float* Bt, float* C, int64_t M, int K, int N, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * a7+a8, a10  GEMM family on f32 MFMA (v_mfma_f32_32x32x2_f32)
  *   C[M,N] = A[M,K] * W[K,N]          pointwise Conv1D(1x1)  reference model.py:48-49

@@ -1,0 +1,30 @@
+"""A/B measurement of the bf16 x 3 split GEMM (EXPERIMENT, csrc/gemm_bf16x3.hip) against the f32-MFMA kernel on the
+eleven pointwise-convolution shapes of the batch-1024 step (forward form; algorithmic 2 M K N FLOPs per launch)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from speech_recognition_amd import _lib
+lib = _lib.load()
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+shapes = [(397,128,128),(199,128,192),(197,192,192),(99,192,256),(97,256,256),(49,256,320),(47,320,320),(24,320,384),(22,384,384),(11,384,512),(9,512,512)]
+S = _lib.stream_ptr()
+def timeit(fn, n=10):
+    fn(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / n
+t1s = t3s = fl = 0.0
+for L, K, N in shapes:
+    M = B * L
+    A = torch.randn(M, K, device='cuda'); W = torch.randn(K, N, device='cuda') * 0.1; Wt = W.t().contiguous()
+    C = torch.empty(M, N, device='cuda')
+    t1 = timeit(lambda: _lib.call("kws_gemm_nn_f32", _lib.ptr(A), _lib.ptr(W), _lib.ptr(C), M, K, N, None, S))
+    t3 = timeit(lambda: _lib.call("kws_gemm_nn_bf16x3_f32", _lib.ptr(A), _lib.ptr(Wt), _lib.ptr(C), M, K, N, S))
+    f = 2.0 * M * K * N
+    byts = 4.0 * (M * K + K * N + M * N)
+    print("M=%7d K=%3d N=%3d  f32 MFMA %6.1f us %6.1f TF | bf16x3 %6.1f us %6.1f TF-equivalent, %5.2f TB/s algorithmic | x%.2f" % (
+        M, K, N, t1 * 1e3, f / t1 / 1e9, t3 * 1e3, f / t3 / 1e9, byts / t3 / 1e9, t1 / t3))
+    t1s += t1; t3s += t3; fl += f
+print("total: f32 MFMA %.3f ms (%.1f TF) | bf16x3 %.3f ms (%.1f TF-equivalent) | x%.2f" % (t1s, fl / t1s / 1e9, t3s, fl / t3s / 1e9, t1s / t3s))

@@ -11,16 +11,16 @@ cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 BENCH="python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-val-acc"
 mkdir -p gpurun_out
-rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_stats -- $BENCH > gpurun_out/${tag}_stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats -- $BENCH > gpurun_out/${tag}_stats.log 2>&1
 f=$(find gpurun_out/${tag}_stats -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && cp "$f" gpurun_out/${tag}_kernel_stats_bench_b1024.csv
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c -d gpurun_out/${tag}_pmc_$c -- python3 bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-val-acc --profile-steps 0 > gpurun_out/${tag}_pmc_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/${tag}_pmc_$c -- python3 bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-val-acc --profile-steps 0 > gpurun_out/${tag}_pmc_$c.log 2>&1
 done
 ff=$(find gpurun_out/${tag}_pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1)
 fw=$(find gpurun_out/${tag}_pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
 python3 scripts/pmc_traffic.py "$ff" "$fw" gpurun_out/${tag}_pmc_traffic.json > gpurun_out/${tag}_pmc_traffic.txt 2>&1
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d gpurun_out/${tag}_pmc_MFMA -- python3 bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-val-acc --profile-steps 0 > gpurun_out/${tag}_pmc_MFMA.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/${tag}_pmc_MFMA -- python3 bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-val-acc --profile-steps 0 > gpurun_out/${tag}_pmc_MFMA.log 2>&1
 fm=$(find gpurun_out/${tag}_pmc_MFMA -name "*counter_collection.csv" | head -1)
 python3 scripts/pmc_mfma_busy.py "$fm" gpurun_out/${tag}_pmc_mfma_busy.json > gpurun_out/${tag}_pmc_mfma_busy.txt 2>&1
 # the raw traces are large: keep the summaries only

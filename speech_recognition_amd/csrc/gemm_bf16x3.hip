@@ -1,0 +1,167 @@
+// EXPERIMENT (A/B arm, not on the product path): the pointwise 1x1 convolution GEMM with every f32 operand split into
+// three bf16 parts (x = hi + mid + lo, 24 mantissa bits in all) and six bf16 MFMA products accumulated in f32:
+//     C = sum_{(p,q) in {lo.hi, hi.lo, mid.mid, mid.hi, hi.mid, hi.hi}} A_p . B_q
+// The f32 matrix pipe runs at 1/16 of the bf16 rate (MI355X_MICROARCH.md), so six bf16 products cost 3/8 of one f32
+// product; the result is as close to the exact product as the f32 MFMA's (measured against float64 in
+// tests/test_bf16x3_gpu.py; NumPy study: 2.8e-7 of the maximum against 6.5e-7 for an f32 matmul).  It is NOT bit-identical
+// to the f32-MFMA kernels, which stay the default: this file exists to measure what the split would buy.
+//
+//   kws_gemm_nn_bf16x3_f32:  C[M,N] = A[M,K] . Bt[N,K]^T        (Bt = the kernel stored [out][in]: k is contiguous for both
+//                                                                 operands, so both are split and staged the same way)
+// 128 x 128 tile per 256-thread workgroup (2 x 2 waves of 64 x 64), K slabs of 32: f32 slab -> registers -> split
+// (v_cvt_pk_bf16_f32: round to nearest even; the residuals are exact in f32) -> three bf16 planes in LDS
+// ([plane][row][32 + 8 pad]: a fragment is one 16-byte read, 16 consecutive rows fall on disjoint banks) ->
+// v_mfma_f32_32x32x16_bf16.  One LDS buffer (60 KB: two workgroups per CU) with the next slab prefetched into registers.
+#include "internal.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int XBM = 128, XBN = 128, XBK = 32;
+constexpr int XLD = XBK + 8;                         // bf16 row stride of a plane
+constexpr int XPLANE = XBM * XLD;                    // bf16 elements per plane (A and B tiles have the same shape)
+
+struct X3Args {
+  const float* A;
+  const float* Bt;
+  float* C;
+  int64_t M;
+  int K, N;
+};
+
+// x -> (hi, mid, lo) per component of a float4, each plane as 4 packed bf16
+__device__ __forceinline__ void split4(const float4 v, bf16x4& hi, bf16x4& mid, bf16x4& lo) {
+  const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const __bf16 h = (__bf16)x[i];
+    const float r1 = x[i] - (float)h;                // exact: h is x rounded to 8 bits
+    const __bf16 m = (__bf16)r1;
+    const float r2 = r1 - (float)m;                  // exact
+    hi[i] = h;
+    mid[i] = m;
+    lo[i] = (__bf16)r2;
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_nn_bf16x3_kernel(X3Args p) {
+  __shared__ __attribute__((aligned(16))) __bf16 smem[2 * 3 * XPLANE];   // A planes then B planes: 61,440 B
+  __bf16* sA = smem;
+  __bf16* sB = smem + 3 * XPLANE;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  const int K = p.K, N = p.N;
+  const int64_t M = p.M;
+  const int n_tiles = (N + XBN - 1) / XBN;          // a ragged last column tile computes on clamped rows of Bt, stores masked
+  const int64_t tile_m = blockIdx.x / n_tiles;
+  const int tile_n = blockIdx.x % n_tiles;
+  const int64_t m0 = tile_m * XBM;
+  const int n0 = tile_n * XBN;
+  // loader role: thread t moves float4 c4 = t % 8 of rows t / 8 + 32 i
+  const int lrow = tid >> 3, lc4 = tid & 7;
+  const float* gA[4];
+  const float* gB[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int64_t ra = m0 + lrow + 32 * i;
+    if (ra >= M) ra = M - 1;                         // rows past M: a valid address, their results are not stored
+    gA[i] = p.A + ra * K + 4 * lc4;
+    int rb = n0 + lrow + 32 * i;
+    if (rb >= N) rb = N - 1;
+    gB[i] = p.Bt + (int64_t)rb * K + 4 * lc4;
+  }
+  float4 ra4[4], rb4[4];
+  auto g_load = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ra4[i] = *reinterpret_cast<const float4*>(gA[i] + k0);
+      rb4[i] = *reinterpret_cast<const float4*>(gB[i] + k0);
+    }
+  };
+  auto s_store = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      bf16x4 hi, mid, lo;
+      const int off = (lrow + 32 * i) * XLD + 4 * lc4;
+      split4(ra4[i], hi, mid, lo);
+      *reinterpret_cast<bf16x4*>(sA + off) = hi;
+      *reinterpret_cast<bf16x4*>(sA + XPLANE + off) = mid;
+      *reinterpret_cast<bf16x4*>(sA + 2 * XPLANE + off) = lo;
+      split4(rb4[i], hi, mid, lo);
+      *reinterpret_cast<bf16x4*>(sB + off) = hi;
+      *reinterpret_cast<bf16x4*>(sB + XPLANE + off) = mid;
+      *reinterpret_cast<bf16x4*>(sB + 2 * XPLANE + off) = lo;
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+  const int G = K / XBK;
+  g_load(0);
+  s_store();
+  __syncthreads();
+  for (int g = 0; g < G; ++g) {
+    if (g + 1 < G) g_load((g + 1) * XBK);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 a[2][3], b[2][3];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          a[i][pl] = *reinterpret_cast<const bf16x8*>(sA + pl * XPLANE + (wm * 64 + 32 * i + r) * XLD + 16 * s + 8 * h);
+          b[i][pl] = *reinterpret_cast<const bf16x8*>(sB + pl * XPLANE + (wn * 64 + 32 * i + r) * XLD + 16 * s + 8 * h);
+        }
+      // smallest products first: lo.hi, hi.lo, mid.mid, mid.hi, hi.mid, hi.hi
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();                                 // every wave has read this slab's planes
+    if (g + 1 < G) s_store();
+    __syncthreads();
+  }
+  // C[row][col]: lane -> col = l & 31, register v -> row = (v & 3) + 8 (v >> 2) + 4 (l >> 5)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int64_t row = m0 + wm * 64 + 32 * i + (v & 3) + 8 * (v >> 2) + 4 * h;
+        const int col = n0 + wn * 64 + 32 * j + r;
+        if (row < M && col < N) p.C[row * N + col] = acc[i][j][v];
+      }
+}
+
+}  // namespace
+
+extern "C" int kws_gemm_nn_bf16x3_f32(const float* A, const float* Bt, float* C, int64_t M, int K, int N, void* stream) {
+  KWS_REQUIRE(A && Bt && C && M > 0, "gemm_nn_bf16x3: bad arguments");
+  KWS_REQUIRE(K >= XBK && K % XBK == 0 && N > 0, "gemm_nn_bf16x3: K=%d must be a multiple of %d (N=%d)", K, XBK, N);
+  const int64_t grid = ceil_div64(M, XBM) * ((N + XBN - 1) / XBN);
+  KWS_REQUIRE(grid <= 0x7FFFFFFF, "gemm_nn_bf16x3: grid out of range");
+  X3Args p{A, Bt, C, M, K, N};
+  KwsProfScope prof("gemm_nn_bf16x3", 2.0 * M * K * N, 4.0 * ((double)M * K + (double)K * N + (double)M * N), (hipStream_t)stream);
+  hipLaunchKernelGGL(gemm_nn_bf16x3_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p);
+  KWS_LAUNCH_CHECK("gemm_nn_bf16x3_kernel");
+  return KWS_OK;
+}

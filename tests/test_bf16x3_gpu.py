@@ -1,0 +1,34 @@
+"""The bf16 x 3 split GEMM (EXPERIMENT, csrc/gemm_bf16x3.hip): as accurate against float64 as the
+f32-MFMA kernel the product uses - which is what would let it replace that kernel without moving a parity tolerance.
+The product path does not call it."""
+import numpy as np
+import pytest
+import torch
+
+from speech_recognition_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("M,K,N", [(1, 128, 128), (130, 128, 128), (4096, 192, 192), (3000, 320, 320), (9216, 512, 512),
+                                   (50000, 256, 320), (777, 384, 512)])
+def test_bf16x3_matches_float64_as_well_as_the_f32_kernel(M, K, N):
+    g = torch.Generator(device="cuda")
+    g.manual_seed(M + K)
+    A = torch.randn((M, K), generator=g, device="cuda") * 1.7
+    A[0, :4] = torch.tensor([1e-30, -3e4, 65504.0, 1.0 + 2.0 ** -20], device="cuda")     # tiny / large / many mantissa bits
+    W = torch.randn((K, N), generator=g, device="cuda") * 0.1
+    Wt = W.t().contiguous()
+    C3 = torch.full((M, N), float("nan"), device="cuda")
+    _lib.call("kws_gemm_nn_bf16x3_f32", _lib.ptr(A), _lib.ptr(Wt), _lib.ptr(C3), M, K, N, _lib.stream_ptr())
+    ref = A.double() @ W.double()
+    scale = float(ref.abs().max())
+    e3 = float((C3.double() - ref).abs().max()) / scale
+    assert torch.isfinite(C3).all()
+    if K % 64 == 0 and N % 64 == 0:
+        C1 = torch.empty((M, N), device="cuda")
+        _lib.call("kws_gemm_nn_f32", _lib.ptr(A), _lib.ptr(W), _lib.ptr(C1), M, K, N, None, _lib.stream_ptr())
+        e1 = float((C1.double() - ref).abs().max()) / scale
+        print("M=%d K=%d N=%d: bf16x3 %.2e, f32 MFMA %.2e of the maximum" % (M, K, N, e3, e1))
+        assert e3 < max(2.0 * e1, 4e-7)
+    assert e3 < 1e-6                 # the f32 kernels' own test bar (tests/test_kernels_gpu.py)
