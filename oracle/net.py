@@ -247,13 +247,15 @@ LM_BLOCKS = [(64, 1), (64, 1), (128, 2), (128, 1), (192, 2), (192, 1), (192, 1),
 
 
 def maxpool_same_fwd(a, pool):
-    """MaxPool1D(pool_size=pool, strides=pool, padding='same') (model.py:1440).  Lengths here are
-    multiples of the pool, so 'same' adds no padding."""
+    """MaxPool1D(pool_size=pool, strides=pool, padding='same') (model.py:1440): ceil(L / pool) windows; TF pads the END
+    of a length that is not a multiple of the pool (with -inf for max pooling), so the last window is short."""
     if pool == 1:
         return a, None
     B, L, C = a.shape
-    assert L % pool == 0
-    w = a.reshape(B, L // pool, pool, C)
+    Lo = -(-L // pool)
+    if Lo * pool != L:
+        a = np.concatenate([a, np.full((B, Lo * pool - L, C), -np.inf, dtype=a.dtype)], axis=1)
+    w = a.reshape(B, Lo, pool, C)
     return w.max(axis=2), w.argmax(axis=2)     # first maximum wins (MaxPoolGrad semantics)
 
 
@@ -264,7 +266,7 @@ def maxpool_same_bwd(do, arg, pool, L):
     d = np.zeros((B, Lo, pool, C), dtype=do.dtype)
     for j in range(pool):
         d[:, :, j, :] = do * (arg == j)
-    return d.reshape(B, L, C)
+    return d.reshape(B, Lo * pool, C)[:, :L, :]   # the padded positions never win
 
 
 class LogMfccNet(object):
@@ -305,19 +307,18 @@ class LogMfccNet(object):
         self.first = (conv(3, num_features, 64, True), bn(64))
         self.blocks = []
         cin, L = 64, spectrogram_length - 2
-        if L % 8 != 0:
-            # Keras' MaxPool1D(2, 2, 'same') / Conv1D(strides=2, 'same') give ceil(L/2) for an odd length (e.g. the
-            # function default spectrogram_length=65, model.py:1410 -> 63 frames); this restatement (and the device
-            # program, net_logmfcc.hip:lm_build) covers the lengths that halve evenly three times (98 -> 96) only
-            raise ValueError("LogMfccNet: spectrogram_length - 2 = %d must be a multiple of 8" % L)
+        if L < 1:
+            raise ValueError("LogMfccNet: spectrogram_length %d is too short" % spectrogram_length)
         for nf, stride in LM_BLOCKS:
-            blk = dict(nf=nf, stride=stride, cin=cin, Lin=L, Lout=L // stride)
+            # Keras' MaxPool1D(2, 2, 'same') and Conv1D(nf, 1, strides=2, 'same') both give ceil(L / 2): the function's
+            # own default spectrogram_length = 65 runs 63 -> 32 -> 16 -> 8 (model.py:1410)
+            blk = dict(nf=nf, stride=stride, cin=cin, Lin=L, Lout=-(-L // stride))
             if stride != 1:
                 blk['short'] = (conv(1, cin, nf, False), bn(nf))   # no kernel_regularizer (model.py:1431-1432)
             blk['dw1'], blk['pw1'], blk['bn1'] = dw(cin), conv(1, cin, nf, True), bn(nf)
             blk['dw2'], blk['pw2'], blk['bn2'] = dw(nf), conv(1, nf, nf, True), bn(nf)
             self.blocks.append(blk)
-            cin, L = nf, L // stride
+            cin, L = nf, -(-L // stride)
         self.T, self.C = L, cin
         self.att = (dw(cin), conv(1, cin, 1, True), bn(1))         # _context_conv(x, 1, 3, 'same'), model.py:1464
         P['dense_1/kernel'] = glorot_uniform(rng, (cin, num_classes), cin, num_classes)

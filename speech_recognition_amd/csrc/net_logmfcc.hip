@@ -384,8 +384,9 @@ int lm_build(kws_net* n) {
   KWS_REQUIRE(c.spectrogram_length >= 19 && c.num_features >= 4 &&
                   c.input_size == c.spectrogram_length * c.num_features,
               "net: log-mfcc input %d != %d x %d", c.input_size, c.spectrogram_length, c.num_features);
-  KWS_REQUIRE((c.spectrogram_length - 2) % 8 == 0, "net: spectrogram_length-2 = %d must be a multiple of 8",
-              c.spectrogram_length - 2);
+  // any length >= 3: the strided blocks are Keras 'same' layers - MaxPool1D(2, 2) and Conv1D(nf, 1, strides=2) both give
+  // ceil(L / 2), e.g. the function's own default spectrogram_length = 65 -> 63 -> 32 -> 16 -> 8 (model.py:1410)
+  KWS_REQUIRE(c.spectrogram_length >= 3, "net: spectrogram_length %d is too short", c.spectrogram_length);
   LmProgram* p = new LmProgram();
   n->lm = p;
   int n_conv = 0, n_bn = 0, n_dw = 0;
@@ -418,7 +419,7 @@ int lm_build(kws_net* n) {
   int cin = p->C0, L = p->L0;
   for (int i = 0; i < 10; ++i) {
     LmBlock b;
-    b.nf = spec[i][0]; b.stride = spec[i][1]; b.cin = cin; b.Lin = L; b.Lout = L / b.stride;
+    b.nf = spec[i][0]; b.stride = spec[i][1]; b.cin = cin; b.Lin = L; b.Lout = (L + b.stride - 1) / b.stride;
     b.has_short = b.stride != 1;
     b.s1 = 1; b.pool = b.stride; b.Lmid = b.Lin; b.pad1 = 1;
     b.ws = 0; b.bns_idx = 0;

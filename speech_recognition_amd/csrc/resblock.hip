@@ -24,16 +24,19 @@ template <int P, bool RES_BN>
 __global__ __launch_bounds__(256) void block_out_fwd_kernel(const float* __restrict__ y, const float* __restrict__ bn,
                                                             const float* __restrict__ res,
                                                             const float* __restrict__ res_bn, float* __restrict__ o,
-                                                            int64_t n4, int Lo, int C) {
+                                                            int64_t n4, int L, int Lo, int C) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n4) return;
   const int C4 = C >> 2;
   const int c = (int)(i % C4) * 4;
   const int64_t bt = i / C4;  // b*Lo + t
+  const int64_t b = bt / Lo;
+  const int t = (int)(bt - b * Lo);
+  const int64_t u0 = b * L + (int64_t)t * P;   // MaxPool1D(P, P, 'same'): window t = inputs P t .. P t + P - 1 that exist
   const float4 sc = ld4(bn + c), sh = ld4(bn + C + c);
-  float4 v = relu6_4(bn4(ld4(y + (bt * P) * C + c), sc, sh));
-  if (P == 2) {
-    const float4 w = relu6_4(bn4(ld4(y + (bt * P + 1) * C + c), sc, sh));
+  float4 v = relu6_4(bn4(ld4(y + u0 * C + c), sc, sh));
+  if (P == 2 && 2 * t + 1 < L) {               // an odd L leaves the last window with one element (Lo = ceil(L / 2))
+    const float4 w = relu6_4(bn4(ld4(y + (u0 + 1) * C + c), sc, sh));
     v = make_float4(fmaxf(v.x, w.x), fmaxf(v.y, w.y), fmaxf(v.z, w.z), fmaxf(v.w, w.w));
   }
   float4 r = ld4(res + bt * C + c);
@@ -46,7 +49,7 @@ __global__ __launch_bounds__(256) void block_out_fwd_kernel(const float* __restr
 template <int P, bool RELU>
 __global__ __launch_bounds__(256) void block_out_bwd_kernel(const float* __restrict__ dO, const float* __restrict__ y,
                                                             const float* __restrict__ bn, float* __restrict__ g,
-                                                            float* __restrict__ part, int B, int Lo, int C,
+                                                            float* __restrict__ part, int B, int L, int Lo, int C,
                                                             int nchunks, int R, int Cb) {
   // blockIdx.y selects a slice of Cb <= 1024 channels (more than 1024 channels: C / Cb slices)
   __shared__ float red[2][256 * 4];
@@ -65,12 +68,15 @@ __global__ __launch_bounds__(256) void block_out_bwd_kernel(const float* __restr
       const int t = chunk * TT + i;
       if (t >= Lo) break;
       const float4 d = ld4(dO + (b * Lo + t) * (int64_t)C + c);
-      const int64_t u0 = (b * Lo + t) * (int64_t)P;
+      const int64_t u0 = b * L + (int64_t)t * P;
+      const bool two = P == 2 && 2 * t + 1 < L;     // an odd L: the last window has one element
       const float4 y0 = ld4(y + u0 * C + c);
       const float4 p0 = bn4(y0, sc, sh);
       float4 g0, g1 = make_float4(0.f, 0.f, 0.f, 0.f), y1 = g1;
       if (P == 1) {
         g0 = RELU ? make_float4(d.x * mk(p0.x), d.y * mk(p0.y), d.z * mk(p0.z), d.w * mk(p0.w)) : d;
+      } else if (!two) {
+        g0 = make_float4(d.x * mk(p0.x), d.y * mk(p0.y), d.z * mk(p0.z), d.w * mk(p0.w));
       } else {
         y1 = ld4(y + (u0 + 1) * C + c);
         const float4 p1 = bn4(y1, sc, sh);
@@ -88,7 +94,7 @@ __global__ __launch_bounds__(256) void block_out_bwd_kernel(const float* __restr
       sgx.y = fmaf(g0.y, (y0.y - mean.y) * rstd.y, sgx.y);
       sgx.z = fmaf(g0.z, (y0.z - mean.z) * rstd.z, sgx.z);
       sgx.w = fmaf(g0.w, (y0.w - mean.w) * rstd.w, sgx.w);
-      if (P == 2) {
+      if (two) {
         *reinterpret_cast<float4*>(g + (u0 + 1) * C + c) = g1;
         sg.x += g1.x; sg.y += g1.y; sg.z += g1.z; sg.w += g1.w;
         sgx.x = fmaf(g1.x, (y1.x - mean.x) * rstd.x, sgx.x);
@@ -716,18 +722,18 @@ int kws_gp_tail_launch(const kws_gp_tail_args* a, int training, hipStream_t st) 
 
 int kws_block_out_fwd(const float* y, const float* bn, const float* res, const float* res_bn, float* o, int B, int L,
                       int C, int pool, hipStream_t st) {
-  KWS_REQUIRE(y && bn && res && o && B > 0 && L > 0 && C % 4 == 0 && (pool == 1 || pool == 2) && L % pool == 0,
+  KWS_REQUIRE(y && bn && res && o && B > 0 && L > 0 && C % 4 == 0 && (pool == 1 || pool == 2),
               "block_out_fwd: bad arguments (L=%d C=%d pool=%d)", L, C, pool);
-  const int Lo = L / pool;
+  const int Lo = (L + pool - 1) / pool;             // 'same' pooling: ceil
   const int64_t n4 = (int64_t)B * Lo * C / 4;
   KwsProfScope prof("block_join", 4.0 * B * L * C, 4.0 * ((double)B * L * C + 2.0 * B * Lo * C), st);
   dim3 g((unsigned)ceil_div64(n4, 256)), b(256);
   if (pool == 1) {
-    if (res_bn) hipLaunchKernelGGL((block_out_fwd_kernel<1, true>), g, b, 0, st, y, bn, res, res_bn, o, n4, Lo, C);
-    else hipLaunchKernelGGL((block_out_fwd_kernel<1, false>), g, b, 0, st, y, bn, res, res_bn, o, n4, Lo, C);
+    if (res_bn) hipLaunchKernelGGL((block_out_fwd_kernel<1, true>), g, b, 0, st, y, bn, res, res_bn, o, n4, L, Lo, C);
+    else hipLaunchKernelGGL((block_out_fwd_kernel<1, false>), g, b, 0, st, y, bn, res, res_bn, o, n4, L, Lo, C);
   } else {
-    if (res_bn) hipLaunchKernelGGL((block_out_fwd_kernel<2, true>), g, b, 0, st, y, bn, res, res_bn, o, n4, Lo, C);
-    else hipLaunchKernelGGL((block_out_fwd_kernel<2, false>), g, b, 0, st, y, bn, res, res_bn, o, n4, Lo, C);
+    if (res_bn) hipLaunchKernelGGL((block_out_fwd_kernel<2, true>), g, b, 0, st, y, bn, res, res_bn, o, n4, L, Lo, C);
+    else hipLaunchKernelGGL((block_out_fwd_kernel<2, false>), g, b, 0, st, y, bn, res, res_bn, o, n4, L, Lo, C);
   }
   KWS_LAUNCH_CHECK("block_out_fwd_kernel");
   return KWS_OK;
@@ -735,21 +741,21 @@ int kws_block_out_fwd(const float* y, const float* bn, const float* res, const f
 
 int64_t kws_block_out_bwd_part_floats(int B, int L, int C, int pool) {
   if (B <= 0 || L <= 0 || !geom_ok(C) || pool < 1) return 0;
-  return geom(B, L / pool, C).grid * 5 * C;
+  return geom(B, (L + pool - 1) / pool, C).grid * 5 * C;
 }
 
 int kws_block_out_bwd(const float* dO, const float* y, const float* bn, float* g, float* part, int B, int L, int C,
                       int pool, int relu, hipStream_t st) {
   KWS_REQUIRE(dO && y && bn && g && part && B > 0 && L > 0 && geom_ok(C) && (pool == 1 || pool == 2) &&
-                  L % pool == 0 && (relu || pool == 1),
+                  (relu || pool == 1),
               "block_out_bwd: bad arguments (L=%d C=%d pool=%d relu=%d)", L, C, pool, relu);
-  const int Lo = L / pool;
+  const int Lo = (L + pool - 1) / pool;
   const Geom ge = geom(B, Lo, C);
   KwsProfScope prof("block_join", 6.0 * B * L * C, 4.0 * (2.0 * B * L * C + (double)B * Lo * C), st);
   dim3 gr((unsigned)ge.grid, (unsigned)ge.ny), b((unsigned)ge.block);
-  if (pool == 2) hipLaunchKernelGGL((block_out_bwd_kernel<2, true>), gr, b, 0, st, dO, y, bn, g, part, B, Lo, C, ge.nchunks, ge.R, ge.Cb);
-  else if (relu) hipLaunchKernelGGL((block_out_bwd_kernel<1, true>), gr, b, 0, st, dO, y, bn, g, part, B, Lo, C, ge.nchunks, ge.R, ge.Cb);
-  else hipLaunchKernelGGL((block_out_bwd_kernel<1, false>), gr, b, 0, st, dO, y, bn, g, part, B, Lo, C, ge.nchunks, ge.R, ge.Cb);
+  if (pool == 2) hipLaunchKernelGGL((block_out_bwd_kernel<2, true>), gr, b, 0, st, dO, y, bn, g, part, B, L, Lo, C, ge.nchunks, ge.R, ge.Cb);
+  else if (relu) hipLaunchKernelGGL((block_out_bwd_kernel<1, true>), gr, b, 0, st, dO, y, bn, g, part, B, L, Lo, C, ge.nchunks, ge.R, ge.Cb);
+  else hipLaunchKernelGGL((block_out_bwd_kernel<1, false>), gr, b, 0, st, dO, y, bn, g, part, B, L, Lo, C, ge.nchunks, ge.R, ge.Cb);
   KWS_LAUNCH_CHECK("block_out_bwd_kernel");
   return KWS_OK;
 }

@@ -7,7 +7,7 @@
   * WAV ingest (row f1): _read_wav_int16 / load_wav_file / save_wav_file against scipy.io.wavfile on mono, stereo,
     odd-sized LIST chunks, short and long files (input_data.py:117-156, 335-336);
   * tta.shard_range (config C5's multi-GPU split): disjoint cover;
-  * the oracle refuses the lengths the device program refuses (net_logmfcc.hip:lm_build).
+  * the oracle's layer lengths follow Keras' 'same' pooling / strided convolution (ceil), odd lengths included.
 No GPU, no libkws_hip.so compute call."""
 import json
 import os
@@ -227,13 +227,16 @@ def test_tta_shard_range_is_a_disjoint_cover(monkeypatch):
 
 
 # ---- oracle refuses what the device refuses ----------------------------------------------------------------------
-def test_logmfcc_oracle_rejects_lengths_that_do_not_halve_evenly():
+def test_logmfcc_oracle_lengths_follow_keras_same_layers():
+    """MaxPool1D(2, 2, 'same') and Conv1D(nf, 1, strides=2, 'same') both give ceil(L / 2) (model.py:1431-1441): the
+    reference function's default spectrogram_length = 65 runs 63 -> 32 -> 16 -> 8."""
     from oracle.net import LogMfccNet
-    LogMfccNet(num_classes=32, spectrogram_length=98, num_features=40)
-    LogMfccNet(num_classes=32, spectrogram_length=66, num_features=40)
-    for T in (65, 97, 99, 64):          # 65 is the reference function's own default (model.py:1410)
-        with pytest.raises(ValueError):
-            LogMfccNet(num_classes=32, spectrogram_length=T, num_features=40)
+    net = LogMfccNet(num_classes=32, spectrogram_length=65, num_features=40)
+    assert [b['Lout'] for b in net.blocks] == [63, 63, 32, 32, 16, 16, 16, 8, 8, 8] and net.T == 8
+    net = LogMfccNet(num_classes=32, spectrogram_length=98, num_features=40)
+    assert [b['Lout'] for b in net.blocks] == [96, 96, 48, 48, 24, 24, 24, 12, 12, 12]
+    with pytest.raises(ValueError):
+        LogMfccNet(num_classes=32, spectrogram_length=2, num_features=40)
 
 
 def test_sampler_refuses_background_no_longer_than_a_clip():

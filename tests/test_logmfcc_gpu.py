@@ -17,8 +17,8 @@ from speech_recognition_amd.net import DeviceNet
 pytestmark = pytest.mark.gpu
 
 
-def _pair(num_classes=32, seed=11, F=40):
-    ora = LogMfccNet(num_classes=num_classes, num_features=F, dtype=np.float64)
+def _pair(num_classes=32, seed=11, F=40, T=98):
+    ora = LogMfccNet(num_classes=num_classes, spectrogram_length=T, num_features=F, dtype=np.float64)
     rng = np.random.RandomState(seed)
     for k in ora.params:
         if k.endswith('gamma'):
@@ -30,22 +30,22 @@ def _pair(num_classes=32, seed=11, F=40):
             ora.state[k] = (0.05 * rng.randn(*ora.state[k].shape)).astype(np.float32)
         else:
             ora.state[k] = (1.0 + 0.2 * rng.rand(*ora.state[k].shape)).astype(np.float32)
-    net = DeviceNet(_lib.KWS_NET_LOG_MFCC, num_classes, input_size=98 * F, spectrogram_length=98, num_features=F)
+    net = DeviceNet(_lib.KWS_NET_LOG_MFCC, num_classes, input_size=T * F, spectrogram_length=T, num_features=F)
     net.set_weights(dict(ora.params, **ora.state))
     return ora, net
 
 
-def _batch(B, nc, seed, F=40):
+def _batch(B, nc, seed, F=40, T=98):
     rng = np.random.RandomState(seed)
     lab = rng.randint(0, nc, B)
-    x = rng.randn(B, 98, F) * 2.0 - 0.7 + 0.5 * np.sin(np.arange(F)[None, None, :] * (1 + lab)[:, None, None] * 0.1)
+    x = rng.randn(B, T, F) * 2.0 - 0.7 + 0.5 * np.sin(np.arange(F)[None, None, :] * (1 + lab)[:, None, None] * 0.1)
     return x.reshape(B, -1).astype(np.float32), np.eye(nc, dtype=np.float32)[lab]
 
 
 def _decisions(net, ora, B):
     """ReLU6 masks per BN index and max-pool winners per strided block from the device tensors (f32 math
     of the kernels: pre = fmaf(y, scale, shift))."""
-    shapes = {ora.first[1]: (B, 96, 64), ora.att[2]: (B, ora.T, 1)}
+    shapes = {ora.first[1]: (B, ora.T0 - 2, 64), ora.att[2]: (B, ora.T, 1)}
     pools = {}
     for i, blk in enumerate(ora.blocks):
         if 'short' in blk:
@@ -71,7 +71,9 @@ def _decisions(net, ora, B):
     for i, idx in pools.items():
         a = np.minimum(np.maximum(pre_of[idx], np.float32(0)), np.float32(6))
         Bc, L, C = a.shape
-        w = a.reshape(Bc, L // 2, 2, C)
+        if L % 2:                                                        # 'same' pooling: the short last window's only
+            a = np.concatenate([a, np.full((Bc, 1, C), -np.inf, np.float32)], axis=1)   # element wins
+        w = a.reshape(Bc, (L + 1) // 2, 2, C)
         args[i] = (w[:, :, 1, :] > w[:, :, 0, :]).astype(np.int64)      # first maximum wins
     return masks, args
 
@@ -185,3 +187,35 @@ def test_spectrogram_family_on_the_spec_generator(repo_root):
         assert np.asarray(X).shape == (64, 98 * 257)
         losses.append(float(model.train_on_batch(X, y)[0]))
     assert np.all(np.isfinite(losses)) and np.mean(losses[-3:]) < np.mean(losses[:3])
+
+
+@pytest.mark.parametrize("T", [65, 67, 99])
+def test_odd_lengths_pool_in_ceil_mode(T):
+    """The reference function's own default spectrogram_length = 65 (model.py:1410): 63 frames after the first
+    convolution, and Keras' MaxPool1D(2, 2, 'same') / Conv1D(strides=2, 'same') give ceil: 63 -> 32 -> 16 -> 8.  Forward,
+    loss and every gradient against the oracle (which is checked against torch's ceil_mode pooling in test_oracle_net)."""
+    B, nc, F = 5, 32, 40
+    ora, net = _pair(nc, F=F, T=T)
+    lens = [T - 2]
+    for blk in ora.blocks:
+        assert blk['Lin'] == lens[-1] and blk['Lout'] == -(-blk['Lin'] // blk['stride'])
+        lens.append(blk['Lout'])
+    assert any(blk['Lin'] % 2 for blk in ora.blocks if blk['stride'] == 2)       # a short last window exists
+    x, y = _batch(B, nc, T, F, T)
+    p_inf = net.predict(torch.from_numpy(x).cuda()).cpu().numpy()
+    ref_inf = ora.forward(x.astype(np.float64), training=False)
+    assert np.abs(p_inf - ref_inf).max() < 1e-5 and np.array_equal(p_inf.argmax(1), ref_inf.argmax(1))
+    probs = net.train_fwd_bwd(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(), seed=5, step=1)
+    torch.cuda.synchronize()
+    masks, args = _decisions(net, ora, B)
+    loss, p, grads, cache = ora.loss_and_grads(x.astype(np.float64), y.astype(np.float64), seed=5, step=1,
+                                               relu_masks=masks, pool_args=args)
+    got = probs.cpu().numpy()
+    assert np.abs(got - p).max() < 2e-5 and np.array_equal(got.argmax(1), p.argmax(1))
+    assert abs(net.metrics.cpu().numpy()[0] / B - loss) < 5e-5
+    g = net.grads_dict()
+    for k, ref in grads.items():
+        if k in ora.l2_names:
+            ref = ref - 2e-5 * ora.params[k].astype(np.float64)
+        ref = ref.reshape(g[k].shape)
+        assert np.abs(g[k] - ref).max() / max(np.abs(ref).max(), 1e-7) < 1e-4, k

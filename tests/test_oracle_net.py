@@ -2,6 +2,7 @@
 against an independent implementation: torch CPU float64 ops + autograd.  This is a sanity
 check of the restatement, not a reference pin (the reference ships no tests)."""
 import numpy as np
+import pytest
 import torch
 import torch.nn.functional as F
 
@@ -110,7 +111,7 @@ def _torch_logmfcc(net, params, x, y, seed, step):
         a = bn(dwpw(h, blk['dw1'], blk['pw1'], blk['cin'], blk['nf']), blk['bn1'])
         a = bn(dwpw(a, blk['dw2'], blk['pw2'], blk['nf'], blk['nf']), blk['bn2'])
         if blk['stride'] != 1:
-            a = F.max_pool1d(a, blk['stride'], blk['stride'])
+            a = F.max_pool1d(a, blk['stride'], blk['stride'], ceil_mode=True)      # Keras padding='same'
         h = a + res
     u = bn(dwpw(h, net.att[0], net.att[1], net.C, 1), net.att[2])        # [B, 1, T]
     att = torch.softmax(u, dim=2)
@@ -132,9 +133,10 @@ def test_logmfcc_param_count_and_shapes():
     assert [b['Lout'] for b in net.blocks] == [96, 96, 48, 48, 24, 24, 24, 12, 12, 12]
 
 
-def test_logmfcc_grads_match_torch_autograd():
+@pytest.mark.parametrize("T", [98, 65])
+def test_logmfcc_grads_match_torch_autograd(T):
     from oracle.net import LogMfccNet
-    net = LogMfccNet(num_classes=32, dtype=np.float64)
+    net = LogMfccNet(num_classes=32, spectrogram_length=T, dtype=np.float64)
     rng = np.random.RandomState(4)
     for k in net.params:
         if k.endswith('gamma'):
@@ -142,7 +144,7 @@ def test_logmfcc_grads_match_torch_autograd():
         if k.endswith('beta') or k.endswith('bias'):
             net.params[k] = (0.1 * rng.randn(*net.params[k].shape)).astype(np.float32)
     B = 4
-    x = (rng.randn(B, 98 * 40) * 3.0).astype(np.float64)
+    x = (rng.randn(B, T * 40) * 3.0).astype(np.float64)
     y = np.eye(32)[[3, 0, 17, 31]]
     loss, p, grads, _ = net.loss_and_grads(x, y, seed=9, step=2)
     tparams = {k: torch.tensor(v.astype(np.float64), requires_grad=True) for k, v in net.params.items()}
