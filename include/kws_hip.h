@@ -193,8 +193,12 @@ int kws_stft_mel_f32(const kws_stft_plan_t* plan, const float* x, int B, int L, 
 
 /* EXPERIMENT (A/B measurement, not called by the network programs): the same product with every f32 operand split
  * into three bf16 parts and six bf16 MFMA products accumulated in f32 - as accurate as the f32 matrix pipe, not
- * bit-identical to it.  C[M,N] = A[M,K] . Bt[N,K]^T (Bt = the kernel stored [out][in]).  K % 32 == 0. */
-int kws_gemm_nn_bf16x3_f32(const float* A, const float* Bt, float* C, int64_t M, int K, int N, void* stream);
+ * bit-identical to it.  C[M,N] = A[M,K] . Bt[N,K]^T (Bt = the kernel stored [out][in]).  K % 32 == 0.  stats_part
+ * (may be NULL): [rows][2][N] column sums / sums of squares as kws_gemm_nn_f32 writes them.  KWS_GEMM_BF16X3=1 makes
+ * the raw-waveform net's training step take this kernel for its forward and input-gradient GEMMs (A/B runs). */
+int kws_gemm_nn_bf16x3_stats_rows(int64_t M);   /* rows of stats_part: one per 128-row tile */
+int kws_gemm_nn_bf16x3_f32(const float* A, const float* Bt, float* C, int64_t M, int K, int N,
+                           float* stats_part, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * a7+a8, a10  GEMM family on f32 MFMA (v_mfma_f32_32x32x2_f32)

@@ -21,7 +21,7 @@ for L, K, N in shapes:
     A = torch.randn(M, K, device='cuda'); W = torch.randn(K, N, device='cuda') * 0.1; Wt = W.t().contiguous()
     C = torch.empty(M, N, device='cuda')
     t1 = timeit(lambda: _lib.call("kws_gemm_nn_f32", _lib.ptr(A), _lib.ptr(W), _lib.ptr(C), M, K, N, None, S))
-    t3 = timeit(lambda: _lib.call("kws_gemm_nn_bf16x3_f32", _lib.ptr(A), _lib.ptr(Wt), _lib.ptr(C), M, K, N, S))
+    t3 = timeit(lambda: _lib.call("kws_gemm_nn_bf16x3_f32", _lib.ptr(A), _lib.ptr(Wt), _lib.ptr(C), M, K, N, None, S))
     f = 2.0 * M * K * N
     byts = 4.0 * (M * K + K * N + M * N)
     print("M=%7d K=%3d N=%3d  f32 MFMA %6.1f us %6.1f TF | bf16x3 %6.1f us %6.1f TF-equivalent, %5.2f TB/s algorithmic | x%.2f" % (

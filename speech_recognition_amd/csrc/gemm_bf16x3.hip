@@ -6,7 +6,7 @@
 // tests/test_bf16x3_gpu.py; NumPy study: 2.8e-7 of the maximum against 6.5e-7 for an f32 matmul).  It is NOT bit-identical
 // to the f32-MFMA kernels, which stay the default: this file exists to measure what the split would buy.
 //
-//   kws_gemm_nn_bf16x3_f32:  C[M,N] = A[M,K] . Bt[N,K]^T        (Bt = the kernel stored [out][in]: k is contiguous for both
+//   kws_gemm_nn_bf16x3_f32:  C[M,N] = A[M,K] . Bt[N,K]^T  (+ optional BatchNorm column sums per 128-row tile)       (Bt = the kernel stored [out][in]: k is contiguous for both
 //                                                                 operands, so both are split and staged the same way)
 // 128 x 128 tile per 256-thread workgroup (2 x 2 waves of 64 x 64), K slabs of 32: f32 slab -> registers -> split
 // (v_cvt_pk_bf16_f32: round to nearest even; the residuals are exact in f32) -> three bf16 planes in LDS
@@ -28,6 +28,7 @@ struct X3Args {
   const float* A;
   const float* Bt;
   float* C;
+  float* stats;      // [ceil(M / 128)][2][N] column sums / sums of squares per row tile, or NULL
   int64_t M;
   int K, N;
 };
@@ -47,6 +48,7 @@ __device__ __forceinline__ void split4(const float4 v, bf16x4& hi, bf16x4& mid, 
   }
 }
 
+template <bool STATS>
 __global__ __launch_bounds__(256, 2) void gemm_nn_bf16x3_kernel(X3Args p) {
   __shared__ __attribute__((aligned(16))) __bf16 smem[2 * 3 * XPLANE];   // A planes then B planes: 61,440 B
   __bf16* sA = smem;
@@ -139,7 +141,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_bf16x3_kernel(X3Args p) {
     if (g + 1 < G) s_store();
     __syncthreads();
   }
-  // C[row][col]: lane -> col = l & 31, register v -> row = (v & 3) + 8 (v >> 2) + 4 (l >> 5)
+  // C[row][col]: lane -> col = l & 31, register v -> row = (v & 3) + 8 (v >> 2) + 4 (l >> 5): a store instruction
+  // writes two full 128-byte row segments
+  float cs[2] = {0.f, 0.f}, css[2] = {0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -148,20 +152,43 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_bf16x3_kernel(X3Args p) {
       for (int v = 0; v < 16; ++v) {
         const int64_t row = m0 + wm * 64 + 32 * i + (v & 3) + 8 * (v >> 2) + 4 * h;
         const int col = n0 + wn * 64 + 32 * j + r;
-        if (row < M && col < N) p.C[row * N + col] = acc[i][j][v];
+        const float c = acc[i][j][v];
+        if (row < M && col < N) p.C[row * N + col] = c;
+        if (STATS && row < M) {                      // BatchNorm column sums in a fixed order: rows of the lane, then
+          cs[j] += c;                                // the two lane halves, then the two row waves
+          css[j] = fmaf(c, c, css[j]);
+        }
       }
+  if (STATS) {
+    float* red = reinterpret_cast<float*>(smem);     // [2 wm][2 q][128]: the planes are dead after the last barrier
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float s2 = cs[j] + __shfl_xor(cs[j], 32), q2 = css[j] + __shfl_xor(css[j], 32);
+      if (h == 0) {
+        red[(wm * 2 + 0) * 128 + wn * 64 + 32 * j + r] = s2;
+        red[(wm * 2 + 1) * 128 + wn * 64 + 32 * j + r] = q2;
+      }
+    }
+    __syncthreads();
+    const int q = tid >> 7, col = tid & 127;         // 256 threads: (sum | sum of squares) x 128 columns
+    if (n0 + col < N) p.stats[((int64_t)tile_m * 2 + q) * N + n0 + col] = red[(0 * 2 + q) * 128 + col] + red[(1 * 2 + q) * 128 + col];
+  }
 }
 
 }  // namespace
 
-extern "C" int kws_gemm_nn_bf16x3_f32(const float* A, const float* Bt, float* C, int64_t M, int K, int N, void* stream) {
+extern "C" int kws_gemm_nn_bf16x3_stats_rows(int64_t M) { return (int)ceil_div64(M, XBM); }
+
+extern "C" int kws_gemm_nn_bf16x3_f32(const float* A, const float* Bt, float* C, int64_t M, int K, int N, float* stats_part,
+                                      void* stream) {
   KWS_REQUIRE(A && Bt && C && M > 0, "gemm_nn_bf16x3: bad arguments");
   KWS_REQUIRE(K >= XBK && K % XBK == 0 && N > 0, "gemm_nn_bf16x3: K=%d must be a multiple of %d (N=%d)", K, XBK, N);
   const int64_t grid = ceil_div64(M, XBM) * ((N + XBN - 1) / XBN);
   KWS_REQUIRE(grid <= 0x7FFFFFFF, "gemm_nn_bf16x3: grid out of range");
-  X3Args p{A, Bt, C, M, K, N};
+  X3Args p{A, Bt, C, stats_part, M, K, N};
   KwsProfScope prof("gemm_nn_bf16x3", 2.0 * M * K * N, 4.0 * ((double)M * K + (double)K * N + (double)M * N), (hipStream_t)stream);
-  hipLaunchKernelGGL(gemm_nn_bf16x3_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p);
+  if (stats_part) hipLaunchKernelGGL(gemm_nn_bf16x3_kernel<true>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(gemm_nn_bf16x3_kernel<false>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p);
   KWS_LAUNCH_CHECK("gemm_nn_bf16x3_kernel");
   return KWS_OK;
 }

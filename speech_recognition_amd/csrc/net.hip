@@ -409,10 +409,26 @@ static int ts_train(const kws_net_t* net, const float* params, float* state, con
   float* red = ws + lo.red;
 
   const bool run_head = phase != 2;                   // forward + tail + the late blocks' backward
+  // KWS_GEMM_BF16X3=1 (A/B experiment, gemm_bf16x3.hip): the pointwise forward and input-gradient GEMMs run as six bf16
+  // MFMA products of three-way operand splits instead of f32 MFMAs; weight gradients and the first convolution stay f32
+  static const bool x3 = getenv("KWS_GEMM_BF16X3") != nullptr;
+  auto transpose_all = [&]() -> int {   // the pointwise kernels [cin][cout] -> [cout][cin]: all of them in one launch
+    static_assert(KWS_TRANSPOSE_BATCH >= 11, "one batch holds every block");
+    const float* tin[KWS_TRANSPOSE_BATCH];
+    float* tout[KWS_TRANSPOSE_BATCH];
+    int trows[KWS_TRANSPOSE_BATCH], tcols[KWS_TRANSPOSE_BATCH];
+    KWS_REQUIRE(nb <= KWS_TRANSPOSE_BATCH, "net: %d blocks exceed the transpose batch", nb);
+    for (int i = 0; i < nb; ++i) {
+      tin[i] = params + net->blocks[i].pw; tout[i] = ws + lo.WT[i];
+      trows[i] = net->blocks[i].cin; tcols[i] = net->blocks[i].cout;
+    }
+    return kws_transpose_batch_f32(tin, tout, trows, tcols, nb, st);
+  };
   kws_ts_tail_args t;
   memset(&t, 0, sizeof(t));
   if (run_head) {
   KWS_HIP(hipMemsetAsync(grads, 0, (size_t)net->n_params * 4, st));
+  if (x3) KWS_TRY(transpose_all());                 // the split GEMM reads the kernels [out][in] in the forward pass already
   // ---------------- forward ----------------
   {
     const int64_t M = (int64_t)B * net->L1;
@@ -432,8 +448,15 @@ static int ts_train(const kws_net_t* net, const float* params, float* state, con
     const int64_t M = (int64_t)B * b.Lout;
     KWS_TRY(kws_dwconv_fwd_f32(ws + lo.y[i], bn_at(i), params + b.dw, ws + lo.z[i], B, b.Lin, b.Lout, b.cin, b.stride,
                                b.pad_l, st));
-    KWS_TRY(kws_gemm_nn_f32(ws + lo.z[i], params + b.pw, ws + lo.y[i + 1], M, b.cin, b.cout, part, st));
-    KWS_TRY(kws_bn_stats_finalize(part, kws_gemm_nn_stats_rows(M, b.cin, b.cout), M, b.cout, params + b.bn.gamma, params + b.bn.beta,
+    int stat_rows;
+    if (x3) {
+      KWS_TRY(kws_gemm_nn_bf16x3_f32(ws + lo.z[i], ws + lo.WT[i], ws + lo.y[i + 1], M, b.cin, b.cout, part, st));
+      stat_rows = kws_gemm_nn_bf16x3_stats_rows(M);
+    } else {
+      KWS_TRY(kws_gemm_nn_f32(ws + lo.z[i], params + b.pw, ws + lo.y[i + 1], M, b.cin, b.cout, part, st));
+      stat_rows = kws_gemm_nn_stats_rows(M, b.cin, b.cout);
+    }
+    KWS_TRY(kws_bn_stats_finalize(part, stat_rows, M, b.cout, params + b.bn.gamma, params + b.bn.beta,
                                   BN_EPS, BN_MOMENTUM, state + b.bn.mm, state + b.bn.mv, bn_at(i + 1), red, st));
   }
   // ---------------- tail forward + backward ----------------
@@ -472,18 +495,7 @@ static int ts_train(const kws_net_t* net, const float* params, float* state, con
     KWS_HIP(hipEventCreateWithFlags(&net->ev_join, hipEventDisableTiming));
   }
   static const int overlap_from = getenv("KWS_OVERLAP_FROM") ? atoi(getenv("KWS_OVERLAP_FROM")) : 0;  // experiment knob
-  if (run_head) {  // the dgrad GEMMs read the pointwise kernels transposed: all of them in one launch
-    static_assert(KWS_TRANSPOSE_BATCH >= 11, "one batch holds every block");
-    const float* tin[KWS_TRANSPOSE_BATCH];
-    float* tout[KWS_TRANSPOSE_BATCH];
-    int trows[KWS_TRANSPOSE_BATCH], tcols[KWS_TRANSPOSE_BATCH];
-    KWS_REQUIRE(nb <= KWS_TRANSPOSE_BATCH, "net: %d blocks exceed the transpose batch", nb);
-    for (int i = 0; i < nb; ++i) {
-      tin[i] = params + net->blocks[i].pw; tout[i] = ws + lo.WT[i];
-      trows[i] = net->blocks[i].cin; tcols[i] = net->blocks[i].cout;
-    }
-    KWS_TRY(kws_transpose_batch_f32(tin, tout, trows, tcols, nb, st));
-  }
+  if (run_head && !x3) KWS_TRY(transpose_all());     // the f32 dgrad GEMMs read the pointwise kernels transposed
   float* Gb[2] = {ws + lo.G, ws + lo.G2};          // gradient wrt y[l] lives in Gb[l % 2]; the tail wrote Gb[nb % 2]
   bool wgrad_pending[2] = {false, false};
   const int i_hi = phase == 2 ? split - 1 : nb - 1, i_lo = phase == 1 ? split : 0;
@@ -496,7 +508,8 @@ static int ts_train(const kws_net_t* net, const float* params, float* state, con
     // below); only the tail hands over a masked gradient that still needs its BatchNorm backward
     if (i == nb - 1)
       KWS_TRY(kws_bn_bwd_apply(Gcur, ws + lo.y[i + 1], bn_at(i + 1), params + b.bn.gamma, coef, M, b.cout, st));
-    KWS_TRY(kws_gemm_nn_f32(Gcur, ws + lo.WT[i], DZ, M, b.cout, b.cin, nullptr, st));
+    if (x3) KWS_TRY(kws_gemm_nn_bf16x3_f32(Gcur, params + b.pw, DZ, M, b.cout, b.cin, nullptr, st));   // Bt = W itself: [cin][cout]
+    else KWS_TRY(kws_gemm_nn_f32(Gcur, ws + lo.WT[i], DZ, M, b.cout, b.cin, nullptr, st));
     const bool ov = overlap && i >= overlap_from;
     hipStream_t sw = ov ? net->side : st;
     if (ov) {

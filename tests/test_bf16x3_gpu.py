@@ -20,7 +20,7 @@ def test_bf16x3_matches_float64_as_well_as_the_f32_kernel(M, K, N):
     W = torch.randn((K, N), generator=g, device="cuda") * 0.1
     Wt = W.t().contiguous()
     C3 = torch.full((M, N), float("nan"), device="cuda")
-    _lib.call("kws_gemm_nn_bf16x3_f32", _lib.ptr(A), _lib.ptr(Wt), _lib.ptr(C3), M, K, N, _lib.stream_ptr())
+    _lib.call("kws_gemm_nn_bf16x3_f32", _lib.ptr(A), _lib.ptr(Wt), _lib.ptr(C3), M, K, N, None, _lib.stream_ptr())
     ref = A.double() @ W.double()
     scale = float(ref.abs().max())
     e3 = float((C3.double() - ref).abs().max()) / scale
