@@ -91,7 +91,9 @@ def main():
                                 verbose=1, callbacks=watchers)
     scores = net.evaluate_generator(feed_val, val_steps)
     ce, acc = recompute_validation(net, proc, session, val_steps)
-    with open('train_result.json', 'w') as f:
+    import os
+    rank = os.environ.get('RANK')
+    with open('train_result.json' if rank is None else 'train_result_rank%s.json' % rank, 'w') as f:
         json.dump({'evaluate': [float(v) for v in scores], 'recomputed_val_loss': ce, 'recomputed_val_acc': acc,
                    'history_keys': sorted(history.history.keys()), 'n_labels': len(labels)}, f)
 
@@ -250,3 +252,33 @@ def test_prediction_caller_tta_inference(dataset, repo_root):
     from speech_recognition_amd.classes import get_int2label
     names = get_int2label(wanted_only=True)
     assert res['labels'] == [names[int(i)] for i in probs.argmax(axis=-1)] and len(res['labels']) == 28
+
+
+def test_training_caller_on_two_data_parallel_ranks(dataset, repo_root, tmp_path):
+    """The same caller under torch.distributed.run with two ranks (both on the one GPU over gloo - the hooks
+    KWS_DIST_BACKEND / KWS_ONE_DEVICE; an N-GPU node runs RCCL): gradients are all-reduced every step, replicas are
+    synchronised at fit start and at every epoch end, and ONLY rank 0 writes the checkpoints, the scalar log and the
+    confusion-matrix files.  Both ranks must end with the same validation numbers."""
+    import shutil
+    work = tmp_path / "dp"
+    work.mkdir()
+    os.symlink(str(dataset / 'data'), str(work / 'data'))
+    shutil.copy(str(dataset / 'train_caller.py'), str(work / 'train_caller.py'))
+    env = dict(os.environ, PYTHONPATH=repo_root, KWS_DIST_BACKEND="gloo", KWS_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29547', '-m', 'speech_recognition_amd.run_script', 'train_caller.py']
+    r = subprocess.run(cmd, cwd=str(work), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert r.returncode == 0, r.stdout.decode(errors='replace')[-4000:]
+    logs = [json.loads(l) for l in open(work / 'tb_scalars' / 'scalars.jsonl')]
+    assert len(logs) == 3                                  # one line per epoch: rank 1 did not write
+    text = open(work / 'confusion_matrix.txt').read()
+    assert text.count('val_categorical_accuracy') == 3
+    r0 = json.load(open(work / 'train_result_rank0.json'))
+    r1 = json.load(open(work / 'train_result_rank1.json'))
+    assert r0['recomputed_val_acc'] == r1['recomputed_val_acc']
+    assert abs(r0['recomputed_val_loss'] - r1['recomputed_val_loss']) < 1e-7          # replicas are identical
+    assert abs(r0['recomputed_val_loss'] - logs[-1]['val_loss']) < 1e-5
+    assert logs[-1]['loss'] < logs[0]['loss']
+    assert len(os.listdir(work / 'saved')) >= 1
