@@ -25,6 +25,8 @@
 // scripts/emulate_stft4.py replays this index algebra in NumPy against numpy.fft.rfft.
 #include "stft_common.h"
 
+#include <initializer_list>
+
 using namespace kws_fft;
 
 // -DKWS_STFT_STAMP builds (scripts/build_variant.sh, scripts/stamps_stft.py): wave 0 of every workgroup accumulates
@@ -60,9 +62,11 @@ __device__ __forceinline__ float blend(unsigned m, float a, float b) {   // m al
   return __uint_as_float((__float_as_uint(a) & m) | (__float_as_uint(b) & ~m));
 }
 
-// NB = mel bands per lane (ceil(n_mel / 16)), MC = four-tap blocks per band window (mel_maxw = 4 MC): compile-time, so
-// the mel stage and the DCT are straight-line code whose LDS reads the compiler can put in flight together.
-template <int NB, int MC>
+// NB = mel bands per lane (ceil(n_mel / 16)); MCP packs, four bits per lane group i, the number of four-tap blocks the
+// bands 16 i .. 16 i + 15 read (the widest of them decides; 80 mel bins: 1, 1, 2, 3, 4); MC = the largest of them (the row
+// width of the weight table).  All compile-time, so the mel stage and the DCT are straight-line code whose LDS reads the
+// compiler can put in flight together.
+template <int NB, int MC, int MCP>
 __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
 #ifdef KWS_STFT_STAMP
@@ -104,10 +108,11 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
     // row m = the weights of bins win_m .. win_m + MAXW - 1, win_m = min(plan window start, MAGF - MAXW): the plan's
     // window (mel_maxw <= MAXW taps from mel_ws[m]) shifted right inside the row where the kernel's starts earlier
     const int m = i / WSTR, q = i - m * WSTR;
+    const int taps = 4 * ((MCP >> (4 * (m >> 4))) & 15);           // what the kernel reads for this band's group
     const int ws0 = pl.mel_ws[m];
-    const int win = ws0 + MAXW <= MAGF ? ws0 : MAGF - MAXW;
+    const int win = ws0 + taps <= MAGF ? ws0 : MAGF - taps;
     const int j = q - (ws0 - win);
-    s_wpad[i] = (q < MAXW && j >= 0 && j < pl.mel_maxw) ? pl.mel_wpad[m * pl.mel_maxw + j] : 0.f;
+    s_wpad[i] = (q < taps && j >= 0 && j < pl.mel_maxw) ? pl.mel_wpad[m * pl.mel_maxw + j] : 0.f;
   }
   if (tid == 0) s_ctr[0] = 0;
   if (l16 < MAGF - 257) s_mag[257 + l16] = 0.f;    // the tap windows may reach past the Nyquist bin: finite zeros there
@@ -127,7 +132,8 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
   for (int i = 0; i < NB; ++i) {
     const int m = l16 + 16 * i < n_mel ? l16 + 16 * i : 0;
     const int ws0 = pl.mel_ws[m];
-    r_mws[i] = ws0 + MAXW <= MAGF ? ws0 : MAGF - MAXW;   // as in the staging loop above
+    const int taps = 4 * ((MCP >> (4 * i)) & 15);
+    r_mws[i] = ws0 + taps <= MAGF ? ws0 : MAGF - taps;   // as in the staging loop above
     r_wofs[i] = m * WSTR;
   }
   const int k1 = l16 < 8 ? l16 : (l16 < 15 ? l16 + 1 : 8);         // KPERM[l16]
@@ -267,23 +273,26 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
         const float* wp = s_wpad + r_wofs[i];
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         constexpr int CH = MC < 8 ? MC : 8;           // blocks in flight per request burst
+        const int mci = (MCP >> (4 * i)) & 15;        // a constant after unrolling: this group's blocks
 #pragma unroll
         for (int t0 = 0; t0 < MC; t0 += CH) {
           float4 wv[CH];
           float mv[CH][4];
 #pragma unroll
-          for (int t = 0; t < CH; ++t) {
-            wv[t] = *reinterpret_cast<const float4*>(wp + 4 * (t0 + t));
+          for (int t = 0; t < CH; ++t)
+            if (t0 + t < mci) {
+              wv[t] = *reinterpret_cast<const float4*>(wp + 4 * (t0 + t));
 #pragma unroll
-            for (int r = 0; r < 4; ++r) mv[t][r] = mp[4 * (t0 + t) + r];
-          }
+              for (int r = 0; r < 4; ++r) mv[t][r] = mp[4 * (t0 + t) + r];
+            }
 #pragma unroll
-          for (int t = 0; t < CH; ++t) {
+          for (int t = 0; t < CH; ++t)
+            if (t0 + t < mci) {
             s0 = fmaf(mv[t][0], wv[t].x, s0);
             s1 = fmaf(mv[t][1], wv[t].y, s1);
             s2 = fmaf(mv[t][2], wv[t].z, s2);
             s3 = fmaf(mv[t][3], wv[t].w, s3);
-          }
+            }
         }
         float sm = ((s0 + s1) + (s2 + s3)) + pl.log_offset;
         if (pl.log_floor > 0.f) sm = fmaxf(sm, pl.log_floor);
@@ -371,34 +380,43 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
 
 }  // namespace
 
-static void stft4_shape(const kws_stft_plan* pl, int* nb, int* mc) {
-  *nb = (pl->n_mel + 15) / 16;
-  const int need = (pl->mel_maxw + 3) / 4;
-  // instantiated shapes: (5, 4) = 80 mel bins at 16 kHz / 512 (input_data.py:366-373 as train.py sets it), (3, 8) = 40 mel
-  // bins; everything else takes the generic (8, 16)
-  if (*nb == 5 && need <= 4) *mc = 4;
-  else if (*nb == 3 && need <= 8) *mc = 8;
-  else { *nb = 8; *mc = 16; }
+// instantiated band shapes: 80 mel bins over 257 bins (input_data.py:366-373 as train.py sets it: blocks 1, 1, 2, 3, 4),
+// 40 mel bins (2, 5, 8), and the same lane counts with every group at the widest width; anything else declines (stft3)
+static int stft4_shape(const kws_stft_plan* pl) {
+  if (pl->mel_maxw <= 0) return 0;
+  const int nb = (pl->n_mel + 15) / 16;
+  auto fits = [&](std::initializer_list<int> mc) {
+    if ((int)mc.size() != nb) return false;
+    int i = 0;
+    for (int v : mc)
+      if (pl->mel_mc[i++] > v) return false;
+    return true;
+  };
+  if (fits({1, 1, 2, 3, 4})) return 1;
+  if (fits({4, 4, 4, 4, 4})) return 2;
+  if (fits({2, 5, 8})) return 3;
+  if (fits({8, 8, 8})) return 4;
+  return 0;
 }
 
 int kws_stft4_lds_bytes(const kws_stft_plan* pl) {
-  if (pl->mel_maxw <= 0 || pl->mel_maxw > 64) return 1 << 30;       // declines: the caller falls back to stft3
-  int nb, mc;
-  stft4_shape(pl, &nb, &mc);
+  const int sh = stft4_shape(pl);
+  if (sh == 0) return 1 << 30;                                       // declines: the caller falls back to stft3
+  const int nb = sh <= 2 ? 5 : 3, mc = sh <= 2 ? 4 : 8;
   const size_t floats = 512 + 512 + 256 + 4 + (size_t)16 * nb * DSTR4 + (size_t)pl->n_mel * (4 * mc + 4) +
                         (size_t)NW4 * (4 * MAGF + ((16 * (16 * nb + 1) + 3) & ~3));
   return (int)(floats * 4);
 }
 
-template <int NB, int MC>
+template <int NB, int MC, int MCP>
 static int stft4_launch_t(const Stft2Args& a, int bytes, int64_t wgs, hipStream_t st) {
   static bool attr_done = false;
   if (!attr_done) {
-    KWS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&stft4_kernel<NB, MC>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024));
+    KWS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&stft4_kernel<NB, MC, MCP>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
-  hipLaunchKernelGGL((stft4_kernel<NB, MC>), dim3((unsigned)wgs), dim3(NW4 * 64), (size_t)bytes, st, a);
+  hipLaunchKernelGGL((stft4_kernel<NB, MC, MCP>), dim3((unsigned)wgs), dim3(NW4 * 64), (size_t)bytes, st, a);
   KWS_LAUNCH_CHECK("stft4_kernel");
   return KWS_OK;
 }
@@ -407,7 +425,8 @@ int kws_stft4_launch(const kws_stft_plan* pl, const float* x, int B, int L, int 
   KWS_REQUIRE(pl->n_out <= 64 && pl->n_mel % 4 == 0 && pl->n_mel <= 128, "stft4: n_mel=%d n_out=%d unsupported",
               pl->n_mel, pl->n_out);
   KWS_REQUIRE(F > 0 && (pl->frame_step % 2) == 0 && (L % 2) == 0 && (pl->frame_len % 2) == 0, "stft4: bad geometry");
-  KWS_REQUIRE(pl->mel_maxw > 0 && pl->mel_maxw <= 64, "stft4: mel bands of up to %d taps unsupported", pl->mel_maxw);
+  const int sh = stft4_shape(pl);
+  KWS_REQUIRE(sh != 0, "stft4: mel band shape (n_mel=%d, up to %d taps) is not instantiated", pl->n_mel, pl->mel_maxw);
   KWS_REQUIRE((int64_t)B * ((F + 3) / 4) < (1ll << 31), "stft4: %d clips x %d frames exceed 2^31 frame quads", B, F);
   Stft2Args a;
   a.pl = *pl;
@@ -418,9 +437,8 @@ int kws_stft4_launch(const kws_stft_plan* pl, const float* x, int B, int L, int 
   KWS_REQUIRE(bytes <= 160 * 1024, "stft4: LDS need %d B exceeds 160 KiB", bytes);
   int64_t wgs = (a.total_quads + NW4 - 1) / NW4;
   if (wgs > 256) wgs = 256;   // persistent: one workgroup per CU, tables staged once
-  int nb, mc;
-  stft4_shape(pl, &nb, &mc);
-  if (nb == 5 && mc == 4) return stft4_launch_t<5, 4>(a, bytes, wgs, st);
-  if (nb == 3 && mc == 8) return stft4_launch_t<3, 8>(a, bytes, wgs, st);
-  return stft4_launch_t<8, 16>(a, bytes, wgs, st);
+  if (sh == 1) return stft4_launch_t<5, 4, 0x43211>(a, bytes, wgs, st);
+  if (sh == 2) return stft4_launch_t<5, 4, 0x44444>(a, bytes, wgs, st);
+  if (sh == 3) return stft4_launch_t<3, 8, 0x852>(a, bytes, wgs, st);
+  return stft4_launch_t<3, 8, 0x888>(a, bytes, wgs, st);
 }
