@@ -17,9 +17,12 @@ net.initialize(seed=3)
 model = Model(net, RMSprop())
 g = torch.Generator(device="cuda")
 g.manual_seed(1)
-x = (torch.randn((B, 16000), generator=g, device="cuda") * 0.0774).clamp_(-1, 1)
+# ROTATE=N: N different input batches in turn (the bench step reads a batch the generator produced ten queue slots
+# earlier, never the tensor of the previous step)
+n_x = int(os.environ.get("ROTATE", "1"))
+xs = [(torch.randn((B, 16000), generator=g, device="cuda") * 0.0774).clamp_(-1, 1) for _ in range(n_x)]
 y = torch.eye(12, device="cuda")[torch.randint(0, 12, (B,), device="cuda")].contiguous()
 row = torch.zeros(4, device="cuda")
-for _ in range(12):
-    model._train_step_async(x, y, row)
+for i in range(24):
+    model._train_step_async(xs[i % n_x], y, row)
 torch.cuda.synchronize()
