@@ -147,11 +147,14 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
   // oldest wave wins the issue arbitration and, with a fixed 8 or 9 quads per wave, finished at 56 us while the youngest
   // ran alone, latency-bound, until 94 us.  A wave collects up to four quads and hands their 16 log-mel rows to one DCT.
   const int64_t q_lo = a.total_quads * blockIdx.x / gridDim.x, q_hi = a.total_quads * (blockIdx.x + 1) / gridDim.x;
-  auto grab = [&]() -> int64_t {
+  // the draw is split in two so that the LDS round trip of the atomic runs under the first-pass MFMAs: grab_issue early in
+  // a pass, grab_value (which waits for it) when the next quad's loads are about to be issued
+  auto grab_issue = [&]() -> int {
     int v = 0;
     if (lane == 0) v = atomicAdd(s_ctr, 1);
-    return q_lo + __builtin_amdgcn_readfirstlane(v);
+    return v;
   };
+  auto grab_value = [&](int v) -> int64_t { return q_lo + __builtin_amdgcn_readfirstlane(v); };
   // A role: PCM of one quad into registers (frames past the clip's last one re-read frame 0: their rows are never stored)
   float2 xv[4][4];
   // Buffer loads: the descriptor spans ONE clip, so a frame's zero-padded tail (samples 480..511 of the last frames run
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
       }
   };
   ST_DECL
-  int64_t cur = grab();
+  int64_t cur = grab_value(grab_issue());
   if (cur < q_hi) issue_loads(cur);
   while (cur < q_hi) {
     int gq[4] = {-1, -1, -1, -1};                   // the quads of this group (scalar registers)
@@ -188,6 +191,7 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
       st_acc[5] += 1;
       st_mark = __builtin_amdgcn_s_memtime();
 #endif
+      const int ticket = grab_issue();              // the next quad's number: asked for now, needed after the MFMAs
       // ---- first pass on the matrix pipe ----------------------------------------------------------------
       f32x4 acc[4][2];
 #pragma unroll
@@ -210,7 +214,7 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
       // the PCM of this wave's NEXT quad is requested as soon as the MFMAs have consumed this quad's: it lands while
       // the vector work of this quad runs
       __builtin_amdgcn_sched_barrier(0);
-      cur = grab();
+      cur = grab_value(ticket);
       if (cur < q_hi) issue_loads(cur);
       __builtin_amdgcn_sched_barrier(0);
       // ---- second pass in registers: lane (g, c) holds Y[k1][n2] of frame g ------------------------------
