@@ -116,3 +116,33 @@ def shard_range(n_items):
     w, r = parallel.world_size(), parallel.rank()
     per = (n_items + w - 1) // w
     return min(r * per, n_items), min((r + 1) * per, n_items)
+
+
+def predict_test_set(model, clips, batch=4096, use_speed_tta=False, gather=True):
+    """BASELINE config C5 as a driver: TTA inference over a whole test set (make_submission.py:86-146 walks its 158,538
+    files in batches and averages the TTA terms per batch), sharded over the data-parallel ranks.
+
+    clips: [n, 16000] host array / tensor holding the WHOLE set on every rank (or any indexable that yields a
+    [k, 16000] block for a slice).  Rank r infers the contiguous range `shard_range(n)` in batches of `batch` clips -
+    no collective on the data path.  With `gather` the per-rank results are exchanged once at the end (control plane:
+    torch.distributed.all_gather_object) and every rank returns the full (probs [n, C], argmax [n]) as NumPy arrays;
+    without it each rank returns (probs, argmax, (lo, hi)) for its own range."""
+    import numpy as np
+    from . import parallel
+    n = len(clips)
+    lo, hi = shard_range(n)
+    probs, amax = [], []
+    for s in range(lo, hi, batch):
+        e = min(s + batch, hi)
+        p, a = predict_tta(model, clips[s:e], use_speed_tta=use_speed_tta)
+        probs.append(p.cpu().numpy())
+        amax.append(a.cpu().numpy())
+    C = model.net.num_classes
+    p_loc = np.concatenate(probs) if probs else np.zeros((0, C), np.float32)
+    a_loc = np.concatenate(amax) if amax else np.zeros((0,), np.int32)
+    if not gather or not parallel.active():
+        return (p_loc, a_loc) if gather else (p_loc, a_loc, (lo, hi))
+    parts = [None] * parallel.world_size()
+    parallel.dist.all_gather_object(parts, (lo, hi, p_loc, a_loc))
+    parts.sort(key=lambda t: t[0])
+    return np.concatenate([t[2] for t in parts]), np.concatenate([t[3] for t in parts])

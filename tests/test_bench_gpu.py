@@ -64,3 +64,31 @@ def test_bench_refuses_more_gpus_than_visible():
                          cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert res.returncode != 0 and not res.stdout.strip()
     assert b"GPU(s) visible" in res.stderr
+
+
+def test_tta_inference_sharded_over_two_ranks_matches_one_rank(tmp_path):
+    """BASELINE config C5's multi-GPU form (scripts/tta_infer.py -> tta.predict_test_set): the test set is split into
+    contiguous ranges by rank, no collective on the data path, results exchanged once at the end.  Two ranks (on the one
+    GPU over gloo) must return exactly what one rank returns."""
+    import numpy as np
+    outs = {}
+    for world in (1, 2):
+        out = str(tmp_path / ("probs_w%d.npy" % world))
+        env = dict(os.environ, KWS_TTA_OUT=out, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        script = os.path.join(ROOT, "scripts", "tta_infer.py")
+        if world == 1:
+            cmd = [sys.executable, script, "5003"]
+        else:
+            env.update(KWS_DIST_BACKEND="gloo", KWS_ONE_DEVICE="1")
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                   "127.0.0.1", "--master-port", "29549", script, "5003"]
+        res = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert res.returncode == 0, res.stderr.decode()[-2000:]
+        line = [l for l in res.stdout.decode().splitlines() if l.lstrip().startswith("{")][-1]
+        info = json.loads(line)
+        assert info["n_gpus"] == world and sum(info["argmax_hist"]) == 5003
+        outs[world] = np.load(out)
+    assert outs[1].shape == (5003, 12)
+    assert np.array_equal(outs[1], outs[2])                 # inference is per clip: the split cannot change a bit
