@@ -227,7 +227,7 @@ ROOFLINE_KERNELS = [
     ("gemm_tn", "gemm_tn_ws_kernel", "mfma", "pointwise 1x1 convolutions: weight gradient"),
     ("conv1_fwd", "conv1_fwd_kernel", "mfma", "first convolution (frames of 40 hop 20, k3 s2) as a Toeplitz GEMM"),
     ("conv1_wgrad", "conv1_wgrad_kernel", "mfma", "first convolution, weight gradient"),
-    ("stft_mel", "stft3_kernel", "hbm", "STFT 480/160/512 -> |X| -> mel 80 -> log -> DCT 60 (generator stream)"),
+    ("stft_mel", "stft4_kernel", "hbm", "STFT 480/160/512 -> |X| -> mel 80 -> log -> DCT 60 (generator stream, low priority)"),
     ("augment", "augment_kernel", "hbm", "gather x foreground volume, circular roll, + noise x volume (generator stream)"),
     ("dwconv_fwd", "dwconv_fwd_kernel", "hbm", "depthwise k3 forward with BN+ReLU6 applied on load"),
     ("dwconv_bwd", "dwconv_bwd_kernel", "hbm", "depthwise k3 backward fused with the BatchNorm backward"),
@@ -451,6 +451,31 @@ def main():
                 stages.append(e)
         roof = stages[0] if stages and stages[0]["family"] == "gemm_nn" else None
     enq.stop()
+    if rank == 0 and stages:
+        # the STFT stage ALONE (its in-situ time above is that of a low-priority stream filling the gaps of the training
+        # stream): 20 back-to-back launches on one batch, HIP events on the launch stream
+        try:
+            torch.cuda.synchronize()
+            (mf, raw), _ = next(gen)
+            raw_t = raw.wait()
+            st = proc._stream
+            with torch.cuda.stream(st):
+                for _ in range(3):
+                    proc._features(raw_t, 0)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(st)
+                for _ in range(20):
+                    proc._features(raw_t, 0)
+                e1.record(st)
+            e1.synchronize()
+            us = 1e3 * e0.elapsed_time(e1) / 20
+            for e in stages:
+                if e["family"] == "stft_mel":
+                    e["alone_avg_launch_us"] = us
+                    e["alone_frac_hbm"] = e["algorithmic_bytes_per_launch"] / (us * 1e-6) / 1e9 / PEAK_HBM_GBS
+                    e["alone_frac_flops"] = e["algorithmic_flops_per_launch"] / (us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS
+        except Exception as ex:
+            sys.stderr.write("standalone STFT timing skipped: %r\n" % (ex,))
 
     out = None
     if rank == 0:
