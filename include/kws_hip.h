@@ -218,14 +218,6 @@ int kws_gemm_nn_stats_rows(int64_t M, int K, int N);
 int kws_gemm_gather_stats_rows(int64_t M);
 int kws_gemm_nn_f32(const float* A, const float* W, float* C, int64_t M, int K, int N,
                     float* stats_part, void* stream);
-/* The same product with the kernel given TRANSPOSED, Wt [N][K] (k contiguous, like the rows of A): the
- * wave-specialised kernel then stages both operands alike and reads its B fragments with 16-byte LDS
- * instructions.  The network keeps both forms of every pointwise kernel (the input-gradient GEMM needs the
- * other one).  Shapes the wave-specialised kernel does not take are refused: ask kws_gemm_nn_bt_ok first.
- * stats_part as for kws_gemm_nn_f32 (same row count). */
-int kws_gemm_nn_bt_ok(int64_t M, int K, int N);
-int kws_gemm_nn_bt_f32(const float* A, const float* Wt, float* C, int64_t M, int K, int N,
-                       float* stats_part, void* stream);
 typedef struct {
   int L_out;             /* rows per clip */
   int cin;               /* channels per tap */

@@ -15,7 +15,7 @@ def timeit(fn, n=10):
     for _ in range(n): fn()
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / n
-tot = [0, 0, 0]; fl = 0; totb = [0, 0]
+tot = [0, 0, 0]; fl = 0
 for L, K, N in shapes:
     M = B * L
     A = torch.randn(M, K, device='cuda'); W = torch.randn(K, N, device='cuda') * 0.1; C = torch.empty(M, N, device='cuda')
@@ -24,13 +24,9 @@ for L, K, N in shapes:
     ws = torch.empty(int(lib.kws_gemm_tn_workspace_floats(M, K, N)), device='cuda')
     t1 = timeit(lambda: _lib.call("kws_gemm_nn_f32", _lib.ptr(A), _lib.ptr(W), _lib.ptr(C), M, K, N, _lib.ptr(part), S))
     t2 = timeit(lambda: _lib.call("kws_gemm_nn_f32", _lib.ptr(G), _lib.ptr(WT), _lib.ptr(DZ), M, N, K, None, S))
-    Wt = W.t().contiguous()
-    tb1 = timeit(lambda: _lib.call("kws_gemm_nn_bt_f32", _lib.ptr(A), _lib.ptr(Wt), _lib.ptr(C), M, K, N, _lib.ptr(part), S))
-    tb2 = timeit(lambda: _lib.call("kws_gemm_nn_bt_f32", _lib.ptr(G), _lib.ptr(W), _lib.ptr(DZ), M, N, K, None, S))
     t3 = timeit(lambda: _lib.call("kws_gemm_tn_f32", _lib.ptr(A), _lib.ptr(G), _lib.ptr(dW), M, K, N, _lib.ptr(ws), S))
     f = 2.0 * M * K * N
-    print("M=%7d K=%3d N=%3d  fwd %6.1f us %6.1f TF (bt %6.1f us %6.1f TF) | dgrad %6.1f us %6.1f TF (bt %6.1f us %6.1f TF) | wgrad %6.1f us %6.1f TF" % (
-        M, K, N, t1 * 1e3, f / t1 / 1e9, tb1 * 1e3, f / tb1 / 1e9, t2 * 1e3, f / t2 / 1e9, tb2 * 1e3, f / tb2 / 1e9, t3 * 1e3, f / t3 / 1e9))
-    tot[0] += t1; tot[1] += t2; tot[2] += t3; fl += f; totb[0] += tb1; totb[1] += tb2
-print("total fwd %.3f ms (%.1f TF; bt %.3f ms %.1f TF)  dgrad %.3f ms (%.1f TF; bt %.3f ms %.1f TF)  wgrad %.3f ms (%.1f TF)" % (
-    tot[0], fl / tot[0] / 1e9, totb[0], fl / totb[0] / 1e9, tot[1], fl / tot[1] / 1e9, totb[1], fl / totb[1] / 1e9, tot[2], fl / tot[2] / 1e9))
+    print("M=%7d K=%3d N=%3d  fwd %6.1f us %6.1f TF | dgrad %6.1f us %6.1f TF | wgrad %6.1f us %6.1f TF  (S*KN=%.1f MB)" % (
+        M, K, N, t1 * 1e3, f / t1 / 1e9, t2 * 1e3, f / t2 / 1e9, t3 * 1e3, f / t3 / 1e9, ws.numel() * 4 / 1e6))
+    tot[0] += t1; tot[1] += t2; tot[2] += t3; fl += f
+print("total fwd %.3f ms (%.1f TF)  dgrad %.3f ms (%.1f TF)  wgrad %.3f ms (%.1f TF)" % (tot[0], fl / tot[0] / 1e9, tot[1], fl / tot[1] / 1e9, tot[2], fl / tot[2] / 1e9))

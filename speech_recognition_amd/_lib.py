@@ -103,8 +103,6 @@ SIGNATURES = {
     "kws_gemm_nn_stats_rows": (_I, [_I64, _I, _I]),
     "kws_gemm_gather_stats_rows": (_I, [_I64]),
     "kws_gemm_nn_f32": (_I, [_P, _P, _P, _I64, _I, _I, _P, _P]),
-    "kws_gemm_nn_bt_ok": (_I, [_I64, _I, _I]),
-    "kws_gemm_nn_bt_f32": (_I, [_P, _P, _P, _I64, _I, _I, _P, _P]),
     "kws_gemm_nn_bf16x3_stats_rows": (_I, [_I64]),
     "kws_gemm_nn_bf16x3_f32": (_I, [_P, _P, _P, _I64, _I, _I, _P, _P]),
     "kws_gemm_gather_f32": (_I, [_P, ctypes.POINTER(GatherDesc), _P, _P, _I, _I, _P, _P]),

@@ -41,7 +41,6 @@ struct NNArgs {
   float* stats;  // [m_tiles][2][N] or nullptr
   kws_gather_t g;
   int m_tiles, n_tiles;
-  int bt;        // W is given as [N][K] (k contiguous): wave-specialised kernel only
 };
 
 // 16 bytes of zeros that masked-out lanes load from instead of branching around their load.
@@ -341,11 +340,7 @@ __device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, int voff, in
 
 // KB = K-slab depth per barrier: 32 for the 128-wide column tiles; the 64-wide tiles (N = 192, 320) take 64 so
 // that an MFMA wave still issues 64 MFMAs per barrier (LDS: 2 x 50.8 KB slots + 34.8 KB staging).
-// BT: the kernel operand arrives as [N][K] (the network keeps both forms of every pointwise kernel: [in][out] and its
-// transpose): the B slab is then staged exactly like the A slab - rows of KB floats with a 4-float pad - and an MFMA wave
-// reads its four k values of a column with ONE 16-byte LDS instruction instead of four 4-byte ones (40 -> 16 LDS
-// instructions per 64 MFMAs; every non-MFMA instruction in an MFMA wave's stream costs ~12 matrix-pipe cycles).
-template <int BN, int KB, int NLW, int NSW, bool STATS, bool BT>
+template <int BN, int KB, int NLW, int NSW, bool STATS>
 __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNArgs p) {
   constexpr int PBK = KB, PLDA = KB + 4;            // shadow the 32-deep constants of the 4-wave kernels
   constexpr int NQ = KB / 8;                        // 8-deep k-groups per slab
@@ -359,7 +354,7 @@ __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNA
   constexpr int B_F4 = PBK * BN / 4 / 64;           // 16 or 8
   constexpr int BN4 = BN / 4;
   constexpr int PBK4 = PBK / 4;
-  constexpr int STAGE = BM * PLDA + (BT ? BN * PLDA : PBK * BN);
+  constexpr int STAGE = BM * PLDA + PBK * BN;
   constexpr int SLD = BN + 4;                       // staging row stride (floats): conflict-free b128 writes
   constexpr int STG_OFF = 2 * STAGE;
   constexpr int RGROUPS = NST / BN4;                // storer row groups
@@ -495,23 +490,14 @@ __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNA
       for (int kt = 0; kt < nk; ++kt, ++g) {
         const int cur = g & 1;
         const float* cA = smem + cur * STAGE + (wm * TM * 32 + li) * PLDA + lh * 4;
-        const float* cB = BT ? smem + cur * STAGE + BM * PLDA + (wn * TN * 32 + li) * PLDA + lh * 4
-                             : smem + cur * STAGE + BM * PLDA + (lh * 4) * BN + wn * TN * 32 + li;
+        const float* cB = smem + cur * STAGE + BM * PLDA + (lh * 4) * BN + wn * TN * 32 + li;
         auto load_frag = [&](Frag& f, int q) {
 #pragma unroll
           for (int i = 0; i < TM; ++i) f.a[i] = *reinterpret_cast<const float4*>(cA + i * 32 * PLDA + q * 8);
-          if (BT) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-              const float4 b4 = *reinterpret_cast<const float4*>(cB + j * 32 * PLDA + q * 8);
-              f.b[0][j] = b4.x; f.b[1][j] = b4.y; f.b[2][j] = b4.z; f.b[3][j] = b4.w;
-            }
-          } else {
+          for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-              for (int j = 0; j < TN; ++j) f.b[r][j] = cB[(q * 8 + r) * BN + j * 32];
-          }
+            for (int j = 0; j < TN; ++j) f.b[r][j] = cB[(q * 8 + r) * BN + j * 32];
         };
         auto mma = [&](const Frag& f) {
 #pragma unroll
@@ -618,23 +604,13 @@ __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNA
       const int rows = tile_ok ? (int)(rows_left < BM ? rows_left : BM) : 0;
       const __amdgpu_buffer_rsrc_t ares = __builtin_amdgcn_make_buffer_rsrc(
           const_cast<float*>(p.A + m0 * K), 0, rows * K * 4, KWS_BUFFER_RSRC_FLAGS);
-      // BT: rows n0 .. n0 + BN - 1 of the [N][K] operand, addressed like the A rows
-      const __amdgpu_buffer_rsrc_t bres = BT ? __builtin_amdgcn_make_buffer_rsrc(
-                                                   const_cast<float*>(p.W + (int64_t)n0 * K), 0, tile_ok ? BN * K * 4 : 0,
-                                                   KWS_BUFFER_RSRC_FLAGS)
-                                             : __builtin_amdgcn_make_buffer_rsrc(
-                                                   const_cast<float*>(p.W + n0), 0, tile_ok ? (K * N - n0) * 4 : 0,
-                                                   KWS_BUFFER_RSRC_FLAGS);
+      const __amdgpu_buffer_rsrc_t bres = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float*>(p.W + n0), 0, tile_ok ? (K * N - n0) * 4 : 0, KWS_BUFFER_RSRC_FLAGS);
       const int k0 = ld_kt * PBK;
 #pragma unroll
       for (int r = 0; r < A_F4; ++r) ra[r] = buf_ld4(ares, a_voff, (k0 + AROWS * r * K) * 4);
-      if (BT) {
 #pragma unroll
-        for (int r = 0; r < B_F4; ++r) rb[r] = buf_ld4(bres, a_voff, (k0 + AROWS * r * K) * 4);
-      } else {
-#pragma unroll
-        for (int r = 0; r < B_F4; ++r) rb[r] = buf_ld4(bres, b_voff, (k0 + BROWS * r) * N * 4);
-      }
+      for (int r = 0; r < B_F4; ++r) rb[r] = buf_ld4(bres, b_voff, (k0 + BROWS * r) * N * 4);
       ld_kt += NLW;
       while (ld_kt >= nk) {
         ld_kt -= nk;
@@ -645,15 +621,9 @@ __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNA
       float* sA = smem + slot * STAGE + arow * PLDA + acol;
 #pragma unroll
       for (int r = 0; r < A_F4; ++r) *reinterpret_cast<float4*>(sA + AROWS * r * PLDA) = ra[r];
-      if (BT) {
-        float* sB = smem + slot * STAGE + BM * PLDA + arow * PLDA + acol;
+      float* sB = smem + slot * STAGE + BM * PLDA + brow * BN + bcol;
 #pragma unroll
-        for (int r = 0; r < B_F4; ++r) *reinterpret_cast<float4*>(sB + AROWS * r * PLDA) = rb[r];
-      } else {
-        float* sB = smem + slot * STAGE + BM * PLDA + brow * BN + bcol;
-#pragma unroll
-        for (int r = 0; r < B_F4; ++r) *reinterpret_cast<float4*>(sB + BROWS * r * BN) = rb[r];
-      }
+      for (int r = 0; r < B_F4; ++r) *reinterpret_cast<float4*>(sB + BROWS * r * BN) = rb[r];
     };
     issue();                     // slab lw
     if (lw == 0) {
@@ -1277,26 +1247,18 @@ int launch_nn(const NNArgs& a0, hipStream_t st) {
   const bool stats = a.stats != nullptr;
   if (pl.ws) {
     dim3 gp((unsigned)pl.wgs), bp(8 * 64);
-#define KWS_NN_WS(BN_, KB_) \
-    do { \
-      if (a.bt) { \
-        if (stats) hipLaunchKernelGGL((gemm_nn_ws_kernel<BN_, KB_, 2, 2, true, true>), gp, bp, 0, st, a); \
-        else hipLaunchKernelGGL((gemm_nn_ws_kernel<BN_, KB_, 2, 2, false, true>), gp, bp, 0, st, a); \
-      } else { \
-        if (stats) hipLaunchKernelGGL((gemm_nn_ws_kernel<BN_, KB_, 2, 2, true, false>), gp, bp, 0, st, a); \
-        else hipLaunchKernelGGL((gemm_nn_ws_kernel<BN_, KB_, 2, 2, false, false>), gp, bp, 0, st, a); \
-      } \
-    } while (0)
-    if (wide) KWS_NN_WS(128, 32);
-    else if (pl.kb == 64) KWS_NN_WS(64, 64);
-    else KWS_NN_WS(64, 32);
-#undef KWS_NN_WS
+    if (wide) {
+      if (stats) hipLaunchKernelGGL((gemm_nn_ws_kernel<128, 32, 2, 2, true>), gp, bp, 0, st, a);
+      else hipLaunchKernelGGL((gemm_nn_ws_kernel<128, 32, 2, 2, false>), gp, bp, 0, st, a);
+    } else if (pl.kb == 64) {
+      if (stats) hipLaunchKernelGGL((gemm_nn_ws_kernel<64, 64, 2, 2, true>), gp, bp, 0, st, a);
+      else hipLaunchKernelGGL((gemm_nn_ws_kernel<64, 64, 2, 2, false>), gp, bp, 0, st, a);
+    } else {
+      if (stats) hipLaunchKernelGGL((gemm_nn_ws_kernel<64, 32, 2, 2, true>), gp, bp, 0, st, a);
+      else hipLaunchKernelGGL((gemm_nn_ws_kernel<64, 32, 2, 2, false>), gp, bp, 0, st, a);
+    }
     KWS_LAUNCH_CHECK("gemm_nn_ws_kernel");
     return KWS_OK;
-  }
-  if (a.bt) {
-    kws_set_error("gemm_nn: the [N][K] operand form needs the wave-specialised kernel (K=%d N=%d)", a.K, a.N);
-    return KWS_E_INVALID;
   }
   {
     // persistent: 2 workgroups per CU (69.6 KB LDS each), 32 CUs per XCD
@@ -1377,20 +1339,6 @@ int kws_gemm_nn_f32(const float* A, const float* W, float* C, int64_t M, int K, 
               (long long)M, K, N);
   NNArgs a{};
   a.A = A; a.W = W; a.C = C; a.M = M; a.K = K; a.N = N; a.stats = stats_part;
-  KwsProfScope prof("gemm_nn", 2.0 * M * K * N, 4.0 * ((double)M * K + (double)K * N + (double)M * N), (hipStream_t)stream);
-  return launch_nn<false>(a, (hipStream_t)stream);
-}
-
-// W given as Wt [N][K]; wave-specialised shapes only (kws_gemm_nn_bt_ok)
-int kws_gemm_nn_bt_ok(int64_t M, int K, int N) { return nn_plan(M, K, N, false).ws ? 1 : 0; }
-
-int kws_gemm_nn_bt_f32(const float* A, const float* Wt, float* C, int64_t M, int K, int N, float* stats_part,
-                       void* stream) {
-  KWS_REQUIRE(A && Wt && C, "gemm_nn_bt: NULL pointer");
-  KWS_REQUIRE(M > 0 && K > 0 && N > 0 && K % 4 == 0 && N % 4 == 0, "gemm_nn_bt: M=%lld K=%d N=%d (K,N %% 4)",
-              (long long)M, K, N);
-  NNArgs a{};
-  a.A = A; a.W = Wt; a.C = C; a.M = M; a.K = K; a.N = N; a.stats = stats_part; a.bt = 1;
   KwsProfScope prof("gemm_nn", 2.0 * M * K * N, 4.0 * ((double)M * K + (double)K * N + (double)M * N), (hipStream_t)stream);
   return launch_nn<false>(a, (hipStream_t)stream);
 }

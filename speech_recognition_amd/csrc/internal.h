@@ -68,4 +68,3 @@ int kws_stft3_launch(const kws_stft_plan* pl, const float* x, int B, int L, int 
 int kws_stft4_lds_bytes(const kws_stft_plan* pl);
 int kws_stft4_launch(const kws_stft_plan* pl, const float* x, int B, int L, int F, float* out, hipStream_t st);
 
-

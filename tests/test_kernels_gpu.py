@@ -77,21 +77,6 @@ def test_gemm_nn_and_stats(M, K, N):
     C2 = torch.empty_like(C)
     _lib.call("kws_gemm_nn_f32", _lib.ptr(dA), _lib.ptr(dW), _lib.ptr(C2), M, K, N, None, S())
     assert torch.equal(C, C2)
-    # the [N][K] operand form (kws_gemm_nn_bt_f32: B fragments read as 16-byte vectors) sums the same products in the
-    # same order: bit-identical C and statistics rows wherever the wave-specialised kernel takes the shape
-    lib = _lib.load()
-    dWt = dev(np.ascontiguousarray(W.T))
-    if lib.kws_gemm_nn_bt_ok(M, K, N):
-        C3 = torch.full((M, N), float("nan"), device="cuda")
-        part3 = torch.full((nt, 2, N), float("nan"), device="cuda")
-        _lib.call("kws_gemm_nn_bt_f32", _lib.ptr(dA), _lib.ptr(dWt), _lib.ptr(C3), M, K, N, _lib.ptr(part3), S())
-        assert torch.equal(C, C3)
-        assert torch.equal(part[:rows], part3[:rows])
-        C4 = torch.empty_like(C)
-        _lib.call("kws_gemm_nn_bt_f32", _lib.ptr(dA), _lib.ptr(dWt), _lib.ptr(C4), M, K, N, None, S())
-        assert torch.equal(C, C4)
-    else:
-        assert lib.kws_gemm_nn_bt_f32(_lib.ptr(dA), _lib.ptr(dWt), _lib.ptr(C2), M, K, N, None, S()) != 0   # refused loudly
 
 
 def _gather_desc(**kw):
