@@ -199,6 +199,13 @@ int kws_stft_mel_f32(const kws_stft_plan_t* plan, const float* x, int B, int L, 
 int kws_gemm_nn_bf16x3_stats_rows(int64_t M);   /* rows of stats_part: one per 128-row tile */
 int kws_gemm_nn_bf16x3_f32(const float* A, const float* Bt, float* C, int64_t M, int K, int N,
                            float* stats_part, void* stream);
+/* second form: the small operand split once into bf16 planes.  kws_bf16x3_split_batch: count <= 24 f32 matrices
+ * [rows][cols] -> out[i] = bf16 [3][rows][cols] (hi, mid, lo), or of the transposed matrix ([3][cols][rows]) where
+ * transpose[i] != 0; kws_gemm_nn_bf16x3p_f32: C[M,N] = A[M,K] . B with Bp = the planes of B stored [N][K]. */
+int kws_bf16x3_split_batch(const float* const* in, void* const* out, const int* rows, const int* cols,
+                           const int* transpose, int count, void* stream);
+int kws_gemm_nn_bf16x3p_f32(const float* A, const void* Bp, float* C, int64_t M, int K, int N,
+                            float* stats_part, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * a7+a8, a10  GEMM family on f32 MFMA (v_mfma_f32_32x32x2_f32)

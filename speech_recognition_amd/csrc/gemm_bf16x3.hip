@@ -13,6 +13,8 @@
 // ([plane][row][32 + 8 pad]: a fragment is one 16-byte read, 16 consecutive rows fall on disjoint banks) ->
 // v_mfma_f32_32x32x16_bf16.  One LDS buffer (60 KB: two workgroups per CU) with the next slab prefetched into registers.
 #include "internal.h"
+#include <algorithm>
+#include <cstring>
 
 namespace {
 
@@ -175,6 +177,227 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_bf16x3_kernel(X3Args p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Second form: the small operand (the pointwise kernel) is split ONCE per step into three bf16 planes
+// (split_planes_kernel), so the GEMM's staging pass splits only the activation slab; the LDS image is unpadded
+// ([plane][row][32 k] bf16 = 64-byte rows, the 16-byte chunk index XOR-ed with (row >> 2) & 3: conflict-free for the
+// lane groups of ds_read_b128 and for the 8- / 16-byte stores, MI355X_MICROARCH.md LDS table), which makes a slab 48 KB:
+// three workgroups per CU, one staging / MFMA phase of each in flight beside the others'.  Workgroup ids are dealt to
+// the XCDs round-robin by the hardware; the id -> tile map below hands every XCD a contiguous range of tiles, so the
+// column tiles that share a 128-row slab of A run on ONE XCD's L2 at about the same time (A comes from HBM once).
+struct P3Args {
+  const float* A;
+  const __bf16* Bp;  // [3][N][K]
+  float* C;
+  float* stats;
+  int64_t M;
+  int K, N, n_tiles;
+  int64_t tiles, per_xcd, plane_stride;
+};
+
+__device__ __forceinline__ int swz(int row, int chunk) { return row * XBK + ((chunk ^ ((row >> 2) & 3)) << 3); }
+
+template <bool STATS, int PF, int ABL = 0>
+__global__ __launch_bounds__(256, PF == 2 ? 2 : 3) void gemm_nn_bf16x3p_kernel(P3Args p) {
+  __shared__ __attribute__((aligned(16))) __bf16 smem[6 * XBM * XBK];   // A planes, B planes: 49,152 B
+  constexpr int PL = XBM * XBK;
+  __bf16* sA = smem;
+  __bf16* sB = smem + 3 * PL;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  const int K = p.K, N = p.N;
+  const int64_t M = p.M;
+  const int64_t q = (int64_t)(blockIdx.x & 7) * p.per_xcd + (blockIdx.x >> 3);
+  if (q >= p.tiles) return;
+  const int64_t tile_m = q / p.n_tiles;
+  const int tile_n = (int)(q - tile_m * p.n_tiles);
+  const int64_t m0 = tile_m * XBM;
+  const int n0 = tile_n * XBN;
+  // A loader role: thread t moves float4 t % 8 of rows t / 8 + 32 i (eight lanes = one 128-byte line)
+  const int lrow = tid >> 3, lc4 = tid & 7;
+  const float* gA[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int64_t ra = m0 + lrow + 32 * i;
+    if (ra >= M) ra = M - 1;                         // rows past M: a valid address, their results are not stored
+    gA[i] = p.A + ra * K + 4 * lc4;
+  }
+  // B loader role: thread t moves 16-byte chunk t % 4 of rows t / 4 + 64 i of every plane
+  const int brow = tid >> 2, bch = tid & 3;
+  const __bf16* gB[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int rb = n0 + brow + 64 * i;
+    if (rb >= N) rb = N - 1;
+    gB[i] = p.Bp + (int64_t)rb * K + 8 * bch;
+  }
+  const int a_off = swz(lrow, lc4 >> 1) + 4 * (lc4 & 1);     // + 32 i rows: (row >> 2) & 3 does not change
+  const int b_off = swz(brow, bch);
+  float4 ra4[PF][4];
+  bf16x8 rb8[2][3];
+  auto ga_load = [&](int slot, int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ra4[slot][i] = *reinterpret_cast<const float4*>(gA[i] + k0);
+  };
+  auto gb_load = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) rb8[i][pl] = *reinterpret_cast<const bf16x8*>(gB[i] + pl * p.plane_stride + k0);
+  };
+  auto s_store = [&](int slot) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      bf16x4 hi, mid, lo;
+      split4(ra4[slot][i], hi, mid, lo);
+      const int off = a_off + 32 * i * XBK;
+      *reinterpret_cast<bf16x4*>(sA + off) = hi;
+      *reinterpret_cast<bf16x4*>(sA + PL + off) = mid;
+      *reinterpret_cast<bf16x4*>(sA + 2 * PL + off) = lo;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<bf16x8*>(sB + pl * PL + b_off + 64 * i * XBK) = rb8[i][pl];
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+  // fragment offsets: row = w * 64 + 32 i + r, chunk = 2 s + h
+  const int fa = (wm * 64 + r) * XBK, fb = (wn * 64 + r) * XBK;
+  const int sw = (r >> 2) & 3;
+  const int c0 = ((0 + h) ^ sw) << 3, c1 = ((2 + h) ^ sw) << 3;
+
+  const int G = K / XBK;
+  ga_load(0, 0);
+  gb_load(0);
+  if (PF == 2 && G > 1) ga_load(1, XBK);
+  s_store(0);
+  __syncthreads();
+  // slots and the two "more slabs follow" flags are compile-time constants at the call sites: loads under a runtime
+  // condition make the compiler wait for every outstanding load at the next use (its counter model merges the paths)
+  auto slab = [&](int g, const int slot_cur, const int slot_next, const bool more1, const bool more2) {
+    if (more1 && ABL != 3 && ABL != 5) gb_load((g + 1) * XBK);
+    if (PF == 2) {                                   // slab g + 2 into the slot slab g has just left
+      if (more2) ga_load(slot_cur, (g + 2) * XBK);
+    } else if (more1 && ABL != 2 && ABL != 5) ga_load(0, (g + 1) * XBK);
+    if (PF == 2) __builtin_amdgcn_sched_barrier(0);  // the requests go out HERE, not where the scheduler finds room
+#pragma unroll
+    for (int s = 0; s < (ABL == 1 ? 0 : 2); ++s) {
+      const int cs = s ? c1 : c0;
+      bf16x8 b[2][3];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) b[j][pl] = *reinterpret_cast<const bf16x8*>(sB + pl * PL + fb + 32 * j * XBK + cs);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        bf16x8 a[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const bf16x8*>(sA + pl * PL + fa + 32 * i * XBK + cs);
+        // smallest products first: lo.hi, hi.lo, mid.mid, mid.hi, hi.mid, hi.hi
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[j][2], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[j][1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[j][1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[j][0], acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+    if (PF == 2) __builtin_amdgcn_sched_barrier(0);  // ... and their results are first touched after the products
+    __syncthreads();                                 // every wave has read this slab's planes
+    if (more1) {
+      s_store(slot_next);
+      __syncthreads();
+    }
+  };
+  if (PF == 2) {                                     // G is even (K % 64 == 0 on this path)
+    for (int g = 0; g < G - 2; g += 2) {
+      slab(g, 0, 1, true, true);
+      slab(g + 1, 1, 0, true, true);
+    }
+    slab(G - 2, 0, 1, true, false);
+    slab(G - 1, 1, 0, false, false);
+  } else {
+    for (int g = 0; g < G - 1; ++g) slab(g, 0, 0, true, false);
+    slab(G - 1, 0, 0, false, false);
+  }
+  float cs[2] = {0.f, 0.f}, css[2] = {0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int64_t row = m0 + wm * 64 + 32 * i + (v & 3) + 8 * (v >> 2) + 4 * h;
+        const int col = n0 + wn * 64 + 32 * j + r;
+        const float c = acc[i][j][v];
+        if (row < M && col < N && (ABL != 4 || c == 123.f)) p.C[row * N + col] = c;
+        if (STATS && row < M) {                      // the same fixed order as the first form
+          cs[j] += c;
+          css[j] = fmaf(c, c, css[j]);
+        }
+      }
+  if (STATS) {
+    float* red = reinterpret_cast<float*>(smem);     // [2 wm][2 q][128]: the planes are dead after the last barrier
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float s2 = cs[j] + __shfl_xor(cs[j], 32), q2 = css[j] + __shfl_xor(css[j], 32);
+      if (h == 0) {
+        red[(wm * 2 + 0) * 128 + wn * 64 + 32 * j + r] = s2;
+        red[(wm * 2 + 1) * 128 + wn * 64 + 32 * j + r] = q2;
+      }
+    }
+    __syncthreads();
+    const int qq = tid >> 7, col = tid & 127;
+    if (n0 + col < N) p.stats[((int64_t)tile_m * 2 + qq) * N + n0 + col] = red[(0 * 2 + qq) * 128 + col] + red[(1 * 2 + qq) * 128 + col];
+  }
+}
+
+// up to KWS_SPLIT_BATCH f32 matrices [rows][cols] -> bf16 planes [3][rows][cols] (or of the transpose: [3][cols][rows])
+constexpr int KWS_SPLIT_BATCH = 24;
+constexpr int PFD = 2;   // A slabs in flight per workgroup
+struct SplitBatch {
+  const float* in[KWS_SPLIT_BATCH];
+  __bf16* out[KWS_SPLIT_BATCH];
+  int rows[KWS_SPLIT_BATCH], cols[KWS_SPLIT_BATCH], transpose[KWS_SPLIT_BATCH];
+};
+
+__global__ __launch_bounds__(256) void split_planes_kernel(SplitBatch b) {
+  const int e = blockIdx.y;
+  const int R = b.rows[e], Cn = b.cols[e];
+  const int64_t n = (int64_t)R * Cn;
+  const float* in = b.in[e];
+  __bf16* out = b.out[e];
+  const bool tr = b.transpose[e] != 0;
+  for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < n; o += (int64_t)gridDim.x * 256) {
+    float x;
+    if (tr) {                                        // o indexes the output [cols][rows]
+      const int64_t oc = o / R, orow = o - oc * R;
+      x = in[orow * Cn + oc];
+    } else {
+      x = in[o];
+    }
+    const __bf16 hi = (__bf16)x;
+    const float r1 = x - (float)hi;
+    const __bf16 mid = (__bf16)r1;
+    const float r2 = r1 - (float)mid;
+    out[o] = hi;
+    out[n + o] = mid;
+    out[2 * n + o] = (__bf16)r2;
+  }
+}
+
 }  // namespace
 
 extern "C" int kws_gemm_nn_bf16x3_stats_rows(int64_t M) { return (int)ceil_div64(M, XBM); }
@@ -190,5 +413,59 @@ extern "C" int kws_gemm_nn_bf16x3_f32(const float* A, const float* Bt, float* C,
   if (stats_part) hipLaunchKernelGGL(gemm_nn_bf16x3_kernel<true>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(gemm_nn_bf16x3_kernel<false>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p);
   KWS_LAUNCH_CHECK("gemm_nn_bf16x3_kernel");
+  return KWS_OK;
+}
+
+// f32 [rows][cols] -> three bf16 planes [3][rows][cols] (transpose[i] != 0: of the transposed matrix, [3][cols][rows]);
+// count <= 24 matrices in one launch.  The planes are what kws_gemm_nn_bf16x3p_f32 reads as its small operand.
+extern "C" int kws_bf16x3_split_batch(const float* const* in, void* const* out, const int* rows, const int* cols,
+                                      const int* transpose, int count, void* stream) {
+  KWS_REQUIRE(in && out && rows && cols && transpose && count > 0 && count <= KWS_SPLIT_BATCH, "bf16x3_split_batch: bad arguments (count=%d)", count);
+  SplitBatch b;
+  memset(&b, 0, sizeof(b));
+  int64_t biggest = 0;
+  for (int i = 0; i < count; ++i) {
+    KWS_REQUIRE(in[i] && out[i] && rows[i] > 0 && cols[i] > 0, "bf16x3_split_batch: bad matrix %d", i);
+    b.in[i] = in[i]; b.out[i] = (__bf16*)out[i]; b.rows[i] = rows[i]; b.cols[i] = cols[i]; b.transpose[i] = transpose[i];
+    biggest = std::max<int64_t>(biggest, (int64_t)rows[i] * cols[i]);
+  }
+  const unsigned gx = (unsigned)std::min<int64_t>(ceil_div64(biggest, 256), 256);
+  hipLaunchKernelGGL(split_planes_kernel, dim3(gx, (unsigned)count), dim3(256), 0, (hipStream_t)stream, b);
+  KWS_LAUNCH_CHECK("split_planes_kernel");
+  return KWS_OK;
+}
+
+// C[M,N] = A[M,K] . B  with B given as the planes of [N][K] (kws_bf16x3_split_batch); stats_part as in
+// kws_gemm_nn_bf16x3_f32 (kws_gemm_nn_bf16x3_stats_rows rows)
+extern "C" int kws_gemm_nn_bf16x3p_f32(const float* A, const void* Bp, float* C, int64_t M, int K, int N, float* stats_part,
+                                       void* stream) {
+  KWS_REQUIRE(A && Bp && C && M > 0, "gemm_nn_bf16x3p: bad arguments");
+  KWS_REQUIRE(K >= XBK && K % XBK == 0 && N > 0, "gemm_nn_bf16x3p: K=%d must be a multiple of %d (N=%d)", K, XBK, N);
+  P3Args p;
+  p.A = A; p.Bp = (const __bf16*)Bp; p.C = C; p.stats = stats_part; p.M = M; p.K = K; p.N = N;
+  p.n_tiles = (N + XBN - 1) / XBN;
+  p.tiles = ceil_div64(M, XBM) * p.n_tiles;
+  p.per_xcd = ceil_div64(p.tiles, 8);
+  p.plane_stride = (int64_t)N * K;
+  const int64_t grid = p.per_xcd * 8;
+  KWS_REQUIRE(grid <= 0x7FFFFFFF, "gemm_nn_bf16x3p: grid out of range");
+  KwsProfScope prof("gemm_nn_bf16x3", 2.0 * M * K * N, 4.0 * ((double)M * K + (double)K * N + (double)M * N), (hipStream_t)stream);
+  static const int pf = getenv("KWS_X3_PF") ? atoi(getenv("KWS_X3_PF")) : PFD;
+  if (pf == 2 && K % (2 * XBK) == 0) {
+    if (stats_part) hipLaunchKernelGGL((gemm_nn_bf16x3p_kernel<true, 2>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((gemm_nn_bf16x3p_kernel<false, 2>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p);
+  } else if (getenv("KWS_X3_ABL")) {
+    switch (atoi(getenv("KWS_X3_ABL"))) {
+      case 1: hipLaunchKernelGGL((gemm_nn_bf16x3p_kernel<false, 1, 1>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p); break;
+      case 2: hipLaunchKernelGGL((gemm_nn_bf16x3p_kernel<false, 1, 2>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p); break;
+      case 3: hipLaunchKernelGGL((gemm_nn_bf16x3p_kernel<false, 1, 3>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p); break;
+      case 4: hipLaunchKernelGGL((gemm_nn_bf16x3p_kernel<false, 1, 4>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p); break;
+      default: hipLaunchKernelGGL((gemm_nn_bf16x3p_kernel<false, 1, 5>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p); break;
+    }
+  } else {
+    if (stats_part) hipLaunchKernelGGL((gemm_nn_bf16x3p_kernel<true, 1>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((gemm_nn_bf16x3p_kernel<false, 1>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p);
+  }
+  KWS_LAUNCH_CHECK("gemm_nn_bf16x3p_kernel");
   return KWS_OK;
 }

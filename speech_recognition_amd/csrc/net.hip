@@ -174,6 +174,7 @@ struct Layout {
   std::vector<int64_t> z;   // z[i], i = 0..10
   int64_t G = 0, G2 = 0, DZ = 0, bn = 0, part = 0, coef = 0, tn = 0, red = 0, swg = 0;
   std::vector<int64_t> WT;  // transposed pointwise kernel of block i (dgrad GEMM operand)
+  std::vector<int64_t> WPf, WPd;  // KWS_GEMM_BF16X3: bf16 planes [3][cout][cin] (forward) / [3][cin][cout] (input gradient)
   int64_t xd = 0, fd = 0, dl1 = 0, dl2 = 0, per_loss = 0, per_correct = 0, att = 0;
   int64_t w1f = 0, g1f = 0;  // folded first-convolution kernel and its gradient [K1f, C1]
   int64_t bn_stride = 0;
@@ -221,6 +222,12 @@ void make_layout(const kws_net* n, int B, bool training, Layout* lo) {
                       std::max((int64_t)n->T * n->C * n->T, (int64_t)2 * n->C * n->NC));
     lo->WT.assign(nb, 0);
     for (int i = 0; i < nb; ++i) lo->WT[i] = bp.take((int64_t)n->blocks[i].cin * n->blocks[i].cout);
+    lo->WPf.assign(nb, 0);
+    lo->WPd.assign(nb, 0);
+    for (int i = 0; i < nb; ++i) {                  // 3 bf16 per weight = 1.5 floats; taken in every mode (1.2 M weights in all)
+      lo->WPf[i] = bp.take(((int64_t)n->blocks[i].cin * n->blocks[i].cout * 3 + 1) / 2);
+      lo->WPd[i] = bp.take(((int64_t)n->blocks[i].cin * n->blocks[i].cout * 3 + 1) / 2);
+    }
     lo->tn = bp.take(max_tn);
     lo->xd = bp.take((int64_t)B * n->T * n->C);
     lo->fd = bp.take((int64_t)B * 2 * n->C);
@@ -428,7 +435,20 @@ static int ts_train(const kws_net_t* net, const float* params, float* state, con
   memset(&t, 0, sizeof(t));
   if (run_head) {
   KWS_HIP(hipMemsetAsync(grads, 0, (size_t)net->n_params * 4, st));
-  if (x3) KWS_TRY(transpose_all());                 // the split GEMM reads the kernels [out][in] in the forward pass already
+  if (x3) {                                         // both operand forms of every pointwise kernel as bf16 planes, one launch
+    const float* sin_[24];
+    void* sout[24];
+    int srows[24], scols[24], str[24];
+    KWS_REQUIRE(2 * nb <= 24, "net: %d blocks exceed the split batch", nb);
+    for (int i = 0; i < nb; ++i) {
+      sin_[2 * i] = sin_[2 * i + 1] = params + net->blocks[i].pw;
+      srows[2 * i] = srows[2 * i + 1] = net->blocks[i].cin;
+      scols[2 * i] = scols[2 * i + 1] = net->blocks[i].cout;
+      sout[2 * i] = ws + lo.WPf[i]; str[2 * i] = 1;            // forward: B = W, stored [cout][cin]
+      sout[2 * i + 1] = ws + lo.WPd[i]; str[2 * i + 1] = 0;    // input gradient: B = W^T, stored [cin][cout] = W itself
+    }
+    KWS_TRY(kws_bf16x3_split_batch(sin_, sout, srows, scols, str, 2 * nb, st));
+  }
   // ---------------- forward ----------------
   {
     const int64_t M = (int64_t)B * net->L1;
@@ -450,7 +470,7 @@ static int ts_train(const kws_net_t* net, const float* params, float* state, con
                                b.pad_l, st));
     int stat_rows;
     if (x3) {
-      KWS_TRY(kws_gemm_nn_bf16x3_f32(ws + lo.z[i], ws + lo.WT[i], ws + lo.y[i + 1], M, b.cin, b.cout, part, st));
+      KWS_TRY(kws_gemm_nn_bf16x3p_f32(ws + lo.z[i], ws + lo.WPf[i], ws + lo.y[i + 1], M, b.cin, b.cout, part, st));
       stat_rows = kws_gemm_nn_bf16x3_stats_rows(M);
     } else {
       KWS_TRY(kws_gemm_nn_f32(ws + lo.z[i], params + b.pw, ws + lo.y[i + 1], M, b.cin, b.cout, part, st));
@@ -508,7 +528,7 @@ static int ts_train(const kws_net_t* net, const float* params, float* state, con
     // below); only the tail hands over a masked gradient that still needs its BatchNorm backward
     if (i == nb - 1)
       KWS_TRY(kws_bn_bwd_apply(Gcur, ws + lo.y[i + 1], bn_at(i + 1), params + b.bn.gamma, coef, M, b.cout, st));
-    if (x3) KWS_TRY(kws_gemm_nn_bf16x3_f32(Gcur, params + b.pw, DZ, M, b.cout, b.cin, nullptr, st));   // Bt = W itself: [cin][cout]
+    if (x3) KWS_TRY(kws_gemm_nn_bf16x3p_f32(Gcur, ws + lo.WPd[i], DZ, M, b.cout, b.cin, nullptr, st));
     else KWS_TRY(kws_gemm_nn_f32(Gcur, ws + lo.WT[i], DZ, M, b.cout, b.cin, nullptr, st));
     const bool ov = overlap && i >= overlap_from;
     hipStream_t sw = ov ? net->side : st;
