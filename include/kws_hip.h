@@ -202,6 +202,8 @@ int kws_gemm_nn_bf16x3_f32(const float* A, const float* Bt, float* C, int64_t M,
 /* second form: the small operand split once into bf16 planes.  kws_bf16x3_split_batch: count <= 24 f32 matrices
  * [rows][cols] -> out[i] = bf16 [3][rows][cols] (hi, mid, lo), or of the transposed matrix ([3][cols][rows]) where
  * transpose[i] != 0; kws_gemm_nn_bf16x3p_f32: C[M,N] = A[M,K] . B with Bp = the planes of B stored [N][K]. */
+int kws_net_get_gemm_mode(void);   /* 0 = f32 MFMA (default), 1 = the bf16 x 3 experiment (KWS_GEMM_BF16X3 at start) */
+int kws_net_set_gemm_mode(int mode);
 int kws_bf16x3_split_batch(const float* const* in, void* const* out, const int* rows, const int* cols,
                            const int* transpose, int count, void* stream);
 int kws_gemm_nn_bf16x3p_f32(const float* A, const void* Bp, float* C, int64_t M, int K, int N,

@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256, PF == 2 ? 2 : 3) void gemm_nn_bf16x3p_kernel(P
 
 // up to KWS_SPLIT_BATCH f32 matrices [rows][cols] -> bf16 planes [3][rows][cols] (or of the transpose: [3][cols][rows])
 constexpr int KWS_SPLIT_BATCH = 24;
-constexpr int PFD = 2;   // A slabs in flight per workgroup
+constexpr int PFD = 1;   // A slabs in flight per workgroup (2: measured slower - only two workgroups fit a CU)
 struct SplitBatch {
   const float* in[KWS_SPLIT_BATCH];
   __bf16* out[KWS_SPLIT_BATCH];

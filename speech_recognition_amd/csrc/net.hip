@@ -10,6 +10,7 @@
 // Backward keeps two scratch tensors (G: gradient wrt a BN output / pre-BN tensor, DZ: gradient wrt
 // a depthwise output) and walks the blocks in reverse.
 #include "net_internal.h"
+#include <atomic>
 
 int64_t kws_net_add_tensor(kws_net* n, const std::string& name, std::vector<int64_t> shape, bool is_state, float l2,
                            int fan_in, int fan_out, float init) {
@@ -396,6 +397,23 @@ int kws_net_predict(const kws_net_t* net, const float* params, const float* stat
 // part 0: the whole step.  part 1: forward, tail and the backward pass down to block `split` (inclusive); part 2: the rest
 // of the backward pass (blocks split-1 .. 0 and the first convolution).  Parts 1 + 2 enqueue exactly the launches of
 // part 0 in the same order - every intermediate lives in the caller's workspace - so the gradients are bit-identical.
+// 0 = f32 MFMA (default), 1 = bf16 x 3 split products for the pointwise forward / input-gradient GEMMs (experiment).
+// Initialised from KWS_GEMM_BF16X3; kws_net_set_gemm_mode switches it at run time (bench.py's A/B leg).
+static std::atomic<int> g_gemm_mode{-1};
+extern "C" int kws_net_get_gemm_mode(void) {
+  int m = g_gemm_mode.load(std::memory_order_relaxed);
+  if (m < 0) {
+    m = getenv("KWS_GEMM_BF16X3") != nullptr ? 1 : 0;
+    g_gemm_mode.store(m, std::memory_order_relaxed);
+  }
+  return m;
+}
+extern "C" int kws_net_set_gemm_mode(int mode) {
+  KWS_REQUIRE(mode == 0 || mode == 1, "net_set_gemm_mode: mode %d (0 = f32 MFMA, 1 = bf16 x 3 split)", mode);
+  g_gemm_mode.store(mode, std::memory_order_relaxed);
+  return KWS_OK;
+}
+
 static int ts_train(const kws_net_t* net, const float* params, float* state, const float* x, const float* y_onehot, int B,
                     float* grads, float* probs, float* metrics, uint64_t seed, uint32_t step, int64_t row_offset,
                     int loss_batch, void* workspace, int64_t workspace_bytes, void* stream, int phase, int split) {
@@ -418,7 +436,7 @@ static int ts_train(const kws_net_t* net, const float* params, float* state, con
   const bool run_head = phase != 2;                   // forward + tail + the late blocks' backward
   // KWS_GEMM_BF16X3=1 (A/B experiment, gemm_bf16x3.hip): the pointwise forward and input-gradient GEMMs run as six bf16
   // MFMA products of three-way operand splits instead of f32 MFMAs; weight gradients and the first convolution stay f32
-  static const bool x3 = getenv("KWS_GEMM_BF16X3") != nullptr;
+  const bool x3 = kws_net_get_gemm_mode() == 1;
   auto transpose_all = [&]() -> int {   // the pointwise kernels [cin][cout] -> [cout][cin]: all of them in one launch
     static_assert(KWS_TRANSPOSE_BATCH >= 11, "one batch holds every block");
     const float* tin[KWS_TRANSPOSE_BATCH];
