@@ -454,8 +454,9 @@ def main():
             if e is not None:
                 stages.append(e)
         roof = stages[0] if stages and stages[0]["family"] == "gemm_nn" else None
-    # ---- A/B leg (experiment): the same step with the pointwise forward / input-gradient GEMMs
-    # as six bf16 MFMA products of three-way operand splits; the line's value / roofline above are the f32-MFMA path
+    # ---- A/B leg (experiment): the same step with the pointwise GEMMs (forward, input gradient,
+    # weight gradient) as six bf16 MFMA products of three-way operand splits; the line's value / roofline above are
+    # the f32-MFMA path
     ab = None
     gemm_mode = _lib.load().kws_net_get_gemm_mode()
     if world == 1 and not args.no_ab and gemm_mode == 0:
@@ -471,8 +472,8 @@ def main():
                 step(base + 8 + i)
             barrier()
             dt_ab = time.time() - t1
-            ab = {"what": "pointwise forward + input-gradient GEMMs as 3-way bf16 splits (six bf16 MFMA products, f32 "
-                          "accumulate; KWS_GEMM_BF16X3=1): an A/B experiment, not the product default",
+            ab = {"what": "pointwise forward / input-gradient / weight-gradient GEMMs as 3-way bf16 splits (six bf16 MFMA "
+                          "products, f32 accumulate; KWS_GEMM_BF16X3=1): an A/B experiment, not the product default",
                   "steps": ab_steps, "ms_per_step": 1e3 * dt_ab / ab_steps, "value": B * ab_steps / dt_ab,
                   "unit": "clips/s"}
         finally:

@@ -208,6 +208,11 @@ int kws_bf16x3_split_batch(const float* const* in, void* const* out, const int* 
                            const int* transpose, int count, void* stream);
 int kws_gemm_nn_bf16x3p_f32(const float* A, const void* Bp, float* C, int64_t M, int K, int N,
                             float* stats_part, void* stream);
+/* the weight gradient in the same arithmetic: dW[K,N] = Z[M,K]^T . G[M,N] (K, N multiples of 64); workspace of
+ * kws_gemm_tn_bf16x3_workspace_floats(M, K, N) floats (partial slabs, summed in a fixed order) */
+int64_t kws_gemm_tn_bf16x3_workspace_floats(int64_t M, int K, int N);
+int kws_gemm_tn_bf16x3_f32(const float* Z, const float* G, float* dW, int64_t M, int K, int N, float* workspace,
+                           void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * a7+a8, a10  GEMM family on f32 MFMA (v_mfma_f32_32x32x2_f32)

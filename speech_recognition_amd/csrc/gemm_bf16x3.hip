@@ -364,6 +364,170 @@ __global__ __launch_bounds__(256, PF == 2 ? 2 : 3) void gemm_nn_bf16x3p_kernel(P
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradient in the same arithmetic: dW[K,N] = Z[M,K]^T . G[M,N], the reduction runs over the rows.  Both operands are
+// activations, so both are split on the way into LDS, and both are staged TRANSPOSED ([k or n][32 m], the image and
+// swizzle of the forward kernel): a thread loads a 4 (m) x 4 (k) block - eight lanes cover a 128-byte line of one row -
+// and writes, per k, the four m values of each plane as one 8-byte store.  Workgroup tile 64 IC x 64 JC (2 x 2 waves),
+// one (tile, row chunk) item per workgroup, partial tiles into [S][K][N] slabs summed by kws_reduce_slabs_f32 in a fixed
+// order.  Rows past M read as zero (range-checked buffer loads).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct T3Args {
+  const float* Z;
+  const float* G;
+  float* ws;
+  int64_t M, chunk, items, per_xcd;
+  int K, N, n_tiles, tiles;
+};
+
+template <int IC, int JC>
+__global__ __launch_bounds__(256, (IC * JC == 4) ? 3 : 4) void gemm_tn_bf16x3_kernel(T3Args p) {
+  constexpr int BKO = 64 * IC, BNO = 64 * JC;
+  constexpr int PLA = BKO * XBK, PLB = BNO * XBK;
+  __shared__ __attribute__((aligned(16))) __bf16 smem[3 * PLA + 3 * PLB];
+  __bf16* sA = smem;
+  __bf16* sB = smem + 3 * PLA;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  const int K = p.K, N = p.N;
+  const int64_t q = (int64_t)(blockIdx.x & 7) * p.per_xcd + (blockIdx.x >> 3);
+  if (q >= p.items) return;
+  const int64_t sp = q / p.tiles;                    // consecutive items = the tiles of one row chunk: Z and G rows are
+  const int tile = (int)(q - sp * p.tiles);          // fetched from HBM once per XCD
+  const int k0 = (tile / p.n_tiles) * BKO, n0 = (tile % p.n_tiles) * BNO;
+  const int64_t m_begin = sp * p.chunk;
+  const int64_t m_end = m_begin + p.chunk < p.M ? m_begin + p.chunk : p.M;
+  const int slabs = (int)((m_end - m_begin + XBK - 1) / XBK);
+  // loader roles: lane -> (column quad lane & 7, row quad lane >> 3), wave -> column octet; 64-wide operands take two
+  // waves (Z waves 0-1, G the other pair when both are narrow).  An idle role loads from beyond the buffer: zeros, no
+  // traffic, and no load sits under a condition (the compiler would wait for ALL outstanding loads at the next use)
+  const int mg = lane >> 3;
+  const bool z_act = IC == 2 || wave < 2;
+  const bool g_act = JC == 2 || (IC == 2 ? wave < 2 : wave >= 2);
+  const int zq = 8 * (wave & (IC == 2 ? 3 : 1)) + (lane & 7);
+  const int gq = 8 * (wave & (JC == 2 ? 3 : 1)) + (lane & 7);
+  const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Z), 0, (int)(p.M * K * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.G), 0, (int)(p.M * N * 4), 0x00020000);
+  const unsigned row0 = (unsigned)(m_begin + 4 * mg);
+  unsigned zoff = z_act ? (row0 * (unsigned)K + (unsigned)(k0 + 4 * zq)) * 4u : 0x80000000u;
+  unsigned goff = g_act ? (row0 * (unsigned)N + (unsigned)(n0 + 4 * gq)) * 4u : 0x80000000u;
+  const int z_st = (4 * zq) * XBK + 4 * (mg & 1), g_st = (4 * gq) * XBK + 4 * (mg & 1);   // + row j, + swizzled chunk
+  const int z_ch = ((mg >> 1) ^ (zq & 3)) << 3, g_ch = ((mg >> 1) ^ (gq & 3)) << 3;      // (row >> 2) & 3 = quad & 3
+  float4 rz[4], rg[4];
+  auto g_load = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rsZ, zoff + (unsigned)(i * K * 4), 0, 0);
+      rz[i] = make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rsG, goff + (unsigned)(i * N * 4), 0, 0);
+      rg[i] = make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w));
+    }
+    zoff += (unsigned)(XBK * K * 4);
+    goff += (unsigned)(XBK * N * 4);
+  };
+  auto t_store = [&](const float4* rr, __bf16* sX, const int PL, const int st, const int ch) {
+    const float v[4][4] = {{rr[0].x, rr[0].y, rr[0].z, rr[0].w}, {rr[1].x, rr[1].y, rr[1].z, rr[1].w},
+                           {rr[2].x, rr[2].y, rr[2].z, rr[2].w}, {rr[3].x, rr[3].y, rr[3].z, rr[3].w}};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                    // column j of the block: its four rows are consecutive m
+      bf16x4 hi, mid, lo;
+      split4(make_float4(v[0][j], v[1][j], v[2][j], v[3][j]), hi, mid, lo);
+      const int off = st + j * XBK + ch;
+      *reinterpret_cast<bf16x4*>(sX + off) = hi;
+      *reinterpret_cast<bf16x4*>(sX + PL + off) = mid;
+      *reinterpret_cast<bf16x4*>(sX + 2 * PL + off) = lo;
+    }
+  };
+  auto s_store = [&]() {
+    if (z_act) t_store(rz, sA, PLA, z_st, z_ch);
+    if (g_act) t_store(rg, sB, PLB, g_st, g_ch);
+  };
+  f32x16 acc[IC][JC];
+#pragma unroll
+  for (int i = 0; i < IC; ++i)
+#pragma unroll
+    for (int j = 0; j < JC; ++j)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+  const int fa = (wm * 32 * IC + r) * XBK, fb = (wn * 32 * JC + r) * XBK;
+  const int sw = (r >> 2) & 3;
+  const int c0 = ((0 + h) ^ sw) << 3, c1 = ((2 + h) ^ sw) << 3;
+  auto products = [&]() {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int cs = s ? c1 : c0;
+      bf16x8 b[JC][3];
+#pragma unroll
+      for (int j = 0; j < JC; ++j)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) b[j][pl] = *reinterpret_cast<const bf16x8*>(sB + pl * PLB + fb + 32 * j * XBK + cs);
+#pragma unroll
+      for (int i = 0; i < IC; ++i) {
+        bf16x8 a[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const bf16x8*>(sA + pl * PLA + fa + 32 * i * XBK + cs);
+#pragma unroll
+        for (int j = 0; j < JC; ++j) {               // smallest products first, as in the forward kernel
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[j][2], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[j][1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[j][1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[j][0], acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+  };
+  g_load();
+  s_store();
+  __syncthreads();
+  for (int g = 0; g < slabs - 1; ++g) {
+    g_load();                                        // slab g + 1
+    products();
+    __syncthreads();                                 // every wave has read slab g
+    s_store();
+    __syncthreads();
+  }
+  products();
+  float* out = p.ws + sp * ((int64_t)K * N);
+#pragma unroll
+  for (int i = 0; i < IC; ++i)
+#pragma unroll
+    for (int j = 0; j < JC; ++j)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int row = k0 + wm * 32 * IC + 32 * i + (v & 3) + 8 * (v >> 2) + 4 * h;
+        const int col = n0 + wn * 32 * JC + 32 * j + r;
+        out[(int64_t)row * N + col] = acc[i][j][v];
+      }
+}
+
+struct T3Plan {
+  int ic, jc, tiles, n_tiles, S;
+  int64_t chunk;
+};
+T3Plan t3_plan(int64_t M, int K, int N) {
+  T3Plan pl;
+  pl.ic = K % 128 == 0 ? 2 : 1;
+  pl.jc = N % 128 == 0 ? 2 : 1;
+  pl.n_tiles = N / (64 * pl.jc);
+  pl.tiles = (K / (64 * pl.ic)) * pl.n_tiles;
+  const int slots = (pl.ic * pl.jc == 4) ? 768 : 1024;   // three / four workgroups per CU
+  int64_t S = slots / pl.tiles;
+  const int64_t maxS = M / 64 > 1 ? M / 64 : 1;          // at least two 32-row slabs per item
+  if (S > maxS) S = maxS;
+  if (S < 1) S = 1;
+  pl.chunk = ceil_div64(ceil_div64(M, S), XBK) * XBK;
+  pl.S = (int)ceil_div64(M, pl.chunk);
+  return pl;
+}
+
 // up to KWS_SPLIT_BATCH f32 matrices [rows][cols] -> bf16 planes [3][rows][cols] (or of the transpose: [3][cols][rows])
 constexpr int KWS_SPLIT_BATCH = 24;
 constexpr int PFD = 1;   // A slabs in flight per workgroup (2: measured slower - only two workgroups fit a CU)
@@ -468,4 +632,32 @@ extern "C" int kws_gemm_nn_bf16x3p_f32(const float* A, const void* Bp, float* C,
   }
   KWS_LAUNCH_CHECK("gemm_nn_bf16x3p_kernel");
   return KWS_OK;
+}
+
+// dW[K,N] = Z[M,K]^T . G[M,N] in the bf16 x 3 arithmetic (K, N multiples of 64); workspace:
+// kws_gemm_tn_bf16x3_workspace_floats(M, K, N) floats of partial slabs
+extern "C" int64_t kws_gemm_tn_bf16x3_workspace_floats(int64_t M, int K, int N) {
+  if (M <= 0 || K <= 0 || N <= 0 || K % 64 || N % 64) return 0;
+  return (int64_t)t3_plan(M, K, N).S * K * N;
+}
+
+extern "C" int kws_gemm_tn_bf16x3_f32(const float* Z, const float* G, float* dW, int64_t M, int K, int N, float* workspace,
+                                      void* stream) {
+  KWS_REQUIRE(Z && G && dW && workspace && M > 0, "gemm_tn_bf16x3: bad arguments");
+  KWS_REQUIRE(K > 0 && N > 0 && K % 64 == 0 && N % 64 == 0, "gemm_tn_bf16x3: K=%d N=%d must be multiples of 64", K, N);
+  KWS_REQUIRE(M * (int64_t)std::max(K, N) * 4 < (1ll << 31), "gemm_tn_bf16x3: operand of %lld rows exceeds the 2 GB buffer view", (long long)M);
+  const T3Plan pl = t3_plan(M, K, N);
+  T3Args p;
+  p.Z = Z; p.G = G; p.ws = workspace; p.M = M; p.chunk = pl.chunk; p.K = K; p.N = N; p.n_tiles = pl.n_tiles; p.tiles = pl.tiles;
+  p.items = (int64_t)pl.tiles * pl.S;
+  p.per_xcd = ceil_div64(p.items, 8);
+  const dim3 grid((unsigned)(p.per_xcd * 8)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  KwsProfScope prof("gemm_tn_bf16x3", 2.0 * M * K * N, 4.0 * ((double)M * K + (double)M * N + (double)K * N), st);
+  if (pl.ic == 2 && pl.jc == 2) hipLaunchKernelGGL((gemm_tn_bf16x3_kernel<2, 2>), grid, block, 0, st, p);
+  else if (pl.ic == 2) hipLaunchKernelGGL((gemm_tn_bf16x3_kernel<2, 1>), grid, block, 0, st, p);
+  else if (pl.jc == 2) hipLaunchKernelGGL((gemm_tn_bf16x3_kernel<1, 2>), grid, block, 0, st, p);
+  else hipLaunchKernelGGL((gemm_tn_bf16x3_kernel<1, 1>), grid, block, 0, st, p);
+  KWS_LAUNCH_CHECK("gemm_tn_bf16x3_kernel");
+  return kws_reduce_slabs_f32(workspace, dW, (int64_t)K * N, pl.S, st);
 }

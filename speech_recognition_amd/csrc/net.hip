@@ -201,7 +201,8 @@ void make_layout(const kws_net* n, int B, bool training, Layout* lo) {
     if (p > max_part) max_part = p;
     const int64_t dp = kws_dwconv_bwd_part_floats(B, b.Lin, b.cin);
     if (dp > max_dwpart) max_dwpart = dp;
-    const int64_t t = kws_gemm_tn_workspace_floats(M, b.cin, b.cout);
+    const int64_t t = std::max(kws_gemm_tn_workspace_floats(M, b.cin, b.cout),
+                               kws_gemm_tn_bf16x3_workspace_floats(M, b.cin, b.cout));   // either arithmetic (run-time switch)
     if (t > max_tn) max_tn = t;
     if (b.cout > maxC) maxC = b.cout;
   }
@@ -435,7 +436,7 @@ static int ts_train(const kws_net_t* net, const float* params, float* state, con
 
   const bool run_head = phase != 2;                   // forward + tail + the late blocks' backward
   // KWS_GEMM_BF16X3=1 (A/B experiment, gemm_bf16x3.hip): the pointwise forward and input-gradient GEMMs run as six bf16
-  // MFMA products of three-way operand splits instead of f32 MFMAs; weight gradients and the first convolution stay f32
+  // MFMA products of three-way operand splits instead of f32 MFMAs (weight gradients too); the first convolution stays f32
   const bool x3 = kws_net_get_gemm_mode() == 1;
   auto transpose_all = [&]() -> int {   // the pointwise kernels [cin][cout] -> [cout][cin]: all of them in one launch
     static_assert(KWS_TRANSPOSE_BATCH >= 11, "one batch holds every block");
@@ -557,7 +558,10 @@ static int ts_train(const kws_net_t* net, const float* params, float* state, con
       KWS_HIP(hipEventRecord(net->ev_join, net->side));
       KWS_HIP(hipStreamWaitEvent(st, net->ev_join, 0));
     }
-    KWS_TRY(kws_gemm_tn_f32(ws + lo.z[i], Gcur, grads + b.pw, M, b.cin, b.cout, ws + lo.tn, sw));
+    if (x3 && b.cin % 64 == 0 && b.cout % 64 == 0)
+      KWS_TRY(kws_gemm_tn_bf16x3_f32(ws + lo.z[i], Gcur, grads + b.pw, M, b.cin, b.cout, ws + lo.tn, sw));
+    else
+      KWS_TRY(kws_gemm_tn_f32(ws + lo.z[i], Gcur, grads + b.pw, M, b.cin, b.cout, ws + lo.tn, sw));
     if (ov) {
       KWS_HIP(hipEventRecord(net->ev_wgrad[(i + 1) % 2], sw));
       wgrad_pending[(i + 1) % 2] = true;

@@ -45,3 +45,31 @@ def test_bf16x3_matches_float64_as_well_as_the_f32_kernel(M, K, N):
         print("M=%d K=%d N=%d: bf16x3 %.2e, f32 MFMA %.2e of the maximum" % (M, K, N, e3, e1))
         assert e3 < max(2.0 * e1, 4e-7)
     assert e3 < 1e-6                 # the f32 kernels' own test bar (tests/test_kernels_gpu.py)
+
+
+@pytest.mark.parametrize("M,K,N", [(64, 128, 128), (100, 64, 64), (4099, 192, 192), (3000, 320, 384), (9216, 512, 512),
+                                   (50001, 256, 320), (777, 384, 128), (33, 128, 192)])
+def test_bf16x3_weight_gradient_matches_float64_as_well_as_the_f32_kernel(M, K, N):
+    g = torch.Generator(device="cuda")
+    g.manual_seed(M + N)
+    Z = torch.randn((M, K), generator=g, device="cuda") * 1.3
+    G = torch.randn((M, N), generator=g, device="cuda") * 0.2
+    Z[0, :3] = torch.tensor([1e-30, -3e4, 1.0 + 2.0 ** -20], device="cuda")
+    lib = _lib.load()
+    ws3 = torch.empty(lib.kws_gemm_tn_bf16x3_workspace_floats(M, K, N), device="cuda")
+    D3 = torch.full((K, N), float("nan"), device="cuda")
+    _lib.call("kws_gemm_tn_bf16x3_f32", _lib.ptr(Z), _lib.ptr(G), _lib.ptr(D3), M, K, N, _lib.ptr(ws3), _lib.stream_ptr())
+    ref = Z.double().t() @ G.double()
+    scale = float(ref.abs().max())
+    e3 = float((D3.double() - ref).abs().max()) / scale
+    assert torch.isfinite(D3).all()
+    ws1 = torch.empty(lib.kws_gemm_tn_workspace_floats(M, K, N), device="cuda")
+    D1 = torch.empty((K, N), device="cuda")
+    _lib.call("kws_gemm_tn_f32", _lib.ptr(Z), _lib.ptr(G), _lib.ptr(D1), M, K, N, _lib.ptr(ws1), _lib.stream_ptr())
+    e1 = float((D1.double() - ref).abs().max()) / scale
+    print("M=%d K=%d N=%d: bf16x3 %.2e, f32 MFMA %.2e of the maximum" % (M, K, N, e3, e1))
+    assert e3 < max(2.0 * e1, 4e-7)
+    assert e3 < 2e-6
+    D3b = torch.empty((K, N), device="cuda")        # bit-reproducible: fixed split and summation order
+    _lib.call("kws_gemm_tn_bf16x3_f32", _lib.ptr(Z), _lib.ptr(G), _lib.ptr(D3b), M, K, N, _lib.ptr(ws3), _lib.stream_ptr())
+    assert torch.equal(D3, D3b)
