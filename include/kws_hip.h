@@ -191,17 +191,11 @@ int kws_stft_num_frames(const kws_stft_plan_t* plan, int L);
 int kws_stft_mel_f32(const kws_stft_plan_t* plan, const float* x, int B, int L, float* out,
                      int out_kind, void* stream);
 
-/* EXPERIMENT (A/B measurement, not called by the network programs): the same product with every f32 operand split
- * into three bf16 parts and six bf16 MFMA products accumulated in f32 - as accurate as the f32 matrix pipe, not
- * bit-identical to it.  C[M,N] = A[M,K] . Bt[N,K]^T (Bt = the kernel stored [out][in]).  K % 32 == 0.  stats_part
- * (may be NULL): [rows][2][N] column sums / sums of squares as kws_gemm_nn_f32 writes them.  KWS_GEMM_BF16X3=1 makes
- * the raw-waveform net's training step take this kernel for its forward and input-gradient GEMMs (A/B runs). */
+/* EXPERIMENT (A/B arm, off by default): the pointwise GEMMs with every f32 operand split into three bf16 parts and six
+ * bf16 MFMA products accumulated in f32 - as accurate as the f32 matrix pipe, not bit-identical to it (csrc/gemm_bf16x3.hip,
+ * DESIGN.md section 5).  KWS_GEMM_BF16X3=1 at start, or kws_net_set_gemm_mode(1) at run time, makes the raw-waveform
+ * net's training step take these kernels for its forward, input-gradient and weight-gradient GEMMs. */
 int kws_gemm_nn_bf16x3_stats_rows(int64_t M);   /* rows of stats_part: one per 128-row tile */
-int kws_gemm_nn_bf16x3_f32(const float* A, const float* Bt, float* C, int64_t M, int K, int N,
-                           float* stats_part, void* stream);
-/* second form: the small operand split once into bf16 planes.  kws_bf16x3_split_batch: count <= 24 f32 matrices
- * [rows][cols] -> out[i] = bf16 [3][rows][cols] (hi, mid, lo), or of the transposed matrix ([3][cols][rows]) where
- * transpose[i] != 0; kws_gemm_nn_bf16x3p_f32: C[M,N] = A[M,K] . B with Bp = the planes of B stored [N][K]. */
 int kws_net_get_gemm_mode(void);   /* 0 = f32 MFMA (default), 1 = the bf16 x 3 experiment (KWS_GEMM_BF16X3 at start) */
 int kws_net_set_gemm_mode(int mode);
 int kws_bf16x3_split_batch(const float* const* in, void* const* out, const int* rows, const int* cols,

@@ -104,7 +104,6 @@ SIGNATURES = {
     "kws_gemm_gather_stats_rows": (_I, [_I64]),
     "kws_gemm_nn_f32": (_I, [_P, _P, _P, _I64, _I, _I, _P, _P]),
     "kws_gemm_nn_bf16x3_stats_rows": (_I, [_I64]),
-    "kws_gemm_nn_bf16x3_f32": (_I, [_P, _P, _P, _I64, _I, _I, _P, _P]),
     "kws_net_get_gemm_mode": (_I, []),
     "kws_net_set_gemm_mode": (_I, [_I]),
     "kws_bf16x3_split_batch": (_I, [_P, _P, _P, _P, _P, _I, _P]),

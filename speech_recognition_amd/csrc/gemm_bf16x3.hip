@@ -1,17 +1,18 @@
-// EXPERIMENT (A/B arm, not on the product path): the pointwise 1x1 convolution GEMM with every f32 operand split into
-// three bf16 parts (x = hi + mid + lo, 24 mantissa bits in all) and six bf16 MFMA products accumulated in f32:
+// EXPERIMENT (A/B arm, not the product default: KWS_GEMM_BF16X3=1 / kws_net_set_gemm_mode(1)): the pointwise 1x1
+// convolution GEMMs with every f32 operand split into three bf16 parts (x = hi + mid + lo, 24 mantissa bits in all) and
+// six bf16 MFMA products accumulated in f32:
 //     C = sum_{(p,q) in {lo.hi, hi.lo, mid.mid, mid.hi, hi.mid, hi.hi}} A_p . B_q
 // The f32 matrix pipe runs at 1/16 of the bf16 rate (MI355X_MICROARCH.md), so six bf16 products cost 3/8 of one f32
 // product; the result is as close to the exact product as the f32 MFMA's (measured against float64 in
 // tests/test_bf16x3_gpu.py; NumPy study: 2.8e-7 of the maximum against 6.5e-7 for an f32 matmul).  It is NOT bit-identical
-// to the f32-MFMA kernels, which stay the default: this file exists to measure what the split would buy.
+// to the f32-MFMA kernels, which stay the default (DESIGN.md 5 has the measurements: x1.4 - x1.5 per kernel, the chip
+// holds 1.4 - 1.5 GHz under these loops, so the split is bounded by power, not by the 8/3 of its instruction count).
 //
-//   kws_gemm_nn_bf16x3_f32:  C[M,N] = A[M,K] . Bt[N,K]^T  (+ optional BatchNorm column sums per 128-row tile)       (Bt = the kernel stored [out][in]: k is contiguous for both
-//                                                                 operands, so both are split and staged the same way)
-// 128 x 128 tile per 256-thread workgroup (2 x 2 waves of 64 x 64), K slabs of 32: f32 slab -> registers -> split
-// (v_cvt_pk_bf16_f32: round to nearest even; the residuals are exact in f32) -> three bf16 planes in LDS
-// ([plane][row][32 + 8 pad]: a fragment is one 16-byte read, 16 consecutive rows fall on disjoint banks) ->
-// v_mfma_f32_32x32x16_bf16.  One LDS buffer (60 KB: two workgroups per CU) with the next slab prefetched into registers.
+//   kws_bf16x3_split_batch    f32 matrices -> bf16 planes [3][rows][cols] (the pointwise kernels, once per step)
+//   kws_gemm_nn_bf16x3p_f32   C[M,N] = A[M,K] . B, B as planes of [N][K]  (+ BatchNorm column sums per 128-row tile)
+//   kws_gemm_tn_bf16x3_f32    dW[K,N] = Z[M,K]^T . G[M,N]
+// 256-thread workgroups (2 x 2 waves), K slabs of 32: f32 slab -> registers -> split (v_cvt_pk_bf16_f32: round to
+// nearest even; the residuals are exact in f32) -> three bf16 planes in LDS -> v_mfma_f32_32x32x16_bf16.
 #include "internal.h"
 #include <algorithm>
 #include <cstring>
@@ -23,17 +24,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int XBM = 128, XBN = 128, XBK = 32;
-constexpr int XLD = XBK + 8;                         // bf16 row stride of a plane
-constexpr int XPLANE = XBM * XLD;                    // bf16 elements per plane (A and B tiles have the same shape)
-
-struct X3Args {
-  const float* A;
-  const float* Bt;
-  float* C;
-  float* stats;      // [ceil(M / 128)][2][N] column sums / sums of squares per row tile, or NULL
-  int64_t M;
-  int K, N;
-};
 
 // x -> (hi, mid, lo) per component of a float4, each plane as 4 packed bf16
 __device__ __forceinline__ void split4(const float4 v, bf16x4& hi, bf16x4& mid, bf16x4& lo) {
@@ -50,142 +40,31 @@ __device__ __forceinline__ void split4(const float4 v, bf16x4& hi, bf16x4& mid, 
   }
 }
 
-template <bool STATS>
-__global__ __launch_bounds__(256, 2) void gemm_nn_bf16x3_kernel(X3Args p) {
-  __shared__ __attribute__((aligned(16))) __bf16 smem[2 * 3 * XPLANE];   // A planes then B planes: 61,440 B
-  __bf16* sA = smem;
-  __bf16* sB = smem + 3 * XPLANE;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int r = lane & 31, h = lane >> 5;
-  const int K = p.K, N = p.N;
-  const int64_t M = p.M;
-  const int n_tiles = (N + XBN - 1) / XBN;          // a ragged last column tile computes on clamped rows of Bt, stores masked
-  const int64_t tile_m = blockIdx.x / n_tiles;
-  const int tile_n = blockIdx.x % n_tiles;
-  const int64_t m0 = tile_m * XBM;
-  const int n0 = tile_n * XBN;
-  // loader role: thread t moves float4 c4 = t % 8 of rows t / 8 + 32 i
-  const int lrow = tid >> 3, lc4 = tid & 7;
-  const float* gA[4];
-  const float* gB[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int64_t ra = m0 + lrow + 32 * i;
-    if (ra >= M) ra = M - 1;                         // rows past M: a valid address, their results are not stored
-    gA[i] = p.A + ra * K + 4 * lc4;
-    int rb = n0 + lrow + 32 * i;
-    if (rb >= N) rb = N - 1;
-    gB[i] = p.Bt + (int64_t)rb * K + 4 * lc4;
-  }
-  float4 ra4[4], rb4[4];
-  auto g_load = [&](int k0) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      ra4[i] = *reinterpret_cast<const float4*>(gA[i] + k0);
-      rb4[i] = *reinterpret_cast<const float4*>(gB[i] + k0);
-    }
-  };
-  auto s_store = [&]() {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      bf16x4 hi, mid, lo;
-      const int off = (lrow + 32 * i) * XLD + 4 * lc4;
-      split4(ra4[i], hi, mid, lo);
-      *reinterpret_cast<bf16x4*>(sA + off) = hi;
-      *reinterpret_cast<bf16x4*>(sA + XPLANE + off) = mid;
-      *reinterpret_cast<bf16x4*>(sA + 2 * XPLANE + off) = lo;
-      split4(rb4[i], hi, mid, lo);
-      *reinterpret_cast<bf16x4*>(sB + off) = hi;
-      *reinterpret_cast<bf16x4*>(sB + XPLANE + off) = mid;
-      *reinterpret_cast<bf16x4*>(sB + 2 * XPLANE + off) = lo;
-    }
-  };
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
-
-  const int G = K / XBK;
-  g_load(0);
-  s_store();
-  __syncthreads();
-  for (int g = 0; g < G; ++g) {
-    if (g + 1 < G) g_load((g + 1) * XBK);
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      bf16x8 a[2][3], b[2][3];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
-          a[i][pl] = *reinterpret_cast<const bf16x8*>(sA + pl * XPLANE + (wm * 64 + 32 * i + r) * XLD + 16 * s + 8 * h);
-          b[i][pl] = *reinterpret_cast<const bf16x8*>(sB + pl * XPLANE + (wn * 64 + 32 * i + r) * XLD + 16 * s + 8 * h);
-        }
-      // smallest products first: lo.hi, hi.lo, mid.mid, mid.hi, hi.mid, hi.hi
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
-        }
-    }
-    __syncthreads();                                 // every wave has read this slab's planes
-    if (g + 1 < G) s_store();
-    __syncthreads();
-  }
-  // C[row][col]: lane -> col = l & 31, register v -> row = (v & 3) + 8 (v >> 2) + 4 (l >> 5): a store instruction
-  // writes two full 128-byte row segments
-  float cs[2] = {0.f, 0.f}, css[2] = {0.f, 0.f};
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        const int64_t row = m0 + wm * 64 + 32 * i + (v & 3) + 8 * (v >> 2) + 4 * h;
-        const int col = n0 + wn * 64 + 32 * j + r;
-        const float c = acc[i][j][v];
-        if (row < M && col < N) p.C[row * N + col] = c;
-        if (STATS && row < M) {                      // BatchNorm column sums in a fixed order: rows of the lane, then
-          cs[j] += c;                                // the two lane halves, then the two row waves
-          css[j] = fmaf(c, c, css[j]);
-        }
-      }
-  if (STATS) {
-    float* red = reinterpret_cast<float*>(smem);     // [2 wm][2 q][128]: the planes are dead after the last barrier
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const float s2 = cs[j] + __shfl_xor(cs[j], 32), q2 = css[j] + __shfl_xor(css[j], 32);
-      if (h == 0) {
-        red[(wm * 2 + 0) * 128 + wn * 64 + 32 * j + r] = s2;
-        red[(wm * 2 + 1) * 128 + wn * 64 + 32 * j + r] = q2;
-      }
-    }
-    __syncthreads();
-    const int q = tid >> 7, col = tid & 127;         // 256 threads: (sum | sum of squares) x 128 columns
-    if (n0 + col < N) p.stats[((int64_t)tile_m * 2 + q) * N + n0 + col] = red[(0 * 2 + q) * 128 + col] + red[(1 * 2 + q) * 128 + col];
-  }
-}
-
-
 // ---------------------------------------------------------------------------------------------------------------------
-// Second form: the small operand (the pointwise kernel) is split ONCE per step into three bf16 planes
+// Forward / input gradient: the small operand (the pointwise kernel) is split ONCE per step into three bf16 planes
 // (split_planes_kernel), so the GEMM's staging pass splits only the activation slab; the LDS image is unpadded
 // ([plane][row][32 k] bf16 = 64-byte rows, the 16-byte chunk index XOR-ed with (row >> 2) & 3: conflict-free for the
 // lane groups of ds_read_b128 and for the 8- / 16-byte stores, MI355X_MICROARCH.md LDS table), which makes a slab 48 KB:
 // three workgroups per CU, one staging / MFMA phase of each in flight beside the others'.  Workgroup ids are dealt to
 // the XCDs round-robin by the hardware; the id -> tile map below hands every XCD a contiguous range of tiles, so the
 // column tiles that share a 128-row slab of A run on ONE XCD's L2 at about the same time (A comes from HBM once).
+// -DKWS_X3_STAMP builds (scripts/build_variant.sh x3stamp "-DKWS_X3_STAMP" gemm_bf16x3; scripts/stamps_x3.py): wave 0 of
+// the first 2048 tiles accumulates s_memtime deltas: [0] entry -> first slab staged, [1] products, [2] barrier after the
+// products, [3] wait for the next slab + split + store, [4] barrier after the store, [5] epilogue, [6] cycles, [7] 100 MHz ticks
+#ifdef KWS_X3_STAMP
+__device__ unsigned long long g_x3_stamps[2048][8];
+extern "C" int kws_debug_read_x3_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_x3_stamps), sizeof(g_x3_stamps));
+}
+#define X3_DECL unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_mark = __builtin_amdgcn_s_memtime(); \
+  const unsigned long long st_t0 = st_mark, st_r0 = __builtin_amdgcn_s_memrealtime();
+#define X3_ST(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long n_ = __builtin_amdgcn_s_memtime(); \
+  st_acc[i] += n_ - st_mark; st_mark = n_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define X3_DECL
+#define X3_ST(i)
+#endif
+
 struct P3Args {
   const float* A;
   const __bf16* Bp;  // [3][N][K]
@@ -198,8 +77,8 @@ struct P3Args {
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * XBK + ((chunk ^ ((row >> 2) & 3)) << 3); }
 
-template <bool STATS, int PF, int ABL = 0>
-__global__ __launch_bounds__(256, PF == 2 ? 2 : 3) void gemm_nn_bf16x3p_kernel(P3Args p) {
+template <bool STATS>
+__global__ __launch_bounds__(256, 3) void gemm_nn_bf16x3p_kernel(P3Args p) {
   __shared__ __attribute__((aligned(16))) __bf16 smem[6 * XBM * XBK];   // A planes, B planes: 49,152 B
   constexpr int PL = XBM * XBK;
   __bf16* sA = smem;
@@ -236,23 +115,21 @@ __global__ __launch_bounds__(256, PF == 2 ? 2 : 3) void gemm_nn_bf16x3p_kernel(P
   }
   const int a_off = swz(lrow, lc4 >> 1) + 4 * (lc4 & 1);     // + 32 i rows: (row >> 2) & 3 does not change
   const int b_off = swz(brow, bch);
-  float4 ra4[PF][4];
+  float4 ra4[4];
   bf16x8 rb8[2][3];
-  auto ga_load = [&](int slot, int k0) {
+  auto g_load = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ra4[slot][i] = *reinterpret_cast<const float4*>(gA[i] + k0);
-  };
-  auto gb_load = [&](int k0) {
+    for (int i = 0; i < 4; ++i) ra4[i] = *reinterpret_cast<const float4*>(gA[i] + k0);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) rb8[i][pl] = *reinterpret_cast<const bf16x8*>(gB[i] + pl * p.plane_stride + k0);
   };
-  auto s_store = [&](int slot) {
+  auto s_store = [&]() {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       bf16x4 hi, mid, lo;
-      split4(ra4[slot][i], hi, mid, lo);
+      split4(ra4[i], hi, mid, lo);
       const int off = a_off + 32 * i * XBK;
       *reinterpret_cast<bf16x4*>(sA + off) = hi;
       *reinterpret_cast<bf16x4*>(sA + PL + off) = mid;
@@ -276,21 +153,14 @@ __global__ __launch_bounds__(256, PF == 2 ? 2 : 3) void gemm_nn_bf16x3p_kernel(P
   const int c0 = ((0 + h) ^ sw) << 3, c1 = ((2 + h) ^ sw) << 3;
 
   const int G = K / XBK;
-  ga_load(0, 0);
-  gb_load(0);
-  if (PF == 2 && G > 1) ga_load(1, XBK);
-  s_store(0);
+  X3_DECL
+  g_load(0);
+  s_store();
   __syncthreads();
-  // slots and the two "more slabs follow" flags are compile-time constants at the call sites: loads under a runtime
-  // condition make the compiler wait for every outstanding load at the next use (its counter model merges the paths)
-  auto slab = [&](int g, const int slot_cur, const int slot_next, const bool more1, const bool more2) {
-    if (more1 && ABL != 3 && ABL != 5) gb_load((g + 1) * XBK);
-    if (PF == 2) {                                   // slab g + 2 into the slot slab g has just left
-      if (more2) ga_load(slot_cur, (g + 2) * XBK);
-    } else if (more1 && ABL != 2 && ABL != 5) ga_load(0, (g + 1) * XBK);
-    if (PF == 2) __builtin_amdgcn_sched_barrier(0);  // the requests go out HERE, not where the scheduler finds room
+  X3_ST(0);
+  auto products = [&]() {
 #pragma unroll
-    for (int s = 0; s < (ABL == 1 ? 0 : 2); ++s) {
+    for (int s = 0; s < 2; ++s) {
       const int cs = s ? c1 : c0;
       bf16x8 b[2][3];
 #pragma unroll
@@ -314,24 +184,24 @@ __global__ __launch_bounds__(256, PF == 2 ? 2 : 3) void gemm_nn_bf16x3p_kernel(P
         }
       }
     }
-    if (PF == 2) __builtin_amdgcn_sched_barrier(0);  // ... and their results are first touched after the products
-    __syncthreads();                                 // every wave has read this slab's planes
-    if (more1) {
-      s_store(slot_next);
-      __syncthreads();
-    }
+#ifdef KWS_X3_STAMP
+    asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[1][1][15]));
+#endif
+    X3_ST(1);
   };
-  if (PF == 2) {                                     // G is even (K % 64 == 0 on this path)
-    for (int g = 0; g < G - 2; g += 2) {
-      slab(g, 0, 1, true, true);
-      slab(g + 1, 1, 0, true, true);
-    }
-    slab(G - 2, 0, 1, true, false);
-    slab(G - 1, 1, 0, false, false);
-  } else {
-    for (int g = 0; g < G - 1; ++g) slab(g, 0, 0, true, false);
-    slab(G - 1, 0, 0, false, false);
+  // the last slab is peeled: a load under a runtime condition makes the compiler wait for EVERY outstanding load at
+  // the next use (its counter model merges the two paths)
+  for (int g = 0; g < G - 1; ++g) {
+    g_load((g + 1) * XBK);
+    products();
+    __syncthreads();                                 // every wave has read this slab's planes
+    X3_ST(2);
+    s_store();
+    X3_ST(3);
+    __syncthreads();
+    X3_ST(4);
   }
+  products();
   float cs[2] = {0.f, 0.f}, css[2] = {0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -342,8 +212,9 @@ __global__ __launch_bounds__(256, PF == 2 ? 2 : 3) void gemm_nn_bf16x3p_kernel(P
         const int64_t row = m0 + wm * 64 + 32 * i + (v & 3) + 8 * (v >> 2) + 4 * h;
         const int col = n0 + wn * 64 + 32 * j + r;
         const float c = acc[i][j][v];
-        if (row < M && col < N && (ABL != 4 || c == 123.f)) p.C[row * N + col] = c;
-        if (STATS && row < M) {                      // the same fixed order as the first form
+        if (row < M && col < N) p.C[row * N + col] = c;
+        if (STATS && row < M) {                      // BatchNorm column sums in a fixed order: rows of the lane, then
+                                                     // the two lane halves, then the two row waves
           cs[j] += c;
           css[j] = fmaf(c, c, css[j]);
         }
@@ -362,6 +233,14 @@ __global__ __launch_bounds__(256, PF == 2 ? 2 : 3) void gemm_nn_bf16x3p_kernel(P
     const int qq = tid >> 7, col = tid & 127;
     if (n0 + col < N) p.stats[((int64_t)tile_m * 2 + qq) * N + n0 + col] = red[(0 * 2 + qq) * 128 + col] + red[(1 * 2 + qq) * 128 + col];
   }
+#ifdef KWS_X3_STAMP
+  X3_ST(5);
+  if (tid == 0 && q < 2048) {
+    for (int i = 0; i < 6; ++i) g_x3_stamps[q][i] = st_acc[i];
+    g_x3_stamps[q][6] = __builtin_amdgcn_s_memtime() - st_t0;
+    g_x3_stamps[q][7] = __builtin_amdgcn_s_memrealtime() - st_r0;
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -530,7 +409,6 @@ T3Plan t3_plan(int64_t M, int K, int N) {
 
 // up to KWS_SPLIT_BATCH f32 matrices [rows][cols] -> bf16 planes [3][rows][cols] (or of the transpose: [3][cols][rows])
 constexpr int KWS_SPLIT_BATCH = 24;
-constexpr int PFD = 1;   // A slabs in flight per workgroup (2: measured slower - only two workgroups fit a CU)
 struct SplitBatch {
   const float* in[KWS_SPLIT_BATCH];
   __bf16* out[KWS_SPLIT_BATCH];
@@ -566,20 +444,6 @@ __global__ __launch_bounds__(256) void split_planes_kernel(SplitBatch b) {
 
 extern "C" int kws_gemm_nn_bf16x3_stats_rows(int64_t M) { return (int)ceil_div64(M, XBM); }
 
-extern "C" int kws_gemm_nn_bf16x3_f32(const float* A, const float* Bt, float* C, int64_t M, int K, int N, float* stats_part,
-                                      void* stream) {
-  KWS_REQUIRE(A && Bt && C && M > 0, "gemm_nn_bf16x3: bad arguments");
-  KWS_REQUIRE(K >= XBK && K % XBK == 0 && N > 0, "gemm_nn_bf16x3: K=%d must be a multiple of %d (N=%d)", K, XBK, N);
-  const int64_t grid = ceil_div64(M, XBM) * ((N + XBN - 1) / XBN);
-  KWS_REQUIRE(grid <= 0x7FFFFFFF, "gemm_nn_bf16x3: grid out of range");
-  X3Args p{A, Bt, C, stats_part, M, K, N};
-  KwsProfScope prof("gemm_nn_bf16x3", 2.0 * M * K * N, 4.0 * ((double)M * K + (double)K * N + (double)M * N), (hipStream_t)stream);
-  if (stats_part) hipLaunchKernelGGL(gemm_nn_bf16x3_kernel<true>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(gemm_nn_bf16x3_kernel<false>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p);
-  KWS_LAUNCH_CHECK("gemm_nn_bf16x3_kernel");
-  return KWS_OK;
-}
-
 // f32 [rows][cols] -> three bf16 planes [3][rows][cols] (transpose[i] != 0: of the transposed matrix, [3][cols][rows]);
 // count <= 24 matrices in one launch.  The planes are what kws_gemm_nn_bf16x3p_f32 reads as its small operand.
 extern "C" int kws_bf16x3_split_batch(const float* const* in, void* const* out, const int* rows, const int* cols,
@@ -599,8 +463,8 @@ extern "C" int kws_bf16x3_split_batch(const float* const* in, void* const* out, 
   return KWS_OK;
 }
 
-// C[M,N] = A[M,K] . B  with B given as the planes of [N][K] (kws_bf16x3_split_batch); stats_part as in
-// kws_gemm_nn_bf16x3_f32 (kws_gemm_nn_bf16x3_stats_rows rows)
+// C[M,N] = A[M,K] . B  with B given as the planes of [N][K] (kws_bf16x3_split_batch); stats_part (may be NULL):
+// [kws_gemm_nn_bf16x3_stats_rows(M)][2][N] column sums / sums of squares per 128-row tile
 extern "C" int kws_gemm_nn_bf16x3p_f32(const float* A, const void* Bp, float* C, int64_t M, int K, int N, float* stats_part,
                                        void* stream) {
   KWS_REQUIRE(A && Bp && C && M > 0, "gemm_nn_bf16x3p: bad arguments");
@@ -614,22 +478,8 @@ extern "C" int kws_gemm_nn_bf16x3p_f32(const float* A, const void* Bp, float* C,
   const int64_t grid = p.per_xcd * 8;
   KWS_REQUIRE(grid <= 0x7FFFFFFF, "gemm_nn_bf16x3p: grid out of range");
   KwsProfScope prof("gemm_nn_bf16x3", 2.0 * M * K * N, 4.0 * ((double)M * K + (double)K * N + (double)M * N), (hipStream_t)stream);
-  static const int pf = getenv("KWS_X3_PF") ? atoi(getenv("KWS_X3_PF")) : PFD;
-  if (pf == 2 && K % (2 * XBK) == 0) {
-    if (stats_part) hipLaunchKernelGGL((gemm_nn_bf16x3p_kernel<true, 2>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((gemm_nn_bf16x3p_kernel<false, 2>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p);
-  } else if (getenv("KWS_X3_ABL")) {
-    switch (atoi(getenv("KWS_X3_ABL"))) {
-      case 1: hipLaunchKernelGGL((gemm_nn_bf16x3p_kernel<false, 1, 1>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p); break;
-      case 2: hipLaunchKernelGGL((gemm_nn_bf16x3p_kernel<false, 1, 2>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p); break;
-      case 3: hipLaunchKernelGGL((gemm_nn_bf16x3p_kernel<false, 1, 3>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p); break;
-      case 4: hipLaunchKernelGGL((gemm_nn_bf16x3p_kernel<false, 1, 4>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p); break;
-      default: hipLaunchKernelGGL((gemm_nn_bf16x3p_kernel<false, 1, 5>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p); break;
-    }
-  } else {
-    if (stats_part) hipLaunchKernelGGL((gemm_nn_bf16x3p_kernel<true, 1>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((gemm_nn_bf16x3p_kernel<false, 1>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p);
-  }
+  if (stats_part) hipLaunchKernelGGL(gemm_nn_bf16x3p_kernel<true>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(gemm_nn_bf16x3p_kernel<false>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p);
   KWS_LAUNCH_CHECK("gemm_nn_bf16x3p_kernel");
   return KWS_OK;
 }
