@@ -296,8 +296,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=5)
     ap.add_argument("--no-ab", action="store_true",
-                    help="skip the A/B leg: the same step with the pointwise GEMMs as bf16 x 3 split products (experiment, "
-                         "off by default in the product; N=1 only)")
+                    help="skip the A/B legs: the same step with the pointwise GEMMs as bf16 x 3 / fp16 x 2 split products "
+                         "(experiments, off by default in the product; N=1 only)")
     ap.add_argument("--no-val-acc", action="store_true",
                     help="skip the short val-acc parity run (scripts/val_acc_parity.py: the same batches trained on the "
                          "device and on the oracle's torch-CPU twin, val_acc next to val_acc_cpu); N=1 only")
@@ -403,7 +403,7 @@ def main():
                          num_classes=settings['label_count'])
     model.seed = 87654321            # one dropout stream for the global batch: rank r uses rows [r*B, (r+1)*B)
     ab_steps = min(args.steps, 50)
-    ring = torch.zeros((args.warmup + args.steps + args.profile_steps + ab_steps + 16, 4), dtype=torch.float32, device=device)
+    ring = torch.zeros((args.warmup + args.steps + args.profile_steps + 2 * (ab_steps + 8) + 8, 4), dtype=torch.float32, device=device)
     enq = GeneratorEnqueuer(gen, max_queue_size=10, device=device)
     enq.start()
 
@@ -457,25 +457,29 @@ def main():
     # ---- A/B leg (experiment): the same step with the pointwise GEMMs (forward, input gradient,
     # weight gradient) as six bf16 MFMA products of three-way operand splits; the line's value / roofline above are
     # the f32-MFMA path
-    ab = None
+    ab = {}
     gemm_mode = _lib.load().kws_net_get_gemm_mode()
+    AB_ARMS = [(1, "ab_gemm_bf16x3", "3-way bf16 splits (six bf16 MFMA products"),
+               (2, "ab_gemm_f16x2", "power-of-two scaled 2-way fp16 splits (three f16 MFMA products")]
     if world == 1 and not args.no_ab and gemm_mode == 0:
         lib = _lib.load()
         base = args.warmup + args.steps + args.profile_steps
-        _lib.check(lib.kws_net_set_gemm_mode(1), "kws_net_set_gemm_mode")
         try:
-            for i in range(8):
-                step(base + i)
-            barrier()
-            t1 = time.time()
-            for i in range(ab_steps):
-                step(base + 8 + i)
-            barrier()
-            dt_ab = time.time() - t1
-            ab = {"what": "pointwise forward / input-gradient / weight-gradient GEMMs as 3-way bf16 splits (six bf16 MFMA "
-                          "products, f32 accumulate; KWS_GEMM_BF16X3=1): an A/B experiment, not the product default",
-                  "steps": ab_steps, "ms_per_step": 1e3 * dt_ab / ab_steps, "value": B * ab_steps / dt_ab,
-                  "unit": "clips/s"}
+            for mode, key, what in AB_ARMS:
+                _lib.check(lib.kws_net_set_gemm_mode(mode), "kws_net_set_gemm_mode")
+                for i in range(8):
+                    step(base + i)
+                barrier()
+                t1 = time.time()
+                for i in range(ab_steps):
+                    step(base + 8 + i)
+                barrier()
+                dt_ab = time.time() - t1
+                base += 8 + ab_steps
+                ab[key] = {"what": "pointwise forward / input-gradient / weight-gradient GEMMs as %s, f32 accumulate): an A/B "
+                                   "experiment, not the product default" % what,
+                           "steps": ab_steps, "ms_per_step": 1e3 * dt_ab / ab_steps, "value": B * ab_steps / dt_ab,
+                           "unit": "clips/s"}
         finally:
             _lib.check(lib.kws_net_set_gemm_mode(0), "kws_net_set_gemm_mode")
     enq.stop()
@@ -512,7 +516,8 @@ def main():
             "value": clips / dt, "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if gemm_mode == 0 else "f32 (pointwise GEMMs as 3-way bf16 splits, f32 accumulate)",
+            "dtype": {0: "f32", 1: "f32 (pointwise GEMMs as 3-way bf16 splits, f32 accumulate)",
+                      2: "f32 (pointwise GEMMs as scaled 2-way fp16 splits, f32 accumulate)"}[gemm_mode],
             "data": "synthetic",
             "config": {"workload": "configs[1]: 12-class conv_1d_time_sliced_with_attention, batch %d/GPU synthetic "
                                    "16000-sample fp32 clips, sampler+augment+STFT/mel(80,60)+raw fwd/bwd+RMSprop" % B,
@@ -524,7 +529,8 @@ def main():
             "train_acc_last": float(ms[-1, 1] / B),
             "roofline": roof,
             "roofline_stages": stages[1:],
-            "ab_gemm_bf16x3": ab,
+            "ab_gemm_bf16x3": ab.get("ab_gemm_bf16x3"),
+            "ab_gemm_f16x2": ab.get("ab_gemm_f16x2"),
             "kernels": prof,
         }
     if dist:

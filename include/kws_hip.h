@@ -196,7 +196,8 @@ int kws_stft_mel_f32(const kws_stft_plan_t* plan, const float* x, int B, int L, 
  * DESIGN.md section 5).  KWS_GEMM_BF16X3=1 at start, or kws_net_set_gemm_mode(1) at run time, makes the raw-waveform
  * net's training step take these kernels for its forward, input-gradient and weight-gradient GEMMs. */
 int kws_gemm_nn_bf16x3_stats_rows(int64_t M);   /* rows of stats_part: one per 128-row tile */
-int kws_net_get_gemm_mode(void);   /* 0 = f32 MFMA (default), 1 = the bf16 x 3 experiment (KWS_GEMM_BF16X3 at start) */
+int kws_net_get_gemm_mode(void);   /* 0 = f32 MFMA (default), 1 = the bf16 x 3 experiment (KWS_GEMM_BF16X3 at start),
+                                    * 2 = the fp16 x 2 experiment (KWS_GEMM_F16X2 at start) */
 int kws_net_set_gemm_mode(int mode);
 int kws_bf16x3_split_batch(const float* const* in, void* const* out, const int* rows, const int* cols,
                            const int* transpose, int count, void* stream);
@@ -207,6 +208,22 @@ int kws_gemm_nn_bf16x3p_f32(const float* A, const void* Bp, float* C, int64_t M,
 int64_t kws_gemm_tn_bf16x3_workspace_floats(int64_t M, int K, int N);
 int kws_gemm_tn_bf16x3_f32(const float* Z, const float* G, float* dW, int64_t M, int K, int N, float* workspace,
                            void* stream);
+
+/* EXPERIMENT 2 (A/B arm, off by default; csrc/gemm_f16x2.hip; KWS_GEMM_F16X2=1 or kws_net_set_gemm_mode(2)): the same
+ * GEMMs with every f32 operand scaled by a power of two and split into TWO fp16 parts, three f16 MFMA products
+ * accumulated in f32 - half the matrix instructions of the bf16 x 3 form at the same accuracy.  The scale of an operand
+ * comes from its |x| maximum, kept on the device in a "slot group" of 256 words (atomicMax of the bit patterns, so it
+ * is the same in every run): kws_absmax_batch_f32 fills groups for arbitrary tensors; inside the network the kernels
+ * that produce a GEMM operand leave its maximum behind.  The largest magnitude lands in [2^14, 2^15) (fp16 overflows at
+ * 65504) and results are multiplied by the two inverse scales on the way out (exact: powers of two). */
+int kws_absmax_batch_f32(const float* const* in, const int64_t* n, unsigned* slots, int count, void* stream);
+int kws_f16x2_split_batch(const float* const* in, void* const* out, const int* rows, const int* cols,
+                          const int* transpose, const unsigned* const* slots, int count, void* stream);
+int kws_gemm_nn_f16x2_f32(const float* A, const void* Bp, float* C, int64_t M, int K, int N,
+                          const unsigned* a_slots, const unsigned* b_slots, float* stats_part, void* stream);
+int64_t kws_gemm_tn_f16x2_workspace_floats(int64_t M, int K, int N);
+int kws_gemm_tn_f16x2_f32(const float* Z, const float* G, float* dW, int64_t M, int K, int N,
+                          const unsigned* z_slots, const unsigned* g_slots, float* workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * a7+a8, a10  GEMM family on f32 MFMA (v_mfma_f32_32x32x2_f32)

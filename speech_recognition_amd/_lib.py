@@ -108,6 +108,11 @@ SIGNATURES = {
     "kws_net_set_gemm_mode": (_I, [_I]),
     "kws_bf16x3_split_batch": (_I, [_P, _P, _P, _P, _P, _I, _P]),
     "kws_gemm_nn_bf16x3p_f32": (_I, [_P, _P, _P, _I64, _I, _I, _P, _P]),
+    "kws_absmax_batch_f32": (_I, [_P, _P, _P, _I, _P]),
+    "kws_f16x2_split_batch": (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),
+    "kws_gemm_nn_f16x2_f32": (_I, [_P, _P, _P, _I64, _I, _I, _P, _P, _P, _P]),
+    "kws_gemm_tn_f16x2_workspace_floats": (_I64, [_I64, _I, _I]),
+    "kws_gemm_tn_f16x2_f32": (_I, [_P, _P, _P, _I64, _I, _I, _P, _P, _P, _P]),
     "kws_gemm_tn_bf16x3_workspace_floats": (_I64, [_I64, _I, _I]),
     "kws_gemm_tn_bf16x3_f32": (_I, [_P, _P, _P, _I64, _I, _I, _P, _P]),
     "kws_gemm_gather_f32": (_I, [_P, ctypes.POINTER(GatherDesc), _P, _P, _I, _I, _P, _P]),

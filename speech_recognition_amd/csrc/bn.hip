@@ -2,7 +2,7 @@
 // The heavy passes live in the producers/consumers (GEMM epilogue statistics, depthwise kernels
 // applying scale/shift on load); what is left here are the per-channel finalisations, which reduce
 // the per-tile partial sums in a FIXED order (double accumulation) so results are bit-reproducible.
-#include "common.h"
+#include "internal.h"
 
 namespace {
 
@@ -171,7 +171,8 @@ __global__ __launch_bounds__(256) void dw_bwd_finalize_kernel(const float* __res
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ g, const float* __restrict__ y,
                                                            const float* __restrict__ bn, const float* __restrict__ gamma,
-                                                           const float* __restrict__ coef, int64_t n4, int C) {
+                                                           const float* __restrict__ coef, int64_t n4, int C,
+                                                           unsigned* amax) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n4) return;
   const int c = (int)((i * 4) % C);
@@ -188,6 +189,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ g
   o.z = ga.z * rstd.z * (gv.z - c1.z - (yv.z - mean.z) * rstd.z * c2.z);
   o.w = ga.w * rstd.w * (gv.w - c1.w - (yv.w - mean.w) * rstd.w * c2.w);
   reinterpret_cast<float4*>(g)[i] = o;
+  if (amax) kws_absmax_commit(amax, kws_abs4max(0.f, o));
 }
 
 // Folds n partial rows of width W into at most KWS_REDUCE_SLICES rows in `scratch` when that pays.
@@ -257,11 +259,17 @@ int kws_dw_bwd_finalize(const float* part, int n_parts, int64_t count, int C, fl
 
 int kws_bn_bwd_apply(float* g, const float* y, const float* bn, const float* gamma, const float* coef, int64_t rows,
                      int C, void* stream) {
+  return kws_bn_bwd_apply_amax(g, y, bn, gamma, coef, rows, C, nullptr, (hipStream_t)stream);
+}
+
+// internal: as kws_bn_bwd_apply, and the |dy| maximum into amax (may be NULL)
+int kws_bn_bwd_apply_amax(float* g, const float* y, const float* bn, const float* gamma, const float* coef, int64_t rows,
+                          int C, unsigned* amax, hipStream_t stream) {
   KWS_REQUIRE(g && y && bn && gamma && coef && rows > 0 && C > 0 && C % 4 == 0, "bn_bwd_apply: bad arguments");
   const int64_t n4 = rows * C / 4;
   KwsProfScope prof("bn_bwd_apply", 6.0 * rows * C, 12.0 * rows * C, (hipStream_t)stream);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)ceil_div64(n4, 256)), dim3(256), 0, (hipStream_t)stream, g, y,
-                     bn, gamma, coef, n4, C);
+                     bn, gamma, coef, n4, C, amax);
   KWS_LAUNCH_CHECK("bn_bwd_apply_kernel");
   return KWS_OK;
 }

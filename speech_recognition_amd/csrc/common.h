@@ -43,6 +43,42 @@ void kws_set_error(const char* fmt, ...);
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// ---- |x| maximum of a tensor, for the fp16 x 2 GEMM arm (gemm_f16x2.hip) -----------------------------------------------
+// Kept as the bit pattern of a non-negative float in KWS_ABSMAX_SLOTS words 64 bytes apart (zeroed at the start of a
+// step): every wave of a producing kernel commits its own maximum with one atomicMax - order-independent, so the value a
+// consumer derives its power-of-two scale from is the same in every run.
+constexpr int KWS_ABSMAX_SLOTS = 16, KWS_ABSMAX_STRIDE = 16, KWS_ABSMAX_WORDS = KWS_ABSMAX_SLOTS * KWS_ABSMAX_STRIDE;
+#ifdef __HIPCC__
+__device__ __forceinline__ float kws_abs4max(float m, const float4 v) {
+  return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+}
+__device__ __forceinline__ void kws_absmax_commit(unsigned* slots, float m) {
+  const unsigned long long act = __ballot(1);      // lanes that are here (a partial last wave, early exits): only their values count
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float other = __shfl_xor(m, o);
+    if ((act >> (lane ^ o)) & 1ull) m = fmaxf(m, other);
+  }
+  if ((threadIdx.x & 63) == 0)
+    atomicMax(slots + ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) % KWS_ABSMAX_SLOTS) * KWS_ABSMAX_STRIDE, __float_as_uint(m));
+}
+// scale = 2^(14 - floor(log2 max)): the largest magnitude lands in [2^14, 2^15), below fp16's 65504; inv = 1 / scale.
+// A zero (or denormal) tensor takes 2^125; an infinite / NaN maximum leaves the infinities in place.
+__device__ __forceinline__ float kws_absmax_scale(const unsigned* slots, float& inv) {
+  unsigned m = 0;
+#pragma unroll
+  for (int i = 0; i < KWS_ABSMAX_SLOTS; ++i) {
+    const unsigned v = slots[i * KWS_ABSMAX_STRIDE];
+    m = v > m ? v : m;
+  }
+  int e = (int)((m >> 23) & 0xffu);
+  if (e < 16) e = 16;
+  inv = __uint_as_float((unsigned)(e - 14) << 23);
+  return __uint_as_float((unsigned)(268 - e) << 23);
+}
+#endif
+
 // ---- counter-based dropout RNG (bit-for-bit the oracle's oracle/layers.py) ----------------
 __host__ __device__ static inline uint32_t kws_fmix32(uint32_t h) {
   h ^= h >> 16;

@@ -2,7 +2,7 @@
 // applied on load.  HBM-bound: every thread owns one float4 of
 // channels (16-B coalesced loads across the C dimension) and walks a short run of time steps so the
 // three taps are reused from registers.
-#include "common.h"
+#include "internal.h"
 
 namespace {
 
@@ -19,8 +19,10 @@ __device__ __forceinline__ float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 
 template <int S, bool HAS_BN>
 __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict__ y, const float* __restrict__ bn,
                                                          const float* __restrict__ w, float* __restrict__ z,
-                                                         int B, int Lin, int Lout, int C, int pad_l, int nchunks) {
+                                                         int B, int Lin, int Lout, int C, int pad_l, int nchunks,
+                                                         unsigned* amax) {
   const int C4 = C >> 2;
+  float zmax = 0.f;                                 // |z| maximum of this thread (fp16 x 2 GEMM arm; amax may be NULL)
   const int64_t total = (int64_t)B * nchunks * C4;
   // grid-stride over (clip, time chunk, channel quad) units with a capped grid: a few resident workgroups per
   // CU that keep streaming beat tens of thousands of short-lived ones (same finding as dwconv_bwd)
@@ -75,6 +77,7 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict
       o = f4_fma(w1, a1, o);
       o = f4_fma(w2, a2, o);
       *reinterpret_cast<float4*>(zb + (int64_t)t * C) = o;
+      zmax = kws_abs4max(zmax, o);
       if (S == 1) {
         a0 = a1;
         a1 = a2;
@@ -83,6 +86,7 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict
       }
     }
   }
+  if (amax) kws_absmax_commit(amax, zmax);
 }
 
 // Backward: one thread per (clip, run of TT input positions, float4 of channels).
@@ -98,7 +102,8 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const float* __restrict
                                                          const float* __restrict__ coef,
                                                          float* __restrict__ g, float* __restrict__ part, int B,
                                                          int Lin, int Lout, int C, int pad_l, int nchunks, int R,
-                                                         int Cb) {
+                                                         int Cb, unsigned* amax) {
+  float gmax = 0.f;                                 // MODE 2: |dy| maximum of this thread (amax may be NULL)
   // blockIdx.y selects a slice of Cb <= 1024 channels (Cb = C unless C > 1024)
   __shared__ float red[5][256 * 4];
   const int C4 = Cb >> 2;
@@ -186,6 +191,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const float* __restrict
         o.z = sc.z * (gv.z - c1.z - (yv.z - mean.z) * rstd.z * c2.z);
         o.w = sc.w * (gv.w - c1.w - (yv.w - mean.w) * rstd.w * c2.w);
         *reinterpret_cast<float4*>(gb + (int64_t)u * C) = o;
+        gmax = kws_abs4max(gmax, o);
         continue;
       }
       if (MODE == 0) {
@@ -203,7 +209,10 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const float* __restrict
       sw2 = f4_fma(d2, a, sw2);
     }
   }
-  if (MODE == 2) return;
+  if (MODE == 2) {
+    if (amax) kws_absmax_commit(amax, gmax);
+    return;
+  }
   *reinterpret_cast<float4*>(&red[0][tid * 4]) = sg;
   *reinterpret_cast<float4*>(&red[1][tid * 4]) = sgx;
   *reinterpret_cast<float4*>(&red[2][tid * 4]) = sw0;
@@ -246,16 +255,17 @@ BwdGeom bwd_geom(int B, int Lin, int C) {
 namespace {
 template <int MODE>
 int launch_dw_bwd(const float* dz, const float* y, const float* bn, const float* w, const float* coef, float* g,
-                  float* part, int B, int L_in, int L_out, int C, int stride, int pad_l, hipStream_t st) {
+                  float* part, int B, int L_in, int L_out, int C, int stride, int pad_l, hipStream_t st,
+                  unsigned* amax = nullptr) {
   const BwdGeom ge = bwd_geom(B, L_in, C);
   KWS_REQUIRE(ge.grid < 0x7FFFFFFF, "dwconv_bwd: grid too large");
   dim3 gr((unsigned)ge.grid, (unsigned)ge.ny), b((unsigned)ge.block);
   if (stride == 1) {
-    if (bn) hipLaunchKernelGGL((dwconv_bwd_kernel<1, true, MODE>), gr, b, 0, st, dz, y, bn, w, coef, g, part, B, L_in, L_out, C, pad_l, ge.nchunks, ge.R, ge.Cb);
-    else hipLaunchKernelGGL((dwconv_bwd_kernel<1, false, MODE>), gr, b, 0, st, dz, y, bn, w, coef, g, part, B, L_in, L_out, C, pad_l, ge.nchunks, ge.R, ge.Cb);
+    if (bn) hipLaunchKernelGGL((dwconv_bwd_kernel<1, true, MODE>), gr, b, 0, st, dz, y, bn, w, coef, g, part, B, L_in, L_out, C, pad_l, ge.nchunks, ge.R, ge.Cb, amax);
+    else hipLaunchKernelGGL((dwconv_bwd_kernel<1, false, MODE>), gr, b, 0, st, dz, y, bn, w, coef, g, part, B, L_in, L_out, C, pad_l, ge.nchunks, ge.R, ge.Cb, amax);
   } else {
-    if (bn) hipLaunchKernelGGL((dwconv_bwd_kernel<2, true, MODE>), gr, b, 0, st, dz, y, bn, w, coef, g, part, B, L_in, L_out, C, pad_l, ge.nchunks, ge.R, ge.Cb);
-    else hipLaunchKernelGGL((dwconv_bwd_kernel<2, false, MODE>), gr, b, 0, st, dz, y, bn, w, coef, g, part, B, L_in, L_out, C, pad_l, ge.nchunks, ge.R, ge.Cb);
+    if (bn) hipLaunchKernelGGL((dwconv_bwd_kernel<2, true, MODE>), gr, b, 0, st, dz, y, bn, w, coef, g, part, B, L_in, L_out, C, pad_l, ge.nchunks, ge.R, ge.Cb, amax);
+    else hipLaunchKernelGGL((dwconv_bwd_kernel<2, false, MODE>), gr, b, 0, st, dz, y, bn, w, coef, g, part, B, L_in, L_out, C, pad_l, ge.nchunks, ge.R, ge.Cb, amax);
   }
   KWS_LAUNCH_CHECK("dwconv_bwd_kernel");
   return KWS_OK;
@@ -266,6 +276,12 @@ extern "C" {
 
 int kws_dwconv_fwd_f32(const float* y, const float* bn, const float* w, float* z, int B, int L_in, int L_out,
                        int C, int stride, int pad_l, void* stream) {
+  return kws_dwconv_fwd_amax_f32(y, bn, w, z, B, L_in, L_out, C, stride, pad_l, nullptr, (hipStream_t)stream);
+}
+
+// internal: as kws_dwconv_fwd_f32, and the |z| maximum into amax (KWS_ABSMAX_WORDS words, may be NULL)
+int kws_dwconv_fwd_amax_f32(const float* y, const float* bn, const float* w, float* z, int B, int L_in, int L_out,
+                            int C, int stride, int pad_l, unsigned* amax, hipStream_t stream) {
   KWS_REQUIRE(y && w && z, "dwconv_fwd: NULL pointer");
   KWS_REQUIRE(B > 0 && L_in > 0 && L_out > 0 && C > 0 && C % 4 == 0, "dwconv_fwd: bad shape B=%d L=%d->%d C=%d",
               B, L_in, L_out, C);
@@ -279,11 +295,11 @@ int kws_dwconv_fwd_f32(const float* y, const float* bn, const float* w, float* z
   hipStream_t st = (hipStream_t)stream;
   KwsProfScope prof("dwconv_fwd", 6.0 * B * L_out * C, 4.0 * ((double)B * L_in * C + (double)B * L_out * C), st);
   if (stride == 1) {
-    if (bn) hipLaunchKernelGGL((dwconv_fwd_kernel<1, true>), g, b, 0, st, y, bn, w, z, B, L_in, L_out, C, pad_l, nchunks);
-    else hipLaunchKernelGGL((dwconv_fwd_kernel<1, false>), g, b, 0, st, y, bn, w, z, B, L_in, L_out, C, pad_l, nchunks);
+    if (bn) hipLaunchKernelGGL((dwconv_fwd_kernel<1, true>), g, b, 0, st, y, bn, w, z, B, L_in, L_out, C, pad_l, nchunks, amax);
+    else hipLaunchKernelGGL((dwconv_fwd_kernel<1, false>), g, b, 0, st, y, bn, w, z, B, L_in, L_out, C, pad_l, nchunks, amax);
   } else {
-    if (bn) hipLaunchKernelGGL((dwconv_fwd_kernel<2, true>), g, b, 0, st, y, bn, w, z, B, L_in, L_out, C, pad_l, nchunks);
-    else hipLaunchKernelGGL((dwconv_fwd_kernel<2, false>), g, b, 0, st, y, bn, w, z, B, L_in, L_out, C, pad_l, nchunks);
+    if (bn) hipLaunchKernelGGL((dwconv_fwd_kernel<2, true>), g, b, 0, st, y, bn, w, z, B, L_in, L_out, C, pad_l, nchunks, amax);
+    else hipLaunchKernelGGL((dwconv_fwd_kernel<2, false>), g, b, 0, st, y, bn, w, z, B, L_in, L_out, C, pad_l, nchunks, amax);
   }
   KWS_LAUNCH_CHECK("dwconv_fwd_kernel");
   return KWS_OK;
@@ -319,6 +335,14 @@ int kws_dwconv_bwd_acc_f32(const float* dz, const float* y, const float* w, cons
 int kws_dwconv_bwd_bn_f32(const float* dz, const float* y, const float* bn, const float* w, const float* coef,
                           float* dy, float* part, int pass, int B, int L_in, int L_out, int C, int stride, int pad_l,
                           void* stream) {
+  return kws_dwconv_bwd_bn_amax_f32(dz, y, bn, w, coef, dy, part, pass, B, L_in, L_out, C, stride, pad_l, nullptr,
+                                    (hipStream_t)stream);
+}
+
+// internal: as kws_dwconv_bwd_bn_f32; pass 2 also leaves the |dy| maximum in amax (may be NULL)
+int kws_dwconv_bwd_bn_amax_f32(const float* dz, const float* y, const float* bn, const float* w, const float* coef,
+                               float* dy, float* part, int pass, int B, int L_in, int L_out, int C, int stride, int pad_l,
+                               unsigned* amax, hipStream_t stream) {
   KWS_REQUIRE(dz && y && bn && w, "dwconv_bwd_bn: NULL pointer");
   KWS_REQUIRE(pass == 1 ? part != nullptr : (pass == 2 && coef != nullptr && dy != nullptr),
               "dwconv_bwd_bn: pass %d needs %s", pass, pass == 1 ? "part" : "coef and dy");
@@ -329,7 +353,7 @@ int kws_dwconv_bwd_bn_f32(const float* dz, const float* y, const float* bn, cons
   KwsProfScope prof("dwconv_bwd", 12.0 * B * L_in * C,
                     4.0 * ((pass == 2 ? 2.0 : 1.0) * B * L_in * C + (double)B * L_out * C), st);
   if (pass == 1) return launch_dw_bwd<1>(dz, y, bn, w, nullptr, nullptr, part, B, L_in, L_out, C, stride, pad_l, st);
-  return launch_dw_bwd<2>(dz, y, bn, w, coef, dy, nullptr, B, L_in, L_out, C, stride, pad_l, st);
+  return launch_dw_bwd<2>(dz, y, bn, w, coef, dy, nullptr, B, L_in, L_out, C, stride, pad_l, st, amax);
 }
 
 }  // extern "C"

@@ -175,7 +175,9 @@ struct Layout {
   std::vector<int64_t> z;   // z[i], i = 0..10
   int64_t G = 0, G2 = 0, DZ = 0, bn = 0, part = 0, coef = 0, tn = 0, red = 0, swg = 0;
   std::vector<int64_t> WT;  // transposed pointwise kernel of block i (dgrad GEMM operand)
-  std::vector<int64_t> WPf, WPd;  // KWS_GEMM_BF16X3: bf16 planes [3][cout][cin] (forward) / [3][cin][cout] (input gradient)
+  std::vector<int64_t> WPf, WPd;  // KWS_GEMM_BF16X3: bf16 planes [3][cout][cin] (forward) / [3][cin][cout] (input gradient);
+                                  // KWS_GEMM_F16X2: fp16 planes [2][..][..] in the same places
+  int64_t amax;                   // KWS_GEMM_F16X2: 3 nb slot groups of |x| maxima: W[i] | z[i] | dy[i + 1]
   int64_t xd = 0, fd = 0, dl1 = 0, dl2 = 0, per_loss = 0, per_correct = 0, att = 0;
   int64_t w1f = 0, g1f = 0;  // folded first-convolution kernel and its gradient [K1f, C1]
   int64_t bn_stride = 0;
@@ -201,8 +203,9 @@ void make_layout(const kws_net* n, int B, bool training, Layout* lo) {
     if (p > max_part) max_part = p;
     const int64_t dp = kws_dwconv_bwd_part_floats(B, b.Lin, b.cin);
     if (dp > max_dwpart) max_dwpart = dp;
-    const int64_t t = std::max(kws_gemm_tn_workspace_floats(M, b.cin, b.cout),
-                               kws_gemm_tn_bf16x3_workspace_floats(M, b.cin, b.cout));   // either arithmetic (run-time switch)
+    const int64_t t = std::max(std::max(kws_gemm_tn_workspace_floats(M, b.cin, b.cout),
+                                        kws_gemm_tn_bf16x3_workspace_floats(M, b.cin, b.cout)),
+                               kws_gemm_tn_f16x2_workspace_floats(M, b.cin, b.cout));    // any arithmetic (run-time switch)
     if (t > max_tn) max_tn = t;
     if (b.cout > maxC) maxC = b.cout;
   }
@@ -230,6 +233,7 @@ void make_layout(const kws_net* n, int B, bool training, Layout* lo) {
       lo->WPf[i] = bp.take(((int64_t)n->blocks[i].cin * n->blocks[i].cout * 3 + 1) / 2);
       lo->WPd[i] = bp.take(((int64_t)n->blocks[i].cin * n->blocks[i].cout * 3 + 1) / 2);
     }
+    lo->amax = bp.take((int64_t)3 * nb * KWS_ABSMAX_WORDS);
     lo->tn = bp.take(max_tn);
     lo->xd = bp.take((int64_t)B * n->T * n->C);
     lo->fd = bp.take((int64_t)B * 2 * n->C);
@@ -398,19 +402,20 @@ int kws_net_predict(const kws_net_t* net, const float* params, const float* stat
 // part 0: the whole step.  part 1: forward, tail and the backward pass down to block `split` (inclusive); part 2: the rest
 // of the backward pass (blocks split-1 .. 0 and the first convolution).  Parts 1 + 2 enqueue exactly the launches of
 // part 0 in the same order - every intermediate lives in the caller's workspace - so the gradients are bit-identical.
-// 0 = f32 MFMA (default), 1 = bf16 x 3 split products for the pointwise forward / input-gradient GEMMs (experiment).
-// Initialised from KWS_GEMM_BF16X3; kws_net_set_gemm_mode switches it at run time (bench.py's A/B leg).
+// 0 = f32 MFMA (default), 1 = bf16 x 3 split products for the pointwise GEMMs (experiment), 2 = fp16 x 2 split products
+// (experiment 2).  Initialised from KWS_GEMM_BF16X3 / KWS_GEMM_F16X2; kws_net_set_gemm_mode switches it at run time
+// (bench.py's A/B legs).
 static std::atomic<int> g_gemm_mode{-1};
 extern "C" int kws_net_get_gemm_mode(void) {
   int m = g_gemm_mode.load(std::memory_order_relaxed);
   if (m < 0) {
-    m = getenv("KWS_GEMM_BF16X3") != nullptr ? 1 : 0;
+    m = getenv("KWS_GEMM_F16X2") != nullptr ? 2 : getenv("KWS_GEMM_BF16X3") != nullptr ? 1 : 0;
     g_gemm_mode.store(m, std::memory_order_relaxed);
   }
   return m;
 }
 extern "C" int kws_net_set_gemm_mode(int mode) {
-  KWS_REQUIRE(mode == 0 || mode == 1, "net_set_gemm_mode: mode %d (0 = f32 MFMA, 1 = bf16 x 3 split)", mode);
+  KWS_REQUIRE(mode >= 0 && mode <= 2, "net_set_gemm_mode: mode %d (0 = f32 MFMA, 1 = bf16 x 3 split, 2 = fp16 x 2 split)", mode);
   g_gemm_mode.store(mode, std::memory_order_relaxed);
   return KWS_OK;
 }
@@ -437,7 +442,13 @@ static int ts_train(const kws_net_t* net, const float* params, float* state, con
   const bool run_head = phase != 2;                   // forward + tail + the late blocks' backward
   // KWS_GEMM_BF16X3=1 (A/B experiment, gemm_bf16x3.hip): the pointwise forward and input-gradient GEMMs run as six bf16
   // MFMA products of three-way operand splits instead of f32 MFMAs (weight gradients too); the first convolution stays f32
-  const bool x3 = kws_net_get_gemm_mode() == 1;
+  const int gemm_mode = kws_net_get_gemm_mode();
+  const bool x3 = gemm_mode == 1, h2 = gemm_mode == 2;
+  // fp16 x 2 arm: slot groups of the operands' |x| maxima (common.h): W of block i, z of block i, dy of block i's output
+  unsigned* amax0 = reinterpret_cast<unsigned*>(ws + lo.amax);
+  auto w_slots = [&](int i) { return amax0 + (int64_t)i * KWS_ABSMAX_WORDS; };
+  auto z_slots = [&](int i) { return amax0 + (int64_t)(nb + i) * KWS_ABSMAX_WORDS; };
+  auto g_slots = [&](int i) { return amax0 + (int64_t)(2 * nb + i) * KWS_ABSMAX_WORDS; };
   auto transpose_all = [&]() -> int {   // the pointwise kernels [cin][cout] -> [cout][cin]: all of them in one launch
     static_assert(KWS_TRANSPOSE_BATCH >= 11, "one batch holds every block");
     const float* tin[KWS_TRANSPOSE_BATCH];
@@ -468,6 +479,28 @@ static int ts_train(const kws_net_t* net, const float* params, float* state, con
     }
     KWS_TRY(kws_bf16x3_split_batch(sin_, sout, srows, scols, str, 2 * nb, st));
   }
+  if (h2) {                                         // maxima of the pointwise kernels (this also zeroes their groups), then
+    const float* win[24];                           // zero the activations' groups, then both operand forms as fp16 planes
+    int64_t wn[24];
+    const float* sin_[24];
+    void* sout[24];
+    const unsigned* ssl[24];
+    int srows[24], scols[24], str[24];
+    KWS_REQUIRE(2 * nb <= 24, "net: %d blocks exceed the split batch", nb);
+    for (int i = 0; i < nb; ++i) {
+      win[i] = params + net->blocks[i].pw;
+      wn[i] = (int64_t)net->blocks[i].cin * net->blocks[i].cout;
+      sin_[2 * i] = sin_[2 * i + 1] = params + net->blocks[i].pw;
+      srows[2 * i] = srows[2 * i + 1] = net->blocks[i].cin;
+      scols[2 * i] = scols[2 * i + 1] = net->blocks[i].cout;
+      ssl[2 * i] = ssl[2 * i + 1] = w_slots(i);
+      sout[2 * i] = ws + lo.WPf[i]; str[2 * i] = 1;
+      sout[2 * i + 1] = ws + lo.WPd[i]; str[2 * i + 1] = 0;
+    }
+    KWS_TRY(kws_absmax_batch_f32(win, wn, w_slots(0), nb, st));
+    KWS_HIP(hipMemsetAsync(z_slots(0), 0, (size_t)2 * nb * KWS_ABSMAX_WORDS * sizeof(unsigned), st));
+    KWS_TRY(kws_f16x2_split_batch(sin_, sout, srows, scols, str, ssl, 2 * nb, st));
+  }
   // ---------------- forward ----------------
   {
     const int64_t M = (int64_t)B * net->L1;
@@ -485,10 +518,13 @@ static int ts_train(const kws_net_t* net, const float* params, float* state, con
   for (int i = 0; i < nb; ++i) {
     const Block& b = net->blocks[i];
     const int64_t M = (int64_t)B * b.Lout;
-    KWS_TRY(kws_dwconv_fwd_f32(ws + lo.y[i], bn_at(i), params + b.dw, ws + lo.z[i], B, b.Lin, b.Lout, b.cin, b.stride,
-                               b.pad_l, st));
+    KWS_TRY(kws_dwconv_fwd_amax_f32(ws + lo.y[i], bn_at(i), params + b.dw, ws + lo.z[i], B, b.Lin, b.Lout, b.cin, b.stride,
+                                    b.pad_l, h2 ? z_slots(i) : nullptr, st));
     int stat_rows;
-    if (x3) {
+    if (h2) {
+      KWS_TRY(kws_gemm_nn_f16x2_f32(ws + lo.z[i], ws + lo.WPf[i], ws + lo.y[i + 1], M, b.cin, b.cout, z_slots(i), w_slots(i), part, st));
+      stat_rows = kws_gemm_nn_bf16x3_stats_rows(M);
+    } else if (x3) {
       KWS_TRY(kws_gemm_nn_bf16x3p_f32(ws + lo.z[i], ws + lo.WPf[i], ws + lo.y[i + 1], M, b.cin, b.cout, part, st));
       stat_rows = kws_gemm_nn_bf16x3_stats_rows(M);
     } else {
@@ -534,7 +570,7 @@ static int ts_train(const kws_net_t* net, const float* params, float* state, con
     KWS_HIP(hipEventCreateWithFlags(&net->ev_join, hipEventDisableTiming));
   }
   static const int overlap_from = getenv("KWS_OVERLAP_FROM") ? atoi(getenv("KWS_OVERLAP_FROM")) : 0;  // experiment knob
-  if (run_head && !x3) KWS_TRY(transpose_all());     // the f32 dgrad GEMMs read the pointwise kernels transposed
+  if (run_head && !x3 && !h2) KWS_TRY(transpose_all());   // the f32 dgrad GEMMs read the pointwise kernels transposed
   float* Gb[2] = {ws + lo.G, ws + lo.G2};          // gradient wrt y[l] lives in Gb[l % 2]; the tail wrote Gb[nb % 2]
   bool wgrad_pending[2] = {false, false};
   const int i_hi = phase == 2 ? split - 1 : nb - 1, i_lo = phase == 1 ? split : 0;
@@ -546,8 +582,10 @@ static int ts_train(const kws_net_t* net, const float* params, float* state, con
     // Gcur holds dy of this block's pointwise output: written by the depthwise backward of block i+1 (pass 2
     // below); only the tail hands over a masked gradient that still needs its BatchNorm backward
     if (i == nb - 1)
-      KWS_TRY(kws_bn_bwd_apply(Gcur, ws + lo.y[i + 1], bn_at(i + 1), params + b.bn.gamma, coef, M, b.cout, st));
-    if (x3) KWS_TRY(kws_gemm_nn_bf16x3p_f32(Gcur, ws + lo.WPd[i], DZ, M, b.cout, b.cin, nullptr, st));
+      KWS_TRY(kws_bn_bwd_apply_amax(Gcur, ws + lo.y[i + 1], bn_at(i + 1), params + b.bn.gamma, coef, M, b.cout,
+                                    h2 ? g_slots(i) : nullptr, st));
+    if (h2) KWS_TRY(kws_gemm_nn_f16x2_f32(Gcur, ws + lo.WPd[i], DZ, M, b.cout, b.cin, g_slots(i), w_slots(i), nullptr, st));
+    else if (x3) KWS_TRY(kws_gemm_nn_bf16x3p_f32(Gcur, ws + lo.WPd[i], DZ, M, b.cout, b.cin, nullptr, st));
     else KWS_TRY(kws_gemm_nn_f32(Gcur, ws + lo.WT[i], DZ, M, b.cout, b.cin, nullptr, st));
     const bool ov = overlap && i >= overlap_from;
     hipStream_t sw = ov ? net->side : st;
@@ -558,7 +596,9 @@ static int ts_train(const kws_net_t* net, const float* params, float* state, con
       KWS_HIP(hipEventRecord(net->ev_join, net->side));
       KWS_HIP(hipStreamWaitEvent(st, net->ev_join, 0));
     }
-    if (x3 && b.cin % 64 == 0 && b.cout % 64 == 0)
+    if (h2 && b.cin % 64 == 0 && b.cout % 64 == 0)
+      KWS_TRY(kws_gemm_tn_f16x2_f32(ws + lo.z[i], Gcur, grads + b.pw, M, b.cin, b.cout, z_slots(i), g_slots(i), ws + lo.tn, sw));
+    else if (x3 && b.cin % 64 == 0 && b.cout % 64 == 0)
       KWS_TRY(kws_gemm_tn_bf16x3_f32(ws + lo.z[i], Gcur, grads + b.pw, M, b.cin, b.cout, ws + lo.tn, sw));
     else
       KWS_TRY(kws_gemm_tn_f32(ws + lo.z[i], Gcur, grads + b.pw, M, b.cin, b.cout, ws + lo.tn, sw));
@@ -578,8 +618,8 @@ static int ts_train(const kws_net_t* net, const float* params, float* state, con
     const int n_parts = (int)(kws_dwconv_bwd_part_floats(B, b.Lin, b.cin) / (5 * b.cin));
     KWS_TRY(kws_dw_bwd_finalize(part, n_parts, (int64_t)B * b.Lin, b.cin, grads + b.dw,
                                 grads + prev.gamma, grads + prev.beta, coef, red, st));
-    KWS_TRY(kws_dwconv_bwd_bn_f32(DZ, ws + lo.y[i], bn_at(i), params + b.dw, coef, Gnext, nullptr, 2, B, b.Lin, b.Lout,
-                                  b.cin, b.stride, b.pad_l, st));
+    KWS_TRY(kws_dwconv_bwd_bn_amax_f32(DZ, ws + lo.y[i], bn_at(i), params + b.dw, coef, Gnext, nullptr, 2, B, b.Lin, b.Lout,
+                                       b.cin, b.stride, b.pad_l, (h2 && i > 0) ? g_slots(i - 1) : nullptr, st));
   }
   if (phase != 1) {
     const int64_t M = (int64_t)B * net->L1;

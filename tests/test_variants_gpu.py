@@ -15,7 +15,8 @@ pytestmark = pytest.mark.gpu
     {"KWS_OVERLAP": "1"},
     {"KWS_STFT_V2": "1"},
     {"KWS_STFT_V3": "1"},
-    {"KWS_GEMM_BF16X3": "1"},     # experiment: pointwise forward / input-gradient GEMMs as bf16 x 3 split products
+    {"KWS_GEMM_BF16X3": "1"},     # experiment: the pointwise GEMMs as bf16 x 3 split products
+    {"KWS_GEMM_F16X2": "1"},      # experiment 2: the pointwise GEMMs as scaled fp16 x 2 split products
 ])
 def test_alternative_paths_pass_the_parity_suites(repo_root, env):
     e = dict(os.environ)
@@ -24,7 +25,7 @@ def test_alternative_paths_pass_the_parity_suites(repo_root, env):
     files = ["tests/test_kernels_gpu.py", "tests/test_net_gpu.py"] if not stft_variant else \
         ["tests/test_kernels_gpu.py", "tests/test_logmfcc_gpu.py", "tests/test_fullsize_gpu.py",
          "tests/test_processor_features_gpu.py", "-k", "stft or c3 or audio"]
-    if "KWS_GEMM_BF16X3" in env:      # the whole-network parity suites incl. the batch-1024 step against the float64 oracle
+    if "KWS_GEMM_BF16X3" in env or "KWS_GEMM_F16X2" in env:      # the whole-network parity suites incl. the batch-1024 step against the float64 oracle
         files = ["tests/test_net_gpu.py", "tests/test_fullsize_gpu.py", "-k", "not stft and not c3 and not augment"]
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider"] + files, cwd=repo_root,
                        env=e, capture_output=True, text=True, timeout=900)
