@@ -28,6 +28,23 @@ __device__ __forceinline__ void split4h(const float4 v, const float s, f16x4& h1
   }
 }
 
+// -DKWS_X3_STAMP builds (scripts/build_variant.sh h2stamp "-DKWS_X3_STAMP" gemm_f16x2; scripts/stamps_x3.py f16x2): wave 0 of
+// the first 2048 tiles accumulates s_memtime deltas: [0] entry -> first slab staged, [1] products, [2] barrier after the
+// products, [3] wait for the next slab + split + store, [4] barrier after the store, [5] epilogue, [6] cycles, [7] 100 MHz ticks
+#ifdef KWS_X3_STAMP
+__device__ unsigned long long g_h2_stamps[2048][8];
+extern "C" int kws_debug_read_h2_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_h2_stamps), sizeof(g_h2_stamps));
+}
+#define X3_DECL unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_mark = __builtin_amdgcn_s_memtime(); \
+  const unsigned long long st_t0 = st_mark, st_r0 = __builtin_amdgcn_s_memrealtime();
+#define X3_ST(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long n_ = __builtin_amdgcn_s_memtime(); \
+  st_acc[i] += n_ - st_mark; st_mark = n_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define X3_DECL
+#define X3_ST(i)
+#endif
+
 struct H2Args {
   const float* A;
   const _Float16* Bp;  // [2][N][K], scaled by the power of two its slots give
@@ -63,41 +80,40 @@ __global__ __launch_bounds__(256, 3) void gemm_nn_f16x2_kernel(H2Args p) {
   const int tile_n = (int)(q - tile_m * p.n_tiles);
   const int64_t m0 = tile_m * XBM;
   const int n0 = tile_n * XBN;
-  // A loader role: thread t moves float4 t % 8 of rows t / 8 + 32 i (eight lanes = one 128-byte line)
+  // A loader role: thread t moves float4 t % 8 of rows t / 8 + 32 i (eight lanes = one 128-byte line); B loader role:
+  // 16-byte chunk t % 4 of rows t / 4 + 64 i of both planes.  Range-checked buffer loads: ONE offset register per
+  // operand, the row / plane / slab steps are scalar offsets; rows past the end read zeros (their results are not stored)
   const int lrow = tid >> 3, lc4 = tid & 7;
-  const float* gA[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int64_t ra = m0 + lrow + 32 * i;
-    if (ra >= M) ra = M - 1;                         // rows past M: a valid address, their results are not stored
-    gA[i] = p.A + ra * K + 4 * lc4;
-  }
-  // B loader role: thread t moves 16-byte chunk t % 4 of rows t / 4 + 64 i of every plane
   const int brow = tid >> 2, bch = tid & 3;
-  const _Float16* gB[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    int rb = n0 + brow + 64 * i;
-    if (rb >= N) rb = N - 1;
-    gB[i] = p.Bp + (int64_t)rb * K + 8 * bch;
-  }
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, (int)(M * K * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.Bp), 0, (int)(p.plane_stride * 4), 0x00020000);
+  const unsigned voA = ((unsigned)(m0 + lrow) * (unsigned)K + 4u * lc4) * 4u;
+  const unsigned voB = ((unsigned)(n0 + brow) * (unsigned)K + 8u * bch) * 2u;
   const int a_off = swz(lrow, lc4 >> 1) + 4 * (lc4 & 1);     // + 32 i rows: (row >> 2) & 3 does not change
   const int b_off = swz(brow, bch);
-  float4 ra4[4];
-  f16x8 rb8[2][2];
-  auto g_load = [&](int k0) {
+  float4 ra4[2][4];                                  // TWO slabs of A in flight (HBM latency x bandwidth needs the bytes)
+  f16x8 rb8[2][2];                                   // one slab of B planes (L2)
+  auto ga_load = [&](const int slot, int k0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ra4[i] = *reinterpret_cast<const float4*>(gA[i] + k0);
+    for (int i = 0; i < 4; ++i) {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsA, voA, (32 * i * K + k0) * 4, 0);
+      ra4[slot][i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    }
+  };
+  auto gb_load = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int pl = 0; pl < 2; ++pl) rb8[i][pl] = *reinterpret_cast<const f16x8*>(gB[i] + pl * p.plane_stride + k0);
+      for (int pl = 0; pl < 2; ++pl) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsB, voB, (int)(pl * p.plane_stride + 64 * i * K + k0) * 2, 0);
+        rb8[i][pl] = __builtin_bit_cast(f16x8, v);
+      }
   };
-  auto s_store = [&]() {
+  auto s_store = [&](const int slot) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       f16x4 h1, h2;
-      split4h(ra4[i], s_a, h1, h2);
+      split4h(ra4[slot][i], s_a, h1, h2);
       const int off = a_off + 32 * i * XBK;
       *reinterpret_cast<f16x4*>(sA + off) = h1;
       *reinterpret_cast<f16x4*>(sA + PL + off) = h2;
@@ -120,9 +136,13 @@ __global__ __launch_bounds__(256, 3) void gemm_nn_f16x2_kernel(H2Args p) {
   const int c0 = ((0 + h) ^ sw) << 3, c1 = ((2 + h) ^ sw) << 3;
 
   const int G = K / XBK;
-  g_load(0);
-  s_store();
+  X3_DECL
+  ga_load(0, 0);
+  gb_load(0);
+  ga_load(1, XBK);                                   // G >= 2: K >= 64 is required
+  s_store(0);
   __syncthreads();
+  X3_ST(0);
   auto products = [&]() {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -146,17 +166,34 @@ __global__ __launch_bounds__(256, 3) void gemm_nn_f16x2_kernel(H2Args p) {
         }
       }
     }
+#ifdef KWS_X3_STAMP
+    asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[1][1][15]));
+#endif
+    X3_ST(1);
   };
-  // the last slab is peeled: a load under a runtime condition makes the compiler wait for EVERY outstanding load at
-  // the next use (its counter model merges the two paths)
-  for (int g = 0; g < G - 1; ++g) {
-    g_load((g + 1) * XBK);
+  // slots and the "more slabs follow" flags are compile-time constants at the call sites: a load under a runtime condition
+  // makes the compiler wait for EVERY outstanding load at the next use (its counter model merges the two paths).  B first,
+  // then A: the store below waits for B (the younger A requests of slab g + 2 stay in flight).
+  auto slab = [&](int g, const int slot_cur, const int slot_next, const bool more1, const bool more2) {
+    if (more1) gb_load((g + 1) * XBK);
+    if (more2) ga_load(slot_cur, (g + 2) * XBK);     // into the registers slab g has just left
+    __builtin_amdgcn_sched_barrier(0);               // the requests go out HERE, not where the scheduler finds room
     products();
-    __syncthreads();                                 // every wave has read this slab's planes
-    s_store();
-    __syncthreads();
+    if (more1) {
+      __syncthreads();                               // every wave has read this slab's planes
+      X3_ST(2);
+      s_store(slot_next);
+      X3_ST(3);
+      __syncthreads();
+      X3_ST(4);
+    }
+  };
+  for (int g = 0; g < G - 2; g += 2) {               // G is even (K % 64 == 0)
+    slab(g, 0, 1, true, true);
+    slab(g + 1, 1, 0, true, true);
   }
-  products();
+  slab(G - 2, 0, 1, true, false);
+  slab(G - 1, 1, 0, false, false);
   float cs[2] = {0.f, 0.f}, css[2] = {0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -188,6 +225,14 @@ __global__ __launch_bounds__(256, 3) void gemm_nn_f16x2_kernel(H2Args p) {
     const int qq = tid >> 7, col = tid & 127;
     if (n0 + col < N) p.stats[((int64_t)tile_m * 2 + qq) * N + n0 + col] = red[(0 * 2 + qq) * 128 + col] + red[(1 * 2 + qq) * 128 + col];
   }
+#ifdef KWS_X3_STAMP
+  X3_ST(5);
+  if (tid == 0 && q < 2048) {
+    for (int i = 0; i < 6; ++i) g_h2_stamps[q][i] = st_acc[i];
+    g_h2_stamps[q][6] = __builtin_amdgcn_s_memtime() - st_t0;
+    g_h2_stamps[q][7] = __builtin_amdgcn_s_memrealtime() - st_r0;
+  }
+#endif
 }
 
 
@@ -426,7 +471,8 @@ extern "C" int kws_f16x2_split_batch(const float* const* in, void* const* out, c
 extern "C" int kws_gemm_nn_f16x2_f32(const float* A, const void* Bp, float* C, int64_t M, int K, int N,
                                      const unsigned* a_slots, const unsigned* b_slots, float* stats_part, void* stream) {
   KWS_REQUIRE(A && Bp && C && a_slots && b_slots && M > 0, "gemm_nn_f16x2: bad arguments");
-  KWS_REQUIRE(K >= XBK && K % XBK == 0 && N > 0, "gemm_nn_f16x2: K=%d must be a multiple of %d (N=%d)", K, XBK, N);
+  KWS_REQUIRE(K >= 2 * XBK && K % (2 * XBK) == 0 && N > 0, "gemm_nn_f16x2: K=%d must be a multiple of %d (N=%d)", K, 2 * XBK, N);
+  KWS_REQUIRE((M + XBM) * (int64_t)K * 4 < (1ll << 31) && (int64_t)(N + XBN) * K * 4 < (1ll << 31), "gemm_nn_f16x2: operand exceeds the 2 GB buffer view (M=%lld K=%d N=%d)", (long long)M, K, N);
   H2Args p;
   p.A = A; p.Bp = (const _Float16*)Bp; p.C = C; p.stats = stats_part; p.M = M; p.K = K; p.N = N;
   p.a_slots = a_slots; p.b_slots = b_slots;
