@@ -194,23 +194,37 @@ __global__ __launch_bounds__(256, 3) void gemm_nn_f16x2_kernel(H2Args p) {
   }
   slab(G - 2, 0, 1, true, false);
   slab(G - 1, 1, 0, false, false);
+  // Epilogue.  The accumulators hold a column per lane (row = (v & 3) + 8 (v >> 2) + 4 h): stored as they are that is 64
+  // four-byte store instructions per wave, and the store queue, not the bandwidth, paces the tile (36 % of a workgroup's
+  // life at K = 128 by the stamps).  Instead each wave turns its tile through its own 8 KB of the (now dead) slab image,
+  // 32 rows at a time, and writes rows as 16-byte pieces: 16 store instructions of four 256-byte row segments each.
   float cs[2] = {0.f, 0.f}, css[2] = {0.f, 0.f};
+  __syncthreads();                                   // every wave has read the last slab's planes
+  float* stage = reinterpret_cast<float*>(smem) + wave * (32 * 64);
+  const float unscale = inv_a * inv_b;               // exact: powers of two
+  const int sr = lane >> 4, sc4 = lane & 15;         // read-back role: row sr + 4 t, columns 4 sc4 .. 4 sc4 + 3
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 2; ++i) {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
-        const int64_t row = m0 + wm * 64 + 32 * i + (v & 3) + 8 * (v >> 2) + 4 * h;
-        const int col = n0 + wn * 64 + 32 * j + r;
-        const float c = acc[i][j][v] * inv_a * inv_b;       // exact: powers of two
-        if (row < M && col < N) p.C[row * N + col] = c;
-        if (STATS && row < M) {                      // BatchNorm column sums in a fixed order: rows of the lane, then
-                                                     // the two lane halves, then the two row waves
-          cs[j] += c;
+        const float c = acc[i][j][v] * unscale;
+        stage[((v & 3) + 8 * (v >> 2) + 4 * h) * 64 + 32 * j + r] = c;
+        if (STATS && m0 + wm * 64 + 32 * i + (v & 3) + 8 * (v >> 2) + 4 * h < M) {   // BatchNorm column sums in a fixed
+          cs[j] += c;                                // order: rows of the lane, then the two lane halves, then the two row waves
           css[j] = fmaf(c, c, css[j]);
         }
       }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const float4 o = *reinterpret_cast<const float4*>(stage + (sr + 4 * t) * 64 + 4 * sc4);
+      const int64_t row = m0 + wm * 64 + 32 * i + sr + 4 * t;
+      const int col = n0 + wn * 64 + 4 * sc4;
+      if (row < M && col < N) *reinterpret_cast<float4*>(p.C + row * N + col) = o;
+    }
+  }
+  if (STATS) __syncthreads();                        // the statistics rows below reuse the first 2 KB of the image
   if (STATS) {
     float* red = reinterpret_cast<float*>(smem);     // [2 wm][2 q][128]: the planes are dead after the last barrier
 #pragma unroll
@@ -471,7 +485,7 @@ extern "C" int kws_f16x2_split_batch(const float* const* in, void* const* out, c
 extern "C" int kws_gemm_nn_f16x2_f32(const float* A, const void* Bp, float* C, int64_t M, int K, int N,
                                      const unsigned* a_slots, const unsigned* b_slots, float* stats_part, void* stream) {
   KWS_REQUIRE(A && Bp && C && a_slots && b_slots && M > 0, "gemm_nn_f16x2: bad arguments");
-  KWS_REQUIRE(K >= 2 * XBK && K % (2 * XBK) == 0 && N > 0, "gemm_nn_f16x2: K=%d must be a multiple of %d (N=%d)", K, 2 * XBK, N);
+  KWS_REQUIRE(K >= 2 * XBK && K % (2 * XBK) == 0 && N > 0 && N % 4 == 0, "gemm_nn_f16x2: K=%d must be a multiple of %d, N=%d of 4", K, 2 * XBK, N);
   KWS_REQUIRE((M + XBM) * (int64_t)K * 4 < (1ll << 31) && (int64_t)(N + XBN) * K * 4 < (1ll << 31), "gemm_nn_f16x2: operand exceeds the 2 GB buffer view (M=%lld K=%d N=%d)", (long long)M, K, N);
   H2Args p;
   p.A = A; p.Bp = (const _Float16*)Bp; p.C = C; p.stats = stats_part; p.M = M; p.K = K; p.N = N;
