@@ -17,6 +17,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 from speech_recognition_amd import _lib  # noqa: E402
+from speech_recognition_amd import _lib as _lib_arm  # noqa: E402
+GEMM_ARM = {0: "f32 MFMA (product default)", 1: "bf16 x 3 split (KWS_GEMM_BF16X3, experiment)",
+            2: "fp16 x 2 split (KWS_GEMM_F16X2, experiment)"}[_lib_arm.load().kws_net_get_gemm_mode()]
 from speech_recognition_amd.features import path_b_tables  # noqa: E402
 from speech_recognition_amd.keras_api import Model, RMSprop  # noqa: E402
 from speech_recognition_amd.net import DeviceNet  # noqa: E402
@@ -64,7 +67,7 @@ def c3():
 
     ms = timed(step, 5, 30)
     print(json.dumps({"config": "C3: 32-class conv_1d_log_mfcc, log-mel 40x98 from raw clips, batch 2048, fwd+bwd+RMSprop",
-                      "ms_per_step": ms, "clips_per_s": B / ms * 1e3, "n_gpus": 1, "dtype": "f32", "data": "synthetic"}))
+                      "ms_per_step": ms, "clips_per_s": B / ms * 1e3, "n_gpus": 1, "dtype": "f32", "gemm_arm": GEMM_ARM, "data": "synthetic"}))
 
 
 def c5():
@@ -77,7 +80,7 @@ def c5():
     ms_tta = timed(lambda: predict_tta(model, x), 3, 10)
     print(json.dumps({"config": "C5: 12-class raw-waveform net, TTA inference x3 (identity, 1.2x, roll 1500), batch 4096",
                       "ms_per_batch": ms_tta, "clips_per_s": B / ms_tta * 1e3, "plain_inference_clips_per_s": B / ms_plain * 1e3,
-                      "n_gpus": 1, "dtype": "f32", "data": "synthetic"}))
+                      "n_gpus": 1, "dtype": "f32", "gemm_arm": GEMM_ARM, "data": "synthetic"}))
     # make_submission.py use_speed_tta: three more passes over the 0.9x time-stretched clips, stretched on the
     # device inside the timed region (the reference reads them from the offline set of create_tta_set.py)
     ms_tta6 = timed(lambda: predict_tta(model, x, use_speed_tta=True), 3, 10)
@@ -85,7 +88,7 @@ def c5():
     print(json.dumps({"config": "C5 + speed TTA: x6 (identity, 1.2x, roll 1500, slow, clip(1.1 slow), 0.9 slow), "
                                 "phase-vocoder stretch on the device, batch 4096",
                       "ms_per_batch": ms_tta6, "clips_per_s": B / ms_tta6 * 1e3, "stretch_ms_per_batch": ms_stretch,
-                      "stretch_clips_per_s": B / ms_stretch * 1e3, "n_gpus": 1, "dtype": "f32", "data": "synthetic"}))
+                      "stretch_clips_per_s": B / ms_stretch * 1e3, "n_gpus": 1, "dtype": "f32", "gemm_arm": GEMM_ARM, "data": "synthetic"}))
 
 
 if __name__ == "__main__":

@@ -252,6 +252,9 @@ void make_layout(const kws_net* n, int B, bool training, Layout* lo) {
       lo->y[i + 1] = (i % 2 == 0) ? yb : ya;
     }
     lo->part = bp.take(64);
+    lo->WPf.assign(nb, 0);                          // the split-GEMM arms in inference: forward planes and |x| maxima (W | z)
+    for (int i = 0; i < nb; ++i) lo->WPf[i] = bp.take(((int64_t)n->blocks[i].cin * n->blocks[i].cout * 3 + 1) / 2);
+    lo->amax = bp.take((int64_t)2 * nb * KWS_ABSMAX_WORDS);
   }
   lo->w1f = bp.take((int64_t)n->K1f * n->C1);
   lo->bn_stride = (4 * maxC + 63) / 64 * 64;
@@ -384,12 +387,42 @@ int kws_net_predict(const kws_net_t* net, const float* params, const float* stat
     KWS_TRY(fold_conv1(net, params, ws + lo.w1f, st));
     KWS_TRY(kws_gemm_gather_f32(x, &net->gather1f, ws + lo.w1f, ws + lo.y[0], B, net->C1, nullptr, st));
   }
+  // the A/B arithmetic arms (kws_net_set_gemm_mode) in inference: forward planes of the pointwise kernels, one launch
+  const int gemm_mode = kws_net_get_gemm_mode();
+  unsigned* amax0 = reinterpret_cast<unsigned*>(ws + lo.amax);
+  auto w_slots = [&](int i) { return amax0 + (int64_t)i * KWS_ABSMAX_WORDS; };
+  auto z_slots = [&](int i) { return amax0 + (int64_t)(nb + i) * KWS_ABSMAX_WORDS; };
+  if (gemm_mode != 0) {
+    const float* sin_[24];
+    void* sout[24];
+    const unsigned* ssl[24];
+    int64_t wn[24];
+    int srows[24], scols[24], str[24];
+    KWS_REQUIRE(nb <= 24, "net: %d blocks exceed the split batch", nb);
+    for (int i = 0; i < nb; ++i) {
+      sin_[i] = params + net->blocks[i].pw; sout[i] = ws + lo.WPf[i]; ssl[i] = w_slots(i);
+      srows[i] = net->blocks[i].cin; scols[i] = net->blocks[i].cout; str[i] = 1;
+      wn[i] = (int64_t)srows[i] * scols[i];
+    }
+    if (gemm_mode == 2) {
+      KWS_TRY(kws_absmax_batch_f32(sin_, wn, w_slots(0), nb, st));
+      KWS_HIP(hipMemsetAsync(z_slots(0), 0, (size_t)nb * KWS_ABSMAX_WORDS * sizeof(unsigned), st));
+      KWS_TRY(kws_f16x2_split_batch(sin_, sout, srows, scols, str, ssl, nb, st));
+    } else {
+      KWS_TRY(kws_bf16x3_split_batch(sin_, sout, srows, scols, str, nb, st));
+    }
+  }
   for (int i = 0; i < nb; ++i) {
     const Block& b = net->blocks[i];
-    KWS_TRY(kws_dwconv_fwd_f32(ws + lo.y[i], bn_at(i), params + b.dw, ws + lo.z[i], B, b.Lin, b.Lout, b.cin, b.stride,
-                               b.pad_l, st));
-    KWS_TRY(kws_gemm_nn_f32(ws + lo.z[i], params + b.pw, ws + lo.y[i + 1], (int64_t)B * b.Lout, b.cin, b.cout, nullptr,
-                            st));
+    const int64_t M = (int64_t)B * b.Lout;
+    KWS_TRY(kws_dwconv_fwd_amax_f32(ws + lo.y[i], bn_at(i), params + b.dw, ws + lo.z[i], B, b.Lin, b.Lout, b.cin, b.stride,
+                                    b.pad_l, gemm_mode == 2 ? z_slots(i) : nullptr, st));
+    if (gemm_mode == 2 && b.cin % 64 == 0)
+      KWS_TRY(kws_gemm_nn_f16x2_f32(ws + lo.z[i], ws + lo.WPf[i], ws + lo.y[i + 1], M, b.cin, b.cout, z_slots(i), w_slots(i), nullptr, st));
+    else if (gemm_mode == 1 && b.cin % 32 == 0)
+      KWS_TRY(kws_gemm_nn_bf16x3p_f32(ws + lo.z[i], ws + lo.WPf[i], ws + lo.y[i + 1], M, b.cin, b.cout, nullptr, st));
+    else
+      KWS_TRY(kws_gemm_nn_f32(ws + lo.z[i], params + b.pw, ws + lo.y[i + 1], M, b.cin, b.cout, nullptr, st));
   }
   kws_ts_tail_args t;
   memset(&t, 0, sizeof(t));
