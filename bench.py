@@ -403,7 +403,7 @@ def main():
                          num_classes=settings['label_count'])
     model.seed = 87654321            # one dropout stream for the global batch: rank r uses rows [r*B, (r+1)*B)
     ab_steps = min(args.steps, 50)
-    ring = torch.zeros((args.warmup + args.steps + args.profile_steps + 2 * (ab_steps + 8) + 8, 4), dtype=torch.float32, device=device)
+    ring = torch.zeros((args.warmup + args.steps + 3 * args.profile_steps + 2 * (ab_steps + 8) + 8, 4), dtype=torch.float32, device=device)
     enq = GeneratorEnqueuer(gen, max_queue_size=10, device=device)
     enq.start()
 
@@ -476,10 +476,29 @@ def main():
                 barrier()
                 dt_ab = time.time() - t1
                 base += 8 + ab_steps
+                # the arm's own GEMM kernels against BOTH roofs (HIP events on the launch stream, as for the product arm):
+                # algorithmic bytes over 8 TB/s, algorithmic FLOPs over the f32-MFMA peak the product arm is priced against
+                arm_stages = []
+                if args.profile_steps > 0:
+                    lib.kws_profile_enable(1)
+                    for i in range(args.profile_steps):
+                        step(base + i)
+                    barrier()
+                    base += args.profile_steps
+                    prof_ab = _lib.profile_collect()
+                    lib.kws_profile_enable(0)
+                    suffix = {1: "bf16x3", 2: "f16x2"}[mode]
+                    for fam, kern, what_k in (("gemm_nn_" + suffix, "gemm_nn_%s_kernel" % ("bf16x3p" if mode == 1 else "f16x2"),
+                                               "pointwise 1x1 convolutions: forward + input gradient"),
+                                              ("gemm_tn_" + suffix, "gemm_tn_%s_kernel" % suffix,
+                                               "pointwise 1x1 convolutions: weight gradient")):
+                        e = roofline_entry(prof_ab, fam, kern, "hbm", what_k, None)
+                        if e is not None:
+                            arm_stages.append(e)
                 ab[key] = {"what": "pointwise forward / input-gradient / weight-gradient GEMMs as %s, f32 accumulate): an A/B "
                                    "experiment, not the product default" % what,
                            "steps": ab_steps, "ms_per_step": 1e3 * dt_ab / ab_steps, "value": B * ab_steps / dt_ab,
-                           "unit": "clips/s"}
+                           "unit": "clips/s", "roofline_stages": arm_stages}
         finally:
             _lib.check(lib.kws_net_set_gemm_mode(0), "kws_net_set_gemm_mode")
     enq.stop()
