@@ -1,9 +1,19 @@
-// EXPERIMENT 2 (A/B arm, off by default): the pointwise GEMMs with every f32 operand scaled by a power of two and split
-// into TWO fp16 parts (x s = h1 + h2: 22 - 24 mantissa bits; the scale puts the operand's largest magnitude at 2^14, so
-// h1 never overflows and h2 only goes subnormal for elements 2^16 below it) and THREE f16 MFMA products accumulated in
-// f32 (h2.h1, h1.h2, h1.h1; h2.h2 is below the f32 rounding of the sum):  half the matrix instructions of the bf16 x 3
-// form (gemm_bf16x3.hip) at the same accuracy (NumPy study and tests/test_f16x2_gpu.py: 1e-7 ... 5e-7 of the maximum
-// against float64, like the f32 matrix pipe).  Layout, swizzle and tiling are those of gemm_bf16x3.hip.
+// EXPERIMENT 2 (A/B arm, off by default: KWS_GEMM_F16X2=1 / kws_net_set_gemm_mode(2)): the pointwise GEMMs with every f32
+// operand scaled by a power of two and split into TWO fp16 parts (x s = h1 + h2: 22 - 24 significand bits, the residual
+// is exact in f32) and THREE f16 MFMA products accumulated in f32 (h2.h1, h1.h2, h1.h1; h2.h2 is below the f32 rounding
+// of the sum): half the matrix instructions of the bf16 x 3 form (gemm_bf16x3.hip) at the same accuracy - closer to
+// float64 than the f32 matrix pipe on every case of tests/test_f16x2_gpu.py.
+// The scale of an operand comes from its |x| maximum (common.h: kws_absmax_commit / kws_absmax_scale): the largest
+// magnitude lands in [2^14, 2^15), below fp16's 65504; h1 stays normal for elements down to 2^-28 of the maximum, h2 down
+// to 2^-16 of it.  The maxima stay on the device: the kernels that produce an operand (dwconv.hip, bn.hip, absmax_kernel
+// here) leave them in 16 words per tensor, the GEMM workgroups read them in their prologue; results are multiplied by
+// the two inverse scales on the way out (exact).
+//
+//   kws_absmax_batch_f32     |x| maxima of arbitrary tensors into slot groups
+//   kws_f16x2_split_batch    f32 matrices -> scaled fp16 planes [2][rows][cols] (the pointwise kernels, once per step)
+//   kws_gemm_nn_f16x2_f32    C[M,N] = A[M,K] . B, B as planes of [N][K]  (+ BatchNorm column sums per 128-row tile)
+//   kws_gemm_tn_f16x2_f32    dW[K,N] = Z[M,K]^T . G[M,N]
+// Slab image, swizzle and tiling are those of gemm_bf16x3.hip with two planes; DESIGN.md section 5 has the measurements.
 #include "internal.h"
 #include <algorithm>
 #include <cstring>
@@ -250,8 +260,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nn_f16x2_kernel(H2Args p) {
 }
 
 
-// f32 matrices [rows][cols], scaled by the power of two their slots give -> fp16 planes [2][rows][cols] (or of the transpose)
-constexpr int KWS_SPLIT_BATCH = 24;
+constexpr int KWS_SPLIT_BATCH = 24;                  // matrices / tensors per batched launch
 // ---------------------------------------------------------------------------------------------------------------------
 // Weight gradient in the same arithmetic: dW[K,N] = Z[M,K]^T . G[M,N], the reduction runs over the rows.  Both operands are
 // activations, so both are scaled and split on the way into LDS, and both are staged TRANSPOSED ([k or n][32 m], the image and
@@ -429,6 +438,7 @@ __global__ __launch_bounds__(256) void absmax_kernel(AbsmaxBatch b) {
   kws_absmax_commit(b.slots + (int64_t)e * KWS_ABSMAX_WORDS, m);
 }
 
+// f32 matrices [rows][cols], scaled by the power of two their slots give -> fp16 planes [2][rows][cols] (or of the transpose)
 struct SplitBatchH {
   const float* in[KWS_SPLIT_BATCH];
   _Float16* out[KWS_SPLIT_BATCH];
