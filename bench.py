@@ -499,6 +499,9 @@ def main():
                                    "experiment, not the product default" % what,
                            "steps": ab_steps, "ms_per_step": 1e3 * dt_ab / ab_steps, "value": B * ab_steps / dt_ab,
                            "unit": "clips/s", "roofline_stages": arm_stages}
+        except Exception as ex:      # an experiment arm must never cost the run its headline measurement
+            ab["error"] = repr(ex)
+            sys.stderr.write("A/B leg failed: %r\n" % (ex,))
         finally:
             _lib.check(lib.kws_net_set_gemm_mode(0), "kws_net_set_gemm_mode")
     enq.stop()
@@ -550,6 +553,7 @@ def main():
             "roofline_stages": stages[1:],
             "ab_gemm_bf16x3": ab.get("ab_gemm_bf16x3"),
             "ab_gemm_f16x2": ab.get("ab_gemm_f16x2"),
+            "ab_error": ab.get("error"),
             "kernels": prof,
         }
     if dist:
