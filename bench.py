@@ -234,13 +234,13 @@ ROOFLINE_KERNELS = [
 ]
 
 
-def load_pmc_traffic():
+def load_pmc_traffic(pattern="r*_pmc_traffic.json"):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (scripts/pmc_traffic.py), newest round first.
     An entry is used only while the kernel's source file still hashes to what was profiled: a changed kernel reports
     traffic null instead of a stale number."""
     import glob
     import hashlib
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
         try:
             with open(path) as f:
                 d = json.load(f)
@@ -492,7 +492,7 @@ def main():
                                                "pointwise 1x1 convolutions: forward + input gradient"),
                                               ("gemm_tn_" + suffix, "gemm_tn_%s_kernel" % suffix,
                                                "pointwise 1x1 convolutions: weight gradient")):
-                        e = roofline_entry(prof_ab, fam, kern, "hbm", what_k, None)
+                        e = roofline_entry(prof_ab, fam, kern, "hbm", what_k, load_pmc_traffic("r*_%s_arm_pmc.json" % suffix))
                         if e is not None:
                             arm_stages.append(e)
                 ab[key] = {"what": "pointwise forward / input-gradient / weight-gradient GEMMs as %s, f32 accumulate): an A/B "
