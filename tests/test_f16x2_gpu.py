@@ -119,3 +119,52 @@ def test_f16x2_weight_gradient_matches_float64_as_well_as_the_f32_kernel(M, K, N
     _lib.call("kws_gemm_tn_f16x2_f32", _lib.ptr(Z), _lib.ptr(G), _lib.ptr(D2b), M, K, N, _lib.ptr(slots[0]), _lib.ptr(slots[1]),
               _lib.ptr(ws2), _lib.stream_ptr())
     assert torch.equal(D2, D2b)
+
+
+def _slot_max(slots):
+    return float(slots.view(16, 16)[:, 0].contiguous().view(torch.float32).max())
+
+
+@pytest.mark.parametrize("B,Lin,C,stride", [(3, 37, 128, 1), (5, 22, 192, 2), (2, 99, 320, 1), (7, 11, 512, 1), (1, 5, 64, 2)])
+def test_producers_leave_the_exact_maximum_of_the_operand_they_write(B, Lin, C, stride):
+    """dwconv_fwd (z), pass 2 of dwconv_bwd and bn_bwd_apply (dy) commit max|x| of what they store - incl. the channel counts
+    whose workgroups end in a partial wave (192: 240 threads) - through the library's internal entry points"""
+    import ctypes as C_
+    lib = C_.CDLL(_lib.LIB_PATH)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(B * 1000 + C)
+    pad_l = 0 if stride == 1 else Lin % 2              # TF 'same', right-biased: (0, 1) for even, (1, 1) for odd lengths
+    Lout = Lin - 2 if stride == 1 else (Lin + 1) // 2
+    y = torch.randn((B, Lin, C), generator=g, device="cuda") * 2.0
+    bn = torch.cat([torch.rand(C, generator=g, device="cuda") + 0.5, torch.randn(C, generator=g, device="cuda") * 0.3,
+                    torch.randn(C, generator=g, device="cuda") * 0.1, torch.rand(C, generator=g, device="cuda") + 0.5]).contiguous()
+    w = torch.randn((3, C), generator=g, device="cuda")
+    S = _lib.stream_ptr()
+    P = C_.c_void_p
+    # forward
+    z = torch.empty((B, Lout, C), device="cuda")
+    slots = torch.zeros(256, dtype=torch.int32, device="cuda")
+    rc = lib.kws_dwconv_fwd_amax_f32(P(y.data_ptr()), P(bn.data_ptr()), P(w.data_ptr()), P(z.data_ptr()), B, Lin, Lout, C, stride,
+                                     pad_l, P(slots.data_ptr()), S)
+    _lib.check(rc, 'internal entry point')
+    assert _slot_max(slots) == float(z.abs().max()) > 0.0
+    z_ref = torch.empty_like(z)                      # the same kernel without the commit writes the same z
+    _lib.call("kws_dwconv_fwd_f32", _lib.ptr(y), _lib.ptr(bn), _lib.ptr(w), _lib.ptr(z_ref), B, Lin, Lout, C, stride, pad_l, S)
+    assert torch.equal(z, z_ref)
+    # backward pass 2
+    dz = torch.randn((B, Lout, C), generator=g, device="cuda") * 1e-6
+    coef = torch.randn(2 * C, generator=g, device="cuda") * 1e-7
+    dy = torch.empty((B, Lin, C), device="cuda")
+    slots.zero_()
+    rc = lib.kws_dwconv_bwd_bn_amax_f32(P(dz.data_ptr()), P(y.data_ptr()), P(bn.data_ptr()), P(w.data_ptr()), P(coef.data_ptr()),
+                                        P(dy.data_ptr()), None, 2, B, Lin, Lout, C, stride, pad_l, P(slots.data_ptr()), S)
+    _lib.check(rc, 'internal entry point')
+    assert _slot_max(slots) == float(dy.abs().max()) > 0.0
+    # BatchNorm backward of the last block
+    gdy = torch.randn((B * Lin, C), generator=g, device="cuda") * 1e-5
+    gamma = torch.rand(C, generator=g, device="cuda") + 0.5
+    slots.zero_()
+    rc = lib.kws_bn_bwd_apply_amax(P(gdy.data_ptr()), P(y.data_ptr()), P(bn.data_ptr()), P(gamma.data_ptr()), P(coef.data_ptr()),
+                                   C_.c_int64(B * Lin), C, P(slots.data_ptr()), S)
+    _lib.check(rc, 'internal entry point')
+    assert _slot_max(slots) == float(gdy.abs().max()) > 0.0
