@@ -120,8 +120,11 @@ def run(device=None, epochs=10, steps=100, batch=64, val_batches=8, bank=4096, q
         cpu_acc.append(float((p.argmax(1) == yt.argmax(1)).mean()))
         cpu_loss.append(float(-(yt * np.log(np.clip(p, 1e-12, 1 - 1e-12))).sum(axis=1).mean()))
     t_cpu = time.time() - t0
-    res = {"val_acc": dev_acc[-1], "val_acc_cpu": cpu_acc[-1],
+    # final-epoch values (the parity bar) and the best epoch (what a save-best checkpoint keeps): with Keras' BatchNorm
+    # momentum of 0.99 the inference-mode accuracy of BOTH sides still moves by a class (0.9 <-> 1.0) between late epochs
+    res = {"val_acc": dev_acc[-1], "val_acc_cpu": cpu_acc[-1], "val_acc_best": max(dev_acc), "val_acc_cpu_best": max(cpu_acc),
            "val_acc_parity": {"tolerance": TOL_VAL_ACC, "ok": abs(dev_acc[-1] - cpu_acc[-1]) <= TOL_VAL_ACC,
+                              "ok_best": abs(max(dev_acc) - max(cpu_acc)) <= TOL_VAL_ACC,
                               "epochs": epochs, "steps_per_epoch": steps, "batch": batch,
                               "validation_clips": val_batches * batch,
                               "device": {"val_acc": dev_acc, "val_loss": dev_loss, "train_acc": dev_train_acc,
