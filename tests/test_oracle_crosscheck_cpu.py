@@ -153,3 +153,29 @@ def test_label_smoothed_cross_entropy_matches_torch():
                                                reduction="none").numpy()
     np.testing.assert_allclose(per, theirs, atol=1e-6)       # Keras clips p to [1e-7, 1 - 1e-7] before the log
     np.testing.assert_allclose(mean, theirs.mean(), atol=1e-6)
+
+
+def test_path_a_filterbank_matches_the_hugging_face_matrix_but_for_tf_kernels_start_index():
+    """audio.py's path A (TF 1.4 C++ MfccMelFilterbank, 40 channels, 20 - 4000 Hz): triangles in HTK-mel space like the
+    path-B op, so the same third-party matrix applies - except that the TF kernel skips the spectrum bins below
+    start_index = int(1.5 + lower / hz_per_bin) (= 2 here: bin 1 at 31.25 Hz lies inside the first triangle but is dropped)."""
+    audio_utils = pytest.importorskip("transformers.audio_utils")
+    theirs = audio_utils.mel_filter_bank(num_frequency_bins=257, num_mel_filters=40, min_frequency=20.0, max_frequency=4000.0,
+                                         sampling_rate=16000, norm=None, mel_scale="htk", triangularize_in_mel_space=True)
+    ours = OF.mfcc_mel_filterbank_dense(257, 16000.0, 40, 20.0, 4000.0)
+    diff = np.abs(ours - theirs)
+    rows = sorted(set(np.argwhere(diff > 1e-9)[:, 0].tolist()))
+    assert rows == [1]                               # the one bin the TF kernel's start index excludes
+    assert np.all(ours[:2] == 0.0) and theirs[1, 0] > 0.3
+    np.testing.assert_allclose(np.delete(ours, 1, axis=0), np.delete(theirs, 1, axis=0), atol=1e-9)
+
+
+def test_path_a_dct_matches_scipy():
+    """TF 1.4 MfccDct: sqrt(2/N) cos(pi i (j + 0.5) / N) = the orthonormal DCT-II except for coefficient 0 (no 1/sqrt 2)"""
+    scipy_fft = pytest.importorskip("scipy.fft")
+    x = np.random.RandomState(11).randn(6, 40)
+    for keep in (40, 13):
+        ours = x @ OF.mfcc_dct_matrix(40, keep)
+        ortho = scipy_fft.dct(x, type=2, norm="ortho", axis=-1)[:, :keep]
+        np.testing.assert_allclose(ours[:, 1:], ortho[:, 1:], atol=1e-12)
+        np.testing.assert_allclose(ours[:, 0], ortho[:, 0] * np.sqrt(2.0), atol=1e-12)
