@@ -47,6 +47,7 @@ extern "C" int kws_debug_read_stft_stamps(unsigned long long* out) {
 #endif
 
 namespace {
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int NW4 = 12;             // waves per workgroup: 3 per SIMD
 constexpr int DSTR4 = 80;           // DCT table row stride (floats), as in stft3
@@ -66,7 +67,8 @@ __device__ __forceinline__ float blend(unsigned m, float a, float b) {   // m al
 // bands 16 i .. 16 i + 15 read (the widest of them decides; 80 mel bins: 1, 1, 2, 3, 4); MC = the largest of them (the row
 // width of the weight table).  All compile-time, so the mel stage and the DCT are straight-line code whose LDS reads the
 // compiler can put in flight together.
-template <int NB, int MC, int MCP>
+// H1: the first pass on the f16 matrix instruction (see the first-pass comment in the kernel); false = v_mfma_f32_16x16x4_f32
+template <int NB, int MC, int MCP, bool H1>
 __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
 #ifdef KWS_STFT_STAMP
@@ -124,6 +126,23 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
   for (int q = 0; q < 4; ++q) {
     const float4 v = *reinterpret_cast<const float4*>(pl.b4 + lane * 16 + 4 * q);
     r_b[4 * q] = v.x; r_b[4 * q + 1] = v.y; r_b[4 * q + 2] = v.z; r_b[4 * q + 3] = v.w;
+  }
+  // H1: the same 16 constants as the B operands of two v_mfma_f32_16x16x32_f16 (column tiles c = 0, 1): element e = 2 j' + s
+  // of the lane's 8 is the constant that multiplied (s = 0: the even / s = 1: the odd sample of) k-chunk j' - the sum over
+  // the 32 k of one f16 instruction is the sum of the eight K = 4 f32 instructions it replaces, term for term.  Scaled by
+  // 2^14 (|b| <= 0.5) and split into two fp16 parts; the samples are scaled by 2^10 (|x w| < 64) and split the same way:
+  // three products h2.h1 + h1.h2 + h1.h1 carry 22 bits (csrc/gemm_f16x2.hip has the argument), the result is multiplied by 2^-24.
+  f16x8 hb1[2], hb2[2];
+  if (H1) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float v = r_b[4 * (e >> 1) + 2 * (e & 1) + c] * 16384.f;
+        const _Float16 h = (_Float16)v;
+        hb1[c][e] = h;
+        hb2[c][e] = (_Float16)(v - (float)h);
+      }
   }
   // mel stage: first bin of the tap window and offset of the weight row of this lane's band l16 + 16 i (band 0's for
   // lanes past n_mel: they compute and do not store)
@@ -199,6 +218,35 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
         acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
         acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
+      if (H1) {
+        // An f32 matrix instruction holds the SIMD's vector issue for all of its 32 cycles (probe):
+        // the 64 of a quad were 2,048 cycles nothing else could use.  The f16 form holds it for 8 of its 16: 24 instructions
+        // (3 products x 4 row blocks x 2 column tiles) + the split of the lane's 32 windowed samples.
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          f16x8 a1, a2;
+#pragma unroll
+          for (int jp = 0; jp < 4; ++jp) {
+            const float2 wv = *reinterpret_cast<const float2*>(s_win + a_off0 + 128 * jp + 8 * t);
+            const float ar = xv[t][jp].x * wv.x * 1024.f, ai = xv[t][jp].y * wv.y * 1024.f;
+            const _Float16 hr = (_Float16)ar, hi = (_Float16)ai;
+            a1[2 * jp] = hr; a1[2 * jp + 1] = hi;
+            a2[2 * jp] = (_Float16)(ar - (float)hr); a2[2 * jp + 1] = (_Float16)(ai - (float)hi);
+          }
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, hb1[c], acc[t][c], 0, 0, 0);
+            acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, hb2[c], acc[t][c], 0, 0, 0);
+            acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, hb1[c], acc[t][c], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[t][c][v] *= 5.9604644775390625e-08f;     // 2^-24: exact
+      } else {
 #pragma unroll
       for (int jp = 0; jp < 4; ++jp) {
 #pragma unroll
@@ -210,6 +258,7 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
           acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai, r_b[4 * jp + 2], acc[t][0], 0, 0, 0);
           acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai, r_b[4 * jp + 3], acc[t][1], 0, 0, 0);
         }
+      }
       }
       // the PCM of this wave's NEXT quad is requested as soon as the MFMAs have consumed this quad's: it lands while
       // the vector work of this quad runs
@@ -412,17 +461,22 @@ int kws_stft4_lds_bytes(const kws_stft_plan* pl) {
   return (int)(floats * 4);
 }
 
-template <int NB, int MC, int MCP>
-static int stft4_launch_t(const Stft2Args& a, int bytes, int64_t wgs, hipStream_t st) {
+template <int NB, int MC, int MCP, bool H1>
+static int stft4_launch_h(const Stft2Args& a, int bytes, int64_t wgs, hipStream_t st) {
   static bool attr_done = false;
   if (!attr_done) {
-    KWS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&stft4_kernel<NB, MC, MCP>),
+    KWS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&stft4_kernel<NB, MC, MCP, H1>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
-  hipLaunchKernelGGL((stft4_kernel<NB, MC, MCP>), dim3((unsigned)wgs), dim3(NW4 * 64), (size_t)bytes, st, a);
+  hipLaunchKernelGGL((stft4_kernel<NB, MC, MCP, H1>), dim3((unsigned)wgs), dim3(NW4 * 64), (size_t)bytes, st, a);
   KWS_LAUNCH_CHECK("stft4_kernel");
   return KWS_OK;
+}
+template <int NB, int MC, int MCP>
+static int stft4_launch_t(const Stft2Args& a, int bytes, int64_t wgs, hipStream_t st) {
+  static const bool f32_pass = getenv("KWS_STFT_F32PASS") != nullptr;   // A/B: the first pass on v_mfma_f32_16x16x4_f32
+  return f32_pass ? stft4_launch_h<NB, MC, MCP, false>(a, bytes, wgs, st) : stft4_launch_h<NB, MC, MCP, true>(a, bytes, wgs, st);
 }
 
 int kws_stft4_launch(const kws_stft_plan* pl, const float* x, int B, int L, int F, float* out, hipStream_t st) {
