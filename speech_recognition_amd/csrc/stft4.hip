@@ -102,9 +102,26 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
   for (int i = tid; i < 256; i += NW4 * 64) s_tw[i] = pl.tw4[(i & 15) * 16 + (i >> 4)];   // [c][n2] -> [n2][c]: a row's
                                                    // 16 lanes read 16 consecutive 8-byte entries (conflict-free)
   for (int i = tid; i < 128; i += NW4 * 64) s_w5[i] = pl.w512p[(i & 15) * 8 + (i >> 4)];  // [c][k2] -> [k2][c]
+  constexpr int KB = (16 * NB + 31) / 32;                           // H1: k-blocks of the DCT product (32 mel bands each)
+  constexpr bool D16 = H1 && KB * 4 * 2 * 64 * 8 * 2 <= 16 * NB * DSTR4 * 4;   // the f16 DCT image must fit the f32 table's LDS
+                                                                                // (80 bands: 24.6 of 25.6 KB; 40 bands keep the f32 DCT)
+  if (D16) {
+    // the DCT table as the B operands of v_mfma_f32_16x16x32_f16, ready to read: [kb][nb][plane][lane][8] fp16, element e of
+    // lane (q = 16 nb + lane % 16, k group lane / 16) = dct[k = lane / 16 + 4 e + 32 kb][q] x 2^14, split in two parts
+    _Float16* s_dh = reinterpret_cast<_Float16*>(s_dct);
+    for (int i = tid; i < KB * 4 * 64 * 8; i += NW4 * 64) {
+      const int e = i & 7, ln = (i >> 3) & 63, nb = (i >> 9) & 3, kb = i >> 11;
+      const int k = (ln >> 4) + 4 * e + 32 * kb, q = 16 * nb + (ln & 15);
+      const float v = (k < n_mel ? pl.dct64[k * 64 + q] : 0.f) * 16384.f;
+      const _Float16 h = (_Float16)v;
+      s_dh[(((kb * 4 + nb) * 2 + 0) * 64 + ln) * 8 + e] = h;
+      s_dh[(((kb * 4 + nb) * 2 + 1) * 64 + ln) * 8 + e] = (_Float16)(v - (float)h);
+    }
+  } else {
   for (int i = tid; i < 16 * NB * DSTR4; i += NW4 * 64) {          // rows n_mel .. 16 NB - 1 are zero
     const int m = i / DSTR4, q = i - m * DSTR4;
     s_dct[i] = (q < 64 && m < n_mel) ? pl.dct64[m * 64 + q] : 0.f;
+  }
   }
   for (int i = tid; i < n_mel * WSTR; i += NW4 * 64) {
     // row m = the weights of bins win_m .. win_m + MAXW - 1, win_m = min(plan window start, MAGF - MAXW): the plan's
@@ -363,7 +380,35 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) dacc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float* pa = s_lm16 + l16 * LMS + fq;
-    const float* pb = s_dct + fq * DSTR4 + l16;
+    if (D16) {
+      // as the first pass: the 20 (K = 80) x 4 f32 instructions of a group held the vector issue for 2,560 cycles; the f16 form
+      // needs KB x 4 x 3 instructions that hold it for 8 each.  Log-mel values lie in [-14, 12]: scaled by 2^9.
+      const _Float16* s_dh = reinterpret_cast<const _Float16*>(s_dct);
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        f16x8 a1, a2;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float v = (4 * e + 32 * kb + 4 <= 16 * NB) ? pa[4 * e + 32 * kb] * 512.f : 0.f;   // k = fq + 4 e + 32 kb < 16 NB
+          const _Float16 hh = (_Float16)v;
+          a1[e] = hh;
+          a2[e] = (_Float16)(v - (float)hh);
+        }
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+          const f16x8 b1 = *reinterpret_cast<const f16x8*>(s_dh + (((kb * 4 + nb) * 2 + 0) * 64 + lane) * 8);
+          const f16x8 b2 = *reinterpret_cast<const f16x8*>(s_dh + (((kb * 4 + nb) * 2 + 1) * 64 + lane) * 8);
+          dacc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b1, dacc[nb], 0, 0, 0);
+          dacc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b2, dacc[nb], 0, 0, 0);
+          dacc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1, dacc[nb], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) dacc[nb][v] *= 1.1920928955078125e-07f;      // 2^-23: exact
+    } else {
+      const float* pb = s_dct + fq * DSTR4 + l16;
     {
       // operands two steps ahead of the MFMAs that use them (one step = 4 MFMAs = 128 cycles of cover, an LDS round trip
       // under 12 waves takes longer)
@@ -390,6 +435,7 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
           bv[1][nb] = bv[2][nb];
         }
       }
+    }
     }
     {
       const int quad = fq == 0 ? gq[0] : (fq == 1 ? gq[1] : (fq == 2 ? gq[2] : gq[3]));   // lane group fq: the group's quad fq
