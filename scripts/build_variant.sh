@@ -6,7 +6,8 @@ cd "$(dirname "$0")/../speech_recognition_amd/csrc"
 f=${3:-gemm}
 mkdir -p ../../variants build/variant
 make -s -j8 >/dev/null
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -ffp-contract=on $2 -c $f.hip -o build/variant/${f}_$1.o
+extra=""; [ "$f" = stft4 ] && extra="-fno-slp-vectorize"   # as the Makefile builds it
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -ffp-contract=on $extra $2 -c $f.hip -o build/variant/${f}_$1.o
 objs=$(ls build/*.o | grep -v "build/$f.o" | tr '\n' ' ')
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../variants/libkws_$1.so $objs build/variant/${f}_$1.o
 echo built variants/libkws_$1.so

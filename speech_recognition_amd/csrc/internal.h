@@ -69,10 +69,12 @@ struct kws_stft_plan {
   int mel_maxw;
   int* mel_ws;        // [n_mel]
   float* mel_wpad;    // [n_mel][mel_maxw]
+  float* img4;        // stft4: the constant part of a workgroup's LDS as one image (kws_stft4_prepare), or NULL
 };
 int kws_stft2_launch(const kws_stft_plan* pl, const float* x, int B, int L, int F, float* out, hipStream_t st);
 int kws_stft3_lds_bytes(const kws_stft_plan* pl);
 int kws_stft3_launch(const kws_stft_plan* pl, const float* x, int B, int L, int F, float* out, hipStream_t st);
+int kws_stft4_prepare(kws_stft_plan* pl);
 int kws_stft4_lds_bytes(const kws_stft_plan* pl);
 int kws_stft4_launch(const kws_stft_plan* pl, const float* x, int B, int L, int F, float* out, hipStream_t st);
 

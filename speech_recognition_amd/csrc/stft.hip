@@ -329,6 +329,7 @@ int kws_stft_plan_create(int frame_len, int frame_step, int fft_len, int n_mel, 
   if (rc == KWS_OK) rc = upload(&p->w512p, w512p);
   if (rc == KWS_OK) rc = upload(&p->mel_ws, mws);
   if (rc == KWS_OK) rc = upload(&p->mel_wpad, wpad);
+  if (rc == KWS_OK) rc = kws_stft4_prepare(p);
   if (rc != KWS_OK) {
     kws_stft_plan_destroy(p);
     return rc;
@@ -339,8 +340,8 @@ int kws_stft_plan_create(int frame_len, int frame_step, int fft_len, int n_mel, 
 
 int kws_stft_plan_destroy(kws_stft_plan_t* p) {
   if (!p) return KWS_OK;
-  void* bufs[15] = {p->window, p->w256, p->w512, p->band_start, p->band_cnt, p->band_ofs, p->band_w, p->dct,
-                    p->tw16, p->dct64, p->b4, p->tw4, p->w512p, p->mel_ws, p->mel_wpad};
+  void* bufs[16] = {p->window, p->w256, p->w512, p->band_start, p->band_cnt, p->band_ofs, p->band_w, p->dct,
+                    p->tw16, p->dct64, p->b4, p->tw4, p->w512p, p->mel_ws, p->mel_wpad, p->img4};
   for (void* q : bufs)
     if (q) (void)hipFree(q);
   delete p;

@@ -54,9 +54,21 @@ constexpr int DSTR4 = 80;           // DCT table row stride (floats), as in stft
 constexpr int MAGF = 260;           // floats of one frame's magnitude row
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float row_mirror(float v) {   // value of lane 15 - (lane % 16) of the same 16-lane row
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));
+}
+
+// two f32 -> their fp16 parts, packed (low half = a): hi = rne(x), lo = rne(x - hi).  The residual comes from ONE
+// v_fma_mix_f32 reading the fp16 half in place (the compiler's own sequence converts hi back first: 6 instructions per
+// pair instead of 4; the kernel is bound by vector issue, section 5 of DESIGN.md)
+__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
+  float la, lb;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(la) : "v"(hi), "v"(a));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(lb) : "v"(hi), "v"(b));
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo) : "v"(la), "v"(lb));
 }
 
 __device__ __forceinline__ float blend(unsigned m, float a, float b) {   // m all ones: a, m zero: b
@@ -68,6 +80,78 @@ __device__ __forceinline__ float blend(unsigned m, float a, float b) {   // m al
 // width of the weight table).  All compile-time, so the mel stage and the DCT are straight-line code whose LDS reads the
 // compiler can put in flight together.
 // H1: the first pass on the f16 matrix instruction (see the first-pass comment in the kernel); false = v_mfma_f32_16x16x4_f32
+//
+// The constant part of a workgroup's LDS - window, twiddles, split factors, the quad counter, DCT operand and mel tap
+// weights - as ONE image, made once per plan by stft4_image_kernel (kws_stft4_prepare) and copied by every workgroup
+// of every launch with 16-byte loads.  Staged table by table in the prologue of the feature kernel it cost 5.6 us of a
+// 61 us launch: eleven trips of dependent global loads (band start -> weight row) before the first frame.
+template <int NB, int MC>
+struct Stft4Lds {
+  static constexpr int MAXW = 4 * MC;                              // taps of a mel band's window
+  static constexpr int WSTR = MAXW + 4;                            // row stride of the weight table: 16-byte reads of 16
+                                                                   // consecutive rows fall on disjoint banks
+  static constexpr int WIN = 0, TW = 512, W5 = 1024, CTR = 1280, DCT = 1284, WPAD = DCT + 16 * NB * DSTR4;
+  __host__ __device__ static constexpr int image_floats(int n_mel) { return WPAD + n_mel * WSTR; }
+};
+
+template <int NB, int MC, int MCP, bool H1>
+__device__ __forceinline__ void stft4_tables(float* lds, const kws_stft_plan& pl, int tid, int nthreads) {
+  using L = Stft4Lds<NB, MC>;
+  constexpr int WSTR = L::WSTR;
+  const int n_mel = pl.n_mel;
+  float* s_win = lds + L::WIN;                                     // [512] zero padded window
+  float2* s_tw = reinterpret_cast<float2*>(lds + L::TW);           // [16 n2][16 c] second-pass twiddles W256^(n2 k1)
+  float2* s_w5 = reinterpret_cast<float2*>(lds + L::W5);           // [8 k2][16 c] split factors W512^(k1 + 16 k2)
+  float* s_dct = lds + L::DCT;                                     // [n_mel][DSTR4]
+  float* s_wpad = lds + L::WPAD;                                   // [n_mel][WSTR] band weights over the band's tap window
+  // H1: the power-of-two scales of the f16 first pass live in the tables (exact): the window carries the samples' 2^10,
+  // the twiddles of n2 >= 1 the products' 2^-24
+  for (int i = tid; i < 512; i += nthreads) s_win[i] = H1 ? pl.window[i] * 1024.f : pl.window[i];
+  for (int i = tid; i < 256; i += nthreads) {      // [c][n2] -> [n2][c]: a row's 16 lanes read 16 consecutive 8-byte
+    float2 v = pl.tw4[(i & 15) * 16 + (i >> 4)];   // entries (conflict-free)
+    if (H1) { v.x *= 5.9604644775390625e-08f; v.y *= 5.9604644775390625e-08f; }
+    s_tw[i] = v;
+  }
+  for (int i = tid; i < 128; i += nthreads) s_w5[i] = pl.w512p[(i & 15) * 8 + (i >> 4)];  // [c][k2] -> [k2][c]
+  constexpr int KB = (16 * NB + 31) / 32;                           // H1: k-blocks of the DCT product (32 mel bands each)
+  constexpr bool D16 = H1 && KB * 4 * 2 * 64 * 8 * 2 <= 16 * NB * DSTR4 * 4;   // the f16 DCT image must fit the f32 table's LDS
+                                                                                // (80 bands: 24.6 of 25.6 KB; 40 bands keep the f32 DCT)
+  if (D16) {
+    // the DCT table as the B operands of v_mfma_f32_16x16x32_f16, ready to read: [kb][nb][plane][lane][8] fp16, element e of
+    // lane (q = 16 nb + lane % 16, k group lane / 16) = dct[k = lane / 16 + 4 e + 32 kb][q] x 2^14, split in two parts
+    _Float16* s_dh = reinterpret_cast<_Float16*>(s_dct);
+    for (int i = tid; i < KB * 4 * 64 * 8; i += nthreads) {
+      const int e = i & 7, ln = (i >> 3) & 63, nb = (i >> 9) & 3, kb = i >> 11;
+      const int k = (ln >> 4) + 4 * e + 32 * kb, q = 16 * nb + (ln & 15);
+      const float v = (k < n_mel ? pl.dct64[k * 64 + q] : 0.f) * 16384.f;
+      const _Float16 h = (_Float16)v;
+      s_dh[(((kb * 4 + nb) * 2 + 0) * 64 + ln) * 8 + e] = h;
+      s_dh[(((kb * 4 + nb) * 2 + 1) * 64 + ln) * 8 + e] = (_Float16)(v - (float)h);
+    }
+  } else {
+  for (int i = tid; i < 16 * NB * DSTR4; i += nthreads) {          // rows n_mel .. 16 NB - 1 are zero
+    const int m = i / DSTR4, q = i - m * DSTR4;
+    s_dct[i] = (q < 64 && m < n_mel) ? pl.dct64[m * 64 + q] : 0.f;
+  }
+  }
+  for (int i = tid; i < n_mel * WSTR; i += nthreads) {
+    // row m = the weights of bins win_m .. win_m + MAXW - 1, win_m = min(plan window start, MAGF - MAXW): the plan's
+    // window (mel_maxw <= MAXW taps from mel_ws[m]) shifted right inside the row where the kernel's starts earlier
+    const int m = i / WSTR, q = i - m * WSTR;
+    const int taps = 4 * ((MCP >> (4 * (m >> 4))) & 15);           // what the kernel reads for this band's group
+    const int ws0 = pl.mel_ws[m];
+    const int win = ws0 + taps <= MAGF ? ws0 : MAGF - taps;
+    const int j = q - (ws0 - win);
+    s_wpad[i] = (q < taps && j >= 0 && j < pl.mel_maxw) ? pl.mel_wpad[m * pl.mel_maxw + j] : 0.f;
+  }
+  for (int i = tid; i < 4; i += nthreads) lds[L::CTR + i] = 0.f;  // the quad counter starts at zero
+}
+
+template <int NB, int MC, int MCP, bool H1>
+__global__ __launch_bounds__(256) void stft4_image_kernel(kws_stft_plan pl, float* img) {
+  stft4_tables<NB, MC, MCP, H1>(img, pl, threadIdx.x, blockDim.x);
+}
+
 template <int NB, int MC, int MCP, bool H1>
 __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -78,17 +162,18 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
   const int n_mel = pl.n_mel, n_out = pl.n_out;
   constexpr int LMS = 16 * NB + 1;                                 // log-mel row stride (odd: conflict-free columns); the
                                                                    // columns n_mel .. 16 NB - 1 stay zero
-  constexpr int MAXW = 4 * MC;                                     // taps of a mel band's window
-  constexpr int WSTR = MAXW + 4;                                   // row stride of the weight table: 16-byte reads of 16
-                                                                   // consecutive rows fall on disjoint banks
-  float* s_win = lds;                                              // [512] zero padded window
-  float2* s_tw = reinterpret_cast<float2*>(s_win + 512);           // [16 n2][16 c] second-pass twiddles W256^(n2 k1)
-  float2* s_w5 = s_tw + 256;                                       // [8 k2][16 c] split factors W512^(k1 + 16 k2)
-  int* s_ctr = reinterpret_cast<int*>(s_win + 512 + 512 + 256);    // [4] the workgroup's quad counter
-  float* s_dct = s_win + 512 + 512 + 256 + 4;                      // [n_mel][DSTR4]
-  float* s_wpad = s_dct + 16 * NB * DSTR4;                         // [n_mel][WSTR] band weights over the band's tap window
-  float* s_wave = s_wpad + n_mel * WSTR;
+  using LT = Stft4Lds<NB, MC>;                                     // the table image (stft4_tables), then the waves' rows
+  constexpr int WSTR = LT::WSTR;
+  float* s_win = lds + LT::WIN;
+  float2* s_tw = reinterpret_cast<float2*>(lds + LT::TW);
+  float2* s_w5 = reinterpret_cast<float2*>(lds + LT::W5);
+  int* s_ctr = reinterpret_cast<int*>(lds + LT::CTR);              // [4] the workgroup's quad counter
+  float* s_dct = lds + LT::DCT;
+  float* s_wpad = lds + LT::WPAD;
+  float* s_wave = lds + LT::image_floats(n_mel);
   constexpr int wave_floats = 4 * MAGF + ((16 * LMS + 3) & ~3);
+  constexpr int KB = (16 * NB + 31) / 32;                           // H1: k-blocks of the DCT product (32 mel bands each)
+  constexpr bool D16 = H1 && KB * 4 * 2 * 64 * 8 * 2 <= 16 * NB * DSTR4 * 4;   // the f16 DCT image must fit the f32 table's LDS
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform by construction; SAYING so keeps the quad
                                                                    // arithmetic and the buffer descriptors in scalar registers
@@ -98,42 +183,13 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
   float* s_mag = s_wave + wave * wave_floats + fq * MAGF;          // this lane row's frame
   float* s_lm16 = s_wave + wave * wave_floats + 4 * MAGF;          // [16][LMS] log-mel rows of a group of four quads
 
-  for (int i = tid; i < 512; i += NW4 * 64) s_win[i] = pl.window[i];
-  for (int i = tid; i < 256; i += NW4 * 64) s_tw[i] = pl.tw4[(i & 15) * 16 + (i >> 4)];   // [c][n2] -> [n2][c]: a row's
-                                                   // 16 lanes read 16 consecutive 8-byte entries (conflict-free)
-  for (int i = tid; i < 128; i += NW4 * 64) s_w5[i] = pl.w512p[(i & 15) * 8 + (i >> 4)];  // [c][k2] -> [k2][c]
-  constexpr int KB = (16 * NB + 31) / 32;                           // H1: k-blocks of the DCT product (32 mel bands each)
-  constexpr bool D16 = H1 && KB * 4 * 2 * 64 * 8 * 2 <= 16 * NB * DSTR4 * 4;   // the f16 DCT image must fit the f32 table's LDS
-                                                                                // (80 bands: 24.6 of 25.6 KB; 40 bands keep the f32 DCT)
-  if (D16) {
-    // the DCT table as the B operands of v_mfma_f32_16x16x32_f16, ready to read: [kb][nb][plane][lane][8] fp16, element e of
-    // lane (q = 16 nb + lane % 16, k group lane / 16) = dct[k = lane / 16 + 4 e + 32 kb][q] x 2^14, split in two parts
-    _Float16* s_dh = reinterpret_cast<_Float16*>(s_dct);
-    for (int i = tid; i < KB * 4 * 64 * 8; i += NW4 * 64) {
-      const int e = i & 7, ln = (i >> 3) & 63, nb = (i >> 9) & 3, kb = i >> 11;
-      const int k = (ln >> 4) + 4 * e + 32 * kb, q = 16 * nb + (ln & 15);
-      const float v = (k < n_mel ? pl.dct64[k * 64 + q] : 0.f) * 16384.f;
-      const _Float16 h = (_Float16)v;
-      s_dh[(((kb * 4 + nb) * 2 + 0) * 64 + ln) * 8 + e] = h;
-      s_dh[(((kb * 4 + nb) * 2 + 1) * 64 + ln) * 8 + e] = (_Float16)(v - (float)h);
-    }
-  } else {
-  for (int i = tid; i < 16 * NB * DSTR4; i += NW4 * 64) {          // rows n_mel .. 16 NB - 1 are zero
-    const int m = i / DSTR4, q = i - m * DSTR4;
-    s_dct[i] = (q < 64 && m < n_mel) ? pl.dct64[m * 64 + q] : 0.f;
+  {
+    // tables: one 16-byte copy of the plan's image (stft4_tables above)
+    const float4* src = reinterpret_cast<const float4*>(pl.img4);
+    float4* dst = reinterpret_cast<float4*>(lds);
+    const int n4 = LT::image_floats(n_mel) / 4;
+    for (int i = tid; i < n4; i += NW4 * 64) dst[i] = src[i];
   }
-  }
-  for (int i = tid; i < n_mel * WSTR; i += NW4 * 64) {
-    // row m = the weights of bins win_m .. win_m + MAXW - 1, win_m = min(plan window start, MAGF - MAXW): the plan's
-    // window (mel_maxw <= MAXW taps from mel_ws[m]) shifted right inside the row where the kernel's starts earlier
-    const int m = i / WSTR, q = i - m * WSTR;
-    const int taps = 4 * ((MCP >> (4 * (m >> 4))) & 15);           // what the kernel reads for this band's group
-    const int ws0 = pl.mel_ws[m];
-    const int win = ws0 + taps <= MAGF ? ws0 : MAGF - taps;
-    const int j = q - (ws0 - win);
-    s_wpad[i] = (q < taps && j >= 0 && j < pl.mel_maxw) ? pl.mel_wpad[m * pl.mel_maxw + j] : 0.f;
-  }
-  if (tid == 0) s_ctr[0] = 0;
   if (l16 < MAGF - 257) s_mag[257 + l16] = 0.f;    // the tap windows may reach past the Nyquist bin: finite zeros there
   // log-mel rows start finite too: a partial last group multiplies rows it never wrote (their outputs are not stored)
   for (int i = lane; i < 16 * LMS; i += 64) s_lm16[i] = 0.f;
@@ -241,15 +297,15 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
         // (3 products x 4 row blocks x 2 column tiles) + the split of the lane's 32 windowed samples.
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          f16x8 a1, a2;
+          u32x4 p1, p2;
 #pragma unroll
           for (int jp = 0; jp < 4; ++jp) {
-            const float2 wv = *reinterpret_cast<const float2*>(s_win + a_off0 + 128 * jp + 8 * t);
-            const float ar = xv[t][jp].x * wv.x * 1024.f, ai = xv[t][jp].y * wv.y * 1024.f;
-            const _Float16 hr = (_Float16)ar, hi = (_Float16)ai;
-            a1[2 * jp] = hr; a1[2 * jp + 1] = hi;
-            a2[2 * jp] = (_Float16)(ar - (float)hr); a2[2 * jp + 1] = (_Float16)(ai - (float)hi);
+            const float2 wv = *reinterpret_cast<const float2*>(s_win + a_off0 + 128 * jp + 8 * t);   // window x 2^10
+            unsigned h, l;
+            split2(xv[t][jp].x * wv.x, xv[t][jp].y * wv.y, h, l);
+            p1[jp] = h; p2[jp] = l;
           }
+          const f16x8 a1 = __builtin_bit_cast(f16x8, p1), a2 = __builtin_bit_cast(f16x8, p2);
 #pragma unroll
           for (int c = 0; c < 2; ++c) {
             acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, hb1[c], acc[t][c], 0, 0, 0);
@@ -257,12 +313,8 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
             acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, hb1[c], acc[t][c], 0, 0, 0);
           }
         }
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-          for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int v = 0; v < 4; ++v) acc[t][c][v] *= 5.9604644775390625e-08f;     // 2^-24: exact
+        acc[0][0][0] *= 5.9604644775390625e-08f;     // 2^-24 (exact): n2 = 0 has no twiddle to carry it
+        acc[0][1][0] *= 5.9604644775390625e-08f;
       } else {
 #pragma unroll
       for (int jp = 0; jp < 4; ++jp) {
@@ -366,7 +418,9 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
         }
         float sm = ((s0 + s1) + (s2 + s3)) + pl.log_offset;
         if (pl.log_floor > 0.f) sm = fmaxf(sm, pl.log_floor);
-        if (l16 + 16 * i < n_mel) lm_row[l16 + 16 * i] = __logf(sm);
+        // v_log_f32 (log2, 1 ulp) x ln 2: sm >= the offset / floor, so none of logf's denormal handling (15 instructions
+        // per band) is needed; with the f16 DCT the row carries that product's 2^9 as well (exact)
+        if (l16 + 16 * i < n_mel) lm_row[l16 + 16 * i] = __builtin_amdgcn_logf(sm) * (D16 ? 0.6931471805599453f * 512.f : 0.6931471805599453f);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();                // s_mag reads done before the next quad overwrites the rows
@@ -386,14 +440,16 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
       const _Float16* s_dh = reinterpret_cast<const _Float16*>(s_dct);
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb) {
-        f16x8 a1, a2;
+        u32x4 p1, p2;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float v = (4 * e + 32 * kb + 4 <= 16 * NB) ? pa[4 * e + 32 * kb] * 512.f : 0.f;   // k = fq + 4 e + 32 kb < 16 NB
-          const _Float16 hh = (_Float16)v;
-          a1[e] = hh;
-          a2[e] = (_Float16)(v - (float)hh);
+        for (int e = 0; e < 8; e += 2) {               // k = fq + 4 e + 32 kb < 16 NB (the rows hold log-mel x 2^9)
+          const float v0 = (4 * e + 32 * kb + 4 <= 16 * NB) ? pa[4 * e + 32 * kb] : 0.f;
+          const float v1 = (4 * e + 32 * kb + 8 <= 16 * NB) ? pa[4 * e + 32 * kb + 4] : 0.f;
+          unsigned h, l;
+          split2(v0, v1, h, l);
+          p1[e >> 1] = h; p2[e >> 1] = l;
         }
+        const f16x8 a1 = __builtin_bit_cast(f16x8, p1), a2 = __builtin_bit_cast(f16x8, p2);
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
           const f16x8 b1 = *reinterpret_cast<const f16x8*>(s_dh + (((kb * 4 + nb) * 2 + 0) * 64 + lane) * 8);
@@ -508,6 +564,35 @@ int kws_stft4_lds_bytes(const kws_stft_plan* pl) {
 }
 
 template <int NB, int MC, int MCP, bool H1>
+static int stft4_image_h(kws_stft_plan* pl) {
+  const size_t bytes = (size_t)Stft4Lds<NB, MC>::image_floats(pl->n_mel) * sizeof(float);
+  KWS_HIP(hipMalloc(reinterpret_cast<void**>(&pl->img4), bytes));
+  hipLaunchKernelGGL((stft4_image_kernel<NB, MC, MCP, H1>), dim3(1), dim3(256), 0, nullptr, *pl, pl->img4);
+  KWS_LAUNCH_CHECK("stft4_image_kernel");
+  KWS_HIP(hipStreamSynchronize(nullptr));
+  return KWS_OK;
+}
+static bool stft4_f32_pass() {
+  static const bool v = getenv("KWS_STFT_F32PASS") != nullptr;      // A/B: the first pass on v_mfma_f32_16x16x4_f32
+  return v;
+}
+template <int NB, int MC, int MCP>
+static int stft4_image_t(kws_stft_plan* pl) {
+  return stft4_f32_pass() ? stft4_image_h<NB, MC, MCP, false>(pl) : stft4_image_h<NB, MC, MCP, true>(pl);
+}
+
+// called once by kws_stft_plan_create after the tables are uploaded: the LDS image of this plan's kernel instance
+int kws_stft4_prepare(kws_stft_plan* pl) {
+  pl->img4 = nullptr;
+  const int sh = stft4_shape(pl);
+  if (sh == 0 || pl->n_mel % 4 != 0) return KWS_OK;                  // stft4 declines this plan: nothing to prepare
+  if (sh == 1) return stft4_image_t<5, 4, 0x43211>(pl);
+  if (sh == 2) return stft4_image_t<5, 4, 0x44444>(pl);
+  if (sh == 3) return stft4_image_t<3, 8, 0x852>(pl);
+  return stft4_image_t<3, 8, 0x888>(pl);
+}
+
+template <int NB, int MC, int MCP, bool H1>
 static int stft4_launch_h(const Stft2Args& a, int bytes, int64_t wgs, hipStream_t st) {
   static bool attr_done = false;
   if (!attr_done) {
@@ -521,8 +606,7 @@ static int stft4_launch_h(const Stft2Args& a, int bytes, int64_t wgs, hipStream_
 }
 template <int NB, int MC, int MCP>
 static int stft4_launch_t(const Stft2Args& a, int bytes, int64_t wgs, hipStream_t st) {
-  static const bool f32_pass = getenv("KWS_STFT_F32PASS") != nullptr;   // A/B: the first pass on v_mfma_f32_16x16x4_f32
-  return f32_pass ? stft4_launch_h<NB, MC, MCP, false>(a, bytes, wgs, st) : stft4_launch_h<NB, MC, MCP, true>(a, bytes, wgs, st);
+  return stft4_f32_pass() ? stft4_launch_h<NB, MC, MCP, false>(a, bytes, wgs, st) : stft4_launch_h<NB, MC, MCP, true>(a, bytes, wgs, st);
 }
 
 int kws_stft4_launch(const kws_stft_plan* pl, const float* x, int B, int L, int F, float* out, hipStream_t st) {
@@ -530,6 +614,7 @@ int kws_stft4_launch(const kws_stft_plan* pl, const float* x, int B, int L, int 
               pl->n_mel, pl->n_out);
   KWS_REQUIRE(F > 0 && (pl->frame_step % 2) == 0 && (L % 2) == 0 && (pl->frame_len % 2) == 0, "stft4: bad geometry");
   const int sh = stft4_shape(pl);
+  KWS_REQUIRE(pl->img4 != nullptr, "stft4: the plan carries no table image (kws_stft4_prepare)");
   KWS_REQUIRE(sh != 0, "stft4: mel band shape (n_mel=%d, up to %d taps) is not instantiated", pl->n_mel, pl->mel_maxw);
   KWS_REQUIRE((int64_t)B * ((F + 3) / 4) < (1ll << 31), "stft4: %d clips x %d frames exceed 2^31 frame quads", B, F);
   Stft2Args a;
