@@ -7,12 +7,15 @@
 #include <vector>
 #include <algorithm>
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define PROBE(NAME, DECL, BODY)                                                                              \
   __global__ void NAME(int iters, unsigned long long* out, float* sink) {                                    \
     const int lane = threadIdx.x & 63;                                                                       \
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);                                       \
     DECL                                                                                                     \
+    __shared__ float sh[4096]; /* 16 KB: the LDS probes address real memory */                               \
+    if (iters < 0) sh[threadIdx.x] = 1.f;                                                                    \
     __syncthreads();                                                                                         \
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();                                              \
     for (int i = 0; i < iters; ++i) {                                                                        \
@@ -20,13 +23,13 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
     }                                                                                                        \
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();                                              \
     float res = 0.f;                                                                                         \
-    for (int u = 0; u < 8; ++u) res += x[u] + y[u].x + y[u].y + __uint_as_float(h[u]);                       \
+    for (int u = 0; u < 8; ++u) res += x[u] + y[u].x + y[u].y + __uint_as_float(h[u]) + z4.x + sh[lane];                       \
     if (lane == 0) out[blockIdx.x * 16 + wave] = t1 - t0;                                                    \
     if (res == 123.456f) sink[0] = res;                                                                      \
   }
 
 #define DECL0                                                                                    \
-  float x[8]; f32x2 y[8]; unsigned h[8];                                                         \
+  float x[8]; f32x2 y[8]; unsigned h[8]; f32x4 z4 = {0, 0, 0, 0}; const unsigned long long smask = 0x0001000100010001ull; (void)smask; (void)z4;                                                    \
   const float m = 1.0001f, c = 0.001f; const f32x2 m2 = {1.0001f, 0.9999f}, c2 = {0.001f, 0.002f}; \
   for (int u = 0; u < 8; ++u) { x[u] = lane * 0.01f + u + 1.f; y[u] = f32x2{x[u], x[u] + 1.f}; h[u] = lane + u; }
 
@@ -43,6 +46,13 @@ PROBE(p_cvt_pk, DECL0, asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h[u]) :
 PROBE(p_fma_mix, DECL0, asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(x[u]) : "v"(h[u]), "v"(m));)
 PROBE(p_dpp, DECL0, asm volatile("v_mov_b32_dpp %0, %1 row_mirror row_mask:0xf bank_mask:0xf" : "=v"(h[u]) : "v"(h[(u + 1) & 7]));)
 PROBE(p_cndmask, DECL0, asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x[u]) : "v"(c));)
+PROBE(p_cndmask_s, DECL0, asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(x[u]) : "v"(c), "s"(smask));)
+PROBE(p_bfi, DECL0, asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(h[u]) : "v"(h[(u + 3) & 7]), "v"(lane));)
+PROBE(p_max, DECL0, asm volatile("v_max_f32 %0, %0, %1" : "+v"(x[u]) : "v"(c));)
+PROBE(p_ds_b32, DECL0, asm volatile("ds_read_b32 %0, %1" : "=v"(x[u]) : "v"(lane * 4 + u * 256)); if (u == 7) asm volatile("s_waitcnt lgkmcnt(0)");)
+PROBE(p_ds_b64, DECL0, asm volatile("ds_read_b64 %0, %1" : "=v"(y[u]) : "v"(lane * 8 + u * 512)); if (u == 7) asm volatile("s_waitcnt lgkmcnt(0)");)
+PROBE(p_ds_b128, DECL0, asm volatile("ds_read_b128 %0, %1" : "=v"(z4) : "v"(lane * 16 + u * 1024)); if (u == 7) asm volatile("s_waitcnt lgkmcnt(0)");)
+PROBE(p_ds_w32, DECL0, asm volatile("ds_write_b32 %0, %1" :: "v"(lane * 4 + u * 256), "v"(x[u])); if (u == 7) asm volatile("s_waitcnt lgkmcnt(0)");)
 PROBE(p_mul_e64, DECL0, asm volatile("v_mul_f32_e64 %0, %0, %1" : "+v"(x[u]) : "v"(m));)
 
 typedef void (*kern_t)(int, unsigned long long*, float*);
@@ -56,7 +66,9 @@ int main() {
     {"v_fma_f32", p_fma}, {"v_add_f32", p_add}, {"v_mul_f32_e64", p_mul_e64}, {"v_pk_fma_f32", p_pk_fma}, {"v_pk_add_f32", p_pk_add},
     {"v_pk_mul_f32", p_pk_mul}, {"v_pk_mov_b32", p_pk_mov}, {"v_sqrt_f32", p_sqrt}, {"v_log_f32", p_log},
     {"v_cvt_pkrtz_f16_f32", p_cvt_pkrtz}, {"v_cvt_pk_f16_f32", p_cvt_pk}, {"v_fma_mix_f32", p_fma_mix},
-    {"v_mov_b32_dpp row_mirror", p_dpp}, {"v_cndmask_b32", p_cndmask}};
+    {"v_mov_b32_dpp row_mirror", p_dpp}, {"v_cndmask_b32 (vcc)", p_cndmask}, {"v_cndmask_b32_e64 (sgpr mask)", p_cndmask_s},
+    {"v_bfi_b32", p_bfi}, {"v_max_f32", p_max}, {"ds_read_b32", p_ds_b32}, {"ds_read_b64", p_ds_b64}, {"ds_read_b128", p_ds_b128},
+    {"ds_write_b32", p_ds_w32}};
   for (auto& k : ks)
     for (int wps : {1, 2, 3}) {
       const int nw = 4 * wps;

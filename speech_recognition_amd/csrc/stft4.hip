@@ -49,7 +49,6 @@ extern "C" int kws_debug_read_stft_stamps(unsigned long long* out) {
 namespace {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int NW4 = 12;             // waves per workgroup: 3 per SIMD
 constexpr int DSTR4 = 80;           // DCT table row stride (floats), as in stft3
 constexpr int MAGF = 260;           // floats of one frame's magnitude row
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -152,7 +151,11 @@ __global__ __launch_bounds__(256) void stft4_image_kernel(kws_stft_plan pl, floa
   stft4_tables<NB, MC, MCP, H1>(img, pl, threadIdx.x, blockDim.x);
 }
 
-template <int NB, int MC, int MCP, bool H1>
+// NW4 waves per workgroup; a wave hands the log-mel rows of GQ quads (4 GQ frames) to one DCT.  GQ = 4 fills the 16 rows
+// of the matrix instruction and needs 5.2 KB of log-mel rows per wave, which caps the workgroup at 12 waves; GQ = 2 (half
+// of the DCT's rows idle) fits 16.  Measured at batch 1024 / 80 bands: 50.3 us with 12 waves, 51.4 us with 16 - the fourth
+// wave per SIMD buys what the idle DCT rows cost - so 12 x 4 is the default and 16 x 2 the KWS_STFT_W16 arm.
+template <int NB, int MC, int MCP, bool H1, int NW4, int GQ>
 __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
 #ifdef KWS_STFT_STAMP
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
   const kws_stft_plan& pl = a.pl;
   const int n_mel = pl.n_mel, n_out = pl.n_out;
   constexpr int LMS = 16 * NB + 1;                                 // log-mel row stride (odd: conflict-free columns); the
-                                                                   // columns n_mel .. 16 NB - 1 stay zero
+                                                                   // columns n_mel .. 16 NB - 1 hold finite values that meet zero DCT rows
   using LT = Stft4Lds<NB, MC>;                                     // the table image (stft4_tables), then the waves' rows
   constexpr int WSTR = LT::WSTR;
   float* s_win = lds + LT::WIN;
@@ -171,7 +174,8 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
   float* s_dct = lds + LT::DCT;
   float* s_wpad = lds + LT::WPAD;
   float* s_wave = lds + LT::image_floats(n_mel);
-  constexpr int wave_floats = 4 * MAGF + ((16 * LMS + 3) & ~3);
+  constexpr int LMR = 4 * GQ;                                      // log-mel rows of a group
+  constexpr int wave_floats = 4 * MAGF + ((LMR * LMS + 3) & ~3);
   constexpr int KB = (16 * NB + 31) / 32;                           // H1: k-blocks of the DCT product (32 mel bands each)
   constexpr bool D16 = H1 && KB * 4 * 2 * 64 * 8 * 2 <= 16 * NB * DSTR4 * 4;   // the f16 DCT image must fit the f32 table's LDS
   const int tid = threadIdx.x, lane = tid & 63;
@@ -192,7 +196,7 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
   }
   if (l16 < MAGF - 257) s_mag[257 + l16] = 0.f;    // the tap windows may reach past the Nyquist bin: finite zeros there
   // log-mel rows start finite too: a partial last group multiplies rows it never wrote (their outputs are not stored)
-  for (int i = lane; i < 16 * LMS; i += 64) s_lm16[i] = 0.f;
+  for (int i = lane; i < LMR * LMS; i += 64) s_lm16[i] = 0.f;
   // per-lane constants: B operand of the 16 (k-chunk, column tile) products
   float r_b[16];
 #pragma unroll
@@ -275,7 +279,7 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
   while (cur < q_hi) {
     int gq[4] = {-1, -1, -1, -1};                   // the quads of this group (scalar registers)
 #pragma unroll 1
-    for (int qq = 0; qq < 4; ++qq) {
+    for (int qq = 0; qq < GQ; ++qq) {
       if (cur >= q_hi) break;                       // wave-uniform: the group is partial
       const int64_t quad = cur;
       if (qq == 0) gq[0] = (int)quad; else if (qq == 1) gq[1] = (int)quad; else if (qq == 2) gq[2] = (int)quad; else gq[3] = (int)quad;
@@ -416,11 +420,15 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
             s3 = fmaf(mv[t][3], wv[t].w, s3);
             }
         }
-        float sm = ((s0 + s1) + (s2 + s3)) + pl.log_offset;
-        if (pl.log_floor > 0.f) sm = fmaxf(sm, pl.log_floor);
+        // floor: a plain maximum (log_floor = 0 leaves the non-negative sum as it is) - no select on a scalar mask, which
+        // issues at 1/7 of the rate of a v_max_f32 here (profiles/r02_probe_valu_rates.txt)
+        const float sm = fmaxf(((s0 + s1) + (s2 + s3)) + pl.log_offset, pl.log_floor);
         // v_log_f32 (log2, 1 ulp) x ln 2: sm >= the offset / floor, so none of logf's denormal handling (15 instructions
         // per band) is needed; with the f16 DCT the row carries that product's 2^9 as well (exact)
-        if (l16 + 16 * i < n_mel) lm_row[l16 + 16 * i] = __builtin_amdgcn_logf(sm) * (D16 ? 0.6931471805599453f * 512.f : 0.6931471805599453f);
+        // lanes past n_mel (band 0's weights, see r_mws) store as well: their columns meet zero rows of the DCT operand, and
+        // an unguarded store keeps the five bands straight-line code whose LDS reads overlap (guarded, each band's reads
+        // were issued inside its own EXEC region, one round trip after the other)
+        lm_row[l16 + 16 * i] = __builtin_amdgcn_logf(sm) * (D16 ? 0.6931471805599453f * 512.f : 0.6931471805599453f);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();                // s_mag reads done before the next quad overwrites the rows
@@ -433,7 +441,7 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
     f32x4 dacc[4];
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) dacc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float* pa = s_lm16 + l16 * LMS + fq;
+    const float* pa = s_lm16 + (l16 & (LMR - 1)) * LMS + fq;        // GQ < 4: rows LMR .. 15 repeat (their outputs are not stored)
     if (D16) {
       // as the first pass: the 20 (K = 80) x 4 f32 instructions of a group held the vector issue for 2,560 cycles; the f16 form
       // needs KB x 4 x 3 instructions that hold it for 8 each.  Log-mel values lie in [-14, 12]: scaled by 2^9.
@@ -495,6 +503,7 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
     }
     {
       const int quad = fq == 0 ? gq[0] : (fq == 1 ? gq[1] : (fq == 2 ? gq[2] : gq[3]));   // lane group fq: the group's quad fq
+                                                                                          // (-1 past GQ: nothing to store)
       if (quad >= 0) {
         const unsigned qu = (unsigned)quad, qpc = (unsigned)a.quads_per_clip;
         const int64_t b = qu / qpc;
@@ -554,14 +563,15 @@ static int stft4_shape(const kws_stft_plan* pl) {
   return 0;
 }
 
-int kws_stft4_lds_bytes(const kws_stft_plan* pl) {
+static int stft4_lds_bytes(const kws_stft_plan* pl, int nw, int gq) {
   const int sh = stft4_shape(pl);
   if (sh == 0) return 1 << 30;                                       // declines: the caller falls back to stft3
   const int nb = sh <= 2 ? 5 : 3, mc = sh <= 2 ? 4 : 8;
   const size_t floats = 512 + 512 + 256 + 4 + (size_t)16 * nb * DSTR4 + (size_t)pl->n_mel * (4 * mc + 4) +
-                        (size_t)NW4 * (4 * MAGF + ((16 * (16 * nb + 1) + 3) & ~3));
+                        (size_t)nw * (4 * MAGF + ((4 * gq * (16 * nb + 1) + 3) & ~3));
   return (int)(floats * 4);
 }
+int kws_stft4_lds_bytes(const kws_stft_plan* pl) { return stft4_lds_bytes(pl, 12, 4); }   // the default form
 
 template <int NB, int MC, int MCP, bool H1>
 static int stft4_image_h(kws_stft_plan* pl) {
@@ -592,21 +602,32 @@ int kws_stft4_prepare(kws_stft_plan* pl) {
   return stft4_image_t<3, 8, 0x888>(pl);
 }
 
-template <int NB, int MC, int MCP, bool H1>
-static int stft4_launch_h(const Stft2Args& a, int bytes, int64_t wgs, hipStream_t st) {
+template <int NB, int MC, int MCP, bool H1, int NW4, int GQ>
+static int stft4_launch_w(const Stft2Args& a, hipStream_t st) {
+  const int bytes = stft4_lds_bytes(&a.pl, NW4, GQ);
+  KWS_REQUIRE(bytes <= 160 * 1024, "stft4: LDS need %d B exceeds 160 KiB", bytes);
   static bool attr_done = false;
   if (!attr_done) {
-    KWS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&stft4_kernel<NB, MC, MCP, H1>),
+    KWS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&stft4_kernel<NB, MC, MCP, H1, NW4, GQ>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
-  hipLaunchKernelGGL((stft4_kernel<NB, MC, MCP, H1>), dim3((unsigned)wgs), dim3(NW4 * 64), (size_t)bytes, st, a);
+  int64_t wgs = (a.total_quads + NW4 - 1) / NW4;
+  if (wgs > 256) wgs = 256;   // persistent: one workgroup per CU, tables copied once
+  hipLaunchKernelGGL((stft4_kernel<NB, MC, MCP, H1, NW4, GQ>), dim3((unsigned)wgs), dim3(NW4 * 64), (size_t)bytes, st, a);
   KWS_LAUNCH_CHECK("stft4_kernel");
   return KWS_OK;
 }
+template <int NB, int MC, int MCP, bool H1>
+static int stft4_launch_h(const Stft2Args& a, hipStream_t st) {
+  static const bool w16 = getenv("KWS_STFT_W16") != nullptr;        // A/B: 16 waves per workgroup, DCT groups of 2 quads
+  if (MC <= 4 && w16 && stft4_lds_bytes(&a.pl, 16, 2) <= 160 * 1024)   // (the 8-block shapes would spill at 128 registers)
+    return stft4_launch_w<NB, MC, MCP, H1, MC <= 4 ? 16 : 12, MC <= 4 ? 2 : 4>(a, st);
+  return stft4_launch_w<NB, MC, MCP, H1, 12, 4>(a, st);
+}
 template <int NB, int MC, int MCP>
-static int stft4_launch_t(const Stft2Args& a, int bytes, int64_t wgs, hipStream_t st) {
-  return stft4_f32_pass() ? stft4_launch_h<NB, MC, MCP, false>(a, bytes, wgs, st) : stft4_launch_h<NB, MC, MCP, true>(a, bytes, wgs, st);
+static int stft4_launch_t(const Stft2Args& a, hipStream_t st) {
+  return stft4_f32_pass() ? stft4_launch_h<NB, MC, MCP, false>(a, st) : stft4_launch_h<NB, MC, MCP, true>(a, st);
 }
 
 int kws_stft4_launch(const kws_stft_plan* pl, const float* x, int B, int L, int F, float* out, hipStream_t st) {
@@ -622,12 +643,8 @@ int kws_stft4_launch(const kws_stft_plan* pl, const float* x, int B, int L, int 
   a.x = x; a.out = out; a.B = B; a.L = L; a.F = F;
   a.quads_per_clip = (F + 3) / 4;
   a.total_quads = (int64_t)B * a.quads_per_clip;
-  const int bytes = kws_stft4_lds_bytes(pl);
-  KWS_REQUIRE(bytes <= 160 * 1024, "stft4: LDS need %d B exceeds 160 KiB", bytes);
-  int64_t wgs = (a.total_quads + NW4 - 1) / NW4;
-  if (wgs > 256) wgs = 256;   // persistent: one workgroup per CU, tables staged once
-  if (sh == 1) return stft4_launch_t<5, 4, 0x43211>(a, bytes, wgs, st);
-  if (sh == 2) return stft4_launch_t<5, 4, 0x44444>(a, bytes, wgs, st);
-  if (sh == 3) return stft4_launch_t<3, 8, 0x852>(a, bytes, wgs, st);
-  return stft4_launch_t<3, 8, 0x888>(a, bytes, wgs, st);
+  if (sh == 1) return stft4_launch_t<5, 4, 0x43211>(a, st);
+  if (sh == 2) return stft4_launch_t<5, 4, 0x44444>(a, st);
+  if (sh == 3) return stft4_launch_t<3, 8, 0x852>(a, st);
+  return stft4_launch_t<3, 8, 0x888>(a, st);
 }
