@@ -46,6 +46,14 @@ extern "C" int kws_debug_read_stft_stamps(unsigned long long* out) {
 #define ST(i)
 #endif
 
+// -DKWS_STFT_ABL=<bits> builds (timing only, results wrong): the kernel without 1 the first-pass products, 2 twiddle +
+// second pass, 4 split + magnitudes, 8 mel + log, 16 the DCT products, 32 the output stores, 64 the PCM loads - what a
+// phase costs IN the overlap of twelve waves, which its stamp (one wave's latency) does not say
+#ifndef KWS_STFT_ABL
+#define KWS_STFT_ABL 0
+#endif
+#define KEEP2(v) asm volatile("" :: "v"((v).x), "v"((v).y))
+
 namespace {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
@@ -269,6 +277,7 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int jp = 0; jp < 4; ++jp) {
+        if (KWS_STFT_ABL & 64) { xv[t][jp] = make_float2(__int_as_float(voff + t), __int_as_float(voff + jp)); continue; }
         const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff + 512 * jp + 32 * t, 0, 0);
         xv[t][jp] = make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
       }
@@ -295,7 +304,12 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
         acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
         acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
-      if (H1) {
+      if (KWS_STFT_ABL & 1) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int jp = 0; jp < 4; ++jp) { acc[t][0][jp] = xv[t][jp].x; acc[t][1][jp] = xv[t][jp].y; }
+      } else if (H1) {
         // An f32 matrix instruction holds the SIMD's vector issue for all of its 32 cycles (probe):
         // the 64 of a quad were 2,048 cycles nothing else could use.  The f16 form holds it for 8 of its 16: 24 instructions
         // (3 products x 4 row blocks x 2 column tiles) + the split of the lane's 32 windowed samples.
@@ -347,9 +361,11 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
       asm volatile("" :: "v"(z[0].x), "v"(z[15].y));   // the MFMA results have landed
 #endif
       ST(0);
+      if (!(KWS_STFT_ABL & 2)) {
 #pragma unroll
       for (int n2 = 1; n2 < 16; ++n2) z[n2] = cmul(z[n2], s_tw[n2 * 16 + l16]);
       fft16(z);                                       // z[k2] = Z[k1 + 16 k2] / 2
+      }
 #ifdef KWS_STFT_STAMP
       asm volatile("" :: "v"(z[0].x), "v"(z[15].y));
 #endif
@@ -358,6 +374,10 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
       // X[k] = E + T and X[256-k] = conj(E - T) with E = (Z[k] + conj Z[256-k]) / 2, T = W512^k (Z[k] - conj Z[256-k]) / 2i
       // (the halves are in z already).  Z[256-k] sits in the mirrored lane's register 15-k2; k1 = 0 (lane 0) and k1 = 8
       // (lane 15) are their own partners, with registers (16-k2)&15 and 15-k2.
+      if (KWS_STFT_ABL & 4) {
+#pragma unroll
+        for (int n2 = 0; n2 < 16; ++n2) KEEP2(z[n2]);
+      } else {
       float2 w5[8];                                   // all eight split factors requested before the first use
 #pragma unroll
       for (int k2 = 0; k2 < 8; ++k2) w5[k2] = s_w5[k2 * 16 + l16];
@@ -383,6 +403,7 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
         const float2 zk = z[8];
         s_mag[128] = 2.0f * __builtin_amdgcn_sqrtf(zk.x * zk.x + zk.y * zk.y);
       }
+      }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -394,7 +415,7 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
       // kernel (a dependent wait per four taps, trip counts that differ lane by lane) took 40 % of a pass.
       float* lm_row = s_lm16 + (4 * qq + fq) * LMS;
 #pragma unroll
-      for (int i = 0; i < NB; ++i) {
+      for (int i = 0; i < ((KWS_STFT_ABL & 8) ? 0 : NB); ++i) {
         const float* mp = s_mag + r_mws[i];
         const float* wp = s_wpad + r_wofs[i];
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -442,7 +463,9 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) dacc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float* pa = s_lm16 + (l16 & (LMR - 1)) * LMS + fq;        // GQ < 4: rows LMR .. 15 repeat (their outputs are not stored)
-    if (D16) {
+    if (KWS_STFT_ABL & 16) {
+      dacc[0][0] = pa[0];
+    } else if (D16) {
       // as the first pass: the 20 (K = 80) x 4 f32 instructions of a group held the vector issue for 2,560 cycles; the f16 form
       // needs KB x 4 x 3 instructions that hold it for 8 each.  Log-mel values lie in [-14, 12]: scaled by 2^9.
       const _Float16* s_dh = reinterpret_cast<const _Float16*>(s_dct);
@@ -514,7 +537,7 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
             float* orow = a.out + (b * a.F + f0 + v) * (int64_t)n_out + l16;
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb)
-              if (16 * nb + l16 < n_out) orow[16 * nb] = dacc[nb][v];
+              if (16 * nb + l16 < n_out && (!(KWS_STFT_ABL & 32) || dacc[nb][v] == 123.456f)) orow[16 * nb] = dacc[nb][v];
           }
         }
       }
