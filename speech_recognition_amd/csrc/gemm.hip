@@ -19,6 +19,8 @@
 #include "common.h"
 #include "internal.h"
 
+#include <type_traits>
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #ifdef KWS_GEMM_STAMP
@@ -41,6 +43,7 @@ struct NNArgs {
   float* stats;  // [m_tiles][2][N] or nullptr
   kws_gather_t g;
   int m_tiles, n_tiles;
+  int half_tail;  // wave-specialised kernel: the tiles of a short last round are walked as 64-row halves
 };
 
 // 16 bytes of zeros that masked-out lanes load from instead of branching around their load.
@@ -375,12 +378,32 @@ __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNA
   const int wgs_per_xcd = gridDim.x / NXCD;
   const int panels = (p.m_tiles - xcd + NXCD - 1) / NXCD;
   const int local_tiles = panels * p.n_tiles;
-  if (wg_in_xcd >= local_tiles) {                   // no tile for this workgroup: its statistics row is zero
+  // The walk of an XCD's workgroups over its tiles ends with a partial round: e_x of the wgs_per_xcd workgroups would
+  // compute one more 128-row tile while the others wait for the kernel to end (6.06 tiles per CU cost 7 rounds).  When
+  // the leftover fits twice (2 e_x <= wgs_per_xcd) those tiles are walked as 64-row HALVES by twice as many workgroups:
+  // a half tile is the same tile view cut at 64 rows (the descriptors' range checks zero-fill / drop the rest) whose MFMA
+  // waves skip their second row block - rows are dealt to the waves as 64 i + 32 wm + lane so that every wave owns one block
+  // of each half.  Each output element is still one wave's fmaf chain over k in the same order: bit-identical results.
+  const int full_rounds = local_tiles / wgs_per_xcd;
+  const int e_x = local_tiles - full_rounds * wgs_per_xcd;
+  const bool halves = p.half_tail && e_x > 0 && 2 * e_x <= wgs_per_xcd;
+  const int first_half = halves ? full_rounds * wgs_per_xcd : local_tiles;   // local index of the first half tile
+  const int local_count = halves ? first_half + 2 * e_x : local_tiles;
+  if (wg_in_xcd >= local_count) {                   // (only when local_tiles < wgs_per_xcd: unreachable with halves)
     if (STATS)
       for (int c = tid; c < 2 * N; c += blockDim.x) p.stats[(int64_t)blockIdx.x * 2 * N + c] = 0.f;
     return;
   }
-  const int n_my = (local_tiles - wg_in_xcd + wgs_per_xcd - 1) / wgs_per_xcd;
+  // local item -> tile view: first row, rows it may touch (128 / 64), first column
+  auto decode = [&](int loc, int64_t& m0, int& cap, int& n0) {
+    const int h = loc - first_half;                 // >= 0: a half tile
+    const int tile = h >= 0 ? first_half + (h >> 1) : loc;
+    const int tile_m = (tile / p.n_tiles) * NXCD + xcd;
+    n0 = (tile % p.n_tiles) * BN;
+    m0 = (int64_t)tile_m * BM + (h >= 0 ? 64 * (h & 1) : 0);
+    cap = h >= 0 ? 64 : BM;
+  };
+  const int n_my = (local_count - wg_in_xcd + wgs_per_xcd - 1) / wgs_per_xcd;
   const int G = n_my * nk;
   // barriers executed by every wave: 1 (prologue) + G (iterations) + 2 (last tile staged / moved out)
   // + 1 when STATS (column sums complete)
@@ -398,8 +421,9 @@ __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNA
       f32x16 t[TM][TN];
     };
     Acc accA, accB;
-    // C[m][n]: m = wm*TM*32 + i*32 + li, n = wn*TN*32 + j*32 + 8*(v>>2) + 4*lh + (v&3)
-    float* const stg = smem + STG_OFF + (wm * TM * 32 + li) * SLD + wn * TN * 32 + 4 * lh;
+    // C[m][n]: m = i*64 + wm*32 + li, n = wn*TN*32 + j*32 + 8*(v>>2) + 4*lh + (v&3)
+    static_assert(TM == 2 && WM == 2, "row blocks are dealt as 64 i + 32 wm");
+    float* const stg = smem + STG_OFF + (wm * 32 + li) * SLD + wn * TN * 32 + 4 * lh;
     auto stage = [&](const Acc& c) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -407,7 +431,7 @@ __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNA
         for (int j = 0; j < TN; ++j)
 #pragma unroll
           for (int v4 = 0; v4 < 4; ++v4)
-            *reinterpret_cast<float4*>(stg + i * 32 * SLD + j * 32 + 8 * v4) =
+            *reinterpret_cast<float4*>(stg + i * 64 * SLD + j * 32 + 8 * v4) =
                 make_float4(c.t[i][j][4 * v4], c.t[i][j][4 * v4 + 1], c.t[i][j][4 * v4 + 2], c.t[i][j][4 * v4 + 3]);
     };
     // BN column sums of a staged tile: VALU work is only cheap inside the MFMA waves' own instruction
@@ -466,8 +490,9 @@ __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNA
       }
     };
     auto set_staged_tile = [&](int ordinal) {
-      const int loc = wg_in_xcd + ordinal * wgs_per_xcd;
-      st_n0 = (loc % p.n_tiles) * BN;
+      int64_t m0;
+      int cap;
+      decode(wg_in_xcd + ordinal * wgs_per_xcd, m0, cap, st_n0);
     };
     if (STATS)
       for (int c = tid; c < 2 * KWS_WS_MAX_N; c += NCT) smem[WACC_OFF + c] = 0.f;
@@ -480,7 +505,8 @@ __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNA
 #define WT(acc_)
 #endif
     int g = 0, tile_ord = 0;
-    auto run_tile = [&](Acc& acc, const Acc& prev, bool have_prev) {
+    auto run_tile_t = [&](auto half_c, Acc& acc, const Acc& prev, bool have_prev) {
+      constexpr int TMR = decltype(half_c)::value ? 1 : TM;   // row blocks this tile computes
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -489,11 +515,11 @@ __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNA
           for (int v = 0; v < 16; ++v) acc.t[i][j][v] = 0.f;
       for (int kt = 0; kt < nk; ++kt, ++g) {
         const int cur = g & 1;
-        const float* cA = smem + cur * STAGE + (wm * TM * 32 + li) * PLDA + lh * 4;
+        const float* cA = smem + cur * STAGE + (wm * 32 + li) * PLDA + lh * 4;
         const float* cB = smem + cur * STAGE + BM * PLDA + (lh * 4) * BN + wn * TN * 32 + li;
         auto load_frag = [&](Frag& f, int q) {
 #pragma unroll
-          for (int i = 0; i < TM; ++i) f.a[i] = *reinterpret_cast<const float4*>(cA + i * 32 * PLDA + q * 8);
+          for (int i = 0; i < TMR; ++i) f.a[i] = *reinterpret_cast<const float4*>(cA + i * 64 * PLDA + q * 8);
 #pragma unroll
           for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -503,7 +529,7 @@ __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNA
 #pragma unroll
           for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
+            for (int i = 0; i < TMR; ++i) {
               const float av = r == 0 ? f.a[i].x : (r == 1 ? f.a[i].y : (r == 2 ? f.a[i].z : f.a[i].w));
 #pragma unroll
               for (int j = 0; j < TN; ++j)   // swapped operands: lane <-> C row, register <-> C column
@@ -554,6 +580,10 @@ __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNA
       }
       ++tile_ord;
     };
+    auto run_tile = [&](Acc& acc, const Acc& prev, bool have_prev) {
+      if (wg_in_xcd + tile_ord * wgs_per_xcd >= first_half) run_tile_t(std::true_type(), acc, prev, have_prev);
+      else run_tile_t(std::false_type(), acc, prev, have_prev);
+    };
     for (int t = 0; t < n_my; t += 2) {
       run_tile(accA, accB, t > 0);
       if (t + 1 < n_my) run_tile(accB, accA, true);
@@ -595,13 +625,12 @@ __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNA
     int ld_i = lw / nk, ld_kt = lw % nk;            // my next slab: tile ordinal, K-slab
     float4 ra[A_F4], rb[B_F4];
     auto issue = [&]() {
-      const int loc = wg_in_xcd + ld_i * wgs_per_xcd;
       const bool tile_ok = ld_i < n_my;
-      const int tile_m = (loc / p.n_tiles) * NXCD + xcd;
-      const int64_t m0 = (int64_t)tile_m * BM;
-      const int n0 = (loc % p.n_tiles) * BN;
+      int64_t m0;
+      int cap, n0;
+      decode(wg_in_xcd + ld_i * wgs_per_xcd, m0, cap, n0);
       const int64_t rows_left = M - m0;
-      const int rows = tile_ok ? (int)(rows_left < BM ? rows_left : BM) : 0;
+      const int rows = tile_ok && rows_left > 0 ? (int)(rows_left < cap ? rows_left : cap) : 0;
       const __amdgpu_buffer_rsrc_t ares = __builtin_amdgcn_make_buffer_rsrc(
           const_cast<float*>(p.A + m0 * K), 0, rows * K * 4, KWS_BUFFER_RSRC_FLAGS);
       const __amdgpu_buffer_rsrc_t bres = __builtin_amdgcn_make_buffer_rsrc(
@@ -665,12 +694,11 @@ __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNA
     int st_i = 0;                                   // ordinal of the next tile to move out
     __amdgpu_buffer_rsrc_t cres = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, 0, KWS_BUFFER_RSRC_FLAGS);
     auto begin_tile = [&]() {
-      const int loc = wg_in_xcd + st_i * wgs_per_xcd;
-      const int tile_m = (loc / p.n_tiles) * NXCD + xcd;
-      const int n0 = (loc % p.n_tiles) * BN;
-      const int64_t m0 = (int64_t)tile_m * BM;
+      int64_t m0;
+      int cap, n0;
+      decode(wg_in_xcd + st_i * wgs_per_xcd, m0, cap, n0);
       const int64_t rows_left = M - m0;
-      const int rows = (int)(rows_left < BM ? rows_left : BM);
+      const int rows = (int)(rows_left < cap ? rows_left : cap);
       // view of C starting at (m0, n0): rows past M fall outside rows*N floats and are dropped
       cres = __builtin_amdgcn_make_buffer_rsrc(p.C + m0 * N + n0, 0, rows > 0 ? (rows * N - n0) * 4 : 0,
                                                KWS_BUFFER_RSRC_FLAGS);
@@ -1203,6 +1231,10 @@ struct NNPlan {
   int wgs;          // its grid (= statistics rows: one per workgroup)
   int m_tiles;      // statistics rows of the tile-per-row kernels
 };
+bool nn_half_tail() {
+  static const bool off = getenv("KWS_GEMM_NO_HALF") != nullptr;   // A/B: whole tiles in the last round too
+  return !off;
+}
 NNPlan nn_plan(int64_t M, int K, int N, bool gather) {
   static const bool use_persist = getenv("KWS_GEMM_PERSIST") != nullptr;  // 4-wave persistent kernel, A/B only
   NNPlan pl;
@@ -1212,8 +1244,13 @@ NNPlan nn_plan(int64_t M, int K, int N, bool gather) {
     // One workgroup per CU walks ceil(tiles / 256) rounds of tiles; the small late layers have 1.1 - 2.3
     // 128-wide tiles per CU and lose 25 - 44 % to the last partial round.  64-wide tiles (0.55 of the time of
     // a 128-wide one with the 64-deep K-slabs) quantise finer: take them when they make the walk shorter.
+    // (a short last round is walked in half tiles, see the kernel: ~0.55 of a round when the leftover fits twice)
     const int64_t t128 = (int64_t)pl.m_tiles * (N / 128);
-    const double cost128 = (double)ceil_div64(t128, 256), cost64 = 0.55 * (double)ceil_div64(2 * t128, 256);
+    auto rounds = [](int64_t t) {
+      const int64_t e = t % 256;
+      return (double)(t / 256) + (e == 0 ? 0.0 : (nn_half_tail() && 2 * e <= 256 ? 0.55 : 1.0));
+    };
+    const double cost128 = rounds(t128), cost64 = 0.55 * rounds(2 * t128);
     if (cost64 < cost128) BN = 64;
   }
   pl.bn = BN;
@@ -1238,6 +1275,7 @@ int launch_nn(const NNArgs& a0, hipStream_t st) {
   const int BN = pl.bn;
   a.m_tiles = (int)ceil_div64(a.M, 128);
   a.n_tiles = ceil_div(a.N, BN);
+  a.half_tail = nn_half_tail() ? 1 : 0;
   const int64_t slots = ceil_div64(a.m_tiles, NXCD) * a.n_tiles;
   const int64_t grid = slots * NXCD;
   if (grid <= 0 || grid > 0x7FFFFFFF) {

@@ -52,7 +52,10 @@ def _need_gpu():
 # (300, 48, 128) fall back to the 4-wave persistent kernel (K % 32 != 0 / K < 64)
 @pytest.mark.parametrize("M,K,N", [(1000, 128, 128), (777, 192, 320), (129, 512, 512), (5, 120, 64), (2560, 384, 192),
                                    (128, 64, 64), (1, 64, 128), (127, 96, 192), (40000, 64, 128), (33000, 128, 256),
-                                   (4100, 256, 1024), (300, 48, 128), (70000, 160, 64)])
+                                   (4100, 256, 1024), (300, 48, 128), (70000, 160, 64),
+                                   # a short last round walked in 64-row half tiles (33 / 34 tiles per XCD on 32 workgroups):
+                                   # last tile of 28 rows (its second half lies past M), of 128 + 64 rows, 64-wide column tiles
+                                   (33692, 128, 128), (33856, 192, 384), (34000, 128, 192)])
 def test_gemm_nn_and_stats(M, K, N):
     rng = np.random.RandomState(M + K + N)
     A = rng.randn(M, K).astype(np.float32)

@@ -15,16 +15,18 @@ pytestmark = pytest.mark.gpu
     {"KWS_OVERLAP": "1"},
     {"KWS_STFT_V2": "1"},
     {"KWS_STFT_V3": "1"},
+    {"KWS_STFT_F32PASS": "1", "KWS_GEMM_NO_HALF": "1"},   # stft4 with the f32 first pass; NN GEMM tails in whole tiles
+    {"KWS_STFT_W16": "1"},        # stft4 with 16 waves per workgroup
     {"KWS_GEMM_BF16X3": "1"},     # experiment: the pointwise GEMMs as bf16 x 3 split products
     {"KWS_GEMM_F16X2": "1"},      # experiment 2: the pointwise GEMMs as scaled fp16 x 2 split products
 ])
 def test_alternative_paths_pass_the_parity_suites(repo_root, env):
     e = dict(os.environ)
     e.update(env)
-    stft_variant = "KWS_STFT_V2" in env or "KWS_STFT_V3" in env
+    stft_variant = any(k.startswith("KWS_STFT_") for k in env)
     files = ["tests/test_kernels_gpu.py", "tests/test_net_gpu.py"] if not stft_variant else \
         ["tests/test_kernels_gpu.py", "tests/test_logmfcc_gpu.py", "tests/test_fullsize_gpu.py",
-         "tests/test_processor_features_gpu.py", "-k", "stft or c3 or audio"]
+         "tests/test_processor_features_gpu.py", "-k", "stft or c3 or audio or gemm_nn"]
     if "KWS_GEMM_BF16X3" in env or "KWS_GEMM_F16X2" in env:      # the whole-network parity suites incl. the batch-1024 step against the float64 oracle
         files = ["tests/test_net_gpu.py", "tests/test_fullsize_gpu.py", "-k", "not stft and not c3 and not augment"]
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider"] + files, cwd=repo_root,
