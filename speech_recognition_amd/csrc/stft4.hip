@@ -162,8 +162,11 @@ __global__ __launch_bounds__(256) void stft4_image_kernel(kws_stft_plan pl, floa
 // NW4 waves per workgroup; a wave hands the log-mel rows of GQ quads (4 GQ frames) to one DCT.  GQ = 4 fills the 16 rows
 // of the matrix instruction and needs 5.2 KB of log-mel rows per wave, which caps the workgroup at 12 waves; GQ = 2 (half
 // of the DCT's rows idle) fits 16.  Measured at batch 1024 / 80 bands: 50.3 us with 12 waves, 51.4 us with 16 - the fourth
-// wave per SIMD buys what the idle DCT rows cost - so 12 x 4 is the default and 16 x 2 the KWS_STFT_W16 arm.
-template <int NB, int MC, int MCP, bool H1, int NW4, int GQ>
+// wave per SIMD buys what the idle DCT rows cost - so 12 x 4 is what the launcher instantiates.
+// V4: rows of the first-pass product are dealt so that a lane's row in the tiles 2p and 2p + 1 holds the complex samples n2 and
+// n2 + 1 (n2 = 2 (i + 4 p) + (t & 1)): ONE 16-byte buffer load / window read feeds two tiles - 8 instead of 16 loads per
+// quad (the ablation prices the 16 at 4.3 us of the launch).  Needs 16-byte aligned frames: L % 4 = 0, frame_step % 4 = 0.
+template <int NB, int MC, int MCP, bool H1, int NW4, int GQ, bool V4>
 __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
 #ifdef KWS_STFT_STAMP
@@ -200,7 +203,22 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
     const float4* src = reinterpret_cast<const float4*>(pl.img4);
     float4* dst = reinterpret_cast<float4*>(lds);
     const int n4 = LT::image_floats(n_mel) / 4;
-    for (int i = tid; i < n4; i += NW4 * 64) dst[i] = src[i];
+    // every thread's loads are requested before its first LDS store (as a plain loop the compiler waits for each load
+    // before the next: one L2 round trip per 12 KB of the 37 KB image)
+    constexpr int TRIPS = 4;
+    for (int i0 = tid; i0 < n4; i0 += TRIPS * NW4 * 64) {
+      float4 v[TRIPS];
+#pragma unroll
+      for (int u = 0; u < TRIPS; ++u) {
+        const int i = i0 + u * NW4 * 64;
+        v[u] = src[i < n4 ? i : 0];
+      }
+#pragma unroll
+      for (int u = 0; u < TRIPS; ++u) {
+        const int i = i0 + u * NW4 * 64;
+        if (i < n4) dst[i] = v[u];
+      }
+    }
   }
   if (l16 < MAGF - 257) s_mag[257 + l16] = 0.f;    // the tap windows may reach past the Nyquist bin: finite zeros there
   // log-mel rows start finite too: a partial last group multiplies rows it never wrote (their outputs are not stored)
@@ -243,8 +261,10 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
   const int k1 = l16 < 8 ? l16 : (l16 < 15 ? l16 + 1 : 8);         // KPERM[l16]
   const unsigned m0 = l16 == 0 ? 0xFFFFFFFFu : 0u, m15 = l16 == 15 ? 0xFFFFFFFFu : 0u;
   // sample offsets of this lane's A-operand loads: 2 (16 (4 j' + s) + 4 t + i), s = fq, i = ar_i
-  const int a_off0 = 2 * (16 * fq + ar_i);                         // + 128 j' + 8 t
-  __syncthreads();
+  // sample offset (floats) of the lane's A-operand data in tile t, k-chunk j': the complex sample 16 (4 j' + fq) + n2 with
+  // n2 = 4 t + i, or V4: n2 = 2 (i + 4 (t >> 1)) + (t & 1)
+  const int a_off0 = V4 ? 32 * fq + 4 * ar_i : 2 * (16 * fq + ar_i);
+  auto a_off = [&](int t, int jp) { return a_off0 + 128 * jp + (V4 ? 16 * (t >> 1) + 2 * (t & 1) : 8 * t); };
 
   // Work items are QUADS of frames.  Every workgroup owns a contiguous range of them (neighbouring frames share samples
   // in L1 / L2) and its waves draw quads from a counter in LDS: the waves of a SIMD do not run at the same speed - the
@@ -273,6 +293,18 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + b * (int64_t)a.L), 0,
                                                                         a.L * 4, 0x00020000);
     const int voff = (fu * pl.frame_step + a_off0) * 4;
+    if (V4) {
+#pragma unroll
+      for (int p2 = 0; p2 < 2; ++p2)
+#pragma unroll
+        for (int jp = 0; jp < 4; ++jp) {
+          if (KWS_STFT_ABL & 64) { xv[2 * p2][jp] = xv[2 * p2 + 1][jp] = make_float2(__int_as_float(voff + p2), __int_as_float(voff + jp)); continue; }
+          const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 512 * jp + 64 * p2, 0, 0);
+          xv[2 * p2][jp] = make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+          xv[2 * p2 + 1][jp] = make_float2(__uint_as_float(v.z), __uint_as_float(v.w));
+        }
+      return;
+    }
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -282,6 +314,7 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
         xv[t][jp] = make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
       }
   };
+  __syncthreads();                                  // tables copied, rows zeroed, counter at zero
   ST_DECL
   int64_t cur = grab_value(grab_issue());
   if (cur < q_hi) issue_loads(cur);
@@ -318,7 +351,7 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
           u32x4 p1, p2;
 #pragma unroll
           for (int jp = 0; jp < 4; ++jp) {
-            const float2 wv = *reinterpret_cast<const float2*>(s_win + a_off0 + 128 * jp + 8 * t);   // window x 2^10
+            const float2 wv = *reinterpret_cast<const float2*>(s_win + a_off(t, jp));   // window x 2^10
             unsigned h, l;
             split2(xv[t][jp].x * wv.x, xv[t][jp].y * wv.y, h, l);
             p1[jp] = h; p2[jp] = l;
@@ -338,7 +371,7 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
       for (int jp = 0; jp < 4; ++jp) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          const float2 wv = *reinterpret_cast<const float2*>(s_win + a_off0 + 128 * jp + 8 * t);
+          const float2 wv = *reinterpret_cast<const float2*>(s_win + a_off(t, jp));
           const float ar = xv[t][jp].x * wv.x, ai = xv[t][jp].y * wv.y;
           acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar, r_b[4 * jp + 0], acc[t][0], 0, 0, 0);
           acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar, r_b[4 * jp + 1], acc[t][1], 0, 0, 0);
@@ -356,7 +389,10 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
       // ---- second pass in registers: lane (g, c) holds Y[k1][n2] of frame g ------------------------------
       float2 z[16];
 #pragma unroll
-      for (int n2 = 0; n2 < 16; ++n2) z[n2] = make_float2(acc[n2 >> 2][0][n2 & 3], acc[n2 >> 2][1][n2 & 3]);
+      for (int n2 = 0; n2 < 16; ++n2) {               // register i of tile t is the row (frame, i): n2 as dealt above
+        const int t = V4 ? 2 * (n2 >> 3) + (n2 & 1) : n2 >> 2, i = V4 ? (n2 >> 1) & 3 : n2 & 3;
+        z[n2] = make_float2(acc[t][0][i], acc[t][1][i]);
+      }
 #ifdef KWS_STFT_STAMP
       asm volatile("" :: "v"(z[0].x), "v"(z[15].y));   // the MFMA results have landed
 #endif
@@ -625,28 +661,29 @@ int kws_stft4_prepare(kws_stft_plan* pl) {
   return stft4_image_t<3, 8, 0x888>(pl);
 }
 
-template <int NB, int MC, int MCP, bool H1, int NW4, int GQ>
+template <int NB, int MC, int MCP, bool H1, int NW4, int GQ, bool V4>
 static int stft4_launch_w(const Stft2Args& a, hipStream_t st) {
   const int bytes = stft4_lds_bytes(&a.pl, NW4, GQ);
   KWS_REQUIRE(bytes <= 160 * 1024, "stft4: LDS need %d B exceeds 160 KiB", bytes);
   static bool attr_done = false;
   if (!attr_done) {
-    KWS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&stft4_kernel<NB, MC, MCP, H1, NW4, GQ>),
+    KWS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&stft4_kernel<NB, MC, MCP, H1, NW4, GQ, V4>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
   int64_t wgs = (a.total_quads + NW4 - 1) / NW4;
   if (wgs > 256) wgs = 256;   // persistent: one workgroup per CU, tables copied once
-  hipLaunchKernelGGL((stft4_kernel<NB, MC, MCP, H1, NW4, GQ>), dim3((unsigned)wgs), dim3(NW4 * 64), (size_t)bytes, st, a);
+  hipLaunchKernelGGL((stft4_kernel<NB, MC, MCP, H1, NW4, GQ, V4>), dim3((unsigned)wgs), dim3(NW4 * 64), (size_t)bytes, st, a);
   KWS_LAUNCH_CHECK("stft4_kernel");
   return KWS_OK;
 }
+// 12 waves per workgroup, DCT groups of 4 quads (16 x 2 was measured - 51.4 us against 50.3 - and is not instantiated);
+// 16-byte PCM loads whenever every frame starts on a 16-byte boundary (KWS_STFT_LD8 keeps the 8-byte loads for A/B runs)
 template <int NB, int MC, int MCP, bool H1>
 static int stft4_launch_h(const Stft2Args& a, hipStream_t st) {
-  static const bool w16 = getenv("KWS_STFT_W16") != nullptr;        // A/B: 16 waves per workgroup, DCT groups of 2 quads
-  if (MC <= 4 && w16 && stft4_lds_bytes(&a.pl, 16, 2) <= 160 * 1024)   // (the 8-block shapes would spill at 128 registers)
-    return stft4_launch_w<NB, MC, MCP, H1, MC <= 4 ? 16 : 12, MC <= 4 ? 2 : 4>(a, st);
-  return stft4_launch_w<NB, MC, MCP, H1, 12, 4>(a, st);
+  static const bool ld8 = getenv("KWS_STFT_LD8") != nullptr;
+  const bool v4 = !ld8 && a.L % 4 == 0 && a.pl.frame_step % 4 == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0;
+  return v4 ? stft4_launch_w<NB, MC, MCP, H1, 12, 4, true>(a, st) : stft4_launch_w<NB, MC, MCP, H1, 12, 4, false>(a, st);
 }
 template <int NB, int MC, int MCP>
 static int stft4_launch_t(const Stft2Args& a, hipStream_t st) {

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
     {"KWS_STFT_V2": "1"},
     {"KWS_STFT_V3": "1"},
     {"KWS_STFT_F32PASS": "1", "KWS_GEMM_NO_HALF": "1"},   # stft4 with the f32 first pass; NN GEMM tails in whole tiles
-    {"KWS_STFT_W16": "1"},        # stft4 with 16 waves per workgroup
+    {"KWS_STFT_LD8": "1"},        # stft4 with 8-byte PCM loads (the row dealing of unaligned frames)
     {"KWS_GEMM_BF16X3": "1"},     # experiment: the pointwise GEMMs as bf16 x 3 split products
     {"KWS_GEMM_F16X2": "1"},      # experiment 2: the pointwise GEMMs as scaled fp16 x 2 split products
 ])
