@@ -25,3 +25,8 @@ print("%s M=%d K=%d N=%d WGs %d iters/WG %.1f | per iteration (cycles): mma %.0f
     np.median(t[:, 4] / t[:, 5]) * 0.1))
 tiles = it[:, 0] / (K // 32)
 print("   storer: %.0f cycles per store_c (tiles/WG %.1f)" % (np.median(st[:len(t)] / np.maximum(tiles - 1, 1)), tiles.mean()))
+sb = buf[256:512, 1].astype(np.float64)[:len(t)]; lb = buf[256:512, 2].astype(np.float64)[:len(t)]
+print("   waiting at the barrier, cycles per iteration: MFMA wave 0 %.0f, loader wave 0 %.0f, storer wave 0 %.0f" % (
+    np.median(t[:, 1] / it[:, 0]), np.median(lb / it[:, 0]), np.median(sb / it[:, 0])))
+wb = buf[512:768].astype(np.float64)[:len(t)]
+print("   barrier wait per iteration by wave (0-3 MFMA, 4-5 loaders, 6-7 storers): " + " ".join("%.0f" % np.median(wb[:, w] / it[:, 0]) for w in range(8)))

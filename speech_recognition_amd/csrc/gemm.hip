@@ -333,6 +333,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_persist_kernel(NNArgs p) {
 // sums are finished at kt=0 of the following tile.
 // Host-checked preconditions: K % 32 == 0, K >= 64, N % BN == 0, 32-bit byte offsets inside a tile view.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// -DKWS_WS_ABL=<bits> (timing only, wrong results): the kernel without 1 the storers' row moves, 2 the loaders' LDS writes,
+// 4 the loaders' global loads, 8 the MFMA waves' staging writes
+#ifndef KWS_WS_ABL
+#define KWS_WS_ABL 0
+#endif
 constexpr int KWS_WS_MAX_N = 1024;                  // widest N the per-workgroup statistics row supports
 constexpr int KWS_BUFFER_RSRC_FLAGS = 0x00020000;   // raw buffer, 32-bit data format (gfx9 family)
 
@@ -425,6 +430,7 @@ __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNA
     static_assert(TM == 2 && WM == 2, "row blocks are dealt as 64 i + 32 wm");
     float* const stg = smem + STG_OFF + (wm * 32 + li) * SLD + wn * TN * 32 + 4 * lh;
     auto stage = [&](const Acc& c) {
+      if (KWS_WS_ABL & 8) { asm volatile("" :: "v"(c.t[0][0][0])); return; }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -592,6 +598,7 @@ __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNA
     if (n_my & 1) stage(accA); else stage(accB);
     set_staged_tile(n_my - 1);
 #ifdef KWS_GEMM_STAMP
+    if ((tid & 63) == 0 && blockIdx.x < 256) g_stamps[blockIdx.x + 512][tid >> 6] = t_bar;   // every wave's barrier wait
     if (tid == 0 && blockIdx.x < 8192) {
       g_stamps[blockIdx.x][0] = t_mma; g_stamps[blockIdx.x][1] = t_bar; g_stamps[blockIdx.x][2] = t_stage;
       g_stamps[blockIdx.x][3] = (unsigned long long)G;
@@ -636,10 +643,12 @@ __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNA
       const __amdgpu_buffer_rsrc_t bres = __builtin_amdgcn_make_buffer_rsrc(
           const_cast<float*>(p.W + n0), 0, tile_ok ? (K * N - n0) * 4 : 0, KWS_BUFFER_RSRC_FLAGS);
       const int k0 = ld_kt * PBK;
+      if (!(KWS_WS_ABL & 4)) {
 #pragma unroll
       for (int r = 0; r < A_F4; ++r) ra[r] = buf_ld4(ares, a_voff, (k0 + AROWS * r * K) * 4);
 #pragma unroll
       for (int r = 0; r < B_F4; ++r) rb[r] = buf_ld4(bres, b_voff, (k0 + BROWS * r) * N * 4);
+      }
       ld_kt += NLW;
       while (ld_kt >= nk) {
         ld_kt -= nk;
@@ -647,6 +656,7 @@ __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNA
       }
     };
     auto write_lds = [&](int slot) {
+      if (KWS_WS_ABL & 2) { asm volatile("" :: "v"(ra[0].x), "v"(rb[0].x)); return; }
       float* sA = smem + slot * STAGE + arow * PLDA + acol;
 #pragma unroll
       for (int r = 0; r < A_F4; ++r) *reinterpret_cast<float4*>(sA + AROWS * r * PLDA) = ra[r];
@@ -661,7 +671,7 @@ __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNA
     }
     __syncthreads();
 #ifdef KWS_GEMM_STAMP
-    unsigned long long t_write = 0, t_issue = 0, t_mark = 0;
+    unsigned long long t_write = 0, t_issue = 0, t_lbar = 0, t_mark = 0;
 #endif
     for (int g = 0; g < G; ++g) {
       if ((g + 1) % NLW == lw) {
@@ -673,12 +683,18 @@ __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNA
         issue();                 // slab g+1+NLW
         WT(t_issue);
       }
+#ifdef KWS_GEMM_STAMP
+      t_mark = __builtin_amdgcn_s_memtime();
+#endif
       __syncthreads();
+      WT(t_lbar);
     }
 #ifdef KWS_GEMM_STAMP
     if (tid == NCT && blockIdx.x < 8192) {
       g_stamps[blockIdx.x][6] = t_write; g_stamps[blockIdx.x][7] = t_issue;
+      g_stamps[blockIdx.x + 256][2] = t_lbar;
     }
+    if ((tid & 63) == 0 && blockIdx.x < 256) g_stamps[blockIdx.x + 512][tid >> 6] = t_lbar;
 #endif
     __syncthreads();
     __syncthreads();
@@ -705,6 +721,7 @@ __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNA
       ++st_i;
     };
     auto move_rows = [&](int lo, int hi) {          // passes [lo, hi) of the staged tile
+      if (KWS_WS_ABL & 1) return;
       const float* stg = smem + STG_OFF + c4 * 4 + r_in * SLD;
       constexpr int GRP = 8;                        // all LDS reads of a group are in flight before its first store
       for (int p0 = lo; p0 < hi; p0 += GRP) {
@@ -723,7 +740,7 @@ __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNA
     };
     __syncthreads();
 #ifdef KWS_GEMM_STAMP
-    unsigned long long t_store = 0, t_mark = 0;
+    unsigned long long t_store = 0, t_sbar = 0, t_mark = 0;
 #endif
     int kt = 0;
     for (int g = 0; g < G; ++g) {
@@ -740,10 +757,18 @@ __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNA
         }
       }
       if (++kt == nk) kt = 0;
+#ifdef KWS_GEMM_STAMP
+      t_mark = __builtin_amdgcn_s_memtime();
+#endif
       __syncthreads();
+      WT(t_sbar);
     }
 #ifdef KWS_GEMM_STAMP
-    if (stt == 0 && blockIdx.x < 8192) g_stamps[blockIdx.x + 256][0] = t_store;
+    if (stt == 0 && blockIdx.x < 8192) {
+      g_stamps[blockIdx.x + 256][0] = t_store;
+      g_stamps[blockIdx.x + 256][1] = t_sbar;
+    }
+    if ((tid & 63) == 0 && blockIdx.x < 256) g_stamps[blockIdx.x + 512][tid >> 6] = t_sbar;
 #endif
     begin_tile();
     __syncthreads();   // last tile staged
