@@ -44,6 +44,8 @@ struct NNArgs {
   kws_gather_t g;
   int m_tiles, n_tiles;
   int half_tail;  // wave-specialised kernel: the tiles of a short last round are walked as 64-row halves
+  int last_rows;  // rows of the last row tile: M - 128 (m_tiles - 1)
+  unsigned inv_n_tiles;   // ceil(2^32 / n_tiles) (0 for n_tiles = 1): tile / n_tiles as one s_mul_hi_u32
 };
 
 // 16 bytes of zeros that masked-out lanes load from instead of branching around their load.
@@ -375,7 +377,6 @@ __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNA
 
   const int tid = threadIdx.x;
   const int K = p.K, N = p.N;
-  const int64_t M = p.M;
   const int nk = K / PBK;                           // >= 2
 
   const int xcd = blockIdx.x % NXCD;
@@ -399,14 +400,23 @@ __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNA
       for (int c = tid; c < 2 * N; c += blockDim.x) p.stats[(int64_t)blockIdx.x * 2 * N + c] = 0.f;
     return;
   }
-  // local item -> tile view: first row, rows it may touch (128 / 64), first column
-  auto decode = [&](int loc, int64_t& m0, int& cap, int& n0) {
+  // local item -> tile view: row tile, first row inside it (0 / 64), rows it holds, first column.  Everything here is 32-bit
+  // scalar arithmetic on purpose: the loader waves run it in front of every slab's loads, and a first version that compared
+  // 64-bit row counts (v_cmp_*_i64: there is no scalar form) and selected 64-bit row offsets cost the 64-wide-tile kernels
+  // 1,800 cycles of barrier wait per iteration - a vector instruction of a non-MFMA wave waits for the matrix pipe's gaps
+  auto decode = [&](int loc, int& tile_m, int& row0, int& rows, int& n0) {
     const int h = loc - first_half;                 // >= 0: a half tile
     const int tile = h >= 0 ? first_half + (h >> 1) : loc;
-    const int tile_m = (tile / p.n_tiles) * NXCD + xcd;
-    n0 = (tile % p.n_tiles) * BN;
-    m0 = (int64_t)tile_m * BM + (h >= 0 ? 64 * (h & 1) : 0);
-    cap = h >= 0 ? 64 : BM;
+    // tile / n_tiles by the host's reciprocal (exact for tile < 2^32 / n_tiles): the compiler's integer division goes
+    // through v_rcp_iflag_f32 - five dependent vector instructions in front of the loads
+    const int tq = p.inv_n_tiles ? (int)__umulhi((unsigned)tile, p.inv_n_tiles) : tile;
+    tile_m = tq * NXCD + xcd;
+    n0 = (tile - tq * p.n_tiles) * BN;
+    row0 = h >= 0 ? 64 * (h & 1) : 0;
+    const int cap = h >= 0 ? 64 : BM;
+    int r = (tile_m < p.m_tiles - 1 ? BM : p.last_rows) - row0;   // rows of the tile from row0 on
+    r = r < 0 ? 0 : r;
+    rows = r < cap ? r : cap;
   };
   const int n_my = (local_count - wg_in_xcd + wgs_per_xcd - 1) / wgs_per_xcd;
   const int G = n_my * nk;
@@ -496,9 +506,8 @@ __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNA
       }
     };
     auto set_staged_tile = [&](int ordinal) {
-      int64_t m0;
-      int cap;
-      decode(wg_in_xcd + ordinal * wgs_per_xcd, m0, cap, st_n0);
+      int tile_m, row0, rows;
+      decode(wg_in_xcd + ordinal * wgs_per_xcd, tile_m, row0, rows, st_n0);
     };
     if (STATS)
       for (int c = tid; c < 2 * KWS_WS_MAX_N; c += NCT) smem[WACC_OFF + c] = 0.f;
@@ -633,11 +642,10 @@ __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNA
     float4 ra[A_F4], rb[B_F4];
     auto issue = [&]() {
       const bool tile_ok = ld_i < n_my;
-      int64_t m0;
-      int cap, n0;
-      decode(wg_in_xcd + ld_i * wgs_per_xcd, m0, cap, n0);
-      const int64_t rows_left = M - m0;
-      const int rows = tile_ok && rows_left > 0 ? (int)(rows_left < cap ? rows_left : cap) : 0;
+      int tile_m, row0, rows_t, n0;
+      decode(wg_in_xcd + ld_i * wgs_per_xcd, tile_m, row0, rows_t, n0);
+      const int64_t m0 = (int64_t)tile_m * BM + row0;
+      const int rows = tile_ok ? rows_t : 0;
       const __amdgpu_buffer_rsrc_t ares = __builtin_amdgcn_make_buffer_rsrc(
           const_cast<float*>(p.A + m0 * K), 0, rows * K * 4, KWS_BUFFER_RSRC_FLAGS);
       const __amdgpu_buffer_rsrc_t bres = __builtin_amdgcn_make_buffer_rsrc(
@@ -710,11 +718,9 @@ __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNA
     int st_i = 0;                                   // ordinal of the next tile to move out
     __amdgpu_buffer_rsrc_t cres = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, 0, KWS_BUFFER_RSRC_FLAGS);
     auto begin_tile = [&]() {
-      int64_t m0;
-      int cap, n0;
-      decode(wg_in_xcd + st_i * wgs_per_xcd, m0, cap, n0);
-      const int64_t rows_left = M - m0;
-      const int rows = (int)(rows_left < cap ? rows_left : cap);
+      int tile_m, row0, rows, n0;
+      decode(wg_in_xcd + st_i * wgs_per_xcd, tile_m, row0, rows, n0);
+      const int64_t m0 = (int64_t)tile_m * BM + row0;
       // view of C starting at (m0, n0): rows past M fall outside rows*N floats and are dropped
       cres = __builtin_amdgcn_make_buffer_rsrc(p.C + m0 * N + n0, 0, rows > 0 ? (rows * N - n0) * 4 : 0,
                                                KWS_BUFFER_RSRC_FLAGS);
@@ -1301,6 +1307,8 @@ int launch_nn(const NNArgs& a0, hipStream_t st) {
   a.m_tiles = (int)ceil_div64(a.M, 128);
   a.n_tiles = ceil_div(a.N, BN);
   a.half_tail = nn_half_tail() ? 1 : 0;
+  a.last_rows = (int)(a.M - (int64_t)(a.m_tiles - 1) * 128);
+  a.inv_n_tiles = a.n_tiles > 1 ? (unsigned)(((1ull << 32) + a.n_tiles - 1) / a.n_tiles) : 0u;
   const int64_t slots = ceil_div64(a.m_tiles, NXCD) * a.n_tiles;
   const int64_t grid = slots * NXCD;
   if (grid <= 0 || grid > 0x7FFFFFFF) {
