@@ -959,6 +959,7 @@ template <int BKO, int BNO>
 __global__ __launch_bounds__((4 + ((128 / BKO) * (128 / BNO) > 2 ? 4 : 2)) * 64, 1) void gemm_tn_ws_kernel(TNArgs p) {
   constexpr int WK = BKO / 64, WN = BNO / 64, WS = 4 / (WK * WN);
   constexpr int U = WS;                             // 32-row units per stage
+  constexpr bool IL = WS != 2;                      // interleaved column blocks (see the fragment reads)
   constexpr int NLW = U > 2 ? 4 : 2;
   constexpr int NCT = 256;
   constexpr int COLS = BKO + BNO;
@@ -997,16 +998,37 @@ __global__ __launch_bounds__((4 + ((128 / BKO) * (128 / BNO) > 2 ? 4 : 2)) * 64,
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
     __syncthreads();
+#ifdef KWS_GEMM_STAMP
+    unsigned long long tn_mma = 0, tn_bar = 0, tn_mark = __builtin_amdgcn_s_memtime();
+    const unsigned long long tn_begin = tn_mark;
+#define TNT(acc_) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc_ += now_ - tn_mark; tn_mark = now_; } while (0)
+#else
+#define TNT(acc_)
+#endif
     for (int g = 0; g < G; ++g) {
       // my 32 rows of this stage = unit wms of slot g & 1; lane half lh takes the odd / even row of a pair
-      const float* cz = smem + (g & 1) * SLOT + wms * UNIT + lh * COLS + wk * 64 + li;
+      // The two 32-wide blocks of a wave's 64 Z (G) columns are INTERLEAVED: block i (j) is the columns 2 li + i, so one
+      // 8-byte LDS read feeds both blocks - 2 reads per 4 MFMAs instead of 4.  (Stamps: with one 4-byte read per MFMA the
+      // wave needed 4,780 cycles to issue the 64 MFMAs of a stage - every non-MFMA instruction in an MFMA wave's stream
+      // costs ~12 matrix cycles.)  The epilogue maps accumulator (block, row / lane) back to 2 x + block.
+      // IL: not for the two-unit stages (128 x 64 / 64 x 128 tiles) - measured, they get 6 - 10 % SLOWER with it: their stage
+      // is paced at ~5,400 cycles by something else (MFMA issue 4,280, every wave waiting > 1,000 at the barrier, with two
+      // or four loader waves alike), and the shorter issue only adds to the wait
+      const float* cz = smem + (g & 1) * SLOT + wms * UNIT + lh * COLS + wk * 64 + (IL ? 2 * li : li);
       const float* cg = cz + BKO - wk * 64 + wn * 64;
       float a0[2], b0[2], a1[2], b1[2];
       auto ld = [&](float (&a)[2], float (&b)[2], int s) {
-        a[0] = cz[2 * s * COLS];
-        a[1] = cz[2 * s * COLS + 32];
-        b[0] = cg[2 * s * COLS];
-        b[1] = cg[2 * s * COLS + 32];
+        if (IL) {
+          const float2 av = *reinterpret_cast<const float2*>(cz + 2 * s * COLS);
+          const float2 bv = *reinterpret_cast<const float2*>(cg + 2 * s * COLS);
+          a[0] = av.x; a[1] = av.y;
+          b[0] = bv.x; b[1] = bv.y;
+        } else {
+          a[0] = cz[2 * s * COLS];
+          a[1] = cz[2 * s * COLS + 32];
+          b[0] = cg[2 * s * COLS];
+          b[1] = cg[2 * s * COLS + 32];
+        }
       };
       auto mm = [&](const float (&a)[2], const float (&b)[2]) {
 #pragma unroll
@@ -1028,20 +1050,24 @@ __global__ __launch_bounds__((4 + ((128 / BKO) * (128 / BNO) > 2 ? 4 : 2)) * 64,
         __builtin_amdgcn_sched_barrier(0);
         if (s + 3 < 16) ld(a1, b1, s + 3);
       }
+      __builtin_amdgcn_sched_barrier(0);
+      TNT(tn_mma);
       __syncthreads();
+      TNT(tn_bar);
     }
+#ifdef KWS_GEMM_STAMP
+    const unsigned long long tn_loop_end = __builtin_amdgcn_s_memtime();
+#endif
     float* out = p.ws + (int64_t)split * K * N;
     if (WS == 1) {
+      // accumulator (i, j) register v of lane (li, lh) is dW[k0 + wk 64 + 2 r + i][n0 + wn 64 + 2 li + j], r = the MFMA's row of
+      // register v: the two column blocks of a row leave as one 8-byte store (256 contiguous bytes per row and wave)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int col = n0 + wn * 64 + j * 32 + li;
-#pragma unroll
-          for (int v = 0; v < 16; ++v) {
-            const int row = k0 + wk * 64 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh;
-            out[(int64_t)row * N + col] = acc[i][j][v];
-          }
+        for (int v = 0; v < 16; ++v) {
+          const int row = k0 + wk * 64 + 2 * ((v & 3) + 8 * (v >> 2) + 4 * lh) + i;
+          *reinterpret_cast<float2*>(out + (int64_t)row * N + n0 + wn * 64 + 2 * li) = make_float2(acc[i][0][v], acc[i][1][v]);
         }
     } else {
       // the pipeline slots are idle now: every wave parks its block, then the WS waves of a block share its
@@ -1052,8 +1078,10 @@ __global__ __launch_bounds__((4 + ((128 / BKO) * (128 / BNO) > 2 ? 4 : 2)) * 64,
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-          for (int v = 0; v < 16; ++v)
-            mine[(i * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh) * 64 + j * 32 + li] = acc[i][j][v];
+          for (int v = 0; v < 16; ++v) {
+            const int r = (v & 3) + 8 * (v >> 2) + 4 * lh;
+            mine[IL ? (2 * r + i) * 64 + 2 * li + j : (i * 32 + r) * 64 + j * 32 + li] = acc[i][j][v];
+          }
       __syncthreads();
       const float* blk = smem + wkn * WS * 4096;
       const int t = wms * 64 + lane;
@@ -1068,6 +1096,12 @@ __global__ __launch_bounds__((4 + ((128 / BKO) * (128 / BNO) > 2 ? 4 : 2)) * 64,
         *reinterpret_cast<float4*>(out + (int64_t)row * N + col) = s;
       }
     }
+#ifdef KWS_GEMM_STAMP
+    if (tid == 0 && blockIdx.x < 4096) {
+      g_stamps[blockIdx.x][0] = tn_mma; g_stamps[blockIdx.x][1] = tn_bar; g_stamps[blockIdx.x][3] = (unsigned long long)G;
+      g_stamps[blockIdx.x][4] = tn_loop_end - tn_begin; g_stamps[blockIdx.x][5] = __builtin_amdgcn_s_memtime() - tn_loop_end;
+    }
+#endif
   } else {
     // ------------------------------------------------------------------ loader waves
     const int lane = tid & 63;
@@ -1107,14 +1141,25 @@ __global__ __launch_bounds__((4 + ((128 / BKO) * (128 / BNO) > 2 ? 4 : 2)) * 64,
     }
     issue(x);
     __syncthreads();
+#ifdef KWS_GEMM_STAMP
+    unsigned long long tl_work = 0, tl_bar = 0, tl_mark = __builtin_amdgcn_s_memtime();
+#define TLT(acc_) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc_ += now_ - tl_mark; tl_mark = now_; } while (0)
+#else
+#define TLT(acc_)
+#endif
     for (int g = 0; g < G; ++g) {
       if (x / U == g + 1) {                         // my unit belongs to the next stage: write it, re-issue
         write_lds(x);
         x += NLW;
         issue(x);
       }
+      TLT(tl_work);
       __syncthreads();
+      TLT(tl_bar);
     }
+#ifdef KWS_GEMM_STAMP
+    if ((tid & 63) == 0 && lw == 0 && blockIdx.x < 4096) { g_stamps[blockIdx.x][6] = tl_work; g_stamps[blockIdx.x][7] = tl_bar; }
+#endif
     if (WS > 1) __syncthreads();
   }
 }
