@@ -1119,12 +1119,14 @@ __global__ __launch_bounds__((4 + ((128 / BKO) * (128 / BNO) > 2 ? 4 : 2)) * 64,
         const_cast<float*>(p.G + m_begin * N), 0, rows * N * 4, KWS_BUFFER_RSRC_FLAGS);
     float4 rz[Z_F4], rg[G_F4];
     auto issue = [&](int x) {                       // unit x = rows [32 x, 32 x + 32) of my split
+      if (KWS_WS_ABL & 4) return;
 #pragma unroll
       for (int r = 0; r < Z_F4; ++r) rz[r] = buf_ld4(zres, z_voff, (x * 32 + RZ * r) * K * 4);
 #pragma unroll
       for (int r = 0; r < G_F4; ++r) rg[r] = buf_ld4(gres, g_voff, (x * 32 + RG * r) * N * 4);
     };
     auto write_lds = [&](int x) {
+      if (KWS_WS_ABL & 2) { asm volatile("" :: "v"(rz[0].x), "v"(rg[0].x)); return; }
       float* dst = smem + ((x / U) & 1) * SLOT + (x % U) * UNIT;
       float* dz = dst + zrow * COLS + zc;
       float* dg = dst + grow * COLS + BKO + gc;
