@@ -1011,9 +1011,9 @@ __global__ __launch_bounds__((4 + ((128 / BKO) * (128 / BNO) > 2 ? 4 : 2)) * 64,
       // 8-byte LDS read feeds both blocks - 2 reads per 4 MFMAs instead of 4.  (Stamps: with one 4-byte read per MFMA the
       // wave needed 4,780 cycles to issue the 64 MFMAs of a stage - every non-MFMA instruction in an MFMA wave's stream
       // costs ~12 matrix cycles.)  The epilogue maps accumulator (block, row / lane) back to 2 x + block.
-      // IL: not for the two-unit stages (128 x 64 / 64 x 128 tiles) - measured, they get 6 - 10 % SLOWER with it: their stage
-      // is paced at ~5,400 cycles by something else (MFMA issue 4,280, every wave waiting > 1,000 at the barrier, with two
-      // or four loader waves alike), and the shorter issue only adds to the wait
+      // IL: not for the two-unit stages (128 x 64 / 64 x 128 tiles) - measured, they get 6 - 10 % SLOWER with it: with the
+      // shorter issue their stage is paced by the loads (5,200 - 5,400 cycles, two or four loader waves alike; 4,350 without
+      // the loaders): these tiles re-read z per column tile and sit on the memory system's rate
       const float* cz = smem + (g & 1) * SLOT + wms * UNIT + lh * COLS + wk * 64 + (IL ? 2 * li : li);
       const float* cg = cz + BKO - wk * 64 + wn * 64;
       float a0[2], b0[2], a1[2], b1[2];
