@@ -121,8 +121,16 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict
 //   recomputes g from the same operands (bit-identical) and stores the BatchNorm input gradient
 //   dy = scale * (g - c1 - xhat * c2) directly - 5 tensor passes instead of the 6 of "store g, then
 //   kws_bn_bwd_apply" for a stride-1 layer, 4 instead of 5.5 for a stride-2 layer.
+// DW_BWD_THREADS threads per workgroup of the modes that write partial rows (0 and 1): 1024 = one workgroup per CU carries
+// the 16 waves that stream best (as 256-thread workgroups that took 1024 of them, i.e. 1024 partial rows and a slice_reduce
+// launch in front of every finalise kernel; with <= 256 rows kws_dw_bwd_finalize sums them directly - one 5 us launch less
+// per block and step: 0.21 -> 0.185 ms of small kernels).  Pass 2 (MODE 2, no partial rows) keeps 256-thread workgroups:
+// measured with 1024 it streams 4 % slower (533 -> 556 us over the eleven layers).
+#ifndef DW_BWD_THREADS
+#define DW_BWD_THREADS 1024
+#endif
 template <int S, bool HAS_BN, int MODE>
-__global__ __launch_bounds__(256) void dwconv_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ y,
+__global__ __launch_bounds__(MODE == 2 ? 256 : DW_BWD_THREADS) void dwconv_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ y,
                                                          const float* __restrict__ bn, const float* __restrict__ w,
                                                          const float* __restrict__ coef,
                                                          float* __restrict__ g, float* __restrict__ part, int B,
@@ -130,7 +138,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const float* __restrict
                                                          int Cb, unsigned* amax) {
   float gmax = 0.f;                                 // MODE 2: |dy| maximum of this thread (amax may be NULL)
   // blockIdx.y selects a slice of Cb <= 1024 channels (Cb = C unless C > 1024)
-  __shared__ float red[5][256 * 4];
+  __shared__ float red[MODE == 2 ? 1 : 5][MODE == 2 ? 4 : DW_BWD_THREADS * 4];   // (pass 2 reduces nothing)
   const int C4 = Cb >> 2;
   const int tid = threadIdx.x;
   const int r = tid / C4, c4 = tid - r * C4;
@@ -238,6 +246,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const float* __restrict
     if (amax) kws_absmax_commit(amax, gmax);
     return;
   }
+  if constexpr (MODE != 2) {
   *reinterpret_cast<float4*>(&red[0][tid * 4]) = sg;
   *reinterpret_cast<float4*>(&red[1][tid * 4]) = sgx;
   *reinterpret_cast<float4*>(&red[2][tid * 4]) = sw0;
@@ -251,27 +260,31 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const float* __restrict
     for (int rr = 0; rr < R; ++rr) s += red[q][(rr * C4) * 4 + ch];
     part[((int64_t)blockIdx.x * 5 + q) * C + blockIdx.y * Cb + ch] = s;
   }
+  }
 }
 
 // measured at batch 1024 (ms per step, dwconv_bwd + finalisation): 256 rows 1.37, 512 1.02, 1024 0.86, 2048 0.91,
 // uncapped (6400) 1.03: four resident workgroups per CU stream best and leave few rows to fold
-constexpr int KWS_DW_BWD_MAX_PARTS = 1024;
+// (the table above is for 256-thread workgroups; DW_BWD_THREADS = 1024 reaches the rate of its 1024-row entry with 256)
+constexpr int KWS_DW_BWD_MAX_PARTS = DW_BWD_THREADS == 1024 ? 256 : 1024;
 struct BwdGeom {
   int nchunks, R, block, ny, Cb;
   int64_t grid;
 };
 bool bwd_geom_ok(int C) { return C > 0 && C % 4 == 0 && (C / 4) % ceil_div(C / 4, 256) == 0; }
-BwdGeom bwd_geom(int B, int Lin, int C) {
+BwdGeom bwd_geom(int B, int Lin, int C, bool parts = true) {
   BwdGeom g;
+  const int threads = parts ? DW_BWD_THREADS : 256;
+  const int max_parts = parts ? KWS_DW_BWD_MAX_PARTS : 1024;
   g.ny = ceil_div(C / 4, 256);   // channel slices of at most 1024 channels
   g.Cb = C / g.ny;
   const int C4 = g.Cb / 4;
   g.nchunks = ceil_div(Lin, TT);
-  g.R = 256 / C4;
+  g.R = threads / C4;
   if (g.R < 1) g.R = 1;
   g.block = g.R * C4;
   g.grid = ceil_div64((int64_t)B * g.nchunks, g.R);
-  if (g.grid > KWS_DW_BWD_MAX_PARTS) g.grid = KWS_DW_BWD_MAX_PARTS;
+  if (g.grid > max_parts) g.grid = max_parts;
   return g;
 }
 
@@ -282,7 +295,7 @@ template <int MODE>
 int launch_dw_bwd(const float* dz, const float* y, const float* bn, const float* w, const float* coef, float* g,
                   float* part, int B, int L_in, int L_out, int C, int stride, int pad_l, hipStream_t st,
                   unsigned* amax = nullptr) {
-  const BwdGeom ge = bwd_geom(B, L_in, C);
+  const BwdGeom ge = bwd_geom(B, L_in, C, MODE != 2);
   KWS_REQUIRE(ge.grid < 0x7FFFFFFF, "dwconv_bwd: grid too large");
   dim3 gr((unsigned)ge.grid, (unsigned)ge.ny), b((unsigned)ge.block);
   if (stride == 1) {
