@@ -14,6 +14,8 @@ Prints ONE JSON line (see DESIGN.md "Measurement" for every field).
 from __future__ import division, print_function
 
 import argparse
+import contextlib
+import glob
 import json
 import math
 import os
@@ -62,17 +64,22 @@ def build_synthetic(device, n_bank, seed, L=16000):
     rng = np.random.RandomState(59185)
     noise = [(rng.randn(960000) * 0.1).astype(np.float32) for _ in range(6)]
     cb = ClipBank(bank, noise, device)
+    # Partitions are DISJOINT row ranges, as the reference's which_set hash split makes them (input_data.py:61-114,
+    # train.py:40-45): validation never scores a clip the training or pseudo partition draws.
     n_pseudo = n_bank // 8
-    train_rows = [r for r in range(n_wanted - n_pseudo // 2)]
-    pseudo_rows = [r for r in range(n_wanted - n_pseudo // 2, n_wanted)]
-    unk_rows = list(range(n_wanted, n_bank))
+    n_val = min(4096, n_bank // 8)
+    n_val_w = n_val // 2                                             # half wanted words, half unknown words
+    val_rows = list(range(n_wanted - n_val_w, n_wanted)) + list(range(n_bank - (n_val - n_val_w), n_bank))
+    pseudo_rows = list(range(n_wanted - n_val_w - n_pseudo // 2, n_wanted - n_val_w))
+    train_rows = list(range(n_wanted - n_val_w - n_pseudo // 2))
+    unk_rows = list(range(n_wanted, n_bank - (n_val - n_val_w)))
     n_sil = int(math.ceil(len(train_rows) * 13.0 / 100))
     n_unk = min(int(math.ceil(len(train_rows) * 60.0 / 100)), len(unk_rows) - n_pseudo // 2)
     index = {
         'training': [(r, word_of_row[r]) for r in train_rows] + [(0, SILENCE_LABEL)] * n_sil +
                     [(r, word_of_row[r]) for r in unk_rows[:n_unk]],
         'pseudo': [(r, word_of_row[r]) for r in pseudo_rows] + [(r, word_of_row[r]) for r in unk_rows[n_unk:n_unk + n_pseudo // 2]],
-        'validation': [(r, word_of_row[r]) for r in range(0, min(4096, n_bank))],
+        'validation': [(r, word_of_row[r]) for r in val_rows],
         'testing': [],
     }
     return {'bank': cb, 'index': index}
@@ -98,7 +105,8 @@ def cpu_baselines(budget_s=30.0):
 
       B1  reference-style generator: ONE clip per call, float64 batch buffer, augment -> STFT -> |X| -> mel -> log ->
           DCT (input_data.py:457-536), single thread like the reference's generator;
-      B2  the same features vectorised over a batch (numpy.fft over [B*98, 512]);
+      B2  the same features batched: scipy.fft.rfft(workers) over [B*98, 512], mel and DCT as one GEMM each, float32, at the
+          best of a few thread counts (its GB/s stands next to the GPU STFT stage's);
       B3  the model step on CPU: forward + backward + optimizer of the 12-class raw-waveform net at batch 64 through
           torch-CPU (oneDNN; oracle/torch_net.py), Keras-SGD(momentum) and RMSprop, at the best of a few thread counts;
       B4  end to end: the B1 generator feeding B3 through a depth-10 queue (Keras fit_generator's default) - the number
@@ -137,17 +145,28 @@ def cpu_baselines(budget_s=30.0):
             n += 16
         out["B1_generator_" + name] = {"value": n / (time.time() - t0), "unit": "clips/s", "cores": 1,
                                        "sample": "%d clips, one per call" % n}
-    # ---- B2: batched features --------------------------------------------------------------------------------
-    clips = np.stack([_cpu_clip(OF, rng, bank, noise) for _ in range(64)])
-    OF.features(clips, tables, 160, dtype=np.float32)
-    n, t0 = 0, time.time()
-    while time.time() - t0 < share / 2:
-        OF.features(clips, tables, 160, dtype=np.float32)
-        n += len(clips)
-    dt = time.time() - t0
-    out["B2_batched_features"] = {"value": n / dt, "unit": "clips/s", "cores": _blas_threads(),
-                                  "GBps_algorithmic": n * (64000 + 98 * 60 * 4) / dt / 1e9,
-                                  "sample": "%d clips in batches of 64" % n}
+    # ---- B2: batched features: ONE scipy.fft.rfft(workers) over [B * 98, 512] + one GEMM each for
+    # mel and DCT, float32; the thread count is chosen like B3's: the best of a few ------------------------------------
+    clips = np.stack([_cpu_clip(OF, rng, bank, noise) for _ in range(256)])
+    best2 = None
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:
+        threadpool_limits = None
+    for thr in sorted(set([min(ncpu, t) for t in (1, 8, 16, 32, 64)])):
+        with (threadpool_limits(limits=thr) if threadpool_limits else contextlib.nullcontext()):
+            OF.features_batched(clips, tables, 160, workers=thr)
+            n, t0 = 0, time.time()
+            while n < 2 * len(clips) or time.time() - t0 < share / 10:
+                OF.features_batched(clips, tables, 160, workers=thr)
+                n += len(clips)
+            rate = n / (time.time() - t0)
+        if best2 is None or rate > best2[0]:
+            best2 = (rate, thr, n)
+    out["B2_batched_features"] = {"value": best2[0], "unit": "clips/s", "cores": best2[1],
+                                  "GBps_algorithmic": best2[0] * (64000 + 98 * 60 * 4) / 1e9,
+                                  "sample": "%d clips in batches of 256: scipy.fft.rfft(workers=%d) over [B*98, 512] + mel GEMM + "
+                                            "log + DCT GEMM, float32 (oracle.features.features_batched)" % (best2[2], best2[1])}
     # ---- B3: model step, torch-CPU ---------------------------------------------------------------------------
     B = 64
     x = (rng.randn(B, 16000) * 0.0774).astype(np.float32)
@@ -296,24 +315,60 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=5)
     ap.add_argument("--no-ab", action="store_true",
-                    help="skip the A/B legs: the same step with the pointwise GEMMs as bf16 x 3 / fp16 x 2 split products "
-                         "(experiments, off by default in the product; N=1 only)")
+                    help="skip the A/B legs: N=1 the same step with the pointwise GEMMs as fp16 x 2 split products (off by "
+                         "default in the product); N>1 the same step with the gradient all-reduce split (--allreduce-split)")
+    ap.add_argument("--allreduce-split", type=int, default=6,
+                    help="N>1 A/B leg: block from which the gradients are all-reduced while the earlier blocks' backward "
+                         "still runs (the headline step sends ONE buffer after the backward pass)")
+    ap.add_argument("--n1-value", type=float, default=None,
+                    help="clips/s of the N=1 run of the same build: fills scaling_vs_n1 = value / (N x n1-value)")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the `configs` legs (BASELINE configs[2] C3 and configs[4] C5 on this one GPU; N=1 only)")
     ap.add_argument("--no-val-acc", action="store_true",
                     help="skip the short val-acc parity run (scripts/val_acc_parity.py: the same batches trained on the "
                          "device and on the oracle's torch-CPU twin, val_acc next to val_acc_cpu); N=1 only")
     return ap.parse_args(argv)
 
 
+def visible_gpu_count():
+    """GPUs this process may use, counted WITHOUT the HIP runtime (the launcher below must not touch the GPU before it
+    starts its ranks): KFD topology nodes with SIMDs (CPU nodes have simd_count 0), cut down by the *_VISIBLE_DEVICES
+    lists.  Returns None when the topology cannot be read (then a CHILD process asks torch)."""
+    n = 0
+    paths = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not paths:
+        return None
+    for path in paths:
+        try:
+            with open(path) as f:
+                props = dict(l.split()[:2] for l in f if len(l.split()) >= 2)
+        except (IOError, OSError):
+            continue
+        if int(props.get("simd_count", "0")) > 0:
+            n += 1
+    # a container may see the whole host's topology but only its own GPUs' render nodes
+    nodes = glob.glob("/dev/dri/renderD*")
+    if nodes:
+        n = min(n, len([d for d in nodes if os.access(d, os.R_OK | os.W_OK)]))
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def launch_ranks(args, json_out):
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves.
 
-    This process has not touched the GPU (torch.cuda.device_count() does not initialise HIP on this image) and never
-    will: the ranks are CHILD processes under torch.distributed.run, their stderr is passed through, rank 0's single
-    JSON line is relayed, the child's return code is ours.  Fewer than N visible devices is an error, never a silent
-    1-GPU run (KWS_BENCH_ONE_DEVICE, the 1-GPU test hook, waives the count)."""
+    This process never touches the GPU: devices are counted from the KFD topology in sysfs (visible_gpu_count; when that
+    is unreadable a throw-away CHILD process asks torch), the ranks are CHILD processes under torch.distributed.run, their
+    stderr is passed through, rank 0's single JSON line is relayed, the child's return code is ours.  Fewer than N
+    visible devices is an error, never a silent 1-GPU run (KWS_BENCH_ONE_DEVICE, the 1-GPU test hook, waives the count)."""
     import socket
     import subprocess
-    n_dev = torch.cuda.device_count()
+    n_dev = visible_gpu_count()
+    if n_dev is None:
+        n_dev = int(subprocess.check_output([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"]).split()[-1])
     if n_dev < args.gpus and not os.environ.get("KWS_BENCH_ONE_DEVICE"):
         raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible" % (args.gpus, n_dev))
     with socket.socket() as s:
@@ -402,6 +457,7 @@ def main():
     model = speech_model('conv_1d_time_sliced_with_attention', settings['desired_samples'],
                          num_classes=settings['label_count'])
     model.seed = 87654321            # one dropout stream for the global batch: rank r uses rows [r*B, (r+1)*B)
+    model.allreduce_split = 0        # the headline step: ONE all-reduce of the flat gradient buffer after the backward pass
     ab_steps = min(args.steps, 50)
     ring = torch.zeros((args.warmup + args.steps + 3 * args.profile_steps + 2 * (ab_steps + 8) + 8, 4), dtype=torch.float32, device=device)
     enq = GeneratorEnqueuer(gen, max_queue_size=10, device=device)
@@ -417,93 +473,134 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed_steps(first, n):
+        """n steps between barrier + synchronize on both sides -> (max over ranks, this rank's own seconds)"""
+        barrier()
+        t0 = time.time()
+        for i in range(n):
+            step(first + i)
+        barrier()
+        own = time.time() - t0
+        if dist:
+            tmax = torch.tensor([own], dtype=torch.float64, device=device)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            return float(tmax.item()), own
+        return own, own
+
     for i in range(args.warmup):
         step(i)
-    barrier()
-    t0 = time.time()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    barrier()
-    dt = time.time() - t0
-    if dist:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    dt, dt_own = timed_steps(args.warmup, args.steps)
     clips = B * world * args.steps
     ms = ring[args.warmup:args.warmup + args.steps].cpu().numpy()
+    per_rank_ms = [1e3 * dt_own / args.steps]
+    if dist:                             # every rank's own wall time per step: a straggler shows here
+        gathered = [torch.zeros(1, dtype=torch.float64, device=device) for _ in range(world)]
+        dist.all_gather(gathered, torch.tensor([1e3 * dt_own / args.steps], dtype=torch.float64, device=device))
+        per_rank_ms = [float(g.item()) for g in gathered]
 
     # ---- per-kernel durations of the same step, HIP events on the launch stream -------------------
     prof = None
     roof = None
     stages = []
+    used = args.warmup + args.steps
     if args.profile_steps > 0:
         # EVERY rank runs the profiled steps (each step contains the gradient all-reduce: a rank that skipped them
-        # would leave the others waiting in the collective); only rank 0 records and reports the kernel times
-        lib = _lib.load()
-        if rank == 0:
-            lib.kws_profile_enable(1)
+        # would leave the others waiting in the collective); only rank 0 records and reports the kernel times.
+        # The profiler is a handle: this thread attaches to it, the generator thread through proc.profiler.
+        profiler = _lib.Profiler() if rank == 0 else None
+        if profiler is not None:
+            profiler.attach()
+            proc.profiler = profiler
         for i in range(args.profile_steps):
-            step(args.warmup + args.steps + i)
+            step(used + i)
         barrier()
-    if rank == 0 and args.profile_steps > 0:
-        prof = _lib.profile_collect()
-        lib.kws_profile_enable(0)
-        pmc = load_pmc_traffic()
-        for family, kernel, bound, what in ROOFLINE_KERNELS:
-            e = roofline_entry(prof, family, kernel, bound, what, pmc)
-            if e is not None:
-                stages.append(e)
-        roof = stages[0] if stages and stages[0]["family"] == "gemm_nn" else None
-    # ---- A/B leg (experiment): the same step with the pointwise GEMMs (forward, input gradient,
-    # weight gradient) as six bf16 MFMA products of three-way operand splits; the line's value / roofline above are
-    # the f32-MFMA path
+        used += args.profile_steps
+        if profiler is not None:
+            proc.profiler = None
+            profiler.detach()
+            prof = profiler.collect()
+            pmc = load_pmc_traffic()
+            for family, kernel, bound, what in ROOFLINE_KERNELS:
+                e = roofline_entry(prof, family, kernel, bound, what, pmc)
+                if e is not None:
+                    stages.append(e)
+            roof = stages[0] if stages and stages[0]["family"] == "gemm_nn" else None
+    # ---- N > 1: what the gradient exchange costs, and the split-overlap form of the same step (DESIGN.md section 6) -----
+    exchange = None
     ab = {}
-    gemm_mode = _lib.load().kws_net_get_gemm_mode()
-    AB_ARMS = [(1, "ab_gemm_bf16x3", "3-way bf16 splits (six bf16 MFMA products"),
-               (2, "ab_gemm_f16x2", "power-of-two scaled 2-way fp16 splits (three f16 MFMA products")]
+    if dist:
+        n_grad = int(model.net.n_params)
+        buf = torch.zeros(n_grad, dtype=torch.float32, device=device)
+        for _ in range(5):
+            dist.all_reduce(buf)
+        barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n_ar = 50
+        t0 = time.time()
+        e0.record()
+        for _ in range(n_ar):
+            dist.all_reduce(buf)         # the collective of parallel.allreduce_grads: the current stream waits for each
+        e1.record()
+        e1.synchronize()
+        host_us = 1e6 * (time.time() - t0) / n_ar
+        ar_us = torch.tensor([1e3 * e0.elapsed_time(e1) / n_ar], dtype=torch.float64, device=device)
+        dist.all_reduce(ar_us, op=dist.ReduceOp.MAX)
+        exchange = {"what": "%d back-to-back all-reduces (sum, in place) of the flat gradient buffer alone, HIP events on "
+                            "the launch stream, max over ranks" % n_ar,
+                    "floats": n_grad, "bytes": 4 * n_grad, "us_per_allreduce": float(ar_us.item()),
+                    "host_us_per_allreduce_rank0": host_us,
+                    "pct_of_ms_per_step": 100.0 * float(ar_us.item()) * 1e-3 / (1e3 * dt / args.steps),
+                    "algorithmic_bus_GBps": 2.0 * (world - 1) / world * 4 * n_grad / (float(ar_us.item()) * 1e-6) / 1e9}
+        if not args.no_ab and 1 <= args.allreduce_split < 11:
+            model.allreduce_split = args.allreduce_split
+            for i in range(8):
+                step(used + i)
+            dt_ab, _ = timed_steps(used + 8, ab_steps)
+            used += 8 + ab_steps
+            model.allreduce_split = 0
+            ab["ab_allreduce_split"] = {
+                "what": "the same step with the gradients of blocks >= %d (+ tail) all-reduced while the earlier blocks' "
+                        "backward still runs, the rest afterwards (bit-identical sums; Model.allreduce_split)" % args.allreduce_split,
+                "split_block": args.allreduce_split, "steps": ab_steps, "ms_per_step": 1e3 * dt_ab / ab_steps,
+                "value": B * world * ab_steps / dt_ab, "unit": "clips/s",
+                "vs_one_buffer": (B * world * ab_steps / dt_ab) / (clips / dt)}
+    # ---- N = 1 A/B leg (DESIGN.md section 5): the same step with the pointwise GEMMs (forward, input gradient, weight
+    # gradient) as three f16 MFMA products of scaled two-way operand splits; the line's value / roofline above are the
+    # f32-MFMA path.  The arm is a property of the net handle (kws_net_set_gemm_mode).
+    gemm_mode = model.net.gemm_mode
     if world == 1 and not args.no_ab and gemm_mode == 0:
-        lib = _lib.load()
-        base = args.warmup + args.steps + args.profile_steps
         try:
-            for mode, key, what in AB_ARMS:
-                _lib.check(lib.kws_net_set_gemm_mode(mode), "kws_net_set_gemm_mode")
-                for i in range(8):
-                    step(base + i)
+            model.net.set_gemm_mode(2)
+            for i in range(8):
+                step(used + i)
+            dt_ab, _ = timed_steps(used + 8, ab_steps)
+            used += 8 + ab_steps
+            # the arm's own GEMM kernels against BOTH roofs (HIP events on the launch stream, as for the product arm):
+            # algorithmic bytes over 8 TB/s, algorithmic FLOPs over the f32-MFMA peak the product arm is priced against
+            arm_stages = []
+            if args.profile_steps > 0:
+                profiler = _lib.Profiler()
+                profiler.attach()
+                for i in range(args.profile_steps):
+                    step(used + i)
                 barrier()
-                t1 = time.time()
-                for i in range(ab_steps):
-                    step(base + 8 + i)
-                barrier()
-                dt_ab = time.time() - t1
-                base += 8 + ab_steps
-                # the arm's own GEMM kernels against BOTH roofs (HIP events on the launch stream, as for the product arm):
-                # algorithmic bytes over 8 TB/s, algorithmic FLOPs over the f32-MFMA peak the product arm is priced against
-                arm_stages = []
-                if args.profile_steps > 0:
-                    lib.kws_profile_enable(1)
-                    for i in range(args.profile_steps):
-                        step(base + i)
-                    barrier()
-                    base += args.profile_steps
-                    prof_ab = _lib.profile_collect()
-                    lib.kws_profile_enable(0)
-                    suffix = {1: "bf16x3", 2: "f16x2"}[mode]
-                    for fam, kern, what_k in (("gemm_nn_" + suffix, "gemm_nn_%s_kernel" % ("bf16x3p" if mode == 1 else "f16x2"),
-                                               "pointwise 1x1 convolutions: forward + input gradient"),
-                                              ("gemm_tn_" + suffix, "gemm_tn_%s_kernel" % suffix,
-                                               "pointwise 1x1 convolutions: weight gradient")):
-                        e = roofline_entry(prof_ab, fam, kern, "hbm", what_k, load_pmc_traffic("r*_%s_arm_pmc.json" % suffix))
-                        if e is not None:
-                            arm_stages.append(e)
-                ab[key] = {"what": "pointwise forward / input-gradient / weight-gradient GEMMs as %s, f32 accumulate): an A/B "
-                                   "experiment, not the product default" % what,
-                           "steps": ab_steps, "ms_per_step": 1e3 * dt_ab / ab_steps, "value": B * ab_steps / dt_ab,
-                           "unit": "clips/s", "roofline_stages": arm_stages}
-        except Exception as ex:      # an experiment arm must never cost the run its headline measurement
+                used += args.profile_steps
+                profiler.detach()
+                prof_ab = profiler.collect()
+                for fam, kern, what_k in (("gemm_nn_f16x2", "gemm_nn_f16x2_kernel", "pointwise 1x1 convolutions: forward + input gradient"),
+                                          ("gemm_tn_f16x2", "gemm_tn_f16x2_kernel", "pointwise 1x1 convolutions: weight gradient")):
+                    e = roofline_entry(prof_ab, fam, kern, "hbm", what_k, load_pmc_traffic("r*_f16x2_arm_pmc.json"))
+                    if e is not None:
+                        arm_stages.append(e)
+            ab["ab_gemm_f16x2"] = {"what": "pointwise forward / input-gradient / weight-gradient GEMMs as power-of-two scaled 2-way "
+                                           "fp16 splits (three f16 MFMA products, f32 accumulate): an A/B arm, not the product default",
+                                   "steps": ab_steps, "ms_per_step": 1e3 * dt_ab / ab_steps, "value": B * ab_steps / dt_ab,
+                                   "unit": "clips/s", "roofline_stages": arm_stages}
+        except Exception as ex:      # an A/B arm must never cost the run its headline measurement
             ab["error"] = repr(ex)
             sys.stderr.write("A/B leg failed: %r\n" % (ex,))
         finally:
-            _lib.check(lib.kws_net_set_gemm_mode(0), "kws_net_set_gemm_mode")
+            model.net.set_gemm_mode(0)
     enq.stop()
     if rank == 0 and stages:
         # the STFT stage ALONE (its in-situ time above is that of a low-priority stream filling the gaps of the training
@@ -531,6 +628,33 @@ def main():
         except Exception as ex:
             sys.stderr.write("standalone STFT timing skipped: %r\n" % (ex,))
 
+    # ---- the other single-GPU BASELINE configurations on the record (N = 1 only; < 2 s each): configs[2] = C3, the 32-class
+    # conv_1d_log_mfcc net at batch 2048 (freeze_graph_32_classes.py:55-69), configs[4] = C5 on this one GPU, TTA inference
+    # (make_submission.py:120-146) at batch 4096.  Their rocprofv3 summaries: profiles/r03_kernel_stats_c3.csv / _c5.csv.
+    configs = None
+    if world == 1 and not args.no_configs:
+        configs = {}
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "scripts"))
+            import bench_configs
+            proc.close()                              # the headline leg's generator stream and clip bank are done
+            del proc, spec, enq, gen
+            torch.cuda.empty_cache()
+            c3 = bench_configs.c3(steps=30, warm=5, profile_steps=3)
+            kern = c3.pop("kernels", None) or {}
+            fams = sorted([f for f in kern if kern[f]["ms"] > 0], key=lambda f: -kern[f]["ms"])
+            c3["kernel_ms_per_step"] = {f: kern[f]["ms"] / 3 for f in fams[:8]}
+            if fams:
+                dom = fams[0]
+                bound = "mfma" if dom.startswith("gemm") or dom.startswith("conv1") else "hbm"
+                c3["roofline"] = roofline_entry(kern, dom, {"gemm_nn": "gemm_nn_ws_kernel", "gemm_tn": "gemm_tn_ws_kernel"}.get(dom, dom + "_kernel"),
+                                                bound, "dominant kernel family of the C3 step by summed HIP-event time", None)
+            configs["C3"] = c3
+            configs["C5"] = bench_configs.c5(speed_tta=False, n=10, warm=3)
+        except Exception as ex:
+            configs["error"] = repr(ex)
+            sys.stderr.write("configs legs failed: %r\n" % (ex,))
+
     out = None
     if rank == 0:
         out = {
@@ -538,8 +662,7 @@ def main():
             "value": clips / dt, "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": {0: "f32", 1: "f32 (pointwise GEMMs as 3-way bf16 splits, f32 accumulate)",
-                      2: "f32 (pointwise GEMMs as scaled 2-way fp16 splits, f32 accumulate)"}[gemm_mode],
+            "dtype": {0: "f32", 2: "f32 (pointwise GEMMs as scaled 2-way fp16 splits, f32 accumulate)"}[gemm_mode],
             "data": "synthetic",
             "config": {"workload": "configs[1]: 12-class conv_1d_time_sliced_with_attention, batch %d/GPU synthetic "
                                    "16000-sample fp32 clips, sampler+augment+STFT/mel(80,60)+raw fwd/bwd+RMSprop" % B,
@@ -547,13 +670,17 @@ def main():
                        "clip_bank": args.bank},
             "rccl_ranks": rccl_ranks,
             "collective_backend": (dist.get_backend() if dist else None),
+            "per_rank_ms": per_rank_ms,
+            "scaling_vs_n1": (clips / dt) / (world * args.n1_value) if args.n1_value else None,
+            "allreduce_only": exchange,
+            "ab_allreduce_split": ab.get("ab_allreduce_split"),
             "train_loss_first_last": [float(ms[0, 0] / B), float(ms[-1, 0] / B)],
             "train_acc_last": float(ms[-1, 1] / B),
             "roofline": roof,
             "roofline_stages": stages[1:],
-            "ab_gemm_bf16x3": ab.get("ab_gemm_bf16x3"),
             "ab_gemm_f16x2": ab.get("ab_gemm_f16x2"),
             "ab_error": ab.get("error"),
+            "configs": configs,
             "kernels": prof,
         }
     if dist:

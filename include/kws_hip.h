@@ -14,7 +14,8 @@
  *  - layout is channels-last row-major fp32 [B, L, C] (= Keras channels_last), so Keras-named
  *    weights load without transposes: conv1d/kernel [k, Cin, Cout], depthwise_kernel [1,3,C,1],
  *    dense/kernel [in, out].
- *  - functions are re-entrant: no global mutable state besides the thread-local error string.
+ *  - functions are re-entrant: no global mutable state besides the thread-local error string and the
+ *    thread-local profiler attachment; switches (profiling, GEMM arithmetic arm) live on handles.
  */
 #ifndef KWS_HIP_H_
 #define KWS_HIP_H_
@@ -30,7 +31,7 @@ extern "C" {
 #define KWS_E_HIP (-2)       /* a HIP runtime call failed */
 #define KWS_E_WORKSPACE (-3) /* caller workspace too small */
 
-#define KWS_ABI_VERSION 1
+#define KWS_ABI_VERSION 2   /* round 3: profiler / gemm-mode state moved onto handles, bf16 x 3 arm removed */
 
 int kws_abi_version(void);
 const char* kws_last_error(void);
@@ -43,14 +44,19 @@ int kws_device_name(char* buf, int cap);
 int kws_stream_create(int cls, void** stream);
 int kws_stream_destroy(void* stream);
 
-/* Optional per-kernel-family profiler (measurement only, off by default).  While enabled every
- * launcher brackets its launch with a hipEvent pair on the launch stream and books the algorithmic
- * FLOPs/bytes of the call; kws_profile_collect() waits for the events and returns the number of
- * families, kws_profile_get() reads one (summed device ms, launches, FLOPs, bytes). */
-int kws_profile_enable(int on);
-int kws_profile_collect(void);
-int kws_profile_get(int idx, char* name, int cap, double* ms, int64_t* count, double* flops,
-                    double* bytes);
+/* Optional per-kernel-family profiler (measurement only).  A profiler is a HANDLE; kws_profiler_attach(p) makes the
+ * CALLING THREAD record into p (NULL detaches): while attached, every launcher called from that thread brackets its
+ * launch with a hipEvent pair on the launch stream and books the algorithmic FLOPs/bytes of the call.  Several threads
+ * may attach the same handle (the batch generator thread and the training thread of bench.py do).
+ * kws_profiler_collect() waits for the recorded events and returns the number of families, kws_profiler_get() reads one
+ * (summed device ms, launches, FLOPs, bytes).  No process-wide switch: a thread that never attaches never records. */
+typedef struct kws_profiler kws_profiler_t;
+int kws_profiler_create(kws_profiler_t** out);
+int kws_profiler_destroy(kws_profiler_t* p);
+int kws_profiler_attach(kws_profiler_t* p);
+int kws_profiler_collect(kws_profiler_t* p);
+int kws_profiler_get(kws_profiler_t* p, int idx, char* name, int cap, double* ms, int64_t* count, double* flops,
+                     double* bytes);
 
 /* ------------------------------------------------------------------------------------------
  * a2  augment graph: decode_wav -> multiply -> tf_roll -> multiply/add -> reshape
@@ -191,27 +197,9 @@ int kws_stft_num_frames(const kws_stft_plan_t* plan, int L);
 int kws_stft_mel_f32(const kws_stft_plan_t* plan, const float* x, int B, int L, float* out,
                      int out_kind, void* stream);
 
-/* EXPERIMENT (A/B arm, off by default): the pointwise GEMMs with every f32 operand split into three bf16 parts and six
- * bf16 MFMA products accumulated in f32 - as accurate as the f32 matrix pipe, not bit-identical to it (csrc/gemm_bf16x3.hip,
- * DESIGN.md section 5).  KWS_GEMM_BF16X3=1 at start, or kws_net_set_gemm_mode(1) at run time, makes the raw-waveform
- * net's training step take these kernels for its forward, input-gradient and weight-gradient GEMMs. */
-int kws_gemm_nn_bf16x3_stats_rows(int64_t M);   /* rows of stats_part: one per 128-row tile */
-int kws_net_get_gemm_mode(void);   /* 0 = f32 MFMA (default), 1 = the bf16 x 3 experiment (KWS_GEMM_BF16X3 at start),
-                                    * 2 = the fp16 x 2 experiment (KWS_GEMM_F16X2 at start) */
-int kws_net_set_gemm_mode(int mode);
-int kws_bf16x3_split_batch(const float* const* in, void* const* out, const int* rows, const int* cols,
-                           const int* transpose, int count, void* stream);
-int kws_gemm_nn_bf16x3p_f32(const float* A, const void* Bp, float* C, int64_t M, int K, int N,
-                            float* stats_part, void* stream);
-/* the weight gradient in the same arithmetic: dW[K,N] = Z[M,K]^T . G[M,N] (K, N multiples of 64); workspace of
- * kws_gemm_tn_bf16x3_workspace_floats(M, K, N) floats (partial slabs, summed in a fixed order) */
-int64_t kws_gemm_tn_bf16x3_workspace_floats(int64_t M, int K, int N);
-int kws_gemm_tn_bf16x3_f32(const float* Z, const float* G, float* dW, int64_t M, int K, int N, float* workspace,
-                           void* stream);
-
-/* EXPERIMENT 2 (A/B arm, off by default; csrc/gemm_f16x2.hip; KWS_GEMM_F16X2=1 or kws_net_set_gemm_mode(2)): the same
+/* A/B arm, off by default (csrc/gemm_f16x2.hip; selected per net handle by kws_net_set_gemm_mode(net, 2)): the pointwise
  * GEMMs with every f32 operand scaled by a power of two and split into TWO fp16 parts, three f16 MFMA products
- * accumulated in f32 - half the matrix instructions of the bf16 x 3 form at the same accuracy.  The scale of an operand
+ * accumulated in f32 - as accurate as the f32 matrix pipe, not bit-identical to it.  The scale of an operand
  * comes from its |x| maximum, kept on the device in a "slot group" of 256 words (atomicMax of the bit patterns, so it
  * is the same in every run): kws_absmax_batch_f32 fills groups for arbitrary tensors; inside the network the kernels
  * that produce a GEMM operand leave its maximum behind.  The largest magnitude lands in [2^14, 2^15) (fp16 overflows at
@@ -219,6 +207,11 @@ int kws_gemm_tn_bf16x3_f32(const float* Z, const float* G, float* dW, int64_t M,
 int kws_absmax_batch_f32(const float* const* in, const int64_t* n, unsigned* slots, int count, void* stream);
 int kws_f16x2_split_batch(const float* const* in, void* const* out, const int* rows, const int* cols,
                           const int* transpose, const unsigned* const* slots, int count, void* stream);
+/* shapes the arm's kernels take (K granule, 32-bit offsets inside a 2 GB buffer view); the network programs fall back
+ * to the f32 kernels for anything else.  stats rows of the NN kernel: one per 128-row tile. */
+int kws_gemm_nn_f16x2_supported(int64_t M, int K, int N);
+int kws_gemm_tn_f16x2_supported(int64_t M, int K, int N);
+int kws_gemm_nn_f16x2_stats_rows(int64_t M);
 int kws_gemm_nn_f16x2_f32(const float* A, const void* Bp, float* C, int64_t M, int K, int N,
                           const unsigned* a_slots, const unsigned* b_slots, float* stats_part, void* stream);
 int64_t kws_gemm_tn_f16x2_workspace_floats(int64_t M, int K, int N);
@@ -368,6 +361,10 @@ typedef struct {
 
 int kws_net_create(const kws_net_config_t* cfg, kws_net_t** net);
 int kws_net_destroy(kws_net_t* net);
+/* arithmetic of this handle's pointwise GEMMs: 0 = f32 MFMA (default, the product path), 2 = the fp16 x 2 A/B arm
+ * (raw-waveform attention net; other kinds ignore it).  State of the handle, not of the process. */
+int kws_net_get_gemm_mode(const kws_net_t* net);
+int kws_net_set_gemm_mode(kws_net_t* net, int mode);
 int64_t kws_net_num_params(const kws_net_t* net);
 int64_t kws_net_num_state(const kws_net_t* net);
 int kws_net_num_tensors(const kws_net_t* net);

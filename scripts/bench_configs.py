@@ -1,13 +1,15 @@
-"""Throughput of the other BASELINE.json configurations on one MI355X (informative lines for DESIGN.md; bench.py is
-the contract benchmark for configs[1]):
+"""The other single-GPU BASELINE.json configurations, measured on one MI355X (bench.py is the contract benchmark for
+configs[1] and calls these as its `configs` legs; `python scripts/bench_configs.py` prints them alone, and
+scripts/prof_c3.py / prof_c5.py are the rocprofv3 targets):
 
-  C3  configs[2]: 32-class conv_1d_log_mfcc net on 40 x 98 log-mel features, batch 2048: STFT/mel(40,40) of the
-      raw clips + forward/backward + RMSprop (6e-4), inputs resident in HBM;
-  C5  configs[4]: TTA inference (identity + 1.2x volume + 1500-sample roll, make_submission.py:125-135) of the
+  C3  configs[2]: 32-class conv_1d_log_mfcc net (model.py:1400-1479; the net freeze_graph_32_classes.py:55-69 freezes) on
+      40 x 98 log-mel features, batch 2048: STFT/mel(40,40) of the raw clips + forward/backward + RMSprop (6e-4),
+      inputs resident in HBM;
+  C5  configs[4] on one GPU: TTA inference (identity + 1.2x volume + 1500-sample roll, make_submission.py:120-146) of the
       12-class raw-waveform net, batches of 4096 clips; plain inference for comparison; and the six-term speed
       TTA with the slow clips stretched on the device.
 
-Prints one JSON line per configuration."""
+Every function returns a dict (one JSON object per configuration)."""
 import ctypes
 import json
 import os
@@ -17,13 +19,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 from speech_recognition_amd import _lib  # noqa: E402
-from speech_recognition_amd import _lib as _lib_arm  # noqa: E402
-GEMM_ARM = {0: "f32 MFMA (product default)", 1: "bf16 x 3 split (KWS_GEMM_BF16X3, experiment)",
-            2: "fp16 x 2 split (KWS_GEMM_F16X2, experiment)"}[_lib_arm.load().kws_net_get_gemm_mode()]
 from speech_recognition_amd.features import path_b_tables  # noqa: E402
 from speech_recognition_amd.keras_api import Model, RMSprop  # noqa: E402
 from speech_recognition_amd.net import DeviceNet  # noqa: E402
 from speech_recognition_amd.tta import predict_tta, time_stretch  # noqa: E402
+
+ARM = {0: "f32 MFMA (product default)", 2: "fp16 x 2 split (A/B arm)"}
 
 
 def timed(fn, warm, n):
@@ -45,7 +46,7 @@ def clips(B, seed):
     return (torch.randn((B, 16000), generator=g, device="cuda") * 0.0774).clamp_(-1, 1).contiguous()
 
 
-def c3():
+def c3(steps=30, warm=5, profile_steps=5):
     B = 2048
     lib = _lib.load()
     t = path_b_tables(480, 40, 40)
@@ -65,32 +66,48 @@ def c3():
         _lib.call("kws_stft_mel_f32", plan, _lib.ptr(x), B, 16000, _lib.ptr(feats), 0, _lib.stream_ptr())
         model._train_step_async(feats, y, row)
 
-    ms = timed(step, 5, 30)
-    print(json.dumps({"config": "C3: 32-class conv_1d_log_mfcc, log-mel 40x98 from raw clips, batch 2048, fwd+bwd+RMSprop",
-                      "ms_per_step": ms, "clips_per_s": B / ms * 1e3, "n_gpus": 1, "dtype": "f32", "gemm_arm": GEMM_ARM, "data": "synthetic"}))
+    ms = timed(step, warm, steps)
+    out = {"config": "C3 (configs[2]): 32-class conv_1d_log_mfcc, log-mel 40x98 from raw clips, batch 2048, "
+                     "STFT/mel + fwd + bwd + RMSprop",
+           "batch": B, "steps": steps, "ms_per_step": ms, "clips_per_s": B / ms * 1e3, "n_gpus": 1, "dtype": "f32",
+           "gemm_arm": ARM[net.gemm_mode], "data": "synthetic"}
+    if profile_steps > 0:        # per-family HIP-event times of the same step (the caller turns the largest into a roofline object)
+        prof = _lib.Profiler()
+        prof.attach()
+        for _ in range(profile_steps):
+            step()
+        torch.cuda.synchronize()
+        out["kernels"] = prof.collect()
+        prof.detach()
+        prof.close()
+    lib.kws_stft_plan_destroy(plan)
+    return out
 
 
-def c5():
+def c5(speed_tta=True, n=10, warm=3):
     B = 4096
     net = DeviceNet(_lib.KWS_NET_TS_ATTENTION, 12)
     net.initialize(seed=3)
     model = Model(net, RMSprop())
     x = clips(B, 2)
-    ms_plain = timed(lambda: net.predict(x), 3, 10)
-    ms_tta = timed(lambda: predict_tta(model, x), 3, 10)
-    print(json.dumps({"config": "C5: 12-class raw-waveform net, TTA inference x3 (identity, 1.2x, roll 1500), batch 4096",
-                      "ms_per_batch": ms_tta, "clips_per_s": B / ms_tta * 1e3, "plain_inference_clips_per_s": B / ms_plain * 1e3,
-                      "n_gpus": 1, "dtype": "f32", "gemm_arm": GEMM_ARM, "data": "synthetic"}))
-    # make_submission.py use_speed_tta: three more passes over the 0.9x time-stretched clips, stretched on the
-    # device inside the timed region (the reference reads them from the offline set of create_tta_set.py)
-    ms_tta6 = timed(lambda: predict_tta(model, x, use_speed_tta=True), 3, 10)
-    ms_stretch = timed(lambda: time_stretch(x, 0.9), 3, 10)
-    print(json.dumps({"config": "C5 + speed TTA: x6 (identity, 1.2x, roll 1500, slow, clip(1.1 slow), 0.9 slow), "
-                                "phase-vocoder stretch on the device, batch 4096",
-                      "ms_per_batch": ms_tta6, "clips_per_s": B / ms_tta6 * 1e3, "stretch_ms_per_batch": ms_stretch,
-                      "stretch_clips_per_s": B / ms_stretch * 1e3, "n_gpus": 1, "dtype": "f32", "gemm_arm": GEMM_ARM, "data": "synthetic"}))
+    ms_plain = timed(lambda: net.predict(x), warm, n)
+    ms_tta = timed(lambda: predict_tta(model, x), warm, n)
+    out = {"config": "C5 (configs[4] on one GPU): 12-class raw-waveform net, TTA inference x3 (identity, 1.2x, roll 1500), "
+                     "batch 4096",
+           "batch": B, "ms_per_batch": ms_tta, "clips_per_s": B / ms_tta * 1e3, "plain_inference_ms_per_batch": ms_plain,
+           "plain_inference_clips_per_s": B / ms_plain * 1e3, "n_gpus": 1, "dtype": "f32", "gemm_arm": ARM[net.gemm_mode],
+           "data": "synthetic"}
+    if speed_tta:
+        # make_submission.py use_speed_tta: three more passes over the 0.9x time-stretched clips, stretched on the
+        # device inside the timed region (the reference reads them from the offline set of create_tta_set.py)
+        ms_tta6 = timed(lambda: predict_tta(model, x, use_speed_tta=True), warm, n)
+        ms_stretch = timed(lambda: time_stretch(x, 0.9), warm, n)
+        out["speed_tta"] = {"what": "x6 (identity, 1.2x, roll 1500, slow, clip(1.1 slow), 0.9 slow), phase-vocoder stretch on "
+                                    "the device", "ms_per_batch": ms_tta6, "clips_per_s": B / ms_tta6 * 1e3,
+                            "stretch_ms_per_batch": ms_stretch, "stretch_clips_per_s": B / ms_stretch * 1e3}
+    return out
 
 
 if __name__ == "__main__":
-    c3()
-    c5()
+    print(json.dumps(c3()))
+    print(json.dumps(c5()))

@@ -1,5 +1,5 @@
-"""A/B measurement of the fp16 x 2 split GEMM (EXPERIMENT 2, csrc/gemm_f16x2.hip) against the f32-MFMA kernel and the
-bf16 x 3 form on the eleven pointwise-convolution shapes of the batch-1024 step (forward and weight-gradient forms)."""
+"""A/B measurement of the fp16 x 2 split GEMM (A/B arm, csrc/gemm_f16x2.hip) against the f32-MFMA kernel on the eleven
+pointwise-convolution shapes of the batch-1024 step (forward and weight-gradient forms)."""
 import ctypes, math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -22,34 +22,29 @@ def absmax_slots(*tensors):
     _lib.call("kws_absmax_batch_f32", PP(*[t.data_ptr() for t in tensors]), LL(*[t.numel() for t in tensors]), _lib.ptr(slots), n, S)
     return slots
 P, I = ctypes.c_void_p * 1, ctypes.c_int * 1
-t1s = t3s = t2s = fl = tw1s = tw3s = tw2s = 0.0
+t1s = t2s = fl = tw1s = tw2s = 0.0
 for L, K, N in shapes:
     M = B * L
     A = torch.randn(M, K, device='cuda'); W = torch.randn(K, N, device='cuda') * 0.1
     C = torch.empty(M, N, device='cuda'); C2 = torch.empty(M, N, device='cuda')
-    Wp3 = torch.empty((3, N, K), dtype=torch.bfloat16, device='cuda')
-    _lib.call("kws_bf16x3_split_batch", P(W.data_ptr()), P(Wp3.data_ptr()), I(K), I(N), I(1), 1, S)
     G = torch.randn(M, N, device='cuda') * 1e-6
     slots = absmax_slots(A, W, G)
     Wp2 = torch.empty((2, N, K), dtype=torch.float16, device='cuda')
     _lib.call("kws_f16x2_split_batch", P(W.data_ptr()), P(Wp2.data_ptr()), I(K), I(N), I(1), P(slots[1].data_ptr()), 1, S)
     t1 = timeit(lambda: _lib.call("kws_gemm_nn_f32", _lib.ptr(A), _lib.ptr(W), _lib.ptr(C), M, K, N, None, S))
-    t3 = timeit(lambda: _lib.call("kws_gemm_nn_bf16x3p_f32", _lib.ptr(A), _lib.ptr(Wp3), _lib.ptr(C), M, K, N, None, S))
     t2 = timeit(lambda: _lib.call("kws_gemm_nn_f16x2_f32", _lib.ptr(A), _lib.ptr(Wp2), _lib.ptr(C2), M, K, N, _lib.ptr(slots[0]), _lib.ptr(slots[1]), None, S))
     D = torch.empty(K, N, device='cuda')
     ws1 = torch.empty(lib.kws_gemm_tn_workspace_floats(M, K, N), device='cuda')
-    ws3 = torch.empty(lib.kws_gemm_tn_bf16x3_workspace_floats(M, K, N), device='cuda')
     ws2 = torch.empty(lib.kws_gemm_tn_f16x2_workspace_floats(M, K, N), device='cuda')
     tw1 = timeit(lambda: _lib.call("kws_gemm_tn_f32", _lib.ptr(A), _lib.ptr(G), _lib.ptr(D), M, K, N, _lib.ptr(ws1), S))
-    tw3 = timeit(lambda: _lib.call("kws_gemm_tn_bf16x3_f32", _lib.ptr(A), _lib.ptr(G), _lib.ptr(D), M, K, N, _lib.ptr(ws3), S))
     tw2 = timeit(lambda: _lib.call("kws_gemm_tn_f16x2_f32", _lib.ptr(A), _lib.ptr(G), _lib.ptr(D), M, K, N, _lib.ptr(slots[0]), _lib.ptr(slots[2]), _lib.ptr(ws2), S))
-    tw1s += tw1; tw3s += tw3; tw2s += tw2
+    tw1s += tw1; tw2s += tw2
     ref = (A[:4096].double() @ W.double())
-    e2 = float((C2[:4096].double() - ref).abs().max() / ref.abs().max()); e3 = float((C[:4096].double() - ref).abs().max() / ref.abs().max())
+    e2 = float((C2[:4096].double() - ref).abs().max() / ref.abs().max()); e1 = float((C[:4096].double() - ref).abs().max() / ref.abs().max())
     f = 2.0 * M * K * N
-    print("M=%7d K=%3d N=%3d  f32 MFMA %6.1f us %6.1f TF | bf16x3 %6.1f us x%.2f (err %.1e) | f16x2 %6.1f us %6.1f TF-eq x%.2f (err %.1e)" % (
-        M, K, N, t1 * 1e3, f / t1 / 1e9, t3 * 1e3, t1 / t3, e3, t2 * 1e3, f / t2 / 1e9, t1 / t2, e2) +
-        " || wgrad f32 %6.1f us | bf16x3 %6.1f us x%.2f | f16x2 %6.1f us x%.2f" % (tw1 * 1e3, tw3 * 1e3, tw1 / tw3, tw2 * 1e3, tw1 / tw2))
-    t1s += t1; t3s += t3; t2s += t2; fl += f
-print("total: f32 MFMA %.3f ms | bf16x3 %.3f ms x%.2f | f16x2 %.3f ms (%.1f TF-equivalent) x%.2f || wgrad f32 %.3f ms | bf16x3 %.3f ms x%.2f | f16x2 %.3f ms x%.2f" % (
-    t1s, t3s, t1s / t3s, t2s, fl / t2s / 1e9, t1s / t2s, tw1s, tw3s, tw1s / tw3s, tw2s, tw1s / tw2s))
+    print("M=%7d K=%3d N=%3d  f32 MFMA %6.1f us %6.1f TF (err %.1e) | f16x2 %6.1f us %6.1f TF-eq x%.2f (err %.1e)" % (
+        M, K, N, t1 * 1e3, f / t1 / 1e9, e1, t2 * 1e3, f / t2 / 1e9, t1 / t2, e2) +
+        " || wgrad f32 %6.1f us | f16x2 %6.1f us x%.2f" % (tw1 * 1e3, tw2 * 1e3, tw1 / tw2))
+    t1s += t1; t2s += t2; fl += f
+print("total: f32 MFMA %.3f ms | f16x2 %.3f ms (%.1f TF-equivalent) x%.2f || wgrad f32 %.3f ms | f16x2 %.3f ms x%.2f" % (
+    t1s, t2s, fl / t2s / 1e9, t1s / t2s, tw1s, tw2s, tw1s / tw2s))

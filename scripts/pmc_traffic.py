@@ -11,7 +11,6 @@ SOURCE_OF = {"gemm_nn_ws_kernel": "gemm.hip", "gemm_tn_ws_kernel": "gemm.hip", "
              "conv1_wgrad_kernel": "conv1.hip", "stft3_kernel": "stft2.hip", "stft2_kernel": "stft2.hip",
              "stft4_kernel": "stft4.hip", "augment_kernel": "augment.hip", "dwconv_fwd_kernel": "dwconv.hip",
              "dwconv_bwd_kernel": "dwconv.hip", "dwconv_bwd_bn_kernel": "dwconv.hip", "ts_tail_kernel": "tail.hip",
-             "gemm_nn_bf16x3p_kernel": "gemm_bf16x3.hip", "gemm_tn_bf16x3_kernel": "gemm_bf16x3.hip",
              "gemm_nn_f16x2_kernel": "gemm_f16x2.hip", "gemm_tn_f16x2_kernel": "gemm_f16x2.hip"}
 
 

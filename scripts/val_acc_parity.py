@@ -102,7 +102,8 @@ def run(device=None, epochs=10, steps=100, batch=64, val_batches=8, bank=4096, q
     dev_train_acc = [float(v) for v in hist.history['categorical_accuracy']]
     # the enqueuer thread may have pulled batches past the last step: the twin trains on the first epochs*steps only
     batches = train.batches[:epochs * steps]
-    vb = val.batches[:val_batches]          # validation walks the partition in order and wraps: every epoch sees these
+    # the validation generator keeps advancing from epoch to epoch (callbacks.py:63-66 calls next() validation_steps
+    # times per epoch): the twin scores, epoch by epoch, the very batches the device callback consumed
     twin = TorchTimeSlicedNet(numpy_net=ora, threads=cpu_threads or min(os.cpu_count() or 1, 16))
     twin.init_optimizer('rmsprop')
     cpu_acc, cpu_loss, cpu_train_acc = [], [], []
@@ -115,6 +116,8 @@ def run(device=None, epochs=10, steps=100, batch=64, val_batches=8, bank=4096, q
             _, a = twin.train_step(X, y, 1e-3, seed=model.seed, step=k)
             accs.append(a)
         cpu_train_acc.append(float(np.mean(accs)))
+        vb = val.batches[e * val_batches:(e + 1) * val_batches]
+        assert len(vb) == val_batches, "the device callback consumed fewer validation batches than expected"
         p = np.concatenate([twin.predict(X) for X, _ in vb])
         yt = np.concatenate([y for _, y in vb])
         cpu_acc.append(float((p.argmax(1) == yt.argmax(1)).mean()))
@@ -133,6 +136,9 @@ def run(device=None, epochs=10, steps=100, batch=64, val_batches=8, bank=4096, q
                               "ok_settled": abs(settled(dev_acc) - settled(cpu_acc)) <= TOL_VAL_ACC,
                               "epochs": epochs, "steps_per_epoch": steps, "batch": batch,
                               "validation_clips": val_batches * batch,
+                              "validation_rows_disjoint_from_training": not (
+                                  set(r for r, _ in spec['index']['validation']) &
+                                  set(r for r, _ in spec['index']['training'] + spec['index']['pseudo'])),
                               "device": {"val_acc": dev_acc, "val_loss": dev_loss, "train_acc": dev_train_acc,
                                          "seconds": t_dev},
                               "cpu": {"val_acc": cpu_acc, "val_loss": cpu_loss, "train_acc": cpu_train_acc,

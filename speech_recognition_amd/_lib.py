@@ -10,6 +10,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KWS_LIB_PATH") or os.path.join(_HERE, "libkws_hip.so")  # override: kernel A/B experiments
 
+ABI_VERSION = 2    # include/kws_hip.h: KWS_ABI_VERSION
+
 KWS_NET_TS_ATTENTION = 1
 KWS_NET_LOG_MFCC = 2
 KWS_NET_STEFFE = 3
@@ -68,10 +70,12 @@ SIGNATURES = {
     "kws_device_name": (_I, [ctypes.c_char_p, _I]),
     "kws_stream_create": (_I, [_I, ctypes.POINTER(_P)]),
     "kws_stream_destroy": (_I, [_P]),
-    "kws_profile_enable": (_I, [_I]),
-    "kws_profile_collect": (_I, []),
-    "kws_profile_get": (_I, [_I, ctypes.c_char_p, _I, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I64),
-                             ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
+    "kws_profiler_create": (_I, [ctypes.POINTER(_P)]),
+    "kws_profiler_destroy": (_I, [_P]),
+    "kws_profiler_attach": (_I, [_P]),
+    "kws_profiler_collect": (_I, [_P]),
+    "kws_profiler_get": (_I, [_P, _I, ctypes.c_char_p, _I, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I64),
+                              ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "kws_sampler_draw": (_I, [_P, ctypes.POINTER(_I), ctypes.POINTER(SamplerSet), ctypes.POINTER(SamplerSet),
                               ctypes.POINTER(SamplerArgs), _P, _P, _P, _P, _P, _P]),
     "kws_augment_f32": (_I, [_P, _I64, _I, _P, _P, _P, _P, _I64, _P, _P, _P, _I, _P]),
@@ -103,18 +107,16 @@ SIGNATURES = {
     "kws_gemm_nn_stats_rows": (_I, [_I64, _I, _I]),
     "kws_gemm_gather_stats_rows": (_I, [_I64]),
     "kws_gemm_nn_f32": (_I, [_P, _P, _P, _I64, _I, _I, _P, _P]),
-    "kws_gemm_nn_bf16x3_stats_rows": (_I, [_I64]),
-    "kws_net_get_gemm_mode": (_I, []),
-    "kws_net_set_gemm_mode": (_I, [_I]),
-    "kws_bf16x3_split_batch": (_I, [_P, _P, _P, _P, _P, _I, _P]),
-    "kws_gemm_nn_bf16x3p_f32": (_I, [_P, _P, _P, _I64, _I, _I, _P, _P]),
+    "kws_net_get_gemm_mode": (_I, [_P]),
+    "kws_net_set_gemm_mode": (_I, [_P, _I]),
+    "kws_gemm_nn_f16x2_supported": (_I, [_I64, _I, _I]),
+    "kws_gemm_tn_f16x2_supported": (_I, [_I64, _I, _I]),
+    "kws_gemm_nn_f16x2_stats_rows": (_I, [_I64]),
     "kws_absmax_batch_f32": (_I, [_P, _P, _P, _I, _P]),
     "kws_f16x2_split_batch": (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),
     "kws_gemm_nn_f16x2_f32": (_I, [_P, _P, _P, _I64, _I, _I, _P, _P, _P, _P]),
     "kws_gemm_tn_f16x2_workspace_floats": (_I64, [_I64, _I, _I]),
     "kws_gemm_tn_f16x2_f32": (_I, [_P, _P, _P, _I64, _I, _I, _P, _P, _P, _P]),
-    "kws_gemm_tn_bf16x3_workspace_floats": (_I64, [_I64, _I, _I]),
-    "kws_gemm_tn_bf16x3_f32": (_I, [_P, _P, _P, _I64, _I, _I, _P, _P]),
     "kws_gemm_gather_f32": (_I, [_P, ctypes.POINTER(GatherDesc), _P, _P, _I, _I, _P, _P]),
     "kws_gemm_tn_workspace_floats": (_I64, [_I64, _I, _I]),
     "kws_gemm_tn_f32": (_I, [_P, _P, _P, _I64, _I, _I, _P, _P]),
@@ -162,12 +164,14 @@ def load():
                        "`python -c 'import __graft_entry__ as g; g.build()'` "
                        "(there is no CPU fallback)" % LIB_PATH)
     lib = ctypes.CDLL(LIB_PATH)
+    lib.kws_abi_version.restype = _I
+    if lib.kws_abi_version() != ABI_VERSION:      # before any other symbol is bound: a stale library says so itself
+        raise KwsError("%s has ABI version %d, this package expects %d - rebuild it (__graft_entry__.build())" %
+                       (LIB_PATH, lib.kws_abi_version(), ABI_VERSION))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
         fn.restype = res
         fn.argtypes = args
-    if lib.kws_abi_version() != 1:
-        raise KwsError("libkws_hip.so ABI version %d, expected 1" % lib.kws_abi_version())
     _lib = lib
     return lib
 
@@ -192,28 +196,75 @@ def stream_ptr(stream=None):
     return ctypes.c_void_p(s.cuda_stream)
 
 
-def make_stream(device, cls):
-    """torch stream object around a HIP stream of scheduling class `cls` (-1 low, 0 normal, +1 high)."""
-    import torch
-    with torch.cuda.device(device):
+class OwnedStream(object):
+    """A HIP stream of scheduling class `cls` (-1 low, 0 normal, +1 high) created by kws_stream_create, viewed by torch as
+    an ExternalStream (which does not own the handle) and destroyed by close() / the finaliser after a synchronise."""
+
+    def __init__(self, device, cls):
+        import torch
+        self.device = device
+        with torch.cuda.device(device):
+            h = ctypes.c_void_p()
+            check(load().kws_stream_create(int(cls), ctypes.byref(h)), "kws_stream_create")
+            self.handle = h.value
+            self.stream = torch.cuda.ExternalStream(h.value, device=device)
+
+    def close(self):
+        h, self.handle = self.handle, None
+        if h and _lib is not None:
+            import torch
+            try:
+                with torch.cuda.device(self.device):
+                    self.stream.synchronize()
+                    _lib.kws_stream_destroy(ctypes.c_void_p(h))
+            except Exception:      # interpreter shutdown: the runtime may be gone already
+                pass
+        self.stream = None
+
+    def __del__(self):
+        self.close()
+
+
+class Profiler(object):
+    """Per-kernel-family HIP-event profiler (kws_profiler_*): a handle that threads attach to.  attach() makes the CALLING
+    thread's launches record into it, detach() stops that; collect() -> {family: {"ms", "count", "flops", "bytes"}} of
+    everything recorded since the last collect()."""
+
+    def __init__(self):
         h = ctypes.c_void_p()
-        check(load().kws_stream_create(int(cls), ctypes.byref(h)), "kws_stream_create")
-        return torch.cuda.ExternalStream(h.value, device=device)
+        check(load().kws_profiler_create(ctypes.byref(h)), "kws_profiler_create")
+        self.handle = h
 
+    def attach(self):
+        check(load().kws_profiler_attach(self.handle), "kws_profiler_attach")
 
-def profile_collect():
-    """{family: {"ms", "count", "flops", "bytes"}} for everything launched since kws_profile_enable(1)."""
-    lib = load()
-    out = {}
-    n = lib.kws_profile_collect()
-    for i in range(n):
-        name = ctypes.create_string_buffer(64)
-        ms, fl, by = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
-        cnt = ctypes.c_int64()
-        check(lib.kws_profile_get(i, name, 64, ctypes.byref(ms), ctypes.byref(cnt), ctypes.byref(fl),
-                                  ctypes.byref(by)), "kws_profile_get")
-        out[name.value.decode()] = {"ms": ms.value, "count": cnt.value, "flops": fl.value, "bytes": by.value}
-    return out
+    @staticmethod
+    def detach():
+        check(load().kws_profiler_attach(None), "kws_profiler_attach")
+
+    def collect(self):
+        lib = load()
+        out = {}
+        n = lib.kws_profiler_collect(self.handle)
+        for i in range(n):
+            name = ctypes.create_string_buffer(64)
+            ms, fl, by = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+            cnt = ctypes.c_int64()
+            check(lib.kws_profiler_get(self.handle, i, name, 64, ctypes.byref(ms), ctypes.byref(cnt), ctypes.byref(fl),
+                                       ctypes.byref(by)), "kws_profiler_get")
+            out[name.value.decode()] = {"ms": ms.value, "count": cnt.value, "flops": fl.value, "bytes": by.value}
+        return out
+
+    def close(self):
+        h, self.handle = self.handle, None
+        if h is not None and _lib is not None:
+            _lib.kws_profiler_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def call(name, *args):

@@ -40,11 +40,17 @@ class ConfusionMatrixCallback(Callback):
         self.all_words = all_words
         self.label2int = label2int
         self.int2label = {v: k for k, v in label2int.items()}
-        self._writes = parallel.rank() == 0      # data-parallel: rank 0 owns the two text files
         for fn in ('confusion_matrix.txt', 'wanted_confusion_matrix.txt'):
-            if self._writes:
+            if self._writes():
                 with open(fn, 'w'):
                     pass
+
+    @staticmethod
+    def _writes():
+        """Data-parallel: rank 0 owns the two text files.  Asked at every use, not once at construction: a callback built
+        before the process group exists (train.py builds its callbacks before fit_generator) must still see its rank -
+        the launcher's RANK variable answers until torch.distributed does."""
+        return (parallel.rank() if parallel.active() else parallel.env_world()[1]) == 0
 
     @staticmethod
     def accuracies(confusion_val):
@@ -76,7 +82,7 @@ class ConfusionMatrixCallback(Callback):
         wanted_accs = self.accuracies(wconf)
         acc_line = "\n[%03d]: val_categorical_accuracy: %.2f, val_mean_categorical_accuracy_wanted: %.2f" % (
             epoch, acc, wanted_accs.mean())
-        if self._writes:
+        if self._writes():
             with open('confusion_matrix.txt', 'a') as f:
                 f.write('%s\n' % acc_line)
                 f.write(_format(labels, conf))

@@ -105,10 +105,10 @@ __device__ static inline bool kws_keep(uint32_t idx, uint32_t key, uint32_t thre
 
 __device__ static inline float relu6f(float v) { return fminf(fmaxf(v, 0.0f), 6.0f); }
 
-// ---- optional per-kernel-family profiler (off by default; bench.py turns it on for a few steps) ----
-// When enabled, every launcher brackets its launch with a hipEvent pair on the launch stream and books
-// the algorithmic FLOPs / bytes it was asked to process; kws_profile_get() then reports, per family,
-// the summed device time between the events.  This is the "HIP events on the stream the kernel is
+// ---- optional per-kernel-family profiler (a handle the calling thread attaches: kws_profiler_attach) ----
+// While a profiler is attached to the calling thread, every launcher brackets its launch with a hipEvent pair
+// on the launch stream and books the algorithmic FLOPs / bytes it was asked to process; kws_profiler_get()
+// then reports, per family, the summed device time between the events.  This is the "HIP events on the stream the kernel is
 // launched on" measurement of the roofline numbers.
 bool kws_prof_on();
 void* kws_prof_begin(hipStream_t st);

@@ -343,8 +343,8 @@ int kws_conv1_stats_rows(int64_t M) {
 }
 
 bool kws_conv1_supported(const kws_gather_t* g, int N) {
-  static const bool off = getenv("KWS_CONV1_GENERIC") != nullptr;   // A/B: the generic gathered GEMMs of gemm.hip
-  return !off && g && g->taps == 1 && g->cin == 80 && N == NOUT && g->stride_t % 2 == 0 && g->base_off % 2 == 0 &&
+  // anything else (filter_mult = 2: 256 output channels) takes the generic gathered GEMMs of gemm.hip
+  return g && g->taps == 1 && g->cin == 80 && N == NOUT && g->stride_t % 2 == 0 && g->base_off % 2 == 0 &&
          g->x_batch_stride % 2 == 0 && g->L_out > 0;
 }
 

@@ -88,22 +88,25 @@ struct ProfAgg {
   double ms = 0, flops = 0, bytes = 0;
   long long count = 0;
 };
-std::mutex g_prof_mu;
-bool g_prof_enabled = false;
-std::vector<ProfRec*> g_prof_recs;
-std::vector<std::pair<std::string, ProfAgg>> g_prof_out;
-
-void prof_clear_locked() {
-  for (ProfRec* r : g_prof_recs) {
-    (void)hipEventDestroy(r->a);
-    (void)hipEventDestroy(r->b);
-    delete r;
-  }
-  g_prof_recs.clear();
-}
 }  // namespace
+// A profiler is a handle (include/kws_hip.h); the calling thread's attachment is the only state outside it.
+struct kws_profiler {
+  std::mutex mu;
+  std::vector<ProfRec*> recs;
+  std::vector<std::pair<std::string, ProfAgg>> out;
+  void clear_locked() {
+    for (ProfRec* r : recs) {
+      (void)hipEventDestroy(r->a);
+      (void)hipEventDestroy(r->b);
+      delete r;
+    }
+    recs.clear();
+  }
+};
+static thread_local kws_profiler* t_prof = nullptr;
+static std::mutex g_roctx_mu;
 
-bool kws_prof_on() { return g_prof_enabled; }
+bool kws_prof_on() { return t_prof != nullptr; }
 
 // ---- roctx ranges (KWS_ROCTX=1) -----------------------------------------------------------------------------
 #include <dlfcn.h>
@@ -116,7 +119,7 @@ int g_roctx_state = -1;   // -1 unknown, 0 off, 1 on
 
 bool kws_roctx_on() {
   if (g_roctx_state < 0) {
-    std::lock_guard<std::mutex> lk(g_prof_mu);
+    std::lock_guard<std::mutex> lk(g_roctx_mu);
     if (g_roctx_state < 0) {
       int st = 0;
       const char* e = getenv("KWS_ROCTX");
@@ -157,28 +160,52 @@ void kws_prof_end(void* token, const char* name, double flops, double bytes, hip
   r->name = name;
   r->flops = flops;
   r->bytes = bytes;
-  std::lock_guard<std::mutex> lk(g_prof_mu);
-  g_prof_recs.push_back(r);
+  kws_profiler* p = t_prof;
+  if (!p) {                       // detached between begin and end: drop the record
+    (void)hipEventDestroy(r->a);
+    (void)hipEventDestroy(r->b);
+    delete r;
+    return;
+  }
+  std::lock_guard<std::mutex> lk(p->mu);
+  p->recs.push_back(r);
 }
 
 extern "C" {
 
-int kws_profile_enable(int on) {
-  std::lock_guard<std::mutex> lk(g_prof_mu);
-  if (on) {
-    prof_clear_locked();
-    g_prof_out.clear();
+int kws_profiler_create(kws_profiler_t** out) {
+  if (!out) {
+    kws_set_error("profiler_create: NULL output");
+    return KWS_E_INVALID;
   }
-  g_prof_enabled = on != 0;
+  *out = new kws_profiler();
   return KWS_OK;
 }
 
-// Waits for every recorded event, aggregates per family; returns the number of families.
-int kws_profile_collect(void) {
-  std::lock_guard<std::mutex> lk(g_prof_mu);
+int kws_profiler_destroy(kws_profiler_t* p) {
+  if (!p) return KWS_OK;
+  if (t_prof == p) t_prof = nullptr;     // other threads must have detached before the handle is destroyed
+  {
+    std::lock_guard<std::mutex> lk(p->mu);
+    p->clear_locked();
+  }
+  delete p;
+  return KWS_OK;
+}
+
+// the CALLING THREAD records into p from now on (NULL: stops recording)
+int kws_profiler_attach(kws_profiler_t* p) {
+  t_prof = p;
+  return KWS_OK;
+}
+
+// Waits for every recorded event, aggregates per family, clears the records; returns the number of families.
+int kws_profiler_collect(kws_profiler_t* p) {
+  if (!p) return 0;
+  std::lock_guard<std::mutex> lk(p->mu);
   std::map<std::string, ProfAgg> agg;
   std::vector<std::string> order;
-  for (ProfRec* r : g_prof_recs) {
+  for (ProfRec* r : p->recs) {
     float ms = 0.f;
     if (hipEventSynchronize(r->b) != hipSuccess || hipEventElapsedTime(&ms, r->a, r->b) != hipSuccess) continue;
     if (!agg.count(r->name)) order.push_back(r->name);
@@ -188,20 +215,25 @@ int kws_profile_collect(void) {
     a.bytes += r->bytes;
     a.count += 1;
   }
-  prof_clear_locked();
-  g_prof_out.clear();
-  for (const std::string& n : order) g_prof_out.push_back({n, agg[n]});
-  return (int)g_prof_out.size();
+  p->clear_locked();
+  p->out.clear();
+  for (const std::string& n : order) p->out.push_back({n, agg[n]});
+  return (int)p->out.size();
 }
 
-int kws_profile_get(int idx, char* name, int cap, double* ms, int64_t* count, double* flops, double* bytes) {
-  std::lock_guard<std::mutex> lk(g_prof_mu);
-  if (idx < 0 || idx >= (int)g_prof_out.size() || !name || cap <= 0) {
-    kws_set_error("profile_get: bad index %d", idx);
+int kws_profiler_get(kws_profiler_t* p, int idx, char* name, int cap, double* ms, int64_t* count, double* flops,
+                     double* bytes) {
+  if (!p || !name || cap <= 0) {
+    kws_set_error("profiler_get: bad arguments");
     return KWS_E_INVALID;
   }
-  snprintf(name, cap, "%s", g_prof_out[idx].first.c_str());
-  const ProfAgg& a = g_prof_out[idx].second;
+  std::lock_guard<std::mutex> lk(p->mu);
+  if (idx < 0 || idx >= (int)p->out.size()) {
+    kws_set_error("profiler_get: bad index %d", idx);
+    return KWS_E_INVALID;
+  }
+  snprintf(name, cap, "%s", p->out[idx].first.c_str());
+  const ProfAgg& a = p->out[idx].second;
   if (ms) *ms = a.ms;
   if (count) *count = a.count;
   if (flops) *flops = a.flops;

@@ -1266,10 +1266,7 @@ struct TNPlan {
   int64_t chunk;
 };
 // ws: the wave-specialised kernel (tile width chosen per dimension); otherwise the 4-wave kernel (square tiles)
-bool tn_ws_eligible(int K, int N, bool gather) {
-  static const bool no_ws = getenv("KWS_GEMM_TN_V1") != nullptr;   // 4-wave kernel, A/B only
-  return !gather && !no_ws && K % 64 == 0 && N % 64 == 0;
-}
+bool tn_ws_eligible(int K, int N, bool gather) { return !gather && K % 64 == 0 && N % 64 == 0; }
 TNPlan tn_plan(int64_t M, int K, int N, bool ws) {
   TNPlan pl;
   if (ws) {
@@ -1289,8 +1286,7 @@ TNPlan tn_plan(int64_t M, int K, int N, bool ws) {
   } else {
     S = ceil_div64(768, tiles);         // 4-wave kernel: ~3 workgroups per CU in flight
   }
-  static const int max_s = getenv("KWS_GEMM_TN_MAXS") ? atoi(getenv("KWS_GEMM_TN_MAXS")) : 256;   // A/B knob
-  if (S > max_s) S = max_s;             // bounds the partial-slab traffic (S * K * N floats)
+  if (S > 256) S = 256;                 // bounds the partial-slab traffic (S * K * N floats); 512 measured slower
   const int64_t maxS = M / 256 > 1 ? M / 256 : 1;
   if (S > maxS) S = maxS;
   if (S < 1) S = 1;
@@ -1309,12 +1305,8 @@ struct NNPlan {
   int wgs;          // its grid (= statistics rows: one per workgroup)
   int m_tiles;      // statistics rows of the tile-per-row kernels
 };
-bool nn_half_tail() {
-  static const bool off = getenv("KWS_GEMM_NO_HALF") != nullptr;   // A/B: whole tiles in the last round too
-  return !off;
-}
+constexpr bool nn_half_tail() { return true; }   // a short last round is walked in 64-row half tiles
 NNPlan nn_plan(int64_t M, int K, int N, bool gather) {
-  static const bool use_persist = getenv("KWS_GEMM_PERSIST") != nullptr;  // 4-wave persistent kernel, A/B only
   NNPlan pl;
   pl.m_tiles = (int)ceil_div64(M, 128);
   int BN = (N % 128 == 0) ? 128 : 64;
@@ -1337,10 +1329,9 @@ NNPlan nn_plan(int64_t M, int K, int N, bool gather) {
   // wave-specialised kernel (default): needs whole K-slabs and column tiles, and 32-bit byte offsets
   // inside one tile's buffer views (128 rows of A / C, all of W); everything else (the gathered first
   // convolution, ragged K or N) takes the persistent kernel
-  pl.ws = !gather && !use_persist && K % pl.kb == 0 && K >= 2 * pl.kb && N % BN == 0 && N <= KWS_WS_MAX_N &&
+  pl.ws = !gather && K % pl.kb == 0 && K >= 2 * pl.kb && N % BN == 0 && N <= KWS_WS_MAX_N &&
           (int64_t)K * N * 4 < (1ll << 31) && 128ll * K * 4 < (1ll << 31) && 128ll * N * 4 < (1ll << 31);
   int per_xcd = (int)(slots < 32 ? slots : 32);    // one 8-wave workgroup per CU (153 KB LDS), 32 CUs per XCD
-  if (const char* e = getenv("KWS_GEMM_WGS_PER_XCD")) per_xcd = atoi(e) > 0 && atoi(e) < slots ? atoi(e) : per_xcd;
   pl.wgs = per_xcd * NXCD;
   return pl;
 }
@@ -1381,8 +1372,7 @@ int launch_nn(const NNArgs& a0, hipStream_t st) {
   {
     // persistent: 2 workgroups per CU (69.6 KB LDS each), 32 CUs per XCD
     int per_xcd = (int)(slots < 64 ? slots : 64);
-    if (const char* e = getenv("KWS_GEMM_WGS_PER_XCD")) per_xcd = atoi(e) > 0 && atoi(e) < slots ? atoi(e) : per_xcd;
-    dim3 gp((unsigned)(per_xcd * NXCD)), bp(256);
+      dim3 gp((unsigned)(per_xcd * NXCD)), bp(256);
     if (wide) {
       if (stats) hipLaunchKernelGGL((gemm_nn_persist_kernel<128, 128, 2, 2, GATHER, true>), gp, bp, 0, st, a);
       else hipLaunchKernelGGL((gemm_nn_persist_kernel<128, 128, 2, 2, GATHER, false>), gp, bp, 0, st, a);

@@ -1,8 +1,8 @@
-// EXPERIMENT 2 (A/B arm, off by default: KWS_GEMM_F16X2=1 / kws_net_set_gemm_mode(2)): the pointwise GEMMs with every f32
+// A/B arm, off by default (kws_net_set_gemm_mode(net, 2); bench.py's ab_gemm_f16x2 leg): the pointwise GEMMs with every f32
 // operand scaled by a power of two and split into TWO fp16 parts (x s = h1 + h2: 22 - 24 significand bits, the residual
 // is exact in f32) and THREE f16 MFMA products accumulated in f32 (h2.h1, h1.h2, h1.h1; h2.h2 is below the f32 rounding
-// of the sum): half the matrix instructions of the bf16 x 3 form (gemm_bf16x3.hip) at the same accuracy - closer to
-// float64 than the f32 matrix pipe on every case of tests/test_f16x2_gpu.py.
+// of the sum) - closer to float64 than the f32 matrix pipe on every case of tests/test_f16x2_gpu.py.  (Round 2 also carried a
+// bf16 x 3 form - three parts, six products: same accuracy, power-limited at 1.4 - 1.5 GHz, slower on every layer; removed.)
 // The scale of an operand comes from its |x| maximum (common.h: kws_absmax_commit / kws_absmax_scale): the largest
 // magnitude lands in [2^14, 2^15), below fp16's 65504; h1 stays normal for elements down to 2^-28 of the maximum, h2 down
 // to 2^-16 of it.  The maxima stay on the device: the kernels that produce an operand (dwconv.hip, bn.hip, absmax_kernel
@@ -13,7 +13,8 @@
 //   kws_f16x2_split_batch    f32 matrices -> scaled fp16 planes [2][rows][cols] (the pointwise kernels, once per step)
 //   kws_gemm_nn_f16x2_f32    C[M,N] = A[M,K] . B, B as planes of [N][K]  (+ BatchNorm column sums per 128-row tile)
 //   kws_gemm_tn_f16x2_f32    dW[K,N] = Z[M,K]^T . G[M,N]
-// Slab image, swizzle and tiling are those of gemm_bf16x3.hip with two planes; DESIGN.md section 5 has the measurements.
+// 256 threads = 2 x 2 waves, 32-deep slabs, an unpadded [plane][row][32] fp16 LDS image whose 16-byte chunks are XOR-swizzled
+// with (row >> 2) & 3, three workgroups per CU, XCD-contiguous tiles; DESIGN.md section 5 has the measurements.
 #include "internal.h"
 #include <algorithm>
 #include <cstring>
@@ -490,13 +491,23 @@ extern "C" int kws_f16x2_split_batch(const float* const* in, void* const* out, c
   return KWS_OK;
 }
 
+// shapes the arm's kernels take; the network programs run the f32 kernels for the rest (K granule of the two-slab pipeline,
+// 32-bit byte offsets inside one buffer view: a per-GPU batch of ~8 k clips at block 0 is past it)
+extern "C" int kws_gemm_nn_f16x2_supported(int64_t M, int K, int N) {
+  return M > 0 && K >= 2 * XBK && K % (2 * XBK) == 0 && N > 0 && N % 4 == 0 && (M + XBM) * (int64_t)K * 4 < (1ll << 31) &&
+         (int64_t)(N + XBN) * K * 4 < (1ll << 31);
+}
+extern "C" int kws_gemm_tn_f16x2_supported(int64_t M, int K, int N) {
+  return M > 0 && K > 0 && N > 0 && K % 64 == 0 && N % 64 == 0 && M * (int64_t)std::max(K, N) * 4 < (1ll << 31);
+}
+extern "C" int kws_gemm_nn_f16x2_stats_rows(int64_t M) { return (int)ceil_div64(M, XBM); }   // one per 128-row tile
+
 // C[M,N] = A[M,K] . B with B given as the fp16 planes of (scaled) B stored [N][K]; a_slots / b_slots: the |A| and |B|
 // maxima (kws_absmax_batch_f32, or the network's producing kernels)
 extern "C" int kws_gemm_nn_f16x2_f32(const float* A, const void* Bp, float* C, int64_t M, int K, int N,
                                      const unsigned* a_slots, const unsigned* b_slots, float* stats_part, void* stream) {
   KWS_REQUIRE(A && Bp && C && a_slots && b_slots && M > 0, "gemm_nn_f16x2: bad arguments");
-  KWS_REQUIRE(K >= 2 * XBK && K % (2 * XBK) == 0 && N > 0 && N % 4 == 0, "gemm_nn_f16x2: K=%d must be a multiple of %d, N=%d of 4", K, 2 * XBK, N);
-  KWS_REQUIRE((M + XBM) * (int64_t)K * 4 < (1ll << 31) && (int64_t)(N + XBN) * K * 4 < (1ll << 31), "gemm_nn_f16x2: operand exceeds the 2 GB buffer view (M=%lld K=%d N=%d)", (long long)M, K, N);
+  KWS_REQUIRE(kws_gemm_nn_f16x2_supported(M, K, N), "gemm_nn_f16x2: unsupported shape M=%lld K=%d N=%d (K a multiple of %d, N of 4, operands within the 2 GB buffer view: kws_gemm_nn_f16x2_supported)", (long long)M, K, N, 2 * XBK);
   H2Args p;
   p.A = A; p.Bp = (const _Float16*)Bp; p.C = C; p.stats = stats_part; p.M = M; p.K = K; p.N = N;
   p.a_slots = a_slots; p.b_slots = b_slots;
@@ -542,8 +553,7 @@ extern "C" int64_t kws_gemm_tn_f16x2_workspace_floats(int64_t M, int K, int N) {
 extern "C" int kws_gemm_tn_f16x2_f32(const float* Z, const float* G, float* dW, int64_t M, int K, int N,
                                      const unsigned* z_slots, const unsigned* g_slots, float* workspace, void* stream) {
   KWS_REQUIRE(Z && G && dW && z_slots && g_slots && workspace && M > 0, "gemm_tn_f16x2: bad arguments");
-  KWS_REQUIRE(K > 0 && N > 0 && K % 64 == 0 && N % 64 == 0, "gemm_tn_f16x2: K=%d N=%d must be multiples of 64", K, N);
-  KWS_REQUIRE(M * (int64_t)std::max(K, N) * 4 < (1ll << 31), "gemm_tn_f16x2: operand of %lld rows exceeds the 2 GB buffer view", (long long)M);
+  KWS_REQUIRE(kws_gemm_tn_f16x2_supported(M, K, N), "gemm_tn_f16x2: unsupported shape M=%lld K=%d N=%d (K, N multiples of 64, operands within the 2 GB buffer view: kws_gemm_tn_f16x2_supported)", (long long)M, K, N);
   const U2Plan pl = u2_plan(M, K, N);
   U2Args p;
   p.Z = Z; p.G = G; p.ws = workspace; p.z_slots = z_slots; p.g_slots = g_slots; p.M = M; p.chunk = pl.chunk; p.K = K; p.N = N;

@@ -43,7 +43,7 @@ constexpr int KWS_TRANSPOSE_BATCH = 16;
 extern "C" int kws_transpose_batch_f32(const float* const* in, float* const* out, const int* rows, const int* cols, int n,
                                        hipStream_t stream);
 
-// ---- STFT plan (device tables), shared by stft.hip (v1, generic) and stft2.hip (v2, features) ------
+// ---- STFT plan (device tables), shared by stft.hip (generic kernel, plan) and stft4.hip (feature kernel) ------
 struct kws_stft_plan {
   int frame_len, frame_step, fft_len, n_bins, n_mel, n_out;
   float log_offset, log_floor;
@@ -56,7 +56,6 @@ struct kws_stft_plan {
   int* band_ofs;      // [n_mel]
   float* band_w;      // [n_w]
   float* dct;         // [n_mel * n_out]
-  float2* tw16;       // [16][16] W256^(n2*k1)
   float* dct64;       // [n_mel][64] zero padded
   // stft4 (first radix-16 pass on the matrix pipe): per-lane constants, columns in the order KPERM = 0..7, 9..15, 8
   float* b4;          // [64 lanes][8 k-chunks][2 column tiles] 0.5 * DFT16 entries of the MFMA B operand
@@ -71,9 +70,6 @@ struct kws_stft_plan {
   float* mel_wpad;    // [n_mel][mel_maxw]
   float* img4;        // stft4: the constant part of a workgroup's LDS as one image (kws_stft4_prepare), or NULL
 };
-int kws_stft2_launch(const kws_stft_plan* pl, const float* x, int B, int L, int F, float* out, hipStream_t st);
-int kws_stft3_lds_bytes(const kws_stft_plan* pl);
-int kws_stft3_launch(const kws_stft_plan* pl, const float* x, int B, int L, int F, float* out, hipStream_t st);
 int kws_stft4_prepare(kws_stft_plan* pl);
 int kws_stft4_lds_bytes(const kws_stft_plan* pl);
 int kws_stft4_launch(const kws_stft_plan* pl, const float* x, int B, int L, int F, float* out, hipStream_t st);

@@ -175,9 +175,8 @@ struct Layout {
   std::vector<int64_t> z;   // z[i], i = 0..10
   int64_t G = 0, G2 = 0, DZ = 0, bn = 0, part = 0, coef = 0, tn = 0, red = 0, swg = 0;
   std::vector<int64_t> WT;  // transposed pointwise kernel of block i (dgrad GEMM operand)
-  std::vector<int64_t> WPf, WPd;  // KWS_GEMM_BF16X3: bf16 planes [3][cout][cin] (forward) / [3][cin][cout] (input gradient);
-                                  // KWS_GEMM_F16X2: fp16 planes [2][..][..] in the same places
-  int64_t amax;                   // KWS_GEMM_F16X2: 3 nb slot groups of |x| maxima: W[i] | z[i] | dy[i + 1]
+  std::vector<int64_t> WPf, WPd;  // fp16 x 2 arm: fp16 planes [2][cout][cin] (forward) / [2][cin][cout] (input gradient)
+  int64_t amax;                   // fp16 x 2 arm: 3 nb slot groups of |x| maxima: W[i] | z[i] | dy[i + 1]
   int64_t xd = 0, fd = 0, dl1 = 0, dl2 = 0, per_loss = 0, per_correct = 0, att = 0;
   int64_t w1f = 0, g1f = 0;  // folded first-convolution kernel and its gradient [K1f, C1]
   int64_t bn_stride = 0;
@@ -203,9 +202,8 @@ void make_layout(const kws_net* n, int B, bool training, Layout* lo) {
     if (p > max_part) max_part = p;
     const int64_t dp = kws_dwconv_bwd_part_floats(B, b.Lin, b.cin);
     if (dp > max_dwpart) max_dwpart = dp;
-    const int64_t t = std::max(std::max(kws_gemm_tn_workspace_floats(M, b.cin, b.cout),
-                                        kws_gemm_tn_bf16x3_workspace_floats(M, b.cin, b.cout)),
-                               kws_gemm_tn_f16x2_workspace_floats(M, b.cin, b.cout));    // any arithmetic (run-time switch)
+    const int64_t t = std::max(kws_gemm_tn_workspace_floats(M, b.cin, b.cout),
+                               kws_gemm_tn_f16x2_workspace_floats(M, b.cin, b.cout));    // either arithmetic (run-time switch)
     if (t > max_tn) max_tn = t;
     if (b.cout > maxC) maxC = b.cout;
   }
@@ -229,9 +227,9 @@ void make_layout(const kws_net* n, int B, bool training, Layout* lo) {
     for (int i = 0; i < nb; ++i) lo->WT[i] = bp.take((int64_t)n->blocks[i].cin * n->blocks[i].cout);
     lo->WPf.assign(nb, 0);
     lo->WPd.assign(nb, 0);
-    for (int i = 0; i < nb; ++i) {                  // 3 bf16 per weight = 1.5 floats; taken in every mode (1.2 M weights in all)
-      lo->WPf[i] = bp.take(((int64_t)n->blocks[i].cin * n->blocks[i].cout * 3 + 1) / 2);
-      lo->WPd[i] = bp.take(((int64_t)n->blocks[i].cin * n->blocks[i].cout * 3 + 1) / 2);
+    for (int i = 0; i < nb; ++i) {                  // 2 fp16 per weight = 1 float; taken in every mode (1.2 M weights in all)
+      lo->WPf[i] = bp.take((int64_t)n->blocks[i].cin * n->blocks[i].cout);
+      lo->WPd[i] = bp.take((int64_t)n->blocks[i].cin * n->blocks[i].cout);
     }
     lo->amax = bp.take((int64_t)3 * nb * KWS_ABSMAX_WORDS);
     lo->tn = bp.take(max_tn);
@@ -253,7 +251,7 @@ void make_layout(const kws_net* n, int B, bool training, Layout* lo) {
     }
     lo->part = bp.take(64);
     lo->WPf.assign(nb, 0);                          // the split-GEMM arms in inference: forward planes and |x| maxima (W | z)
-    for (int i = 0; i < nb; ++i) lo->WPf[i] = bp.take(((int64_t)n->blocks[i].cin * n->blocks[i].cout * 3 + 1) / 2);
+    for (int i = 0; i < nb; ++i) lo->WPf[i] = bp.take((int64_t)n->blocks[i].cin * n->blocks[i].cout);
     lo->amax = bp.take((int64_t)2 * nb * KWS_ABSMAX_WORDS);
   }
   lo->w1f = bp.take((int64_t)n->K1f * n->C1);
@@ -297,11 +295,6 @@ int kws_net_create(const kws_net_config_t* cfg, kws_net_t** out) {
 int kws_net_destroy(kws_net_t* net) {
   if (net) {
     lm_free(net);
-    if (net->ev_fork) (void)hipEventDestroy(net->ev_fork);
-    if (net->ev_wgrad[0]) (void)hipEventDestroy(net->ev_wgrad[0]);
-    if (net->ev_wgrad[1]) (void)hipEventDestroy(net->ev_wgrad[1]);
-    if (net->ev_join) (void)hipEventDestroy(net->ev_join);
-    if (net->side) (void)hipStreamDestroy(net->side);
   }
   delete net;
   return KWS_OK;
@@ -387,12 +380,13 @@ int kws_net_predict(const kws_net_t* net, const float* params, const float* stat
     KWS_TRY(fold_conv1(net, params, ws + lo.w1f, st));
     KWS_TRY(kws_gemm_gather_f32(x, &net->gather1f, ws + lo.w1f, ws + lo.y[0], B, net->C1, nullptr, st));
   }
-  // the A/B arithmetic arms (kws_net_set_gemm_mode) in inference: forward planes of the pointwise kernels, one launch
-  const int gemm_mode = kws_net_get_gemm_mode();
+  // the fp16 x 2 arithmetic arm (kws_net_set_gemm_mode) in inference: forward planes of the pointwise kernels, one launch;
+  // a layer the arm's kernels cannot take (kws_gemm_nn_f16x2_supported) runs the f32 kernel
+  const bool h2 = kws_net_get_gemm_mode(net) == 2;
   unsigned* amax0 = reinterpret_cast<unsigned*>(ws + lo.amax);
   auto w_slots = [&](int i) { return amax0 + (int64_t)i * KWS_ABSMAX_WORDS; };
   auto z_slots = [&](int i) { return amax0 + (int64_t)(nb + i) * KWS_ABSMAX_WORDS; };
-  if (gemm_mode != 0) {
+  if (h2) {
     const float* sin_[24];
     void* sout[24];
     const unsigned* ssl[24];
@@ -404,23 +398,17 @@ int kws_net_predict(const kws_net_t* net, const float* params, const float* stat
       srows[i] = net->blocks[i].cin; scols[i] = net->blocks[i].cout; str[i] = 1;
       wn[i] = (int64_t)srows[i] * scols[i];
     }
-    if (gemm_mode == 2) {
-      KWS_TRY(kws_absmax_batch_f32(sin_, wn, w_slots(0), nb, st));
-      KWS_HIP(hipMemsetAsync(z_slots(0), 0, (size_t)nb * KWS_ABSMAX_WORDS * sizeof(unsigned), st));
-      KWS_TRY(kws_f16x2_split_batch(sin_, sout, srows, scols, str, ssl, nb, st));
-    } else {
-      KWS_TRY(kws_bf16x3_split_batch(sin_, sout, srows, scols, str, nb, st));
-    }
+    KWS_TRY(kws_absmax_batch_f32(sin_, wn, w_slots(0), nb, st));
+    KWS_HIP(hipMemsetAsync(z_slots(0), 0, (size_t)nb * KWS_ABSMAX_WORDS * sizeof(unsigned), st));
+    KWS_TRY(kws_f16x2_split_batch(sin_, sout, srows, scols, str, ssl, nb, st));
   }
   for (int i = 0; i < nb; ++i) {
     const Block& b = net->blocks[i];
     const int64_t M = (int64_t)B * b.Lout;
     KWS_TRY(kws_dwconv_fwd_amax_f32(ws + lo.y[i], bn_at(i), params + b.dw, ws + lo.z[i], B, b.Lin, b.Lout, b.cin, b.stride,
-                                    b.pad_l, gemm_mode == 2 ? z_slots(i) : nullptr, st));
-    if (gemm_mode == 2 && b.cin % 64 == 0)
+                                    b.pad_l, h2 ? z_slots(i) : nullptr, st));
+    if (h2 && kws_gemm_nn_f16x2_supported(M, b.cin, b.cout))
       KWS_TRY(kws_gemm_nn_f16x2_f32(ws + lo.z[i], ws + lo.WPf[i], ws + lo.y[i + 1], M, b.cin, b.cout, z_slots(i), w_slots(i), nullptr, st));
-    else if (gemm_mode == 1 && b.cin % 32 == 0)
-      KWS_TRY(kws_gemm_nn_bf16x3p_f32(ws + lo.z[i], ws + lo.WPf[i], ws + lo.y[i + 1], M, b.cin, b.cout, nullptr, st));
     else
       KWS_TRY(kws_gemm_nn_f32(ws + lo.z[i], params + b.pw, ws + lo.y[i + 1], M, b.cin, b.cout, nullptr, st));
   }
@@ -432,27 +420,19 @@ int kws_net_predict(const kws_net_t* net, const float* params, const float* stat
   return kws_ts_tail_launch(&t, st);
 }
 
-// part 0: the whole step.  part 1: forward, tail and the backward pass down to block `split` (inclusive); part 2: the rest
-// of the backward pass (blocks split-1 .. 0 and the first convolution).  Parts 1 + 2 enqueue exactly the launches of
-// part 0 in the same order - every intermediate lives in the caller's workspace - so the gradients are bit-identical.
-// 0 = f32 MFMA (default), 1 = bf16 x 3 split products for the pointwise GEMMs (experiment), 2 = fp16 x 2 split products
-// (experiment 2).  Initialised from KWS_GEMM_BF16X3 / KWS_GEMM_F16X2; kws_net_set_gemm_mode switches it at run time
-// (bench.py's A/B legs).
-static std::atomic<int> g_gemm_mode{-1};
-extern "C" int kws_net_get_gemm_mode(void) {
-  int m = g_gemm_mode.load(std::memory_order_relaxed);
-  if (m < 0) {
-    m = getenv("KWS_GEMM_F16X2") != nullptr ? 2 : getenv("KWS_GEMM_BF16X3") != nullptr ? 1 : 0;
-    g_gemm_mode.store(m, std::memory_order_relaxed);
-  }
-  return m;
-}
-extern "C" int kws_net_set_gemm_mode(int mode) {
-  KWS_REQUIRE(mode >= 0 && mode <= 2, "net_set_gemm_mode: mode %d (0 = f32 MFMA, 1 = bf16 x 3 split, 2 = fp16 x 2 split)", mode);
-  g_gemm_mode.store(mode, std::memory_order_relaxed);
+// Arithmetic of the pointwise GEMMs of ONE net handle: 0 = f32 MFMA (the product path), 2 = power-of-two scaled fp16 x 2 split
+// products (A/B arm, gemm_f16x2.hip).  Kept on the handle (no process-wide switch); bench.py's A/B leg flips it between steps.
+extern "C" int kws_net_get_gemm_mode(const kws_net_t* net) { return net ? net->gemm_mode.load(std::memory_order_relaxed) : 0; }
+extern "C" int kws_net_set_gemm_mode(kws_net_t* net, int mode) {
+  KWS_REQUIRE(net != nullptr, "net_set_gemm_mode: NULL net");
+  KWS_REQUIRE(mode == 0 || mode == 2, "net_set_gemm_mode: mode %d (0 = f32 MFMA, 2 = fp16 x 2 split)", mode);
+  net->gemm_mode.store(mode, std::memory_order_relaxed);
   return KWS_OK;
 }
 
+// part 0: the whole step.  part 1: forward, tail and the backward pass down to block `split` (inclusive); part 2: the rest
+// of the backward pass (blocks split-1 .. 0 and the first convolution).  Parts 1 + 2 enqueue exactly the launches of
+// part 0 in the same order - every intermediate lives in the caller's workspace - so the gradients are bit-identical.
 static int ts_train(const kws_net_t* net, const float* params, float* state, const float* x, const float* y_onehot, int B,
                     float* grads, float* probs, float* metrics, uint64_t seed, uint32_t step, int64_t row_offset,
                     int loss_batch, void* workspace, int64_t workspace_bytes, void* stream, int phase, int split) {
@@ -473,10 +453,10 @@ static int ts_train(const kws_net_t* net, const float* params, float* state, con
   float* red = ws + lo.red;
 
   const bool run_head = phase != 2;                   // forward + tail + the late blocks' backward
-  // KWS_GEMM_BF16X3=1 (A/B experiment, gemm_bf16x3.hip): the pointwise forward and input-gradient GEMMs run as six bf16
-  // MFMA products of three-way operand splits instead of f32 MFMAs (weight gradients too); the first convolution stays f32
-  const int gemm_mode = kws_net_get_gemm_mode();
-  const bool x3 = gemm_mode == 1, h2 = gemm_mode == 2;
+  // fp16 x 2 arm (kws_net_set_gemm_mode(net, 2), gemm_f16x2.hip): the pointwise forward, input-gradient and weight-gradient
+  // GEMMs run as three f16 MFMA products of scaled two-way operand splits; the first convolution stays f32, and so does any
+  // GEMM whose shape the arm's kernels cannot take (kws_gemm_*_f16x2_supported: K granule, 2 GB buffer views)
+  const bool h2 = kws_net_get_gemm_mode(net) == 2;
   // fp16 x 2 arm: slot groups of the operands' |x| maxima (common.h): W of block i, z of block i, dy of block i's output
   unsigned* amax0 = reinterpret_cast<unsigned*>(ws + lo.amax);
   auto w_slots = [&](int i) { return amax0 + (int64_t)i * KWS_ABSMAX_WORDS; };
@@ -498,20 +478,6 @@ static int ts_train(const kws_net_t* net, const float* params, float* state, con
   memset(&t, 0, sizeof(t));
   if (run_head) {
   KWS_HIP(hipMemsetAsync(grads, 0, (size_t)net->n_params * 4, st));
-  if (x3) {                                         // both operand forms of every pointwise kernel as bf16 planes, one launch
-    const float* sin_[24];
-    void* sout[24];
-    int srows[24], scols[24], str[24];
-    KWS_REQUIRE(2 * nb <= 24, "net: %d blocks exceed the split batch", nb);
-    for (int i = 0; i < nb; ++i) {
-      sin_[2 * i] = sin_[2 * i + 1] = params + net->blocks[i].pw;
-      srows[2 * i] = srows[2 * i + 1] = net->blocks[i].cin;
-      scols[2 * i] = scols[2 * i + 1] = net->blocks[i].cout;
-      sout[2 * i] = ws + lo.WPf[i]; str[2 * i] = 1;            // forward: B = W, stored [cout][cin]
-      sout[2 * i + 1] = ws + lo.WPd[i]; str[2 * i + 1] = 0;    // input gradient: B = W^T, stored [cin][cout] = W itself
-    }
-    KWS_TRY(kws_bf16x3_split_batch(sin_, sout, srows, scols, str, 2 * nb, st));
-  }
   if (h2) {                                         // maxima of the pointwise kernels (this also zeroes their groups), then
     const float* win[24];                           // zero the activations' groups, then both operand forms as fp16 planes
     int64_t wn[24];
@@ -554,12 +520,9 @@ static int ts_train(const kws_net_t* net, const float* params, float* state, con
     KWS_TRY(kws_dwconv_fwd_amax_f32(ws + lo.y[i], bn_at(i), params + b.dw, ws + lo.z[i], B, b.Lin, b.Lout, b.cin, b.stride,
                                     b.pad_l, h2 ? z_slots(i) : nullptr, st));
     int stat_rows;
-    if (h2) {
+    if (h2 && kws_gemm_nn_f16x2_supported(M, b.cin, b.cout)) {
       KWS_TRY(kws_gemm_nn_f16x2_f32(ws + lo.z[i], ws + lo.WPf[i], ws + lo.y[i + 1], M, b.cin, b.cout, z_slots(i), w_slots(i), part, st));
-      stat_rows = kws_gemm_nn_bf16x3_stats_rows(M);
-    } else if (x3) {
-      KWS_TRY(kws_gemm_nn_bf16x3p_f32(ws + lo.z[i], ws + lo.WPf[i], ws + lo.y[i + 1], M, b.cin, b.cout, part, st));
-      stat_rows = kws_gemm_nn_bf16x3_stats_rows(M);
+      stat_rows = kws_gemm_nn_f16x2_stats_rows(M);
     } else {
       KWS_TRY(kws_gemm_nn_f32(ws + lo.z[i], params + b.pw, ws + lo.y[i + 1], M, b.cin, b.cout, part, st));
       stat_rows = kws_gemm_nn_stats_rows(M, b.cin, b.cout);
@@ -586,26 +549,12 @@ static int ts_train(const kws_net_t* net, const float* params, float* state, con
   }
   }  // run_head
   // ---------------- backward through the blocks ----------------
-  // One stream by default.  The weight-gradient GEMM of a block depends only on dy and z, so it CAN run on a side
-  // stream beside the HBM-bound depthwise / BN kernels of the main chain (KWS_OVERLAP=1; the masked gradient then
-  // ping-pongs between two buffers so that the depthwise backward never overwrites a dy the side stream still
-  // reads).  That bought 3 % while the depthwise backward was one unfused pass; with the fused two-pass kernels both
-  // orders take the same 5.14 - 5.20 ms: the early-layer GEMMs (32 FLOP/B) draw 3.7 TB/s themselves, so each side
-  // slows the other by what the overlap gains.  Moving only the small off-chain kernels (transposes, slab sums,
-  // the tail's weight gradients) to a helper stream was measured too: the event traffic costs what it hides.
-  static const bool overlap_env = getenv("KWS_OVERLAP") != nullptr;
-  const bool overlap = overlap_env && phase == 0;     // the side-stream program is a whole-step program
-  if (overlap && net->side == nullptr) {
-    KWS_HIP(hipStreamCreateWithFlags(&net->side, hipStreamNonBlocking));
-    KWS_HIP(hipEventCreateWithFlags(&net->ev_fork, hipEventDisableTiming));
-    KWS_HIP(hipEventCreateWithFlags(&net->ev_wgrad[0], hipEventDisableTiming));
-    KWS_HIP(hipEventCreateWithFlags(&net->ev_wgrad[1], hipEventDisableTiming));
-    KWS_HIP(hipEventCreateWithFlags(&net->ev_join, hipEventDisableTiming));
-  }
-  static const int overlap_from = getenv("KWS_OVERLAP_FROM") ? atoi(getenv("KWS_OVERLAP_FROM")) : 0;  // experiment knob
-  if (run_head && !x3 && !h2) KWS_TRY(transpose_all());   // the f32 dgrad GEMMs read the pointwise kernels transposed
+  // One stream: the weight-gradient GEMM of a block depends only on dy and z and COULD run beside the HBM-bound depthwise /
+  // BN kernels, but the early-layer GEMMs (32 FLOP/B) draw 3.7 TB/s themselves - with the fused two-pass depthwise
+  // backward a side-stream program took the same 5.14 - 5.20 ms (measured in rounds 1 and 2, then removed).
+  // The f32 dgrad GEMMs read the pointwise kernels transposed (the fp16 arm too, for the layers it hands back)
+  if (run_head) KWS_TRY(transpose_all());
   float* Gb[2] = {ws + lo.G, ws + lo.G2};          // gradient wrt y[l] lives in Gb[l % 2]; the tail wrote Gb[nb % 2]
-  bool wgrad_pending[2] = {false, false};
   const int i_hi = phase == 2 ? split - 1 : nb - 1, i_lo = phase == 1 ? split : 0;
   for (int i = i_hi; i >= i_lo; --i) {
     const Block& b = net->blocks[i];
@@ -617,32 +566,14 @@ static int ts_train(const kws_net_t* net, const float* params, float* state, con
     if (i == nb - 1)
       KWS_TRY(kws_bn_bwd_apply_amax(Gcur, ws + lo.y[i + 1], bn_at(i + 1), params + b.bn.gamma, coef, M, b.cout,
                                     h2 ? g_slots(i) : nullptr, st));
-    if (h2) KWS_TRY(kws_gemm_nn_f16x2_f32(Gcur, ws + lo.WPd[i], DZ, M, b.cout, b.cin, g_slots(i), w_slots(i), nullptr, st));
-    else if (x3) KWS_TRY(kws_gemm_nn_bf16x3p_f32(Gcur, ws + lo.WPd[i], DZ, M, b.cout, b.cin, nullptr, st));
-    else KWS_TRY(kws_gemm_nn_f32(Gcur, ws + lo.WT[i], DZ, M, b.cout, b.cin, nullptr, st));
-    const bool ov = overlap && i >= overlap_from;
-    hipStream_t sw = ov ? net->side : st;
-    if (ov) {
-      KWS_HIP(hipEventRecord(net->ev_fork, st));
-      KWS_HIP(hipStreamWaitEvent(sw, net->ev_fork, 0));
-    } else if (overlap) {                           // the TN workspace is shared: drain the side stream first
-      KWS_HIP(hipEventRecord(net->ev_join, net->side));
-      KWS_HIP(hipStreamWaitEvent(st, net->ev_join, 0));
-    }
-    if (h2 && b.cin % 64 == 0 && b.cout % 64 == 0)
-      KWS_TRY(kws_gemm_tn_f16x2_f32(ws + lo.z[i], Gcur, grads + b.pw, M, b.cin, b.cout, z_slots(i), g_slots(i), ws + lo.tn, sw));
-    else if (x3 && b.cin % 64 == 0 && b.cout % 64 == 0)
-      KWS_TRY(kws_gemm_tn_bf16x3_f32(ws + lo.z[i], Gcur, grads + b.pw, M, b.cin, b.cout, ws + lo.tn, sw));
+    if (h2 && kws_gemm_nn_f16x2_supported(M, b.cout, b.cin))
+      KWS_TRY(kws_gemm_nn_f16x2_f32(Gcur, ws + lo.WPd[i], DZ, M, b.cout, b.cin, g_slots(i), w_slots(i), nullptr, st));
     else
-      KWS_TRY(kws_gemm_tn_f32(ws + lo.z[i], Gcur, grads + b.pw, M, b.cin, b.cout, ws + lo.tn, sw));
-    if (ov) {
-      KWS_HIP(hipEventRecord(net->ev_wgrad[(i + 1) % 2], sw));
-      wgrad_pending[(i + 1) % 2] = true;
-    }
-    if (overlap && wgrad_pending[i % 2]) {          // the wgrad of block i+1 read Gnext
-      KWS_HIP(hipStreamWaitEvent(st, net->ev_wgrad[i % 2], 0));
-      wgrad_pending[i % 2] = false;
-    }
+      KWS_TRY(kws_gemm_nn_f32(Gcur, ws + lo.WT[i], DZ, M, b.cout, b.cin, nullptr, st));
+    if (h2 && kws_gemm_tn_f16x2_supported(M, b.cin, b.cout))
+      KWS_TRY(kws_gemm_tn_f16x2_f32(ws + lo.z[i], Gcur, grads + b.pw, M, b.cin, b.cout, z_slots(i), g_slots(i), ws + lo.tn, st));
+    else
+      KWS_TRY(kws_gemm_tn_f32(ws + lo.z[i], Gcur, grads + b.pw, M, b.cin, b.cout, ws + lo.tn, st));
     const BnRef& prev = (i == 0) ? net->bn1 : net->blocks[i - 1].bn;
     // depthwise backward + BatchNorm backward of this block's input without materialising the masked
     // gradient: reduce, fold (dw, dgamma, dbeta, c1 | c2), recompute and write dy of the previous block
@@ -657,10 +588,6 @@ static int ts_train(const kws_net_t* net, const float* params, float* state, con
   if (phase != 1) {
     const int64_t M = (int64_t)B * net->L1;
     (void)M;                                        // Gb[0] already holds dy of the first convolution
-    if (overlap) {                                  // the side stream's TN workspace is free once its queue drains
-      KWS_HIP(hipEventRecord(net->ev_join, net->side));
-      KWS_HIP(hipStreamWaitEvent(st, net->ev_join, 0));
-    }
     if (kws_conv1_supported(&net->gather1f, net->C1)) {
       KWS_TRY(kws_conv1_wgrad(x, &net->gather1f, &net->gather1, Gb[0], grads + net->conv1, B, net->C1, ws + lo.tn, st));
     } else {

@@ -4,6 +4,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -43,10 +44,8 @@ struct kws_net {
   int K1f = 0;            // folded K
   // LOG_MFCC
   LmProgram* lm = nullptr;
-  // side stream of the training step (weight-gradient GEMMs run beside the memory-bound backward kernels);
-  // created on first use on the caller's current device
-  mutable hipStream_t side = nullptr;
-  mutable hipEvent_t ev_fork = nullptr, ev_wgrad[2] = {nullptr, nullptr}, ev_join = nullptr;
+  // arithmetic of the pointwise GEMMs (kws_net_set_gemm_mode): 0 = f32 MFMA, 2 = fp16 x 2 split products (A/B arm)
+  std::atomic<int> gemm_mode{0};
 };
 
 // Appends a Keras-named tensor to the flat parameter (or state) buffer; returns its float offset.

@@ -184,12 +184,8 @@ int launch_stft(const StftArgs& a, int B, hipStream_t st) {
                         ((pl.n_w + 3) & ~3) + (size_t)NW * WAVE_FLOATS;
   const size_t bytes = floats * 4;
   KWS_REQUIRE(bytes <= 160 * 1024, "stft: LDS need %zu B exceeds 160 KiB", bytes);
-  static bool attr_done = false;
-  if (!attr_done) {
-    KWS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&stft_kernel<NW, FPW>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
-  }
+  KWS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&stft_kernel<NW, FPW>),   // per device, cheap: every launch
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   dim3 g((unsigned)ceil_div(a.F, NW * FPW), (unsigned)B), blk(NW * 64);
   hipLaunchKernelGGL((stft_kernel<NW, FPW>), g, blk, bytes, st, a);
   KWS_LAUNCH_CHECK("stft_kernel");
@@ -248,13 +244,7 @@ int kws_stft_plan_create(int frame_len, int frame_step, int fft_len, int n_mel, 
   if (bw.empty()) bw.push_back(0.f);
   p->n_w = (int)bw.size();
   std::vector<float> d(dct, dct + (size_t)n_mel * n_out);
-  // v2 kernel tables: inter-stage twiddles W256^(n2*k1) as [n2][k1], DCT matrix padded to 64 columns
-  std::vector<float2> tw16(256);
-  for (int n2 = 0; n2 < 16; ++n2)
-    for (int k1 = 0; k1 < 16; ++k1) {
-      const double ang = -2.0 * M_PI * (n2 * k1) / 256.0;
-      tw16[n2 * 16 + k1] = make_float2((float)cos(ang), (float)sin(ang));
-    }
+  // stft4 tables: the DCT matrix padded to 64 columns
   std::vector<float> d64((size_t)n_mel * 64, 0.f);
   for (int m = 0; m < n_mel; ++m)
     for (int q = 0; q < n_out && q < 64; ++q) d64[(size_t)m * 64 + q] = dct[(size_t)m * n_out + q];
@@ -322,7 +312,6 @@ int kws_stft_plan_create(int frame_len, int frame_step, int fft_len, int n_mel, 
   if (rc == KWS_OK) rc = upload(&p->band_ofs, bo);
   if (rc == KWS_OK) rc = upload(&p->band_w, bw);
   if (rc == KWS_OK) rc = upload(&p->dct, d);
-  if (rc == KWS_OK) rc = upload(&p->tw16, tw16);
   if (rc == KWS_OK) rc = upload(&p->dct64, d64);
   if (rc == KWS_OK) rc = upload(&p->b4, b4);
   if (rc == KWS_OK) rc = upload(&p->tw4, tw4);
@@ -340,8 +329,8 @@ int kws_stft_plan_create(int frame_len, int frame_step, int fft_len, int n_mel, 
 
 int kws_stft_plan_destroy(kws_stft_plan_t* p) {
   if (!p) return KWS_OK;
-  void* bufs[16] = {p->window, p->w256, p->w512, p->band_start, p->band_cnt, p->band_ofs, p->band_w, p->dct,
-                    p->tw16, p->dct64, p->b4, p->tw4, p->w512p, p->mel_ws, p->mel_wpad, p->img4};
+  void* bufs[15] = {p->window, p->w256, p->w512, p->band_start, p->band_cnt, p->band_ofs, p->band_w, p->dct,
+                    p->dct64, p->b4, p->tw4, p->w512p, p->mel_ws, p->mel_wpad, p->img4};
   for (void* q : bufs)
     if (q) (void)hipFree(q);
   delete p;
@@ -367,16 +356,11 @@ int kws_stft_mel_f32(const kws_stft_plan_t* plan, const float* x, int B, int L, 
   // ~5 N log2 N for the 256-point complex FFT + split + sparse mel + dense DCT, per frame
   const double fl = (double)B * a.F * (5.0 * 256 * 8 + 12.0 * 257 + 2.0 * plan->n_w + 2.0 * plan->n_mel * plan->n_out);
   KwsProfScope prof("stft_mel", fl, 4.0 * ((double)B * L + (double)B * a.F * width), st);
-  static const bool force_v1 = getenv("KWS_STFT_V1") != nullptr;
-  static const bool force_v2 = getenv("KWS_STFT_V2") != nullptr;
-  static const bool force_v3 = getenv("KWS_STFT_V3") != nullptr;
-  if (out_kind == 0 && plan->n_out <= 64 && plan->n_mel <= 128 && plan->frame_len % 2 == 0 && !force_v1) {
-    if (!force_v2 && !force_v3 && plan->n_mel % 4 == 0 && plan->mel_maxw > 0 && kws_stft4_lds_bytes(plan) <= 160 * 1024)
-      return kws_stft4_launch(plan, x, B, L, a.F, out, st);   // first radix-16 pass + DCT on the matrix pipe
-    if (!force_v2 && plan->n_mel % 4 == 0 && kws_stft3_lds_bytes(plan) <= 160 * 1024)
-      return kws_stft3_launch(plan, x, B, L, a.F, out, st);   // tables in registers, DCT on the matrix pipe
-    return kws_stft2_launch(plan, x, B, L, a.F, out, st);
-  }
+  // the feature form the reference's settings produce (train.py:38, settings.py:3, audio.py:20-23) runs stft4_kernel (first
+  // radix-16 pass + DCT on the matrix pipe); any other table shape or output kind takes the generic kernel below
+  if (out_kind == 0 && plan->n_out <= 64 && plan->n_mel <= 128 && plan->n_mel % 4 == 0 && plan->frame_len % 2 == 0 &&
+      plan->mel_maxw > 0 && plan->img4 != nullptr && kws_stft4_lds_bytes(plan) <= 160 * 1024)
+    return kws_stft4_launch(plan, x, B, L, a.F, out, st);
   if (a.F % 14 == 0) {
     a.run_samples = (7 * 2 - 1) * plan->frame_step + plan->frame_len;
     return launch_stft<7, 2>(a, B, st);

@@ -604,7 +604,7 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
 }  // namespace
 
 // instantiated band shapes: 80 mel bins over 257 bins (input_data.py:366-373 as train.py sets it: blocks 1, 1, 2, 3, 4),
-// 40 mel bins (2, 5, 8), and the same lane counts with every group at the widest width; anything else declines (stft3)
+// 40 mel bins (2, 5, 8), and the same lane counts with every group at the widest width; anything else declines (the generic kernel of stft.hip)
 static int stft4_shape(const kws_stft_plan* pl) {
   if (pl->mel_maxw <= 0) return 0;
   const int nb = (pl->n_mel + 15) / 16;
@@ -624,7 +624,7 @@ static int stft4_shape(const kws_stft_plan* pl) {
 
 static int stft4_lds_bytes(const kws_stft_plan* pl, int nw, int gq) {
   const int sh = stft4_shape(pl);
-  if (sh == 0) return 1 << 30;                                       // declines: the caller falls back to stft3
+  if (sh == 0) return 1 << 30;                                       // declines: the caller falls back to the generic kernel
   const int nb = sh <= 2 ? 5 : 3, mc = sh <= 2 ? 4 : 8;
   const size_t floats = 512 + 512 + 256 + 4 + (size_t)16 * nb * DSTR4 + (size_t)pl->n_mel * (4 * mc + 4) +
                         (size_t)nw * (4 * MAGF + ((4 * gq * (16 * nb + 1) + 3) & ~3));
@@ -641,14 +641,8 @@ static int stft4_image_h(kws_stft_plan* pl) {
   KWS_HIP(hipStreamSynchronize(nullptr));
   return KWS_OK;
 }
-static bool stft4_f32_pass() {
-  static const bool v = getenv("KWS_STFT_F32PASS") != nullptr;      // A/B: the first pass on v_mfma_f32_16x16x4_f32
-  return v;
-}
 template <int NB, int MC, int MCP>
-static int stft4_image_t(kws_stft_plan* pl) {
-  return stft4_f32_pass() ? stft4_image_h<NB, MC, MCP, false>(pl) : stft4_image_h<NB, MC, MCP, true>(pl);
-}
+static int stft4_image_t(kws_stft_plan* pl) { return stft4_image_h<NB, MC, MCP, true>(pl); }
 
 // called once by kws_stft_plan_create after the tables are uploaded: the LDS image of this plan's kernel instance
 int kws_stft4_prepare(kws_stft_plan* pl) {
@@ -665,12 +659,9 @@ template <int NB, int MC, int MCP, bool H1, int NW4, int GQ, bool V4>
 static int stft4_launch_w(const Stft2Args& a, hipStream_t st) {
   const int bytes = stft4_lds_bytes(&a.pl, NW4, GQ);
   KWS_REQUIRE(bytes <= 160 * 1024, "stft4: LDS need %d B exceeds 160 KiB", bytes);
-  static bool attr_done = false;
-  if (!attr_done) {
-    KWS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&stft4_kernel<NB, MC, MCP, H1, NW4, GQ, V4>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
-  }
+  // per device and cheap: set on every launch (a process-wide "done" flag would miss the second device of a process)
+  KWS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&stft4_kernel<NB, MC, MCP, H1, NW4, GQ, V4>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   int64_t wgs = (a.total_quads + NW4 - 1) / NW4;
   if (wgs > 256) wgs = 256;   // persistent: one workgroup per CU, tables copied once
   hipLaunchKernelGGL((stft4_kernel<NB, MC, MCP, H1, NW4, GQ, V4>), dim3((unsigned)wgs), dim3(NW4 * 64), (size_t)bytes, st, a);
@@ -678,16 +669,11 @@ static int stft4_launch_w(const Stft2Args& a, hipStream_t st) {
   return KWS_OK;
 }
 // 12 waves per workgroup, DCT groups of 4 quads (16 x 2 was measured - 51.4 us against 50.3 - and is not instantiated);
-// 16-byte PCM loads whenever every frame starts on a 16-byte boundary (KWS_STFT_LD8 keeps the 8-byte loads for A/B runs)
-template <int NB, int MC, int MCP, bool H1>
-static int stft4_launch_h(const Stft2Args& a, hipStream_t st) {
-  static const bool ld8 = getenv("KWS_STFT_LD8") != nullptr;
-  const bool v4 = !ld8 && a.L % 4 == 0 && a.pl.frame_step % 4 == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0;
-  return v4 ? stft4_launch_w<NB, MC, MCP, H1, 12, 4, true>(a, st) : stft4_launch_w<NB, MC, MCP, H1, 12, 4, false>(a, st);
-}
+// 16-byte PCM loads whenever every frame starts on a 16-byte boundary, 8-byte loads otherwise
 template <int NB, int MC, int MCP>
 static int stft4_launch_t(const Stft2Args& a, hipStream_t st) {
-  return stft4_f32_pass() ? stft4_launch_h<NB, MC, MCP, false>(a, st) : stft4_launch_h<NB, MC, MCP, true>(a, st);
+  const bool v4 = a.L % 4 == 0 && a.pl.frame_step % 4 == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0;
+  return v4 ? stft4_launch_w<NB, MC, MCP, true, 12, 4, true>(a, st) : stft4_launch_w<NB, MC, MCP, true, 12, 4, false>(a, st);
 }
 
 int kws_stft4_launch(const kws_stft_plan* pl, const float* x, int B, int L, int F, float* out, hipStream_t st) {

@@ -508,8 +508,7 @@ int kws_ts_tail_launch(const kws_ts_tail_args* p, hipStream_t st) {
   KwsProfScope prof(p->train ? "tail_train" : "tail_infer", 4.0 * p->B * TC * p->T * (p->train ? 2 : 1), 4.0 * p->B * TC * (p->train ? 4 : 1), st);
   // T = 9 (16000-sample input) takes the vectorised W1 passes; W1 rows must then be 16-byte aligned in
   // groups of 4 (T*C % 4 == 0 and an aligned base, both true for the flat parameter buffer)
-  const bool fast9 = p->T == 9 && TC % 4 == 0 && (reinterpret_cast<uintptr_t>(p->W1) & 15) == 0 &&
-                     getenv("KWS_TAIL_GENERIC") == nullptr;
+  const bool fast9 = p->T == 9 && TC % 4 == 0 && (reinterpret_cast<uintptr_t>(p->W1) & 15) == 0;
   const void* fn = p->train ? (fast9 ? reinterpret_cast<const void*>(&ts_tail_kernel<true, 9>)
                                      : reinterpret_cast<const void*>(&ts_tail_kernel<true, 0>))
                             : (fast9 ? reinterpret_cast<const void*>(&ts_tail_kernel<false, 9>)

@@ -332,6 +332,9 @@ class Model(object):
         self._reg_value = None
         self.device = net.device
         self.stream = torch.cuda.current_stream(net.device)
+        # data-parallel gradient exchange: 0 = ONE all-reduce of the flat buffer after the backward pass; k >= 1 = the
+        # gradients of blocks >= k (+ tail) are summed while the earlier blocks' backward still runs (bit-identical)
+        self.allreduce_split = parallel.split_block_from_env()
 
     # -- weights -----------------------------------------------------------------------------------
     def count_params(self):
@@ -404,7 +407,7 @@ class Model(object):
         world, rank = parallel.world_size(), parallel.rank()
         B = xd.shape[0]
         net.metrics = metrics_row
-        split = parallel.split_block_from_env() if world > 1 and net.kind == _lib.KWS_NET_TS_ATTENTION else 0
+        split = self.allreduce_split if world > 1 and net.kind == _lib.KWS_NET_TS_ATTENTION else 0
         if split > 0:
             # the late layers' gradients (a contiguous tail of the flat buffer) are summed over the ranks while the early
             # layers' backward still runs; the two slices together are the one-buffer all-reduce, element for element

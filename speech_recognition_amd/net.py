@@ -25,7 +25,7 @@ class DeviceNet(object):
     """One model replica on one GPU."""
 
     def __init__(self, kind, num_classes, filter_mult=1, input_size=16000, spectrogram_length=0,
-                 num_features=0, device=None, seed=87654321):
+                 num_features=0, device=None, seed=87654321, gemm_mode=None):
         if not torch.cuda.is_available():
             raise _lib.KwsError("no MI355X visible to this process: the HIP path is the only path "
                                 "(no CPU fallback)")
@@ -62,7 +62,20 @@ class DeviceNet(object):
             self.reg_loss = torch.zeros(1, dtype=torch.float32, device=self.device)
         self._ws = None
         self._ws_key = None
+        # arithmetic of the pointwise GEMMs, a property of THIS handle: 0 = f32 MFMA (the product path), 2 = the fp16 x 2
+        # A/B arm.  KWS_GEMM_F16X2=1 only picks the default of nets that do not say (test / profiling runs of the arm).
+        if gemm_mode is None:
+            import os
+            gemm_mode = 2 if os.environ.get("KWS_GEMM_F16X2") else 0
+        self.set_gemm_mode(gemm_mode)
         self.initialize(seed)
+
+    @property
+    def gemm_mode(self):
+        return int(self.lib.kws_net_get_gemm_mode(self.handle))
+
+    def set_gemm_mode(self, mode):
+        _lib.check(self.lib.kws_net_set_gemm_mode(self.handle, int(mode)), "kws_net_set_gemm_mode")
 
     def __del__(self):
         try:

@@ -70,9 +70,9 @@ def allreduce_wait(handle):
 
 
 def split_block_from_env():
-    """KWS_ALLREDUCE_SPLIT=<block>: all-reduce the gradients of blocks >= <block> (+ tail) while the earlier blocks'
-    backward still runs.  Unset / 0 = one buffer after the backward pass (the default until an N-GPU run shows which
-    wins: the 4.8 MB message is latency-bound either way)."""
+    """Default of Model.allreduce_split: KWS_ALLREDUCE_SPLIT=<block> all-reduces the gradients of blocks >= <block> (+ tail)
+    while the earlier blocks' backward still runs.  Unset / 0 = one buffer after the backward pass (the default until an
+    N-GPU run shows which wins: the 4.8 MB message is latency-bound either way; bench.py --gpus N measures both)."""
     try:
         return int(os.environ.get("KWS_ALLREDUCE_SPLIT", "0"))
     except ValueError:

@@ -28,7 +28,7 @@ def test_library_loads_and_exports_every_symbol(repo_root):
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in _header_functions(repo_root):
         assert hasattr(lib, name), name
-    assert _lib.load().kws_abi_version() == 1
+    assert _lib.load().kws_abi_version() == _lib.ABI_VERSION == 2
 
 
 def test_product_path_fails_loudly_without_gpu():

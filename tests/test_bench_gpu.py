@@ -33,6 +33,16 @@ def test_bench_two_ranks_print_one_json_line():
     assert out["value"] > 0 and out["roofline"] is not None and out["rccl_ranks"] == 2
     assert out["cpu_baseline"]["value"] > 0 and out["cpu_baseline"]["kind"] == "port"      # N>1 lines carry it too
     assert out["train_loss_first_last"][0] == out["train_loss_first_last"][0]      # finite
+    # the N > 1 line diagnoses itself: the gradient exchange alone, the split-overlap form of the same step, every rank's time
+    ar = out["allreduce_only"]
+    assert ar["floats"] == 1191433 and ar["bytes"] == 4 * 1191433 and ar["us_per_allreduce"] > 0
+    assert 0 < ar["pct_of_ms_per_step"] and ar["algorithmic_bus_GBps"] > 0
+    sp = out["ab_allreduce_split"]
+    assert sp["split_block"] == 6 and sp["ms_per_step"] > 0 and sp["value"] > 0 and 0.3 < sp["vs_one_buffer"] < 3.0
+    assert len(out["per_rank_ms"]) == 2 and all(v > 0 for v in out["per_rank_ms"])
+    assert max(out["per_rank_ms"]) <= out["ms_per_step"] * 1.001          # the line's time is the MAX over ranks
+    assert out["scaling_vs_n1"] is None                                   # no --n1-value given
+    assert out["ab_gemm_f16x2"] is None and out["configs"] is None        # single-GPU legs stay out of N > 1 lines
     print("non-JSON stdout lines of the launcher:", other)
 
 
@@ -40,19 +50,33 @@ def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher around it (how the driver may call it): bench.py starts the two
     ranks itself as child processes BEFORE touching the GPU, relays rank 0's line and reports n_gpus 2 - never a
     silent 1-GPU run.  (--no-cpu-baseline: the other test covers that leg.)"""
-    # KWS_ALLREDUCE_SPLIT: this run also takes the two-part step with the late layers' all-reduce started early
-    env = dict(os.environ, KWS_BENCH_ONE_DEVICE="1", KWS_BENCH_TRACE="240", HSA_ENABLE_IPC_MODE_LEGACY="0",
-               KWS_ALLREDUCE_SPLIT="6")
+    env = dict(os.environ, KWS_BENCH_ONE_DEVICE="1", KWS_BENCH_TRACE="240", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--bank", "8192",
-           "--batch", "256", "--no-cpu-baseline"]
+           "--batch", "256", "--no-cpu-baseline", "--allreduce-split", "3", "--n1-value", "100000"]
     res = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=400)
     assert res.returncode == 0, res.stderr.decode()[-2000:]
     lines = [l for l in res.stdout.decode().splitlines() if l.strip()]
     assert len(lines) == 1, lines
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["config"]["global_batch"] == 512
+    assert out["ab_allreduce_split"]["split_block"] == 3 and out["ab_allreduce_split"]["value"] > 0     # the argument, not the environment
+    assert out["allreduce_only"]["us_per_allreduce"] > 0 and len(out["per_rank_ms"]) == 2
+    assert abs(out["scaling_vs_n1"] - out["value"] / (2 * 100000.0)) < 1e-9
+
+
+def test_launcher_counts_devices_without_the_hip_runtime():
+    """The parent of `bench.py --gpus N` must not touch the GPU before it starts its ranks: the count comes from the KFD
+    topology in sysfs and agrees with what the runtime reports on this box."""
+    code = ("import sys; sys.argv = ['bench.py']; import bench, torch\n"
+            "n = bench.visible_gpu_count()\n"
+            "assert not torch.cuda.is_initialized()\n"
+            "print(n, torch.cuda.device_count())\n")
+    res = subprocess.run([sys.executable, "-c", code], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    n_sysfs, n_rt = res.stdout.decode().split()[-2:]
+    assert n_sysfs == "None" or int(n_sysfs) == int(n_rt) >= 1, (n_sysfs, n_rt)
 
 
 def test_bench_refuses_more_gpus_than_visible():

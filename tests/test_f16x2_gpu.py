@@ -1,7 +1,7 @@
-"""The fp16 x 2 split GEMMs (EXPERIMENT 2, csrc/gemm_f16x2.hip): every f32 operand scaled by a power of two taken from
+"""The fp16 x 2 split GEMMs (A/B arm, csrc/gemm_f16x2.hip): every f32 operand scaled by a power of two taken from
 its |x| maximum, split into two fp16 parts, three f16 MFMA products accumulated in f32.  As accurate against float64 as
 the f32-MFMA kernels the product uses, over the magnitudes a training step produces (activations of order one,
-gradients of order 1e-7) and beyond.  Off by default (KWS_GEMM_F16X2 / kws_net_set_gemm_mode(2))."""
+gradients of order 1e-7) and beyond.  Off by default (kws_net_set_gemm_mode(net, 2))."""
 import ctypes
 
 import numpy as np
@@ -59,7 +59,7 @@ def test_f16x2_forward_matches_float64_as_well_as_the_f32_kernel(M, K, N, a_scal
               _lib.stream_ptr())
     assert torch.isfinite(Wp.float()).all() and float(Wp[0].float().abs().max()) < 65504.0
     C2 = torch.full((M, N), float("nan"), device="cuda")
-    stats = torch.full((_lib.load().kws_gemm_nn_bf16x3_stats_rows(M), 2, N), float("nan"), device="cuda")
+    stats = torch.full((_lib.load().kws_gemm_nn_f16x2_stats_rows(M), 2, N), float("nan"), device="cuda")
     _lib.call("kws_gemm_nn_f16x2_f32", _lib.ptr(A), _lib.ptr(Wp), _lib.ptr(C2), M, K, N, _lib.ptr(slots[0]), _lib.ptr(slots[1]),
               _lib.ptr(stats), _lib.stream_ptr())
     ref = A.double() @ W.double()

@@ -256,8 +256,9 @@ def test_train_step_full_batch_matches_oracle():
     got = probs.cpu().numpy()
     err_p = np.abs(got - p).max()
     flips = sum(int((masks[i] != OL.relu6_mask(cache['bn%d' % i][3])).sum()) for i in range(1, 13))
-    print("B=%d: max |softmax - oracle| = %.3g, kink flips handed over: %d of %d" %
-          (B, err_p, flips, sum(m.size for m in masks.values())))
+    n_act = sum(m.size for m in masks.values())
+    print("B=%d: max |softmax - oracle| = %.3g, kink flips handed over: %d of %d" % (B, err_p, flips, n_act))
+    assert flips < 1e-4 * n_act          # the handed-over decisions are the oracle's own but for rounding at the kinks
     assert err_p < 1e-4
     assert np.array_equal(got.argmax(1), p.argmax(1))                   # class indices bit-exact
     m = net.metrics.cpu().numpy()
@@ -280,3 +281,64 @@ def test_train_step_full_batch_matches_oracle():
         mv = ora.state['batch_normalization_%d/moving_variance' % idx].astype(np.float64)
         np.testing.assert_allclose(w['batch_normalization_%d/moving_mean' % idx], mm - (mm - mean) * 0.01, atol=2e-6)
         np.testing.assert_allclose(w['batch_normalization_%d/moving_variance' % idx], mv - (mv - var) * 0.01, rtol=2e-5)
+
+
+def test_config_c3_train_step_full_batch_matches_oracle():
+    """configs[2] at ITS size: one training-mode forward + backward of conv_1d_log_mfcc (model.py:1400-1479, 32 classes) at
+    batch 2048 against LogMfccNet.loss_and_grads in float64 - the size the C3 clips/s figure is quoted on, where the
+    C3-only kernels run with cross-workgroup partial slabs (block_out_bwd_kernel, the strided shortcut
+    kws_gemm_tn_gather_f32 at M = 98 k, the softmax-over-time tail backward); the small-batch tests stop at B = 19.
+    Decisions (ReLU6 masks, max-pool winners) are read back from the device and handed over (top of test_net_gpu.py), and
+    the number handed over that differ from the oracle's own is bounded.  Bars: softmax 1e-4 (north_star 1e-3), class
+    indices identical, loss 1e-4, every gradient tensor 2e-4 of its maximum, BN moving statistics; and a second run of
+    the same step returns the same bits (fixed-order slab sums at this size too)."""
+    import psutil
+    from oracle import layers as OL
+    from test_logmfcc_gpu import _batch as lm_batch, _decisions as lm_decisions, _pair as lm_pair
+    B = 2048
+    if psutil.virtual_memory().available < 40 * 2 ** 30:
+        pytest.skip("the float64 oracle needs ~25 GB of host memory at batch 2048")
+    ora, net = lm_pair(32, seed=21)
+    x, y = lm_batch(B, 32, 2048)
+    dx, dy = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    state0 = net.state.clone()
+    probs = net.train_fwd_bwd(dx, dy, seed=31337, step=4).clone()
+    torch.cuda.synchronize()
+    g_first = net.grads.clone()
+    w = net.get_weights()                                   # moving statistics after ONE update
+    masks, args = lm_decisions(net, ora, B)
+    loss, p, grads, cache = ora.loss_and_grads(x.astype(np.float64), y.astype(np.float64), seed=31337, step=4,
+                                               relu_masks=masks, pool_args=args)
+    got = probs.cpu().numpy()
+    err_p = np.abs(got - p).max()
+    own = {idx: OL.relu6_mask(cache['bn%d' % idx][3]) for idx in masks if ('bn%d' % idx) in cache}
+    flips = sum(int((masks[idx].reshape(own[idx].shape) != own[idx]).sum()) for idx in own)
+    n_act = sum(own[idx].size for idx in own)
+    print("C3 B=%d: max |softmax - oracle| = %.3g, kink flips handed over: %d of %d" % (B, err_p, flips, n_act))
+    assert len(own) >= 20 and flips < 1e-4 * n_act
+    assert err_p < 1e-4
+    assert np.array_equal(got.argmax(1), p.argmax(1))
+    m = net.metrics.cpu().numpy()
+    assert abs(m[0] / B - loss) < 1e-4
+    assert m[1] == (p.argmax(1) == y.argmax(1)).sum()
+    g = net.grads_dict()
+    worst = ("", 0.0)
+    for k, ref in grads.items():
+        if k in ora.l2_names:
+            ref = ref - 2e-5 * ora.params[k].astype(np.float64)
+        ref = ref.reshape(g[k].shape)
+        err = np.abs(g[k] - ref).max() / max(np.abs(ref).max(), 1e-7)
+        if err > worst[1]:
+            worst = (k, err)
+        assert err < 2e-4, (k, err)
+    print("worst C3 gradient tensor: %s %.3g" % worst)
+    for idx, (mean, var) in cache['batch_stats'].items():
+        mm = ora.state['batch_normalization_%d/moving_mean' % idx].astype(np.float64)
+        mv = ora.state['batch_normalization_%d/moving_variance' % idx].astype(np.float64)
+        np.testing.assert_allclose(w['batch_normalization_%d/moving_mean' % idx], mm - (mm - mean) * 0.01, atol=5e-6)
+        np.testing.assert_allclose(w['batch_normalization_%d/moving_variance' % idx], mv - (mv - var) * 0.01, rtol=5e-5, atol=1e-7)
+    # run-to-run: the same step from the same state returns the same bits
+    net.state.copy_(state0)
+    probs2 = net.train_fwd_bwd(dx, dy, seed=31337, step=4)
+    torch.cuda.synchronize()
+    assert torch.equal(probs2, probs) and torch.equal(net.grads, g_first)

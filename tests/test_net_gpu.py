@@ -21,8 +21,8 @@ from speech_recognition_amd.net import DeviceNet
 pytestmark = pytest.mark.gpu
 
 
-def _oracle(num_classes=12, seed=5):
-    ora = TimeSlicedAttentionNet(num_classes=num_classes, dtype=np.float64)
+def _oracle(num_classes=12, seed=5, **kw):
+    ora = TimeSlicedAttentionNet(num_classes=num_classes, dtype=np.float64, **kw)
     rng = np.random.RandomState(seed)
     for k in ora.params:                      # de-trivialise BN affine / bias so their grads matter
         if k.endswith('gamma'):
@@ -37,18 +37,18 @@ def _oracle(num_classes=12, seed=5):
     return ora
 
 
-def _pair(num_classes=12, seed=5):
-    ora = _oracle(num_classes, seed)
-    net = DeviceNet(_lib.KWS_NET_TS_ATTENTION, num_classes)
+def _pair(num_classes=12, seed=5, **kw):
+    ora = _oracle(num_classes, seed, **kw)
+    net = DeviceNet(_lib.KWS_NET_TS_ATTENTION, num_classes, **kw)
     net.set_weights(dict(ora.params, **ora.state))
     return ora, net
 
 
-def _batch(B, num_classes, seed):
+def _batch(B, num_classes, seed, L=16000):
     rng = np.random.RandomState(seed)
-    t = np.arange(16000) / 16000.0
+    t = np.arange(L) / 16000.0
     lab = rng.randint(0, num_classes, B)
-    x = rng.randn(B, 16000) * 0.0774 + 0.05 * np.sin(2 * np.pi * 200.0 * (1 + lab)[:, None] * t[None])
+    x = rng.randn(B, L) * 0.0774 + 0.05 * np.sin(2 * np.pi * 200.0 * (1 + lab)[:, None] * t[None])
     return x.astype(np.float32), np.eye(num_classes, dtype=np.float32)[lab]
 
 
@@ -57,7 +57,7 @@ def _device_decisions(net, ora, B):
     pre-BN tensors / BN tables / attention weights with the kernel's f32 arithmetic."""
     masks = {}
     pre12 = None
-    shapes = [(B, 399, 128)] + [(B, b['Lout'], b['cout']) for b in ora.blocks]
+    shapes = [(B, ora.blocks[0]['Lin'], ora.blocks[0]['cin'])] + [(B, b['Lout'], b['cout']) for b in ora.blocks]
     for l in range(12):
         y = net.debug_view(B, 0, l).reshape(shapes[l])
         bn = net.debug_view(B, 2, l)
@@ -79,6 +79,9 @@ def _check_grads(ora, net, x, y, seed, step, B, tol=5e-5, **kw):
                                                relu_masks=masks, pool_ind=ind, **kw)
     g = net.grads_dict()
     flips = sum(int((masks[i] != OL.relu6_mask(cache['bn%d' % i][3])).sum()) for i in range(1, 13))
+    # the decisions handed over are the oracle's own but for pre-activations within f32 rounding of a kink: a device whose
+    # pre-activation PATTERN were wrong would show here, whatever the aligned gradients say
+    assert flips <= max(2, 1e-4 * sum(m.size for m in masks.values())), "kink flips: %d" % flips
     for k, ref in grads.items():
         if k in ora.l2_names:                   # the HIP path folds L2 into the optimizer
             ref = ref - 2e-5 * ora.params[k].astype(np.float64)
@@ -130,9 +133,9 @@ def test_train_fwd_bwd_matches_oracle(B):
         np.testing.assert_allclose(w['batch_normalization_%d/moving_variance' % idx], mv - (mv - var) * 0.01, rtol=2e-5)
 
 
-@pytest.mark.parametrize("opt", ["sgd", "rmsprop"])
-def test_training_steps_teacher_forced(opt):
-    """Four consecutive train_on_batch steps (BASELINE C1: Keras SGD momentum .9; reference
+@pytest.mark.parametrize("opt,B,n_steps", [("sgd", 8, 4), ("rmsprop", 8, 4), ("sgd", 64, 5)])
+def test_training_steps_teacher_forced(opt, B, n_steps):
+    """Consecutive train_on_batch steps (BASELINE configs[0] / C1: Keras SGD momentum .9 at ITS batch of 64; reference
     model.py:834: RMSprop 1e-3).  Training is chaotic across ReLU6 kinks and RMSprop's sign-like first
     steps, so the oracle is re-synchronised to the device weights before every step; what must hold
     at EVERY step: softmax 2e-5 (bar 1e-3), identical class indices, total loss (data + L2) 5e-5, all
@@ -140,9 +143,8 @@ def test_training_steps_teacher_forced(opt):
     applied to the device's own gradient."""
     ora, net = _pair()
     lr = 0.01 if opt == "sgd" else 1e-3
-    B = 8
     names = [k for k in ora.params]
-    for step in range(4):
+    for step in range(n_steps):
         w0 = net.get_weights()
         slots0 = net.slots.cpu().numpy()
         for k in names:
@@ -227,43 +229,19 @@ def test_tta_inference_matches_oracle():
 @pytest.mark.parametrize("B", [1, 50, 130])
 def test_first_convolution_kernels_at_awkward_batch_sizes(B):
     """conv1.hip at row counts that are not multiples of its 64-row tiles / 32-row units and where its statistics rows
-    (one per workgroup, up to 768) outnumber the generic kernel's (one per 128-row tile): a training step must still
-    match the same step taken through the generic gathered GEMMs bit for bit in its discrete outputs and to rounding in
-    the rest (the two paths differ only in summation order)."""
-    import os
-    import subprocess
-    import sys
-    code = (
-        "import numpy as np, torch, sys\n"
-        "from speech_recognition_amd import _lib\n"
-        "from speech_recognition_amd.net import DeviceNet\n"
-        "B = %d\n"
-        "net = DeviceNet(_lib.KWS_NET_TS_ATTENTION, 12)\n"
-        "net.initialize(seed=3)\n"
-        "rng = np.random.RandomState(B)\n"
-        "x = torch.from_numpy((rng.randn(B, 16000) * 0.0774).astype(np.float32)).cuda()\n"
-        "y = torch.eye(12)[torch.from_numpy(rng.randint(0, 12, B))].cuda().contiguous()\n"
-        "p = net.train_fwd_bwd(x, y, seed=5, step=1)\n"
-        "torch.cuda.synchronize()\n"
-        "g = net.grads.cpu().numpy()\n"
-        "np.save(sys.argv[1], np.concatenate([p.cpu().numpy().ravel(), g]))\n" % B)
-    outs = []
-    for env in ({}, {"KWS_CONV1_GENERIC": "1"}):
-        e = dict(os.environ)
-        e.update(env)
-        path = "/tmp/conv1_cmp_%d_%d.npy" % (B, len(env))
-        r = subprocess.run([sys.executable, "-c", code, path], env=e, capture_output=True, text=True, timeout=600,
-                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-        assert r.returncode == 0, r.stderr[-2000:]
-        outs.append(np.load(path))
-    a, b = outs
-    assert np.all(np.isfinite(a)) and np.all(np.isfinite(b))
-    scale = np.abs(b).max()
-    d = np.abs(a - b)
-    # a ReLU6 gate within rounding of its kink may open in one summation order and not in the other: isolated elements
-    # move by up to a gradient term, everything else agrees to f32 rounding
-    assert d.max() < 5e-2 * scale
-    assert np.percentile(d, 99.9) < 2e-3 * scale and np.median(d) < 1e-6 * scale
+    (one per workgroup, up to 768) outnumber a tile-per-row count: the whole training step against the float64 oracle
+    (B = 1: BatchNorm over a single clip's time steps; 50 x 399 and 130 x 399 rows end inside a tile and a unit)."""
+    ora, net = _pair()
+    x, y = _batch(B, 12, 100 + B)
+    probs = net.train_fwd_bwd(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(), seed=5, step=1)
+    torch.cuda.synchronize()
+    loss, p, grads, cache = _check_grads(ora, net, x, y, 5, 1, B, tol=1e-4)
+    got = probs.cpu().numpy()
+    assert np.abs(got - p).max() < 2e-5
+    assert np.array_equal(got.argmax(1), p.argmax(1))
+    y0 = net.debug_view(B, 0, 0).reshape(B, 399, 128)            # the first convolution's own output, pre-BN
+    ref0 = cache['bn1'][0]
+    assert np.abs(y0 - ref0.reshape(y0.shape)).max() < 2e-5 * max(1.0, np.abs(ref0).max())
 
 
 @pytest.mark.parametrize("split", [1, 6, 10])

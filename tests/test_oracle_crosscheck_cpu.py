@@ -179,3 +179,18 @@ def test_path_a_dct_matches_scipy():
         ortho = scipy_fft.dct(x, type=2, norm="ortho", axis=-1)[:, :keep]
         np.testing.assert_allclose(ours[:, 1:], ortho[:, 1:], atol=1e-12)
         np.testing.assert_allclose(ours[:, 0], ortho[:, 0] * np.sqrt(2.0), atol=1e-12)
+
+
+@pytest.mark.parametrize("path", ["B", "A"])
+def test_batched_f32_feature_path_of_the_cpu_baseline_matches_the_float64_oracle(path):
+    """oracle.features.features_batched (bench.py's CPU baseline B2: scipy.fft.rfft(workers) + two GEMMs, float32) computes
+    what features() computes in float64 - the baseline times the right arithmetic."""
+    rng = np.random.RandomState(11)
+    t = np.arange(16000) / 16000.0
+    x = (rng.randn(6, 16000) * 0.0774 + 0.05 * np.sin(2 * np.pi * 600 * t)[None]).astype(np.float32)
+    tables = OF.tables_path_b(480, 80, 60) if path == "B" else OF.tables_path_a(480, 16000, 40, 40)
+    ref = OF.features(x.astype(np.float64), tables, 160)
+    for workers in (1, 2):
+        got = OF.features_batched(x, tables, 160, workers=workers)
+        assert got.shape == ref.shape and got.dtype == np.float32
+        assert np.abs(got - ref).max() < 2e-3          # the device kernels' own bar (tests/test_kernels_gpu.py)

@@ -2,7 +2,7 @@
 products and f32 accumulation per matrix instruction, three bf16 parts / six products and two scaled fp16 parts / three
 products are as close to float64 as f32 operands with f32 accumulation - over activations, tiny gradients, heavy tails
 and operands whose elements are orders of magnitude apart.  (The device kernels are held to the same comparison against
-the f32-MFMA kernels in tests/test_bf16x3_gpu.py and tests/test_f16x2_gpu.py.)"""
+the f32-MFMA kernels in tests/test_f16x2_gpu.py.)"""
 import os
 import sys
 
