@@ -105,8 +105,8 @@ def cpu_baselines(budget_s=30.0):
 
       B1  reference-style generator: ONE clip per call, float64 batch buffer, augment -> STFT -> |X| -> mel -> log ->
           DCT (input_data.py:457-536), single thread like the reference's generator;
-      B2  the same features batched: scipy.fft.rfft(workers) over [B*98, 512], mel and DCT as one GEMM each, float32, at the
-          best of a few thread counts (its GB/s stands next to the GPU STFT stage's);
+      B2  the same features batched: scipy.fft.rfft over frame matrices, mel and DCT as one GEMM each, float32, cache-sized
+          chunks on a pool of worker threads, at the best of a few worker counts (its GB/s stands next to the GPU STFT stage's);
       B3  the model step on CPU: forward + backward + optimizer of the 12-class raw-waveform net at batch 64 through
           torch-CPU (oneDNN; oracle/torch_net.py), Keras-SGD(momentum) and RMSprop, at the best of a few thread counts;
       B4  end to end: the B1 generator feeding B3 through a depth-10 queue (Keras fit_generator's default) - the number
@@ -145,16 +145,17 @@ def cpu_baselines(budget_s=30.0):
             n += 16
         out["B1_generator_" + name] = {"value": n / (time.time() - t0), "unit": "clips/s", "cores": 1,
                                        "sample": "%d clips, one per call" % n}
-    # ---- B2: batched features: ONE scipy.fft.rfft(workers) over [B * 98, 512] + one GEMM each for
-    # mel and DCT, float32; the thread count is chosen like B3's: the best of a few ------------------------------------
-    clips = np.stack([_cpu_clip(OF, rng, bank, noise) for _ in range(256)])
+    # ---- B2: batched features: scipy.fft.rfft over [clips * 98, 512] frame matrices + one GEMM each
+    # for mel and DCT, float32, in cache-sized chunks of 16 clips dealt to a pool of worker threads (BLAS pinned to one
+    # thread per worker); the worker count is chosen like B3's thread count: the best of a few ---------------------------
+    clips = np.stack([_cpu_clip(OF, rng, bank, noise) for _ in range(1024)])
     best2 = None
     try:
         from threadpoolctl import threadpool_limits
     except Exception:
         threadpool_limits = None
     for thr in sorted(set([min(ncpu, t) for t in (1, 8, 16, 32, 64)])):
-        with (threadpool_limits(limits=thr) if threadpool_limits else contextlib.nullcontext()):
+        with (threadpool_limits(limits=1) if threadpool_limits else contextlib.nullcontext()):
             OF.features_batched(clips, tables, 160, workers=thr)
             n, t0 = 0, time.time()
             while n < 2 * len(clips) or time.time() - t0 < share / 10:
@@ -165,8 +166,9 @@ def cpu_baselines(budget_s=30.0):
             best2 = (rate, thr, n)
     out["B2_batched_features"] = {"value": best2[0], "unit": "clips/s", "cores": best2[1],
                                   "GBps_algorithmic": best2[0] * (64000 + 98 * 60 * 4) / 1e9,
-                                  "sample": "%d clips in batches of 256: scipy.fft.rfft(workers=%d) over [B*98, 512] + mel GEMM + "
-                                            "log + DCT GEMM, float32 (oracle.features.features_batched)" % (best2[2], best2[1])}
+                                  "sample": "%d clips in batches of 1024: %d worker threads x chunks of 16 clips, scipy.fft.rfft over "
+                                            "[16*98, 512] + mel GEMM + log + DCT GEMM, float32 (oracle.features.features_batched)"
+                                            % (best2[2], best2[1])}
     # ---- B3: model step, torch-CPU ---------------------------------------------------------------------------
     B = 64
     x = (rng.randn(B, 16000) * 0.0774).astype(np.float32)

@@ -6,7 +6,10 @@ from speech_recognition_amd import _lib
 from speech_recognition_amd.features import path_b_tables
 lib = _lib.load()
 S = _lib.stream_ptr()
-for (B, n_mel, n_out) in [(1024, 80, 60), (2048, 40, 40), (8192, 80, 60)]:
+cases = [(1024, 80, 60), (2048, 40, 40), (8192, 80, 60)]
+if len(sys.argv) > 1:                     # e.g. `bench_stft.py 1024,80,60`: one case only (the PMC passes)
+    cases = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]]
+for (B, n_mel, n_out) in cases:
     t = path_b_tables(480, n_mel, n_out)
     plan = ctypes.c_void_p()
     _lib.check(lib.kws_stft_plan_create(480, 160, 512, n_mel, n_out, t['window'].ctypes.data_as(ctypes.c_void_p),

@@ -19,7 +19,12 @@ MOVING statistics (momentum 0.99): for the first ~300 steps they lag
 both runs validate at chance (measured: val_loss 2.487 = ln 12 on both sides after 120 steps while the training
 accuracy is already 0.94; over 500 steps val_loss climbs in step on both sides - 2.49 / 2.51 / 2.59 / 2.83 device,
 2.49 / 2.52 / 2.60 / 2.87 CPU - and then collapses to 0.55 within one epoch, which the two chaotic trajectories reach
-an epoch apart), hence the default of 10 x 100 steps, by which both have converged.
+an epoch apart), hence the default of 12 x 100 steps, by which both have converged.  The reference ends its runs on a
+reduced learning rate (train.py:62-63: ReduceLROnPlateau(factor 0.5, patience 4); its logged series halve 1e-3 down to
+6e-5, fixture K3); a 12-epoch run never waits out a patience of 4, so BOTH sides take the same fixed schedule here: 1e-3,
+then one halving per epoch over the last three epochs.  With the weights slowing down the BatchNorm moving statistics
+catch up and the inference-mode accuracy of either side stops hopping by a class between epochs (at a constant 1e-3 the
+CPU twin ended repeated runs at 1.000 / 0.93 / 0.92 on the held-out partition).
 
 The oracle is used here as the CHECKER (this script is measurement / test infrastructure, like bench.cpu_baseline).
 usage:  python scripts/val_acc_parity.py [--epochs 3] [--steps 40] [--batch 64] [--json out.json]
@@ -60,8 +65,14 @@ class Recorder(object):
     next = __next__
 
 
-def run(device=None, epochs=10, steps=100, batch=64, val_batches=8, bank=4096, quiet=False, cpu_threads=None):
+def lr_of_epoch(epoch, epochs, base=1e-3, tail=3):
+    """the schedule of both sides: base, then one halving per epoch over the last `tail` epochs (ReduceLROnPlateau's factor)"""
+    return base * 0.5 ** max(0, epoch - (epochs - tail) + 1)
+
+
+def run(device=None, epochs=12, steps=100, batch=64, val_batches=8, bank=4096, quiet=False, cpu_threads=None):
     import bench
+    from speech_recognition_amd.keras_api import Callback
     from oracle.net import TimeSlicedAttentionNet
     from oracle.torch_net import TorchTimeSlicedNet
     from speech_recognition_amd.callbacks import ConfusionMatrixCallback
@@ -89,8 +100,12 @@ def run(device=None, epochs=10, steps=100, batch=64, val_batches=8, bank=4096, q
         ora = TimeSlicedAttentionNet(num_classes=settings['label_count'], dtype=np.float32)
         model.net.set_weights(dict(ora.params, **ora.state))          # both runs start from the same weights
         cb = ConfusionMatrixCallback(val, val_batches, wanted_words=words, all_words=words, label2int=proc.word_to_index)
+
+        class Schedule(Callback):
+            def on_epoch_begin(self, epoch, logs=None):
+                self.model.optimizer.lr.value = np.float32(lr_of_epoch(epoch, epochs))
         t0 = time.time()
-        hist = model.fit_generator(train, steps_per_epoch=steps, epochs=epochs, verbose=0, callbacks=[cb],
+        hist = model.fit_generator(train, steps_per_epoch=steps, epochs=epochs, verbose=0, callbacks=[Schedule(), cb],
                                    max_queue_size=1)
         torch.cuda.synchronize()
         t_dev = time.time() - t0
@@ -113,7 +128,7 @@ def run(device=None, epochs=10, steps=100, batch=64, val_batches=8, bank=4096, q
         for s in range(steps):
             k = e * steps + s
             X, y = batches[k]
-            _, a = twin.train_step(X, y, 1e-3, seed=model.seed, step=k)
+            _, a = twin.train_step(X, y, float(np.float32(lr_of_epoch(e, epochs))), seed=model.seed, step=k)
             accs.append(a)
         cpu_train_acc.append(float(np.mean(accs)))
         vb = val.batches[e * val_batches:(e + 1) * val_batches]
@@ -149,7 +164,7 @@ def run(device=None, epochs=10, steps=100, batch=64, val_batches=8, bank=4096, q
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--epochs", type=int, default=10)
+    ap.add_argument("--epochs", type=int, default=12)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--val-batches", type=int, default=8)

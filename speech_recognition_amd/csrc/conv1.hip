@@ -69,22 +69,35 @@ __global__ __launch_bounds__(256, 3) void conv1_fwd_kernel(Conv1Args p) {
   __shared__ float sRed[2][2][NOUT];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
   const int wr = wave >> 1, wc = wave & 1;
+  // Fold on load.  Every tap's candidate is requested unconditionally (the address of a tap that does not reach sample s is
+  // that of a zero buffer) and the taps are added in tap order: the 24 loads of a K group are in flight together.  Written as
+  // `for (j < taps) if (inside) w += W[..]` the compiler made 80 loops of load -> s_waitcnt vmcnt(0) -> add: ~120 DEPENDENT
+  // L2 round trips per lane before the first MFMA of every one of the 768 workgroups (round 3: 126 -> see DESIGN.md section 5).
   float wreg[NQ][4][2];
 #pragma unroll
-  for (int q = 0; q < NQ; ++q)
+  for (int q = 0; q < NQ; ++q) {
+    float wv[3][4][2];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          const int sidx = q * 8 + lh * 4 + r, n = wc * 64 + jj * 32 + li;
+          const int c = sidx - p.hop * j;
+          const bool ok = j < p.taps && c >= 0 && c < p.cin;
+          const float* src = ok ? p.W + ((int64_t)j * p.cin + c) * NOUT + n : g_zero64;
+          wv[j][r][jj] = *src;
+        }
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
-        // the kernel rows that hit sample s, added in tap order (what net.hip's fold_taps_kernel computes)
-        const int sidx = q * 8 + lh * 4 + r, n = wc * 64 + jj * 32 + li;
-        float w = 0.f;
-        for (int j = 0; j < p.taps; ++j) {
-          const int c = sidx - p.hop * j;
-          if (c >= 0 && c < p.cin) w += p.W[((int64_t)j * p.cin + c) * NOUT + n];
-        }
-        wreg[q][r][jj] = w;
-      }
+        wreg[q][r][jj] = ((0.f + wv[0][r][jj]) + wv[1][r][jj]) + wv[2][r][jj];   // = fold_taps_kernel's order
+        asm volatile("" : "+v"(wreg[q][r][jj]));    // folded HERE: one K group's 24 candidates live at a time (hoisted across
+      }                                             // the groups, the 240 loads spilled)
+    __builtin_amdgcn_sched_barrier(0);
+  }
   const int srow = tid >> 2, sq = tid & 3;
   float2 ra[NL];
   auto load_rows = [&](int tile) {
@@ -351,6 +364,7 @@ bool kws_conv1_supported(const kws_gather_t* g, int N) {
 int kws_conv1_fwd(const float* x, const kws_gather_t* g, const kws_gather_t* unfolded, const float* W, float* y, int B, int N,
                   float* stats, hipStream_t st) {
   KWS_REQUIRE(x && g && unfolded && W && y && B > 0 && kws_conv1_supported(g, N), "conv1_fwd: unsupported shape");
+  KWS_REQUIRE(unfolded->taps >= 1 && unfolded->taps <= 3, "conv1_fwd: %d taps (the fold-on-load prologue handles 1..3)", unfolded->taps);
   Conv1Args a{};
   a.x = x; a.W = W; a.y = y; a.stats = stats; a.g = *g; a.B = B; a.M = (int64_t)B * g->L_out;
   a.taps = unfolded->taps; a.cin = unfolded->cin; a.hop = unfolded->stride_j;

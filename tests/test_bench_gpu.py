@@ -35,7 +35,8 @@ def test_bench_two_ranks_print_one_json_line():
     assert out["train_loss_first_last"][0] == out["train_loss_first_last"][0]      # finite
     # the N > 1 line diagnoses itself: the gradient exchange alone, the split-overlap form of the same step, every rank's time
     ar = out["allreduce_only"]
-    assert ar["floats"] == 1191433 and ar["bytes"] == 4 * 1191433 and ar["us_per_allreduce"] > 0
+    # the flat gradient buffer: 1,191,433 trainable floats, each tensor padded to 16 bytes
+    assert 1191433 <= ar["floats"] <= 1191433 + 64 and ar["bytes"] == 4 * ar["floats"] and ar["us_per_allreduce"] > 0
     assert 0 < ar["pct_of_ms_per_step"] and ar["algorithmic_bus_GBps"] > 0
     sp = out["ab_allreduce_split"]
     assert sp["split_block"] == 6 and sp["ms_per_step"] > 0 and sp["value"] > 0 and 0.3 < sp["vs_one_buffer"] < 3.0

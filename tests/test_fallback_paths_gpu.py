@@ -28,6 +28,9 @@ def test_train_step_on_fallback_shapes_matches_oracle(kw, B):
     ora, net = _pair(**kw)
     L = kw.get("input_size", 16000)
     x, y = _batch(B, 12, 7 + B, L=L)
+    pr = net.predict(torch.from_numpy(x).cuda()).cpu().numpy()          # the inference program on the same shapes (before the
+    ref = ora.forward(x.astype(np.float64), training=False)              # training step moves the BN moving statistics)
+    assert np.abs(pr - ref).max() < 1e-5 and np.array_equal(pr.argmax(1), ref.argmax(1))
     probs = net.train_fwd_bwd(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(), seed=99, step=2)
     torch.cuda.synchronize()
     loss, p, grads, cache = _check_grads(ora, net, x, y, 99, 2, B, tol=1e-4)
@@ -35,9 +38,6 @@ def test_train_step_on_fallback_shapes_matches_oracle(kw, B):
     assert np.abs(got - p).max() < 2e-5
     assert np.array_equal(got.argmax(1), p.argmax(1))
     assert abs(float(net.metrics.cpu().numpy()[0]) / B - loss) < 2e-5
-    pr = net.predict(torch.from_numpy(x).cuda()).cpu().numpy()          # the inference program on the same shapes
-    ref = ora.forward(x.astype(np.float64), training=False)
-    assert np.abs(pr - ref).max() < 1e-5 and np.array_equal(pr.argmax(1), ref.argmax(1))
 
 
 def _features(plan, dx, B, L, width):
