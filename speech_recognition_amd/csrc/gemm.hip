@@ -19,6 +19,7 @@
 #include "common.h"
 #include "internal.h"
 
+#include <algorithm>
 #include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -954,7 +955,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs p) {
 //              loader wave x % NLW, written into LDS during the stage before it is used and re-issued
 //              (buffer loads, SGPR row offsets, descriptor range check zero-fills rows past the split)
 //              right after, so each load has about a full stage to land.
-// Host-checked: K % BKO == 0, N % BNO == 0, chunk % 128 == 0, 32-bit byte offsets inside a split.
+// Host-checked: K % BKO == 0, N % BNO == 0, chunk = whole stages (32 U rows), 32-bit byte offsets inside a split.
 template <int BKO, int BNO>
 __global__ __launch_bounds__((4 + ((128 / BKO) * (128 / BNO) > 2 ? 4 : 2)) * 64, 1) void gemm_tn_ws_kernel(TNArgs p) {
   constexpr int WK = BKO / 64, WN = BNO / 64, WS = 4 / (WK * WN);
@@ -1267,6 +1268,27 @@ struct TNPlan {
 };
 // ws: the wave-specialised kernel (tile width chosen per dimension); otherwise the 4-wave kernel (square tiles)
 bool tn_ws_eligible(int K, int N, bool gather) { return !gather && K % 64 == 0 && N % 64 == 0; }
+// How M is cut into splits.  A work item = (output tile, split); the kernel deals split s to XCD s % 8 (all tiles of a split
+// re-read the same row panels: one L2), an XCD has 32 CUs, and a CU holds one workgroup (two for the 64 KB 128 x 128 kernel).
+// Round 2 took S = 512 / tiles: for 256 -> 320 that is 49 splits = 7 on XCD 0 and 6 on the others - 70 items on one XCD's 32
+// CUs is THREE rounds where 60 is two, and the launch ran 126 us instead of 85 (320 -> 320: 75 against 50 items, 135 against
+// 91 us; in-kernel stamps and rocprofv3 agree, profiles/r03_tn_plan.txt).  The split size is now searched: every candidate
+// (whole stages of the tile shape) is priced as the busiest XCD's items per CU x (stages x cycles per stage + the fixed
+// cost of an item: first loads, epilogue) + the slab sum's traffic, and the cheapest wins.
+int64_t tn_cost(int64_t M, int K, int N, int tiles, int U, int64_t chunk, int* S_out) {
+  const int64_t S = ceil_div64(M, chunk);
+  const int64_t stages = ceil_div64(chunk, 32 * U);
+  const int64_t t_stage = U == 1 ? 4370 : (U == 2 ? 4870 : 4550);   // measured shader cycles per stage (64 MFMAs per wave)
+  int64_t worst = 0;
+  for (int x = 0; x < NXCD; ++x) {
+    const int64_t cnt = x < S ? (S - x + NXCD - 1) / NXCD : 0;
+    const int64_t per_cu = ceil_div64(tiles * cnt, 32);
+    const int64_t t = per_cu * (stages * t_stage + 4500);
+    if (t > worst) worst = t;
+  }
+  *S_out = (int)S;
+  return worst + (int64_t)((double)S * K * N * 4.0 * 0.8e-3) + 6000;   // + slab sum: bytes at ~2.5 TB/s, one launch
+}
 TNPlan tn_plan(int64_t M, int K, int N, bool ws) {
   TNPlan pl;
   if (ws) {
@@ -1278,22 +1300,35 @@ TNPlan tn_plan(int64_t M, int K, int N, bool ws) {
   pl.k_tiles = ceil_div(K, pl.bko);
   pl.n_tiles = ceil_div(N, pl.bno);
   const int tiles = pl.k_tiles * pl.n_tiles;
-  int64_t S;
-  if (ws) {
-    // the work items (tile, split) should fill whole residency rounds: 2 workgroups per CU for the 64 KB
-    // 128x128 kernel, 1 per CU for the others; ~512 items measured best (768 leaves half-empty rounds)
-    S = 512 / tiles;                    // floor: tiles * S <= 512 = 1 round of 512 slots or 2 rounds of 256
-  } else {
-    S = ceil_div64(768, tiles);         // 4-wave kernel: ~3 workgroups per CU in flight
+  if (!ws) {
+    // 4-wave kernel (gathered operands, ragged widths): ~3 workgroups per CU in flight
+    int64_t S = ceil_div64(768, tiles);
+    if (S > 256) S = 256;               // bounds the partial-slab traffic (S * K * N floats)
+    const int64_t maxS = M / 256 > 1 ? M / 256 : 1;
+    if (S > maxS) S = maxS;
+    int64_t chunk = ceil_div64(ceil_div64(M, S), 128) * 128;
+    if (chunk < 128) chunk = 128;
+    pl.chunk = chunk;
+    pl.S = (int)ceil_div64(M > 0 ? M : 1, chunk);
+    return pl;
   }
-  if (S > 256) S = 256;                 // bounds the partial-slab traffic (S * K * N floats); 512 measured slower
-  const int64_t maxS = M / 256 > 1 ? M / 256 : 1;
-  if (S > maxS) S = maxS;
-  if (S < 1) S = 1;
-  int64_t chunk = ceil_div64(ceil_div64(M, S), 128) * 128;   // whole stages of every tile shape (32 / 64 / 128 rows)
-  if (chunk < 128) chunk = 128;
-  pl.chunk = chunk;
-  pl.S = (int)ceil_div64(M > 0 ? M : 1, chunk);
+  const int U = 4 / ((pl.bko / 64) * (pl.bno / 64));   // 32-row units per stage of the wave-specialised kernel
+  const int64_t g = 32 * U;
+  const int64_t s_lo = std::max<int64_t>(1, ceil_div64(M, 256 * g));   // S <= 256: bounds the slab traffic
+  int64_t best = -1, best_chunk = s_lo * g;
+  const int64_t max_chunk = ((1ll << 31) - 1) / (4ll * (K > N ? K : N));   // 32-bit byte offsets inside a split's buffer views
+  for (int64_t st = s_lo; st < s_lo * 16 + 64; ++st) {
+    if (st * g > max_chunk && st > s_lo) break;
+    int S = 0;
+    const int64_t c = tn_cost(M, K, N, tiles, U, st * g, &S);
+    if (best < 0 || c < best) {
+      best = c;
+      best_chunk = st * g;
+    }
+    if (S <= 1) break;
+  }
+  pl.chunk = best_chunk;
+  pl.S = (int)ceil_div64(M > 0 ? M : 1, best_chunk);
   return pl;
 }
 
@@ -1388,8 +1423,11 @@ int launch_nn(const NNArgs& a0, hipStream_t st) {
 template <bool GATHER>
 int launch_tn(TNArgs a, float* dW, hipStream_t st) {
   bool ws_ok = tn_ws_eligible(a.K, a.N, GATHER);
-  const TNPlan pl = tn_plan(a.M, a.K, a.N, ws_ok);
-  ws_ok = ws_ok && pl.chunk * (int64_t)(a.K > a.N ? a.K : a.N) * 4 < (1ll << 31);   // 32-bit offsets inside a split
+  TNPlan pl = tn_plan(a.M, a.K, a.N, ws_ok);
+  if (ws_ok && pl.chunk * (int64_t)(a.K > a.N ? a.K : a.N) * 4 >= (1ll << 31)) {   // 32-bit offsets inside a split
+    ws_ok = false;                                     // (a split of > 1 M rows: M > 2^28): the 4-wave kernel and ITS plan
+    pl = tn_plan(a.M, a.K, a.N, false);
+  }
   a.chunk = pl.chunk;
   a.k_tiles = pl.k_tiles;
   a.n_tiles = pl.n_tiles;
