@@ -10,9 +10,10 @@
 //   * forward: persistent workgroups hold the folded [80, 128] kernel in REGISTERS for all their tiles (see the kernel),
 //     next tile's rows in flight in registers while the current one is multiplied; one BN statistics row per workgroup;
 //   * weight gradient: dW[80, 128] = A^T G split over M into one slab per workgroup (fixed-order slab sum afterwards),
-//     32-row units; wave w owns output columns [32 w, 32 w + 32) x 96 rows (3 MFMA blocks, rows 80..95 multiply LDS zeros).
+//     32-row units; wave w owns output columns [32 w, 32 w + 32) x 80 rows (ten 16 x 16 accumulators, v_mfma_f32_16x16x4_f32).
 //     Measured alone at batch 1024: 64-row units with A and G in LDS and one workgroup per CU 157 us, 32-row units two
-//     per CU 127 us, G straight into registers and three per CU 111 us (the generic gathered kernel: 156 us).
+//     per CU 127 us, G straight into registers and three per CU 111 us (the generic gathered kernel: 156 us) - those with
+//     three 32 x 32 blocks per wave whose rows 80..95 multiplied LDS zeros; round 3 see the kernel.
 // Three things the compiler had to be told (each visible in the ISA): selecting between a row pointer and a `const`
 // zero buffer makes the loads FLAT loads (the zero buffer is a plain __device__ array); the next tile's global loads
 // sink below the MFMA loop unless a memory clobber pins them; the LDS operand reads are issued one pair at a time with
@@ -204,26 +205,32 @@ __global__ __launch_bounds__(256, 3) void conv1_fwd_kernel(Conv1Args p) {
   }
 }
 
-// Weight gradient.  dy goes from global memory STRAIGHT into the MFMA operand registers: lane (li, lh) of wave w needs
-// dy[m][32 w + li] for the 16 rows m = 8 q + 4 lh + r of a 32-row unit - per (q, r) the wave reads two rows x 32 consecutive
-// floats, and every dy element is read by exactly one wave.  Only the Toeplitz rows of x pass through LDS (25.6 KB double
-// buffered -> three workgroups per CU).
+// Weight gradient.  dy goes from global memory STRAIGHT into the MFMA operand registers and only the Toeplitz rows of x pass
+// through LDS (20.5 KB double buffered -> three workgroups per CU).  Round 3: v_mfma_f32_16x16x4_f32 instead of 32x32x2 - the
+// 80 folded kernel rows are FIVE 16-row blocks exactly, where three 32-row blocks multiplied 16 rows of LDS zeros (one MFMA
+// cycle in six); a wave owns 32 output columns = two column blocks x five row blocks = ten accumulators of 16 x 16.
+//   A (x rows)   lane (i = lane % 16, k = lane / 16): sA[row 4 s + k][16 rb + i] of K step s - row pitch 80 floats = 16 banks
+//                mod 32, so the four rows of a read fall on disjoint bank halves;
+//   B (dy)       lane (k, j = lane % 16): dy[m0 + 4 s + k][32 w + 2 j + cb] - ONE 8-byte load per K step feeds both column
+//                blocks (block cb = the columns of parity cb: 16 lanes read 128 contiguous bytes of a row);
+//   D            register v of block (rb, cb): dW[16 rb + 4 (lane / 16) + v][32 w + 2 j + cb] - the two blocks leave as 8-byte stores.
 template <int KF>
 __global__ __launch_bounds__(256, 3) void conv1_wgrad_kernel(Conv1Args p) {
-  constexpr int PA = 100;           // 96 columns (3 MFMA row blocks of dW) + 4; columns KF..95 stay zero
+  constexpr int PA = KF;            // row pitch of the staged rows: 80 = 16 mod 32 banks
   constexpr int TPR = 256 / UM;     // A-staging threads per row
   constexpr int QF = KF / TPR;      // floats per A-staging thread
-  constexpr int NQ = UM / 8;
-  static_assert(KF % (2 * TPR) == 0, "8-byte staging loads");
+  constexpr int NS = UM / 4;        // K steps (4 rows each) per unit
+  constexpr int RB = KF / 16;       // row blocks of dW
+  static_assert(KF % 16 == 0 && KF % (2 * TPR) == 0, "whole 16-row blocks, 8-byte staging loads");
   constexpr int NL = QF / 2;
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
   __shared__ float sA[2][UM * PA];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
-  for (int i = tid; i < 2 * UM * PA; i += 256) (&sA[0][0])[i] = 0.f;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l16 = lane & 15, lk = lane >> 4;
   const int64_t m_begin = (int64_t)blockIdx.x * p.chunk;
   const int64_t m_end = m_begin + p.chunk < p.M ? m_begin + p.chunk : p.M;
   const int arow = tid / TPR, aq = tid % TPR;
   float2 ra[NL];
-  float g_cur[NQ][4], g_nxt[NQ][4];
+  float2 g_cur[NS], g_nxt[NS];
   auto load_unit = [&](int64_t mb) {
     const int64_t m = mb + arow;
     const bool row_ok = m < m_end;
@@ -240,13 +247,11 @@ __global__ __launch_bounds__(256, 3) void conv1_wgrad_kernel(Conv1Args p) {
       for (int i = 0; i < NL; ++i) ra[i] = load2_or_zero(xb, e0 + 2 * i, p.g.x_len);
     }
 #pragma unroll
-    for (int q = 0; q < NQ; ++q)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int64_t gm = mb + q * 8 + lh * 4 + r;
-        const float* gsrc = gm < m_end ? p.G + gm * NOUT + wave * 32 + li : g_zero64;   // address select, not a branch
-        g_nxt[q][r] = *gsrc;
-      }
+    for (int s2 = 0; s2 < NS; ++s2) {
+      const int64_t gm = mb + 4 * s2 + lk;
+      const float* gsrc = gm < m_end ? p.G + gm * NOUT + wave * 32 + 2 * l16 : g_zero64;   // address select, not a branch
+      g_nxt[s2] = *reinterpret_cast<const float2*>(gsrc);
+    }
   };
   auto store_unit = [&](int buf) {
     float* dst = &sA[buf][arow * PA + aq * QF];
@@ -255,16 +260,13 @@ __global__ __launch_bounds__(256, 3) void conv1_wgrad_kernel(Conv1Args p) {
   };
   auto take_g = [&]() {
 #pragma unroll
-    for (int q = 0; q < NQ; ++q)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) g_cur[q][r] = g_nxt[q][r];
+    for (int s2 = 0; s2 < NS; ++s2) g_cur[s2] = g_nxt[s2];
   };
-  f32x16 acc[3];
+  f32x4 acc[RB][2];
 #pragma unroll
-  for (int j = 0; j < 3; ++j)
+  for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-    for (int v = 0; v < 16; ++v) acc[j][v] = 0.f;
-  __syncthreads();   // zero fill done before the first rows land
+    for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (m_begin < m_end) {
     load_unit(m_begin);
     store_unit(0);
@@ -276,29 +278,24 @@ __global__ __launch_bounds__(256, 3) void conv1_wgrad_kernel(Conv1Args p) {
     const bool has_next = mb + UM < m_end;
     if (has_next) load_unit(mb + UM);
     asm volatile("" ::: "memory");   // keep the next unit's loads above the MFMA loop
-    const float* cA = &sA[buf][(lh * 4) * PA + li];
-    float a_cur[4][3], a_nxt[4][3];   // software-pipelined LDS reads, as in the forward kernel
+    const float* cA = &sA[buf][lk * PA + l16];
+    float a_cur[RB], a_nxt[RB];       // software-pipelined LDS reads: one K step ahead
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int rb = 0; rb < RB; ++rb) a_cur[rb] = cA[16 * rb];
 #pragma unroll
-      for (int j = 0; j < 3; ++j) a_cur[r][j] = cA[r * PA + j * 32];
+    for (int s2 = 0; s2 < NS; ++s2) {
+      if (s2 + 1 < NS) {
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      if (q + 1 < NQ) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int j = 0; j < 3; ++j) a_nxt[r][j] = cA[((q + 1) * 8 + r) * PA + j * 32];
+        for (int rb = 0; rb < RB; ++rb) a_nxt[rb] = cA[(4 * (s2 + 1)) * PA + 16 * rb];
       }
       __builtin_amdgcn_sched_barrier(0);   // the reads above stay above the MFMAs below
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
+      for (int rb = 0; rb < RB; ++rb) {
+        acc[rb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[rb], g_cur[s2].x, acc[rb][0], 0, 0, 0);
+        acc[rb][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[rb], g_cur[s2].y, acc[rb][1], 0, 0, 0);
+      }
 #pragma unroll
-        for (int j = 0; j < 3; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[r][j], g_cur[q][r], acc[j], 0, 0, 0);
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) a_cur[r][j] = a_nxt[r][j];
+      for (int rb = 0; rb < RB; ++rb) a_cur[rb] = a_nxt[rb];
     }
     if (has_next) {
       store_unit(buf ^ 1);
@@ -309,11 +306,11 @@ __global__ __launch_bounds__(256, 3) void conv1_wgrad_kernel(Conv1Args p) {
   }
   float* slab = p.ws + (int64_t)blockIdx.x * KF * NOUT;
 #pragma unroll
-  for (int j = 0; j < 3; ++j)
+  for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-    for (int v = 0; v < 16; ++v) {
-      const int k = j * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh;
-      if (k < KF) slab[k * NOUT + wave * 32 + li] = acc[j][v];
+    for (int v = 0; v < 4; ++v) {
+      const int k = 16 * rb + 4 * lk + v;
+      *reinterpret_cast<float2*>(slab + k * NOUT + wave * 32 + 2 * l16) = make_float2(acc[rb][0][v], acc[rb][1][v]);
     }
 }
 
