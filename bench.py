@@ -527,6 +527,14 @@ def main():
                 if e is not None:
                     stages.append(e)
             roof = stages[0] if stages and stages[0]["family"] == "gemm_nn" else None
+            # the weight-gradient GEMMs' slab sums run as ONE batched launch per step ("slab_sum"): priced into their family
+            ss = prof.get("slab_sum")
+            for e in stages:
+                if e["family"] == "gemm_tn" and ss and ss["count"] > 0:
+                    us = e["avg_launch_us"] + 1e3 * ss["ms"] / e["launches"]
+                    e["slab_sum_us_per_step"] = 1e3 * ss["ms"] / ss["count"]
+                    e["avg_launch_us_incl_slab_sum"] = us
+                    e["frac_incl_slab_sum"] = e["algorithmic_flops_per_launch"] / (us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS
     # ---- N > 1: what the gradient exchange costs, and the split-overlap form of the same step -----
     exchange = None
     ab = {}

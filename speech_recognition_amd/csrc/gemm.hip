@@ -1260,6 +1260,48 @@ __global__ __launch_bounds__(256) void transpose_batch_kernel(TransposeBatch b) 
   }
 }
 
+// The slab sums of SEVERAL weight-gradient GEMMs in one launch (net.hip: the eleven pointwise layers of a training step wrote
+// their slabs into regions of their own; summing them per layer cost fourteen 5 - 10 us launches on the dependency chain).
+// One workgroup = 64 float4 columns of one GEMM; 4 slab groups (k = grp, grp + 4, ...) with four loads in flight each,
+// combined in a fixed order: bit-reproducible.
+struct SlabBatch {
+  const float* ws[KWS_SLAB_BATCH];
+  float* out[KWS_SLAB_BATCH];
+  int64_t n4[KWS_SLAB_BATCH];
+  int S[KWS_SLAB_BATCH], blk_end[KWS_SLAB_BATCH];
+  int n;
+};
+__device__ __forceinline__ void add4(float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+__global__ __launch_bounds__(256) void reduce_slabs_batch_kernel(SlabBatch b) {
+  __shared__ float4 red[4][64];
+  int m = 0;
+  while (m + 1 < b.n && (int)blockIdx.x >= b.blk_end[m]) ++m;
+  const int t = blockIdx.x - (m ? b.blk_end[m - 1] : 0);
+  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int64_t n4 = b.n4[m];
+  const int S = b.S[m];
+  const int64_t i = (int64_t)t * 64 + col;
+  const float4* w = reinterpret_cast<const float4*>(b.ws[m]);
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+  if (i < n4) {
+    int k = grp;
+    for (; k + 12 < S; k += 16) {
+      const float4 v0 = w[(int64_t)k * n4 + i], v1 = w[(int64_t)(k + 4) * n4 + i];
+      const float4 v2 = w[(int64_t)(k + 8) * n4 + i], v3 = w[(int64_t)(k + 12) * n4 + i];
+      add4(s0, v0); add4(s1, v1); add4(s2, v2); add4(s3, v3);
+    }
+    for (; k < S; k += 4) add4(s0, w[(int64_t)k * n4 + i]);
+    add4(s0, s1); add4(s2, s3); add4(s0, s2);
+  }
+  red[grp][col] = s0;
+  __syncthreads();
+  if (grp == 0 && i < n4) {
+    float4 r = red[0][col];
+    add4(r, red[1][col]); add4(r, red[2][col]); add4(r, red[3][col]);
+    reinterpret_cast<float4*>(b.out[m])[i] = r;
+  }
+}
+
 // split heuristic of the TN kernel: enough workgroups to fill 256 CUs, slabs no larger than needed
 struct TNPlan {
   int bko, bno;  // 128 or 64 each
@@ -1420,8 +1462,9 @@ int launch_nn(const NNArgs& a0, hipStream_t st) {
   return KWS_OK;
 }
 
+// dW == nullptr: the slabs only (the caller sums them later: kws_reduce_slabs_batch); *S_out = how many were written
 template <bool GATHER>
-int launch_tn(TNArgs a, float* dW, hipStream_t st) {
+int launch_tn(TNArgs a, float* dW, hipStream_t st, int* S_out = nullptr) {
   bool ws_ok = tn_ws_eligible(a.K, a.N, GATHER);
   TNPlan pl = tn_plan(a.M, a.K, a.N, ws_ok);
   if (ws_ok && pl.chunk * (int64_t)(a.K > a.N ? a.K : a.N) * 4 >= (1ll << 31)) {   // 32-bit offsets inside a split
@@ -1444,6 +1487,8 @@ int launch_tn(TNArgs a, float* dW, hipStream_t st) {
     hipLaunchKernelGGL((gemm_tn_kernel<64, 64, GATHER>), g, b, 0, st, a);
   }
   KWS_LAUNCH_CHECK("gemm_tn_kernel");
+  if (S_out) *S_out = pl.S;
+  if (dW == nullptr) return KWS_OK;
   const int64_t n4 = (int64_t)a.K * a.N / 4;
   hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)ceil_div64(n4, 64)), dim3(256), 0, st, a.ws, dW, n4, pl.S,
                      (int64_t)-1, 0, (int64_t)0);
@@ -1515,6 +1560,36 @@ int kws_gemm_tn_f32(const float* A, const float* G, float* dW, int64_t M, int K,
   a.A = A; a.G = G; a.ws = workspace; a.M = M; a.K = K; a.N = N;
   KwsProfScope prof("gemm_tn", 2.0 * M * K * N, 4.0 * ((double)M * K + (double)M * N + (double)K * N), (hipStream_t)stream);
   return launch_tn<false>(a, dW, (hipStream_t)stream);
+}
+
+// internal (net.hip): the weight-gradient GEMM WITHOUT its slab sum - workspace (kws_gemm_tn_workspace_floats) receives *S slabs
+// of [K, N]; kws_reduce_slabs_batch sums the slabs of several such calls in one launch
+int kws_gemm_tn_slabs_f32(const float* A, const float* G, int64_t M, int K, int N, float* workspace, int* S, hipStream_t stream) {
+  KWS_REQUIRE(A && G && workspace && S, "gemm_tn_slabs: NULL pointer");
+  KWS_REQUIRE(M > 0 && K > 0 && N > 0 && K % 4 == 0 && N % 4 == 0, "gemm_tn_slabs: M=%lld K=%d N=%d", (long long)M, K, N);
+  TNArgs a{};
+  a.A = A; a.G = G; a.ws = workspace; a.M = M; a.K = K; a.N = N;
+  KwsProfScope prof("gemm_tn", 2.0 * M * K * N, 4.0 * ((double)M * K + (double)M * N + (double)K * N), stream);
+  return launch_tn<false>(a, nullptr, stream, S);
+}
+
+int kws_reduce_slabs_batch(const float* const* ws, float* const* out, const int64_t* n, const int* S, int count, hipStream_t stream) {
+  KWS_REQUIRE(ws && out && n && S && count > 0 && count <= KWS_SLAB_BATCH, "reduce_slabs_batch: bad arguments (count=%d)", count);
+  SlabBatch b;
+  int blocks = 0;
+  double bytes = 0;
+  for (int i = 0; i < count; ++i) {
+    KWS_REQUIRE(ws[i] && out[i] && n[i] > 0 && n[i] % 4 == 0 && S[i] > 0, "reduce_slabs_batch: bad entry %d", i);
+    b.ws[i] = ws[i]; b.out[i] = out[i]; b.n4[i] = n[i] / 4; b.S[i] = S[i];
+    blocks += (int)ceil_div64(n[i] / 4, 64);
+    b.blk_end[i] = blocks;
+    bytes += 4.0 * n[i] * (S[i] + 1);
+  }
+  b.n = count;
+  KwsProfScope prof("slab_sum", 0.0, bytes, stream);
+  hipLaunchKernelGGL(reduce_slabs_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, b);
+  KWS_LAUNCH_CHECK("reduce_slabs_batch_kernel");
+  return KWS_OK;
 }
 
 int kws_gemm_tn_gather_f32(const float* X, const kws_gather_t* g, const float* G, float* dW, int B, int N,

@@ -39,6 +39,12 @@ extern "C" int kws_bn_bwd_apply_amax(float* g, const float* y, const float* bn, 
                                      int64_t rows, int C, unsigned* amax, hipStream_t stream);
 extern "C" int kws_dwconv_bwd_acc_f32(const float* dz, const float* y, const float* w, const float* add, float* g, float* part,
                                       int B, int L_in, int L_out, int C, int stride, int pad_l, hipStream_t st);
+// gemm.hip: the weight-gradient GEMM without its slab sum, and the slab sums of several of them in one launch
+constexpr int KWS_SLAB_BATCH = 16;
+extern "C" int kws_gemm_tn_slabs_f32(const float* A, const float* G, int64_t M, int K, int N, float* workspace, int* S,
+                                     hipStream_t stream);
+extern "C" int kws_reduce_slabs_batch(const float* const* ws, float* const* out, const int64_t* n, const int* S, int count,
+                                      hipStream_t stream);
 constexpr int KWS_TRANSPOSE_BATCH = 16;
 extern "C" int kws_transpose_batch_f32(const float* const* in, float* const* out, const int* rows, const int* cols, int n,
                                        hipStream_t stream);

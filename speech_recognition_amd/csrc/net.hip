@@ -175,6 +175,7 @@ struct Layout {
   std::vector<int64_t> z;   // z[i], i = 0..10
   int64_t G = 0, G2 = 0, DZ = 0, bn = 0, part = 0, coef = 0, tn = 0, red = 0, swg = 0;
   std::vector<int64_t> WT;  // transposed pointwise kernel of block i (dgrad GEMM operand)
+  std::vector<int64_t> tns; // weight-gradient slabs of block i: a region of its own, summed for all blocks in ONE launch
   std::vector<int64_t> WPf, WPd;  // fp16 x 2 arm: fp16 planes [2][cout][cin] (forward) / [2][cin][cout] (input gradient)
   int64_t amax;                   // fp16 x 2 arm: 3 nb slot groups of |x| maxima: W[i] | z[i] | dy[i + 1]
   int64_t xd = 0, fd = 0, dl1 = 0, dl2 = 0, per_loss = 0, per_correct = 0, att = 0;
@@ -233,6 +234,9 @@ void make_layout(const kws_net* n, int B, bool training, Layout* lo) {
     }
     lo->amax = bp.take((int64_t)3 * nb * KWS_ABSMAX_WORDS);
     lo->tn = bp.take(max_tn);
+    lo->tns.assign(nb, 0);
+    for (int i = 0; i < nb; ++i)
+      lo->tns[i] = bp.take(kws_gemm_tn_workspace_floats((int64_t)B * n->blocks[i].Lout, n->blocks[i].cin, n->blocks[i].cout));
     lo->xd = bp.take((int64_t)B * n->T * n->C);
     lo->fd = bp.take((int64_t)B * 2 * n->C);
     lo->dl1 = bp.take((int64_t)B * n->T);
@@ -555,6 +559,12 @@ static int ts_train(const kws_net_t* net, const float* params, float* state, con
   // The f32 dgrad GEMMs read the pointwise kernels transposed (the fp16 arm too, for the layers it hands back)
   if (run_head) KWS_TRY(transpose_all());
   float* Gb[2] = {ws + lo.G, ws + lo.G2};          // gradient wrt y[l] lives in Gb[l % 2]; the tail wrote Gb[nb % 2]
+  // the f32 weight-gradient GEMMs leave their slabs in per-block regions; ONE launch sums them when this call's blocks are done
+  const float* sl_ws[KWS_SLAB_BATCH];
+  float* sl_out[KWS_SLAB_BATCH];
+  int64_t sl_n[KWS_SLAB_BATCH];
+  int sl_S[KWS_SLAB_BATCH], n_sl = 0;
+  KWS_REQUIRE(nb <= KWS_SLAB_BATCH, "net: %d blocks exceed the slab batch", nb);
   const int i_hi = phase == 2 ? split - 1 : nb - 1, i_lo = phase == 1 ? split : 0;
   for (int i = i_hi; i >= i_lo; --i) {
     const Block& b = net->blocks[i];
@@ -572,8 +582,11 @@ static int ts_train(const kws_net_t* net, const float* params, float* state, con
       KWS_TRY(kws_gemm_nn_f32(Gcur, ws + lo.WT[i], DZ, M, b.cout, b.cin, nullptr, st));
     if (h2 && kws_gemm_tn_f16x2_supported(M, b.cin, b.cout))
       KWS_TRY(kws_gemm_tn_f16x2_f32(ws + lo.z[i], Gcur, grads + b.pw, M, b.cin, b.cout, z_slots(i), g_slots(i), ws + lo.tn, st));
-    else
-      KWS_TRY(kws_gemm_tn_f32(ws + lo.z[i], Gcur, grads + b.pw, M, b.cin, b.cout, ws + lo.tn, st));
+    else {
+      sl_ws[n_sl] = ws + lo.tns[i]; sl_out[n_sl] = grads + b.pw; sl_n[n_sl] = (int64_t)b.cin * b.cout;
+      KWS_TRY(kws_gemm_tn_slabs_f32(ws + lo.z[i], Gcur, M, b.cin, b.cout, ws + lo.tns[i], &sl_S[n_sl], st));
+      ++n_sl;
+    }
     const BnRef& prev = (i == 0) ? net->bn1 : net->blocks[i - 1].bn;
     // depthwise backward + BatchNorm backward of this block's input without materialising the masked
     // gradient: reduce, fold (dw, dgamma, dbeta, c1 | c2), recompute and write dy of the previous block
@@ -585,6 +598,7 @@ static int ts_train(const kws_net_t* net, const float* params, float* state, con
     KWS_TRY(kws_dwconv_bwd_bn_amax_f32(DZ, ws + lo.y[i], bn_at(i), params + b.dw, coef, Gnext, nullptr, 2, B, b.Lin, b.Lout,
                                        b.cin, b.stride, b.pad_l, (h2 && i > 0) ? g_slots(i - 1) : nullptr, st));
   }
+  if (n_sl > 0) KWS_TRY(kws_reduce_slabs_batch(sl_ws, sl_out, sl_n, sl_S, n_sl, st));   // (a part's gradients are final when it returns)
   if (phase != 1) {
     const int64_t M = (int64_t)B * net->L1;
     (void)M;                                        // Gb[0] already holds dy of the first convolution
