@@ -632,6 +632,13 @@ def main():
             us = 1e3 * e0.elapsed_time(e1) / 20
             for e in stages:
                 if e["family"] == "stft_mel":
+                    # floors of the PRESENT kernel structure: HBM = algorithmic bytes at 8 TB/s;
+                    # vector issue = the ISA census of a frame quad (435 FMA-class x 1.9 + 117 conversions / DPP / selects x 3.0 +
+                    # 22 sqrt / log x 5.8 + 33 MFMA x 8 cycles of held issue = 1,776 cycles) x quads per SIMD at 2.1 GHz
+                    quads = B * 25.0
+                    e["stage_floor_us"] = {"hbm": e["algorithmic_bytes_per_launch"] / PEAK_HBM_GBS / 1e3,
+                                           "vector_issue": 1776.0 * quads / 1024.0 / 2.1e3,
+                                           "source": "profiles/r03_stft4_isa_per_quad_before_rewrite.txt x profiles/r02_probe_valu_rates.txt"}
                     e["alone_avg_launch_us"] = us
                     e["alone_frac_hbm"] = e["algorithmic_bytes_per_launch"] / (us * 1e-6) / 1e9 / PEAK_HBM_GBS
                     e["alone_frac_flops"] = e["algorithmic_flops_per_launch"] / (us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS
