@@ -465,8 +465,14 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
           for (int t = 0; t < CH; ++t)
             if (t0 + t < mci) {
               wv[t] = *reinterpret_cast<const float4*>(wp + 4 * (t0 + t));
+              if (NB >= 5) {                     // the windows start on even bins (stft.hip): 8-byte reads
+                const float2 m01 = *reinterpret_cast<const float2*>(mp + 4 * (t0 + t));
+                const float2 m23 = *reinterpret_cast<const float2*>(mp + 4 * (t0 + t) + 2);
+                mv[t][0] = m01.x; mv[t][1] = m01.y; mv[t][2] = m23.x; mv[t][3] = m23.y;
+              } else {
 #pragma unroll
-              for (int r = 0; r < 4; ++r) mv[t][r] = mp[4 * (t0 + t) + r];
+                for (int r = 0; r < 4; ++r) mv[t][r] = mp[4 * (t0 + t) + r];
+              }
             }
 #pragma unroll
           for (int t = 0; t < CH; ++t)
@@ -603,8 +609,9 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
 
 }  // namespace
 
-// instantiated band shapes: 80 mel bins over 257 bins (input_data.py:366-373 as train.py sets it: blocks 1, 1, 2, 3, 4),
-// 40 mel bins (2, 5, 8), and the same lane counts with every group at the widest width; anything else declines (the generic kernel of stft.hip)
+// instantiated band shapes (four-tap blocks per lane group): 80 mel bins over 257 bins (input_data.py:366-373 as train.py sets it,
+// windows starting on even bins: 1, 2, 2, 3, 4), 40 mel bins (2, 5, 8; audio.py's 40 bands fit: 1, 3, 4), and the same lane counts
+// with every group at the widest width; anything else declines (the generic kernel of stft.hip)
 static int stft4_shape(const kws_stft_plan* pl) {
   if (pl->mel_maxw <= 0) return 0;
   const int nb = (pl->n_mel + 15) / 16;
@@ -615,7 +622,7 @@ static int stft4_shape(const kws_stft_plan* pl) {
       if (pl->mel_mc[i++] > v) return false;
     return true;
   };
-  if (fits({1, 1, 2, 3, 4})) return 1;
+  if (fits({1, 2, 2, 3, 4})) return 1;
   if (fits({4, 4, 4, 4, 4})) return 2;
   if (fits({2, 5, 8})) return 3;
   if (fits({8, 8, 8})) return 4;
@@ -649,7 +656,7 @@ int kws_stft4_prepare(kws_stft_plan* pl) {
   pl->img4 = nullptr;
   const int sh = stft4_shape(pl);
   if (sh == 0 || pl->n_mel % 4 != 0) return KWS_OK;                  // stft4 declines this plan: nothing to prepare
-  if (sh == 1) return stft4_image_t<5, 4, 0x43211>(pl);
+  if (sh == 1) return stft4_image_t<5, 4, 0x43221>(pl);
   if (sh == 2) return stft4_image_t<5, 4, 0x44444>(pl);
   if (sh == 3) return stft4_image_t<3, 8, 0x852>(pl);
   return stft4_image_t<3, 8, 0x888>(pl);
@@ -689,7 +696,7 @@ int kws_stft4_launch(const kws_stft_plan* pl, const float* x, int B, int L, int 
   a.x = x; a.out = out; a.B = B; a.L = L; a.F = F;
   a.quads_per_clip = (F + 3) / 4;
   a.total_quads = (int64_t)B * a.quads_per_clip;
-  if (sh == 1) return stft4_launch_t<5, 4, 0x43211>(a, st);
+  if (sh == 1) return stft4_launch_t<5, 4, 0x43221>(a, st);
   if (sh == 2) return stft4_launch_t<5, 4, 0x44444>(a, st);
   if (sh == 3) return stft4_launch_t<3, 8, 0x852>(a, st);
   return stft4_launch_t<3, 8, 0x888>(a, st);
