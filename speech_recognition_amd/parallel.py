@@ -24,8 +24,8 @@ def init_from_env(backend=None):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
     if backend is None:
-        # KWS_DIST_BACKEND / KWS_ONE_DEVICE: test hooks - N ranks on ONE GPU over gloo (a 1-GPU box cannot run RCCL x N)
-        backend = os.environ.get("KWS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        # KWS_ONE_DEVICE: the test hook - N ranks on ONE GPU, over gloo (a 1-GPU box cannot run RCCL x N)
+        backend = "nccl" if torch.cuda.is_available() and not os.environ.get("KWS_ONE_DEVICE") else "gloo"
     if os.environ.get("KWS_ONE_DEVICE"):
         local_rank = 0
     kw = {}

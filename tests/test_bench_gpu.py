@@ -106,7 +106,7 @@ def test_tta_inference_sharded_over_two_ranks_matches_one_rank(tmp_path):
         if world == 1:
             cmd = [sys.executable, script, "5003"]
         else:
-            env.update(KWS_DIST_BACKEND="gloo", KWS_ONE_DEVICE="1")
+            env.update(KWS_ONE_DEVICE="1")
             cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                    "127.0.0.1", "--master-port", "29549", script, "5003"]
         res = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)

@@ -256,7 +256,7 @@ def test_prediction_caller_tta_inference(dataset, repo_root):
 
 def test_training_caller_on_two_data_parallel_ranks(dataset, repo_root, tmp_path):
     """The same caller under torch.distributed.run with two ranks (both on the one GPU over gloo - the hooks
-    KWS_DIST_BACKEND / KWS_ONE_DEVICE; an N-GPU node runs RCCL): gradients are all-reduced every step, replicas are
+    KWS_ONE_DEVICE; an N-GPU node runs RCCL): gradients are all-reduced every step, replicas are
     synchronised at fit start and at every epoch end, and ONLY rank 0 writes the checkpoints, the scalar log and the
     confusion-matrix files.  Both ranks must end with the same validation numbers."""
     import shutil
@@ -264,7 +264,7 @@ def test_training_caller_on_two_data_parallel_ranks(dataset, repo_root, tmp_path
     work.mkdir()
     os.symlink(str(dataset / 'data'), str(work / 'data'))
     shutil.copy(str(dataset / 'train_caller.py'), str(work / 'train_caller.py'))
-    env = dict(os.environ, PYTHONPATH=repo_root, KWS_DIST_BACKEND="gloo", KWS_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, PYTHONPATH=repo_root, KWS_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
