@@ -1,4 +1,4 @@
-"""NumPy study behind the two split-GEMM arms (csrc/gemm_bf16x3.hip, csrc/gemm_f16x2.hip): how close to the float64
+"""NumPy study behind the split-GEMM arms (csrc/gemm_f16x2.hip, and round 2's bf16 x 3 arm, removed in round 3): how close to the float64
 product are
   * f32 operands with f32 accumulation (what an f32 matrix pipe does),
   * three bf16 parts per operand, six products (lo.hi, hi.lo, mid.mid, mid.hi, hi.mid, hi.hi),

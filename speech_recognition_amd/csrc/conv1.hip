@@ -21,6 +21,12 @@
 // __builtin_amdgcn_sched_barrier (168 -> 157 us).
 #include "internal.h"
 
+// -DKWS_C1_ABL=<bits> builds (timing only, wrong results) of conv1_fwd_kernel: without 1 the output stores, 2 the BN statistics
+// sums, 4 the MFMAs, 8 the global row loads
+#ifndef KWS_C1_ABL
+#define KWS_C1_ABL 0
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -133,7 +139,7 @@ __global__ __launch_bounds__(256, 3) void conv1_fwd_kernel(Conv1Args p) {
   for (; tile < p.m_tiles; tile += gridDim.x) {
     const int next = tile + gridDim.x;
     const bool has_next = next < p.m_tiles;
-    if (has_next) load_rows(next);
+    if (has_next && !(KWS_C1_ABL & 8)) load_rows(next);
     asm volatile("" ::: "memory");   // the loads are issued HERE (the scheduler otherwise sinks them below the MFMA loop)
     f32x16 acc[2];
 #pragma unroll
@@ -154,13 +160,18 @@ __global__ __launch_bounds__(256, 3) void conv1_fwd_kernel(Conv1Args p) {
       for (int r = 0; r < 4; ++r) {
         const float a = r == 0 ? ac.x : (r == 1 ? ac.y : (r == 2 ? ac.z : ac.w));
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj) acc[jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wreg[q][r][jj], acc[jj], 0, 0, 0);
+        for (int jj = 0; jj < 2; ++jj) {
+          if (KWS_C1_ABL & 4) { acc[jj][(q * 4 + r) & 15] += a * wreg[q][r][jj]; continue; }
+          acc[jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wreg[q][r][jj], acc[jj], 0, 0, 0);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
     // epilogue: a store instruction covers 2 rows x 32 consecutive columns (two 128-byte segments)
     const int64_t m0 = (int64_t)tile * FM + wr * 32 + 4 * lh;
-    if ((int64_t)(tile + 1) * FM <= p.M) {   // whole tile inside: no per-row test
+    if (KWS_C1_ABL & 1) {
+      if (acc[0][0] == 123.456f) p.y[m0] = acc[1][5];
+    } else if ((int64_t)(tile + 1) * FM <= p.M) {   // whole tile inside: no per-row test
       float* y0 = p.y + m0 * NOUT + wc * 64 + li;
 #pragma unroll
       for (int v = 0; v < 16; ++v)
@@ -177,7 +188,7 @@ __global__ __launch_bounds__(256, 3) void conv1_fwd_kernel(Conv1Args p) {
         }
       }
     }
-    if (STATS) {   // rows past M were staged as zeros: they add nothing
+    if (STATS && !(KWS_C1_ABL & 2)) {   // rows past M were staged as zeros: they add nothing
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj)
 #pragma unroll

@@ -1,9 +1,9 @@
 // STFT -> |X| -> mel -> log -> DCT feature kernel, fourth generation (reference
 // input_data.py:361-381, audio.py:15-23).
 //
-// The third kernel (stft2.hip: stft3_kernel) is bound by vector-instruction issue at 2 waves per SIMD: both radix-16
-// passes of the 16 x 16 Cooley-Tukey split run on the vector pipe, the passes are joined by a transpose through LDS,
-// and 94 registers per lane hold FFT constants.  Here the FIRST pass is a matrix product on the matrix pipe:
+// Round 1's kernel (stft3_kernel, removed in round 3) was bound by vector-instruction issue at 2 waves per SIMD: both
+// radix-16 passes of the 16 x 16 Cooley-Tukey split ran on the vector pipe, joined by a transpose through LDS, with 94
+// registers per lane of FFT constants.  Here the FIRST pass is a matrix product on the matrix pipe:
 //
 //   z[m] = w x[2m] + i w x[2m+1],  m = 16 n1 + n2,  Z[k1 + 16 k2] = sum_n2 W256^(n2 k1) W16^(n2 k2) Y[k1][n2]
 //   Y[k1][n2] = sum_n1 z[16 n1 + n2] W16^(n1 k1)                      <- 16-point DFTs over n1 = [rows x 32] x [32 x 32]
@@ -57,7 +57,7 @@ extern "C" int kws_debug_read_stft_stamps(unsigned long long* out) {
 namespace {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int DSTR4 = 80;           // DCT table row stride (floats), as in stft3
+constexpr int DSTR4 = 80;           // DCT table row stride (floats)
 constexpr int MAGF = 260;           // floats of one frame's magnitude row
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));

@@ -1,4 +1,4 @@
-// Device helpers shared by the register-FFT feature kernels (stft2.hip: stft2_kernel / stft3_kernel, stft4.hip).
+// Device helpers of the register-FFT feature kernel (stft4.hip): complex arithmetic, the in-register 16-point FFT, launch arguments.
 #pragma once
 #include "internal.h"
 
