@@ -315,6 +315,12 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
       }
   };
   __syncthreads();                                  // tables copied, rows zeroed, counter at zero
+  // the eight split factors of the lane stay in registers for all its quads (16 of the 40 the budget of three waves per SIMD
+  // leaves: 48.0 -> 47.5 us; the twiddles in registers as well - 4 / 8 / 12 of the 15 - bought nothing more and cost the
+  // 40-band instance its occupancy)
+  float2 r_w5[8];
+#pragma unroll
+  for (int k2 = 0; k2 < 8; ++k2) r_w5[k2] = s_w5[k2 * 16 + l16];
   ST_DECL
   int64_t cur = grab_value(grab_issue());
   if (cur < q_hi) issue_loads(cur);
@@ -414,9 +420,7 @@ __global__ __launch_bounds__(NW4 * 64, 1) void stft4_kernel(Stft2Args a) {
 #pragma unroll
         for (int n2 = 0; n2 < 16; ++n2) KEEP2(z[n2]);
       } else {
-      float2 w5[8];                                   // all eight split factors requested before the first use
-#pragma unroll
-      for (int k2 = 0; k2 < 8; ++k2) w5[k2] = s_w5[k2 * 16 + l16];
+      const float2 (&w5)[8] = r_w5;
 #pragma unroll
       for (int k2 = 0; k2 < 8; ++k2) {
         const float2 pa = z[15 - k2], pb = z[(16 - k2) & 15];
