@@ -45,6 +45,40 @@ extern "C" int kws_gemm_tn_slabs_f32(const float* A, const float* G, int64_t M, 
                                      hipStream_t stream);
 extern "C" int kws_reduce_slabs_batch(const float* const* ws, float* const* out, const int64_t* n, const int* S, int count,
                                       hipStream_t stream);
+extern "C" int64_t kws_gemm_tn_workspace_floats(int64_t M, int K, int N);
+// The weight-gradient GEMMs of one backward pass, their slab sums deferred: gemm() launches the GEMM into the next piece of
+// `base` (cap floats: the sum of the calls' kws_gemm_tn_workspace_floats, each rounded up to 64) and flush() sums the slabs
+// of up to KWS_SLAB_BATCH of them in one launch.  A gradient is final only after the flush that follows its gemm().
+struct KwsSlabQueue {
+  const float* ws[KWS_SLAB_BATCH];
+  float* out[KWS_SLAB_BATCH];
+  int64_t n[KWS_SLAB_BATCH];
+  int S[KWS_SLAB_BATCH];
+  int count = 0;
+  float* base = nullptr;
+  int64_t used = 0, cap = 0;
+  int flush(hipStream_t st) {
+    if (count == 0) return 0;
+    const int rc = kws_reduce_slabs_batch(ws, out, n, S, count, st);
+    count = 0;
+    used = 0;           // the pieces are free again: later GEMMs follow the sum in stream order
+    return rc;
+  }
+  int gemm(const float* A, const float* G, float* dW, int64_t M, int K, int N, hipStream_t st) {
+    const int64_t need = (kws_gemm_tn_workspace_floats(M, K, N) + 63) / 64 * 64;
+    if (count == KWS_SLAB_BATCH || used + need > cap) {
+      const int rc = flush(st);
+      if (rc) return rc;
+    }
+    if (need > cap) return KWS_E_WORKSPACE;   // (the layout reserved the sum of all calls: unreachable)
+    ws[count] = base + used; out[count] = dW; n[count] = (int64_t)K * N;
+    const int rc = kws_gemm_tn_slabs_f32(A, G, M, K, N, base + used, &S[count], st);
+    if (rc) return rc;
+    used += need;
+    ++count;
+    return 0;
+  }
+};
 constexpr int KWS_TRANSPOSE_BATCH = 16;
 extern "C" int kws_transpose_batch_f32(const float* const* in, float* const* out, const int* rows, const int* cols, int n,
                                        hipStream_t stream);

@@ -88,6 +88,7 @@ struct LmLayout {
   int64_t y0 = 0, a0 = 0;
   std::vector<int64_t> ys, z1, y1, z2, y2, o;
   int64_t bn = 0, bn_stride = 0, part = 0, red = 0, coef = 0, WT = 0, tn = 0, swg = 0;
+  int64_t tnq = 0, tnq_floats = 0;         // slabs of the pointwise weight gradients of one backward pass (KwsSlabQueue)
   int64_t dOa = 0, dOb = 0, G = 0, DZ = 0, DXS = 0;
   int64_t u = 0, fd = 0, dl = 0, gu = 0, coef2 = 0, per_loss = 0, per_correct = 0, att = 0;
   int64_t xpad = 0, wpad = 0, gwpad = 0;  // only when Fp != F (style 0) / always (style 1: padded first kernel)
@@ -113,6 +114,11 @@ void lm_layout(const kws_net* n, int B, LmLayout* lo) {
     max_wt = std::max(max_wt, (int64_t)K * N);
     max_tn = std::max(max_tn, kws_gemm_tn_workspace_floats(M, K, N));
   };
+  int64_t sum_tnq = 0;                     // the pointwise weight gradients keep their slabs until one batched sum
+  auto upd_pw = [&](int64_t M, int K, int N) {
+    upd_gemm(M, K, N);
+    sum_tnq += (kws_gemm_tn_workspace_floats(M, K, N) + 63) / 64 * 64;
+  };
   upd_gemm((int64_t)B * p.L0, p.style == 1 ? p.K0p : 3 * p.Fp, p.C0);
   if (p.style == 3) {
     upd_gemm((int64_t)B * p.L0, p.g0r.taps * p.g0r.cin, p.Cr);
@@ -125,7 +131,7 @@ void lm_layout(const kws_net* n, int B, LmLayout* lo) {
     lo->yc = bp.take((int64_t)B * p.L0 * p.C0);
     lo->ac = bp.take((int64_t)B * p.L0 * p.C0);
     max_z = (int64_t)B * p.L0 * p.C0;
-    upd_gemm((int64_t)B * p.L0, p.C0, p.C0);
+    upd_pw((int64_t)B * p.L0, p.C0, p.C0);
     max_part = std::max(max_part, kws_dwconv_bwd_part_floats(B, p.L0, p.C0));
   }
   for (int i = 0; i < nb; ++i) {
@@ -140,8 +146,8 @@ void lm_layout(const kws_net* n, int B, LmLayout* lo) {
     max_y = std::max(max_y, (int64_t)B * b.Lmid * b.nf);
     max_z = std::max(max_z, std::max((int64_t)B * b.Lmid * b.cin, (int64_t)B * b.Lmid * b.nf));
     max_xs = std::max(max_xs, (int64_t)B * b.Lout * b.cin);
-    upd_gemm((int64_t)B * b.Lmid, b.cin, b.nf);
-    upd_gemm((int64_t)B * b.Lmid, b.nf, b.nf);
+    upd_pw((int64_t)B * b.Lmid, b.cin, b.nf);
+    upd_pw((int64_t)B * b.Lmid, b.nf, b.nf);
     if (b.has_short) upd_gemm((int64_t)B * b.Lout, b.cin, b.nf);
     max_part = std::max(max_part, kws_dwconv_bwd_part_floats(B, b.Lin, b.cin));
     max_part = std::max(max_part, kws_dwconv_bwd_part_floats(B, b.Lmid, b.nf));
@@ -157,7 +163,7 @@ void lm_layout(const kws_net* n, int B, LmLayout* lo) {
     max_y = std::max(max_y, (int64_t)B * q.Lout * q.cout);
     max_z = std::max(max_z, (int64_t)B * q.Lout * q.cin);
     max_o = std::max(max_o, std::max((int64_t)B * q.Lin * q.cin, (int64_t)B * q.Lout * q.cout));
-    upd_gemm((int64_t)B * q.Lout, q.cin, q.cout);
+    upd_pw((int64_t)B * q.Lout, q.cin, q.cout);
     max_part = std::max(max_part, kws_dwconv_bwd_part_floats(B, q.Lin, q.cin));
     max_part = std::max(max_part, kws_block_out_bwd_part_floats(B, q.Lout, q.cout, 1));
   }
@@ -180,6 +186,8 @@ void lm_layout(const kws_net* n, int B, LmLayout* lo) {
   for (size_t j = 0; j < p.plain.size(); ++j) lo->wt_plain[j] = bp.take((int64_t)p.plain[j].cin * p.plain[j].cout);
   if (p.style == 1) lo->wt_ctx = bp.take((int64_t)p.C0 * p.C0);
   lo->tn = bp.take(max_tn);
+  lo->tnq_floats = sum_tnq;
+  lo->tnq = bp.take(sum_tnq);
   lo->swg = bp.take((int64_t)KWS_SMALL_WGRAD_SLICES * feat * p.NC);
   lo->dOa = bp.take(max_o);
   lo->dOb = bp.take(max_o);
@@ -841,6 +849,8 @@ int lm_train(const kws_net* n, const float* params, float* state, const float* x
   float* DZ = ws + lo.DZ;
   float* dO = ws + lo.dOa;
   float* dX = ws + lo.dOb;
+  KwsSlabQueue sq;
+  sq.base = ws + lo.tnq; sq.cap = lo.tnq_floats;
   // ---- tail forward + backward ----
   if (p.style != 0) {
     kws_gp_tail_args g;
@@ -866,7 +876,7 @@ int lm_train(const kws_net* n, const float* params, float* state, const float* x
         KWS_TRY(kws_bn_bwd_apply(G, ws + lo.py[j], c.bn_at(q.bn_idx), params + q.bn.gamma, coef, M, q.cout, st));
       }  // else: G already holds dy of this block (pass 2 of the next block's depthwise backward)
       KWS_TRY(kws_gemm_nn_f32(G, ws + lo.wt_plain[j], DZ, M, q.cout, q.cin, nullptr, st));
-      KWS_TRY(kws_gemm_tn_f32(ws + lo.pz[j], G, grads + q.pw, M, q.cin, q.cout, ws + lo.tn, st));
+      KWS_TRY(sq.gemm(ws + lo.pz[j], G, grads + q.pw, M, q.cin, q.cout, st));
       const int np = (int)(kws_dwconv_bwd_part_floats(B, q.Lin, q.cin) / (5 * q.cin));
       if (j > 0) {
         const LmPlain& r = p.plain[j - 1];
@@ -911,7 +921,7 @@ int lm_train(const kws_net* n, const float* params, float* state, const float* x
     KWS_TRY(kws_dw_bwd_finalize(part, np, M, b.nf, nullptr, grads + b.bn2.gamma, grads + b.bn2.beta, coef, red, st));
     KWS_TRY(kws_bn_bwd_apply(G, ws + lo.y2[i], c.bn_at(b.bn2_idx), params + b.bn2.gamma, coef, M, b.nf, st));
     KWS_TRY(kws_gemm_nn_f32(G, ws + lo.wt_pw2[i], DZ, M, b.nf, b.nf, nullptr, st));
-    KWS_TRY(kws_gemm_tn_f32(ws + lo.z2[i], G, grads + b.pw2, M, b.nf, b.nf, ws + lo.tn, st));
+    KWS_TRY(sq.gemm(ws + lo.z2[i], G, grads + b.pw2, M, b.nf, b.nf, st));
     // depthwise 2 -> BN1 -> pointwise 1
     // (two passes over dz and y1 instead of "store g, then kws_bn_bwd_apply": the masked gradient is never stored)
     KWS_TRY(kws_dwconv_bwd_bn_f32(DZ, ws + lo.y1[i], c.bn_at(b.bn1_idx), params + b.dw2, nullptr, nullptr, part, 1, B,
@@ -921,7 +931,7 @@ int lm_train(const kws_net* n, const float* params, float* state, const float* x
     KWS_TRY(kws_dwconv_bwd_bn_f32(DZ, ws + lo.y1[i], c.bn_at(b.bn1_idx), params + b.dw2, coef, G, nullptr, 2, B, b.Lmid,
                                   b.Lmid, b.nf, 1, 1, st));
     KWS_TRY(kws_gemm_nn_f32(G, ws + lo.wt_pw1[i], DZ, M, b.nf, b.cin, nullptr, st));
-    KWS_TRY(kws_gemm_tn_f32(ws + lo.z1[i], G, grads + b.pw1, M, b.cin, b.nf, ws + lo.tn, st));
+    KWS_TRY(sq.gemm(ws + lo.z1[i], G, grads + b.pw1, M, b.cin, b.nf, st));
     // depthwise 1 on the (materialised) block input
     if (!b.has_short)   // identity shortcut: the join's other gradient is added while the depthwise input gradient is written
       KWS_TRY(kws_dwconv_bwd_acc_f32(DZ, xin, params + b.dw1, dO, dX, part, B, b.Lin, b.Lmid, b.cin, b.s1, b.pad1, st));
@@ -949,7 +959,7 @@ int lm_train(const kws_net* n, const float* params, float* state, const float* x
     KWS_TRY(kws_dw_bwd_finalize(part, np, M, p.C0, nullptr, grads + p.ctx_bn.gamma, grads + p.ctx_bn.beta, coef, red, st));
     KWS_TRY(kws_bn_bwd_apply(G, ws + lo.yc, c.bn_at(p.ctx_bn_idx), params + p.ctx_bn.gamma, coef, M, p.C0, st));
     KWS_TRY(kws_gemm_nn_f32(G, ws + lo.wt_ctx, DZ, M, p.C0, p.C0, nullptr, st));
-    KWS_TRY(kws_gemm_tn_f32(ws + lo.zc, G, grads + p.ctx_pw, M, p.C0, p.C0, ws + lo.tn, st));
+    KWS_TRY(sq.gemm(ws + lo.zc, G, grads + p.ctx_pw, M, p.C0, p.C0, st));
     KWS_TRY(kws_dwconv_bwd_f32(DZ, ws + lo.a0, nullptr, params + p.ctx_dw, dX, part, B, p.L0, p.L0, p.C0, 1, 1, st));
     np = (int)(kws_dwconv_bwd_part_floats(B, p.L0, p.C0) / (5 * p.C0));
     KWS_TRY(kws_dw_bwd_finalize(part, np, M, p.C0, grads + p.ctx_dw, nullptr, nullptr, nullptr, red, st));
@@ -971,8 +981,10 @@ int lm_train(const kws_net* n, const float* params, float* state, const float* x
       KWS_TRY(kws_bn_bwd_apply(G, sm.y, c.bn_at(sm.idx), params + sm.bn->gamma, coef, M, sm.C, st));
       KWS_TRY(kws_gemm_tn_gather_f32(x, sm.g, G, grads + sm.w, B, sm.C, ws + lo.tn, st));
     }
+    KWS_TRY(sq.flush(st));
     return KWS_OK;
   }
+  KWS_TRY(sq.flush(st));   // the pointwise weight gradients of the whole pass: one sum (two past 16 layers)
   // ---- first convolution ----
   {
     const int64_t M = (int64_t)B * p.L0;
