@@ -10,8 +10,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 layers = [(399, 128, 1), (397, 128, 2), (199, 192, 1), (197, 192, 2), (99, 256, 1), (97, 256, 2), (49, 320, 1), (47, 320, 2),
           (24, 384, 1), (22, 384, 2), (11, 512, 1)]
 S = _lib.stream_ptr()
-def timeit(fn, n=10):
-    fn(); torch.cuda.synchronize()
+def timeit(fn, n=30):
+    fn(); fn(); fn(); torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(n): fn()

@@ -32,6 +32,9 @@ __device__ __forceinline__ void st4_stream(float* p, float4 o) {
 
 
 constexpr int TT = 8;  // time steps per thread
+#ifndef DW_FWD_GRID
+#define DW_FWD_GRID 4096
+#endif
 
 __device__ __forceinline__ float4 f4_fma(float4 a, float4 b, float4 c) {
   return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
@@ -67,48 +70,39 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict
     const float4 w2 = *reinterpret_cast<const float4*>(w + 2 * C + c);
     const float* yb = y + b * (int64_t)Lin * C + c;
     float* zb = z + b * (int64_t)Lout * C + c;
-    // SAME padding pads the ACTIVATION with zeros: the load is unconditional (a branch per load would put a
-    // vmcnt(0) wait behind each one), out-of-range taps read position 0 and are zeroed after the activation
-    auto act = [&](int u) -> float4 {
-      const bool ok = u >= 0 && u < Lin;
-      float4 v = ld4_stream(yb + (int64_t)(ok ? u : 0) * C);
+    // SAME padding pads the ACTIVATION with zeros.  All NL input rows of the unit are loaded first - unconditionally, a row
+    // outside the clip reads row 0 and is zeroed after the activation - and then consumed (a load per step behind an
+    // "if (t >= Lout) break" left one or two loads in flight per wave; see dwconv_bwd_kernel)
+    constexpr int NL = S == 1 ? TT + 2 : 2 * TT + 1;
+    const int t0 = chunk * TT;
+    const int u_lo = S * t0 - pad_l;
+    float4 av[NL];
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      const int u = u_lo + k;
+      av[k] = ld4_stream(yb + (int64_t)(u >= 0 && u < Lin ? u : 0) * C);
+    }
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      const int u = u_lo + k;
+      float4 v = av[k];
       if (HAS_BN) {
         v.x = relu6f(fmaf(v.x, sc.x, sh.x));
         v.y = relu6f(fmaf(v.y, sc.y, sh.y));
         v.z = relu6f(fmaf(v.z, sc.z, sh.z));
         v.w = relu6f(fmaf(v.w, sc.w, sh.w));
       }
-      return ok ? v : f4_zero();
-    };
-    const int t0 = chunk * TT;
-    float4 a0 = f4_zero(), a1 = f4_zero(), a2;
+      av[k] = u >= 0 && u < Lin ? v : f4_zero();
+    }
 #pragma unroll
     for (int i = 0; i < TT; ++i) {
       const int t = t0 + i;
-      if (t >= Lout) break;
-      const int u = S * t - pad_l;
-      if (S == 1) {
-        if (i == 0) {
-          a0 = act(u);
-          a1 = act(u + 1);
-        }
-        a2 = act(u + 2);
-      } else {
-        if (i == 0) a0 = act(u);
-        a1 = act(u + 1);
-        a2 = act(u + 2);
-      }
-      float4 o = f4_mul(w0, a0);
-      o = f4_fma(w1, a1, o);
-      o = f4_fma(w2, a2, o);
+      if (t >= Lout) continue;
+      float4 o = f4_mul(w0, av[S * i]);
+      o = f4_fma(w1, av[S * i + 1], o);
+      o = f4_fma(w2, av[S * i + 2], o);
       st4_stream(zb + (int64_t)t * C, o);
       zmax = kws_abs4max(zmax, o);
-      if (S == 1) {
-        a0 = a1;
-        a1 = a2;
-      } else {
-        a0 = a2;
-      }
     }
   }
   if (amax) kws_absmax_commit(amax, zmax);
@@ -127,10 +121,19 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict
 // per block and step: 0.21 -> 0.185 ms of small kernels).  Pass 2 (MODE 2, no partial rows) keeps 256-thread workgroups:
 // measured with 1024 it streams 4 % slower (533 -> 556 us over the eleven layers).
 #ifndef DW_BWD_THREADS
-#define DW_BWD_THREADS 1024
+#define DW_BWD_THREADS 512
+#endif
+#ifndef DW_BWD_HT
+#define DW_BWD_HT 8      // positions per batch of loads (divides TT)
+#endif
+#ifndef DW_BWD2_THREADS
+#define DW_BWD2_THREADS 512
+#endif
+#ifndef DW_BWD_PARTS
+#define DW_BWD_PARTS 256
 #endif
 template <int S, bool HAS_BN, int MODE>
-__global__ __launch_bounds__(MODE == 2 ? 256 : DW_BWD_THREADS) void dwconv_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ y,
+__global__ __launch_bounds__(MODE == 2 ? DW_BWD2_THREADS : DW_BWD_THREADS) void dwconv_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ y,
                                                          const float* __restrict__ bn, const float* __restrict__ w,
                                                          const float* __restrict__ coef,
                                                          float* __restrict__ g, float* __restrict__ part, int B,
@@ -170,76 +173,90 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : DW_BWD_THREADS) void dwconv_bwd_k
     const float* yb = y + b * (int64_t)Lin * C + c;
     float* gb = g + b * (int64_t)Lin * C + c;
     const float* dzb = dz + b * (int64_t)Lout * C + c;
-    auto ldz = [&](int t) -> float4 {
-      if (t < 0 || t >= Lout) return f4_zero();
-      return ld4_stream(dzb + (int64_t)t * C);
-    };
     const int u0 = chunk * TT;
-    float4 d0 = f4_zero(), d1 = f4_zero(), d2 = f4_zero();  // dz at taps 0,1,2 of the current u
+    // The unit's TT positions in batches of HT: ALL loads of a batch are issued first - unconditionally, from clamped
+    // addresses, zeroed afterwards where the tap falls outside the clip - and only then consumed.  (Written as "load when
+    // inside, use, next position" the compiler put a vmcnt(0) wait behind every position's pair of loads: two 16-byte loads
+    // in flight per wave, eight dependent round trips per unit - 5.1 TB/s for pass 1 where the forward kernel streams 6.1.)
+    constexpr int HT = DW_BWD_HT;
+    constexpr int ND = S == 1 ? HT + 2 : HT / 2 + 2;  // dz rows a batch touches
+    const bool podd = (pad_l & 1) != 0;               // S == 2: parity of (u + pad_l) at the even positions of a batch
 #pragma unroll
-    for (int i = 0; i < TT; ++i) {
-      const int u = u0 + i;
-      if (u >= Lin) break;
-      const int base = u + pad_l;  // tap j reads dz[(base - j)/S] when divisible
-      if (S == 1) {
-        if (i == 0) {
-          d1 = ldz(base - 1);
-          d2 = ldz(base - 2);
+    for (int h = 0; h < TT / HT; ++h) {
+      const int ub = u0 + h * HT;                      // even (u0 is a multiple of TT)
+      if (ub >= Lin) break;
+      float4 yv[HT], D[ND];
+#pragma unroll
+      for (int i = 0; i < HT; ++i) yv[i] = ld4_stream(yb + (int64_t)(ub + i < Lin ? ub + i : ub) * C);
+      // S == 1: tap j of position u reads dz[u + pad_l - j]: rows ub + pad_l - 2 ... ub + pad_l + HT - 1
+      // S == 2: tap j reads dz[(u + pad_l - j) / 2] when that is whole: rows ((ub + pad_l) >> 1) - 1 ... + ND - 1
+      const int t_lo = S == 1 ? ub + pad_l - 2 : ((ub + pad_l) >> 1) - 1;
+#pragma unroll
+      for (int j = 0; j < ND; ++j) {
+        const int t = t_lo + j;
+        D[j] = ld4_stream(dzb + (int64_t)(t < 0 ? 0 : (t < Lout ? t : Lout - 1)) * C);
+      }
+#pragma unroll
+      for (int j = 0; j < ND; ++j) {
+        const int t = t_lo + j;
+        if (t < 0 || t >= Lout) D[j] = f4_zero();
+      }
+#pragma unroll
+      for (int i = 0; i < HT; ++i) {
+        const int u = ub + i;
+        if (u >= Lin) continue;
+        float4 d0, d1, d2;
+        if (S == 1) {
+          d0 = D[i + 2]; d1 = D[i + 1]; d2 = D[i];
+        } else if ((i & 1) == 0) {                     // u + pad_l even <=> !podd: taps 0 and 2; odd: tap 1
+          d0 = podd ? f4_zero() : D[i / 2 + 1];
+          d2 = podd ? f4_zero() : D[i / 2];
+          d1 = podd ? D[i / 2 + 1] : f4_zero();
         } else {
-          d2 = d1;
-          d1 = d0;
+          d0 = podd ? D[(i + 1) / 2 + 1] : f4_zero();
+          d2 = podd ? D[(i + 1) / 2] : f4_zero();
+          d1 = podd ? f4_zero() : D[(i - 1) / 2 + 1];
         }
-        d0 = ldz(base);
-      } else {
-        if ((base & 1) == 0) {
-          d0 = ldz(base >> 1);
-          d1 = f4_zero();
-          d2 = ldz((base >> 1) - 1);
-        } else {
-          d0 = f4_zero();
-          d1 = ldz((base - 1) >> 1);
-          d2 = f4_zero();
+        const float4 yy = yv[i];
+        float4 a = yy, mk = make_float4(1.f, 1.f, 1.f, 1.f), xh = f4_zero();
+        if (HAS_BN) {
+          const float4 pre = make_float4(fmaf(yy.x, sc.x, sh.x), fmaf(yy.y, sc.y, sh.y), fmaf(yy.z, sc.z, sh.z),
+                                         fmaf(yy.w, sc.w, sh.w));
+          a = make_float4(relu6f(pre.x), relu6f(pre.y), relu6f(pre.z), relu6f(pre.w));
+          mk = make_float4((pre.x > 0.f && pre.x <= 6.f) ? 1.f : 0.f, (pre.y > 0.f && pre.y <= 6.f) ? 1.f : 0.f,
+                           (pre.z > 0.f && pre.z <= 6.f) ? 1.f : 0.f, (pre.w > 0.f && pre.w <= 6.f) ? 1.f : 0.f);
+          xh = make_float4((yy.x - mean.x) * rstd.x, (yy.y - mean.y) * rstd.y, (yy.z - mean.z) * rstd.z,
+                           (yy.w - mean.w) * rstd.w);
         }
-      }
-      const float4 yv = ld4_stream(yb + (int64_t)u * C);
-      float4 a = yv, mk = make_float4(1.f, 1.f, 1.f, 1.f), xh = f4_zero();
-      if (HAS_BN) {
-        const float4 pre = make_float4(fmaf(yv.x, sc.x, sh.x), fmaf(yv.y, sc.y, sh.y), fmaf(yv.z, sc.z, sh.z),
-                                       fmaf(yv.w, sc.w, sh.w));
-        a = make_float4(relu6f(pre.x), relu6f(pre.y), relu6f(pre.z), relu6f(pre.w));
-        mk = make_float4((pre.x > 0.f && pre.x <= 6.f) ? 1.f : 0.f, (pre.y > 0.f && pre.y <= 6.f) ? 1.f : 0.f,
-                         (pre.z > 0.f && pre.z <= 6.f) ? 1.f : 0.f, (pre.w > 0.f && pre.w <= 6.f) ? 1.f : 0.f);
-        xh = make_float4((yv.x - mean.x) * rstd.x, (yv.y - mean.y) * rstd.y, (yv.z - mean.z) * rstd.z,
-                         (yv.w - mean.w) * rstd.w);
-      }
-      float4 da = f4_mul(w0, d0);
-      da = f4_fma(w1, d1, da);
-      da = f4_fma(w2, d2, da);
-      const float4 gv = f4_mul(da, mk);
-      if (MODE == 2) {
-        // same expression as bn_bwd_apply_kernel (bn.hip), with scale = gamma * rstd from the BN table
-        float4 o;
-        o.x = sc.x * (gv.x - c1.x - (yv.x - mean.x) * rstd.x * c2.x);
-        o.y = sc.y * (gv.y - c1.y - (yv.y - mean.y) * rstd.y * c2.y);
-        o.z = sc.z * (gv.z - c1.z - (yv.z - mean.z) * rstd.z * c2.z);
-        o.w = sc.w * (gv.w - c1.w - (yv.w - mean.w) * rstd.w * c2.w);
-        st4_stream(gb + (int64_t)u * C, o);
-        gmax = kws_abs4max(gmax, o);
-        continue;
-      }
-      if (MODE == 0) {
-        float4 o = gv;
-        if (coef != nullptr) {   // MODE 0 reuses `coef` as an optional tensor added to the input gradient (residual join)
-          const float4 ad = *reinterpret_cast<const float4*>(coef + (b * (int64_t)Lin + u) * C + c);
-          o = make_float4(o.x + ad.x, o.y + ad.y, o.z + ad.z, o.w + ad.w);
+        float4 da = f4_mul(w0, d0);
+        da = f4_fma(w1, d1, da);
+        da = f4_fma(w2, d2, da);
+        const float4 gv = f4_mul(da, mk);
+        if (MODE == 2) {
+          // same expression as bn_bwd_apply_kernel (bn.hip), with scale = gamma * rstd from the BN table
+          float4 o;
+          o.x = sc.x * (gv.x - c1.x - (yy.x - mean.x) * rstd.x * c2.x);
+          o.y = sc.y * (gv.y - c1.y - (yy.y - mean.y) * rstd.y * c2.y);
+          o.z = sc.z * (gv.z - c1.z - (yy.z - mean.z) * rstd.z * c2.z);
+          o.w = sc.w * (gv.w - c1.w - (yy.w - mean.w) * rstd.w * c2.w);
+          st4_stream(gb + (int64_t)u * C, o);
+          gmax = kws_abs4max(gmax, o);
+          continue;
         }
-        st4_stream(gb + (int64_t)u * C, o);
+        if (MODE == 0) {
+          float4 o = gv;
+          if (coef != nullptr) {   // MODE 0 reuses `coef` as an optional tensor added to the input gradient (residual join)
+            const float4 ad = *reinterpret_cast<const float4*>(coef + (b * (int64_t)Lin + u) * C + c);
+            o = make_float4(o.x + ad.x, o.y + ad.y, o.z + ad.z, o.w + ad.w);
+          }
+          st4_stream(gb + (int64_t)u * C, o);
+        }
+        sg.x += gv.x; sg.y += gv.y; sg.z += gv.z; sg.w += gv.w;
+        sgx = f4_fma(gv, xh, sgx);
+        sw0 = f4_fma(d0, a, sw0);
+        sw1 = f4_fma(d1, a, sw1);
+        sw2 = f4_fma(d2, a, sw2);
       }
-      sg.x += gv.x; sg.y += gv.y; sg.z += gv.z; sg.w += gv.w;
-      sgx = f4_fma(gv, xh, sgx);
-      sw0 = f4_fma(d0, a, sw0);
-      sw1 = f4_fma(d1, a, sw1);
-      sw2 = f4_fma(d2, a, sw2);
     }
   }
   if (MODE == 2) {
@@ -266,7 +283,7 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : DW_BWD_THREADS) void dwconv_bwd_k
 // measured at batch 1024 (ms per step, dwconv_bwd + finalisation): 256 rows 1.37, 512 1.02, 1024 0.86, 2048 0.91,
 // uncapped (6400) 1.03: four resident workgroups per CU stream best and leave few rows to fold
 // (the table above is for 256-thread workgroups; DW_BWD_THREADS = 1024 reaches the rate of its 1024-row entry with 256)
-constexpr int KWS_DW_BWD_MAX_PARTS = DW_BWD_THREADS == 1024 ? 256 : 1024;
+constexpr int KWS_DW_BWD_MAX_PARTS = DW_BWD_PARTS;
 struct BwdGeom {
   int nchunks, R, block, ny, Cb;
   int64_t grid;
@@ -274,7 +291,7 @@ struct BwdGeom {
 bool bwd_geom_ok(int C) { return C > 0 && C % 4 == 0 && (C / 4) % ceil_div(C / 4, 256) == 0; }
 BwdGeom bwd_geom(int B, int Lin, int C, bool parts = true) {
   BwdGeom g;
-  const int threads = parts ? DW_BWD_THREADS : 256;
+  const int threads = parts ? DW_BWD_THREADS : DW_BWD2_THREADS;
   const int max_parts = parts ? KWS_DW_BWD_MAX_PARTS : 1024;
   g.ny = ceil_div(C / 4, 256);   // channel slices of at most 1024 channels
   g.Cb = C / g.ny;
@@ -328,7 +345,7 @@ int kws_dwconv_fwd_amax_f32(const float* y, const float* bn, const float* w, flo
   const int nchunks = ceil_div(L_out, TT);
   const int64_t threads = (int64_t)B * nchunks * (C / 4);
   int64_t grid = ceil_div64(threads, 256);
-  if (grid > 4096) grid = 4096;   // grid-stride; 1024 .. uncapped measured within noise of each other
+  if (grid > DW_FWD_GRID) grid = DW_FWD_GRID;   // grid-stride; 1024 .. uncapped measured within noise of each other
   dim3 g((unsigned)grid), b(256);
   hipStream_t st = (hipStream_t)stream;
   KwsProfScope prof("dwconv_fwd", 6.0 * B * L_out * C, 4.0 * ((double)B * L_in * C + (double)B * L_out * C), st);
