@@ -48,6 +48,36 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// all-lanes reductions of one wave (xor butterfly: the same fixed order on every lane)
+__device__ __forceinline__ float wave_all_sum(float v) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_all_max(float v) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ int wave_all_min_i(int v) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int w = __shfl_xor(v, o);
+    v = w < v ? w : v;
+  }
+  return v;
+}
+// softmax of n <= 64 values in LDS by the first wave, one value per lane (the single-thread loop this replaces was a chain
+// of n dependent expf / divisions on the kernel's critical path)
+__device__ __forceinline__ void wave_softmax(const float* in, float* out, int n) {
+  const int lane = threadIdx.x;
+  const float v = lane < n ? in[lane] : -INFINITY;
+  const float m = wave_all_max(v);
+  const float e = lane < n ? expf(v - m) : 0.f;
+  const float den = wave_all_sum(e);
+  if (lane < n) out[lane] = e / den;
+}
+
 // sums `nv` (<= NV) per-thread values over the 256-thread block; result broadcast through out[] (LDS).
 // vals is indexed with compile-time constants only (runtime-indexed register arrays go to scratch).
 template <int NV>
@@ -74,7 +104,7 @@ __device__ void block_sum(const float (&vals)[NV], int nv, float* scratch /*[4*M
 // with 4-byte strided loads: at T = 9 every wave-load touched 18 cache lines and the 1024 workgroups pulled
 // ~1.8 GB through L1 per step (0.35 ms; this kernel's HBM-side traffic is only ~60 MB).
 template <bool TRAIN, int TT>
-__global__ __launch_bounds__(256) void ts_tail_kernel(TailArgs a) {
+__global__ __launch_bounds__(256, 4) void ts_tail_kernel(TailArgs a) {   // 4 waves per SIMD: every clip of a 1024 batch resident
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int T = a.T, C = a.C, NC = a.NC, TC = T * C;
   float* xs = lds;                 // [TC]   x = relu6(bn(y)); overwritten in place by dx in the backward half
@@ -96,12 +126,54 @@ __global__ __launch_bounds__(256) void ts_tail_kernel(TailArgs a) {
   const uint32_t row = (uint32_t)(a.row_offset + b);
 
   // ---- x = relu6(bn(y)), dropout 1 -----------------------------------------------------------
+  // The kernel is one serial chain per clip with every clip resident at once: its duration is the chain's LATENCY.  Global
+  // loads are therefore issued in batches (a "load, use, next element" loop costs one memory round trip per iteration: the
+  // 18 of this loop and the 18 of the last one were most of the kernel's 62 us) and the few scalars the single-thread
+  // sections need (labels, attention bias) are fetched into LDS here, under the first batch.
+  float* lab = part16 + 256;       // [MAXNC] this clip's labels
+  float* b1s = lab + MAXNC;        // [MAXT]
+  if (TRAIN && tid < NC) lab[tid] = a.labels[(int64_t)b * NC + tid];
+  if (tid >= 64 && tid < 64 + T) b1s[tid - 64] = a.b1[tid - 64];
+  if (TT > 0) {                    // (T C and C are multiples of 4: host-checked for this instance)
+    constexpr int NB1 = 5;         // 16-byte loads in flight per thread
+    const int n4 = TC >> 2;
+    for (int i0 = 0; i0 < n4; i0 += 256 * NB1) {
+      float4 yv[NB1], scv[NB1], shv[NB1];
+#pragma unroll
+      for (int k = 0; k < NB1; ++k) {
+        const int i = i0 + 256 * k + tid;
+        const int ii = i < n4 ? i : 0;
+        yv[k] = reinterpret_cast<const float4*>(yb)[ii];
+        scv[k] = *reinterpret_cast<const float4*>(a.bn + (4 * ii) % C);
+        shv[k] = *reinterpret_cast<const float4*>(a.bn + C + (4 * ii) % C);
+      }
+#pragma unroll
+      for (int k = 0; k < NB1; ++k) {
+        const int i = i0 + 256 * k + tid;
+        if (i >= n4) continue;
+        const int e = 4 * i;
+        const float4 sc = scv[k], sh = shv[k];
+        const float4 x = make_float4(relu6f(fmaf(yv[k].x, sc.x, sh.x)), relu6f(fmaf(yv[k].y, sc.y, sh.y)),
+                                     relu6f(fmaf(yv[k].z, sc.z, sh.z)), relu6f(fmaf(yv[k].w, sc.w, sh.w)));
+        *reinterpret_cast<float4*>(xs + e) = x;
+        if (TRAIN) {
+          const uint32_t id = row * (uint32_t)TC + (uint32_t)e;
+          const float4 d = make_float4(kws_keep(id, a.key1, a.thresh) ? x.x * a.inv_keep : 0.f,
+                                       kws_keep(id + 1, a.key1, a.thresh) ? x.y * a.inv_keep : 0.f,
+                                       kws_keep(id + 2, a.key1, a.thresh) ? x.z * a.inv_keep : 0.f,
+                                       kws_keep(id + 3, a.key1, a.thresh) ? x.w * a.inv_keep : 0.f);
+          *reinterpret_cast<float4*>(a.xd + (int64_t)b * TC + e) = d;
+        }
+      }
+    }
+  } else {
   for (int e = tid; e < TC; e += 256) {
     const int c = e % C;
     const float x = relu6f(fmaf(yb[e], a.bn[c], a.bn[C + c]));
     xs[e] = x;
     if (TRAIN)   // the dropped activations are only stored for the dW1 reduction; the logits recompute the mask
       a.xd[(int64_t)b * TC + e] = kws_keep(row * (uint32_t)TC + (uint32_t)e, a.key1, a.thresh) ? x * a.inv_keep : 0.f;
+  }
   }
   auto dropped = [&](float x, int e) -> float {
     if (!TRAIN) return x;
@@ -133,7 +205,7 @@ __global__ __launch_bounds__(256) void ts_tail_kernel(TailArgs a) {
           for (int t = 0; t < TV; ++t) pl[t] = fmaf(xr[r], wv[r * TV + t], pl[t]);
       }
       block_sum(pl, TV, scratch, l1);
-      if (tid < T) l1[tid] += a.b1[tid];
+      if (tid < T) l1[tid] += b1s[tid];
       __syncthreads();
     } else {
       // generic T: thread (t = tid%16, slice = tid/16)
@@ -144,22 +216,13 @@ __global__ __launch_bounds__(256) void ts_tail_kernel(TailArgs a) {
       part16[sl * 16 + t] = s;
       __syncthreads();
       if (tid < T) {
-        float acc = a.b1[tid];
+        float acc = b1s[tid];
         for (int k = 0; k < 16; ++k) acc += part16[k * 16 + tid];
         l1[tid] = acc;
       }
       __syncthreads();
     }
-    if (tid == 0) {
-      float m = l1[0];
-      for (int k = 1; k < T; ++k) m = fmaxf(m, l1[k]);
-      float den = 0.f;
-      for (int k = 0; k < T; ++k) {
-        att[k] = expf(l1[k] - m);
-        den += att[k];
-      }
-      for (int k = 0; k < T; ++k) att[k] /= den;
-    }
+    if (tid < 64) wave_softmax(l1, att, T);
     __syncthreads();
     if (TRAIN && a.att_out != nullptr && tid < T) a.att_out[(int64_t)b * T + tid] = att[tid];
   }
@@ -191,18 +254,32 @@ __global__ __launch_bounds__(256) void ts_tail_kernel(TailArgs a) {
       float pl[16];
 #pragma unroll
       for (int q = 0; q < 16; ++q) pl[q] = 0.f;
-      for (int i = tid; i < 2 * C; i += 256) {
-        const float f = dfeat[i];
-        const float4* wp = reinterpret_cast<const float4*>(a.W2 + (int64_t)i * NC);
+      // four rows of W2 (<= 16 vectors) per thread and trip, all requested before the first is used
+      const int nv = NC >> 2;
+      for (int i0 = tid; i0 < 2 * C; i0 += 4 * 256) {
+        float4 w4[4][4];
+        float f[4];
 #pragma unroll
-        for (int v = 0; v < 4; ++v)
-          if (4 * v < NC) {
-            const float4 w4 = wp[v];
-            pl[4 * v] = fmaf(f, w4.x, pl[4 * v]);
-            pl[4 * v + 1] = fmaf(f, w4.y, pl[4 * v + 1]);
-            pl[4 * v + 2] = fmaf(f, w4.z, pl[4 * v + 2]);
-            pl[4 * v + 3] = fmaf(f, w4.w, pl[4 * v + 3]);
-          }
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + 256 * u;
+          const bool ok = i < 2 * C;
+          const float4* wp = reinterpret_cast<const float4*>(a.W2 + (int64_t)(ok ? i : 0) * NC);
+#pragma unroll
+          for (int v = 0; v < 4; ++v) w4[u][v] = wp[v < nv ? v : 0];
+          f[u] = dfeat[ok ? i : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (i0 + 256 * u >= 2 * C) continue;       // (the rows that exist, in row order)
+#pragma unroll
+          for (int v = 0; v < 4; ++v)
+            if (v < nv) {
+              pl[4 * v] = fmaf(f[u], w4[u][v].x, pl[4 * v]);
+              pl[4 * v + 1] = fmaf(f[u], w4[u][v].y, pl[4 * v + 1]);
+              pl[4 * v + 2] = fmaf(f[u], w4[u][v].z, pl[4 * v + 2]);
+              pl[4 * v + 3] = fmaf(f[u], w4[u][v].w, pl[4 * v + 3]);
+            }
+        }
       }
       block_sum(pl, NC, scratch, l2);
     } else {
@@ -215,71 +292,74 @@ __global__ __launch_bounds__(256) void ts_tail_kernel(TailArgs a) {
       if (tid < NC) l2[tid] = ((scratch[tid] + scratch[MAXNC + tid]) + scratch[2 * MAXNC + tid]) + scratch[3 * MAXNC + tid];
       __syncthreads();
     }
-    if (tid == 0) {
-      float m = l2[0];
-      for (int q = 1; q < NC; ++q) m = fmaxf(m, l2[q]);
-      float den = 0.f;
-      for (int q = 0; q < NC; ++q) {
-        pp[q] = expf(l2[q] - m);
-        den += pp[q];
-      }
-      for (int q = 0; q < NC; ++q) pp[q] /= den;
-    }
+    if (tid < 64) wave_softmax(l2, pp, NC);
     __syncthreads();
     if (tid < NC) a.probs[(int64_t)b * NC + tid] = pp[tid];
   }
   if (!TRAIN) return;
 
   // ---- loss: softmax-CE on log(clip(p)) with label smoothing (utils.py:100-108) --------------
-  if (tid == 0) {
+  if (tid < 64) {   // one class per lane (NC <= 64); sums and the two arg-maxima as wave reductions
     const float eps = 1e-7f;
-    const float* yl = a.labels + (int64_t)b * NC;
-    float S = 0.f, ysum = 0.f;
-    for (int q = 0; q < NC; ++q) S += fminf(fmaxf(pp[q], eps), 1.f - eps);
+    const bool in = tid < NC;
+    const float pq = in ? pp[tid] : 0.f, yq = in ? lab[tid] : 0.f;
+    const float pc = fminf(fmaxf(pq, eps), 1.f - eps);
+    const float S = wave_all_sum(in ? pc : 0.f);
     const float logS = logf(S);
-    float loss = 0.f;
-    int am_p = 0, am_y = 0;
-    for (int q = 0; q < NC; ++q) {
-      const float ysm = yl[q] * (1.f - a.label_smoothing) + a.label_smoothing / (float)NC;
-      ysum += ysm;
-      const float pc = fminf(fmaxf(pp[q], eps), 1.f - eps);
-      loss -= ysm * (logf(pc) - logS);
-      if (pp[q] > pp[am_p]) am_p = q;
-      if (yl[q] > yl[am_y]) am_y = q;
+    const float ysm = in ? yq * (1.f - a.label_smoothing) + a.label_smoothing / (float)NC : 0.f;
+    const float ysum = wave_all_sum(ysm);
+    const float loss = -wave_all_sum(in ? ysm * (logf(pc) - logS) : 0.f);
+    // first index of the maximum, as the serial "if (v[q] > v[best]) best = q" walk finds it
+    const float pmax = wave_all_max(in ? pq : -INFINITY), ymax = wave_all_max(in ? yq : -INFINITY);
+    const int am_p = wave_all_min_i(in && pq == pmax ? tid : 64), am_y = wave_all_min_i(in && yq == ymax ? tid : 64);
+    if (tid == 0) {
+      a.per_loss[b] = loss;
+      a.per_correct[b] = (am_p == am_y) ? 1.f : 0.f;
     }
-    a.per_loss[b] = loss;
-    a.per_correct[b] = (am_p == am_y) ? 1.f : 0.f;
     // dL/dp (clip passes gradient inside [eps, 1-eps]), then softmax backward
-    float dot = 0.f;
-    for (int q = 0; q < NC; ++q) {
-      const float ysm = yl[q] * (1.f - a.label_smoothing) + a.label_smoothing / (float)NC;
-      const float pc = fminf(fmaxf(pp[q], eps), 1.f - eps);
-      const float inside = (pp[q] >= eps && pp[q] <= 1.f - eps) ? 1.f : 0.f;
-      const float dp = (-ysm / pc + ysum / S) * a.inv_loss_batch * inside;
-      dl2[q] = dp;
-      dot += dp * pp[q];
-    }
-    for (int q = 0; q < NC; ++q) dl2[q] = pp[q] * (dl2[q] - dot);
+    const float inside = (pq >= eps && pq <= 1.f - eps) ? 1.f : 0.f;
+    const float dp = in ? (-ysm / pc + ysum / S) * a.inv_loss_batch * inside : 0.f;
+    const float dot = wave_all_sum(dp * pq);
+    if (in) dl2[tid] = pq * (dp - dot);
   }
   __syncthreads();
   if (tid < NC) a.dl2[(int64_t)b * NC + tid] = dl2[tid];
   // ---- dfeat = (W2 . dl2) * mask2 / keep ------------------------------------------------------
-  for (int i = tid; i < 2 * C; i += 256) {
-    float s = 0.f;
-    if ((NC & 3) == 0) {
-      const float4* wp = reinterpret_cast<const float4*>(a.W2 + (int64_t)i * NC);
-      for (int v = 0; v < NC / 4; ++v) {
-        const float4 w4 = wp[v];
-        s = fmaf(w4.x, dl2[4 * v], s);
-        s = fmaf(w4.y, dl2[4 * v + 1], s);
-        s = fmaf(w4.z, dl2[4 * v + 2], s);
-        s = fmaf(w4.w, dl2[4 * v + 3], s);
+  if ((NC & 3) == 0 && NC <= 16) {
+    const int nv = NC >> 2;
+    for (int i0 = tid; i0 < 2 * C; i0 += 4 * 256) {
+      float4 w4[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + 256 * u;
+        const float4* wp = reinterpret_cast<const float4*>(a.W2 + (int64_t)(i < 2 * C ? i : 0) * NC);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) w4[u][v] = wp[v < nv ? v : 0];
       }
-    } else {
-      for (int q = 0; q < NC; ++q) s = fmaf(a.W2[(int64_t)i * NC + q], dl2[q], s);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + 256 * u;
+        if (i >= 2 * C) continue;
+        float s = 0.f;
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+          if (v < nv) {
+            s = fmaf(w4[u][v].x, dl2[4 * v], s);
+            s = fmaf(w4[u][v].y, dl2[4 * v + 1], s);
+            s = fmaf(w4[u][v].z, dl2[4 * v + 2], s);
+            s = fmaf(w4[u][v].w, dl2[4 * v + 3], s);
+          }
+        const bool keep = kws_keep(row * (uint32_t)(2 * C) + (uint32_t)i, a.key2, a.thresh);
+        dfeat[i] = keep ? s * a.inv_keep : 0.f;
+      }
     }
-    const bool keep = kws_keep(row * (uint32_t)(2 * C) + (uint32_t)i, a.key2, a.thresh);
-    dfeat[i] = keep ? s * a.inv_keep : 0.f;
+  } else {
+    for (int i = tid; i < 2 * C; i += 256) {
+      float s = 0.f;
+      for (int q = 0; q < NC; ++q) s = fmaf(a.W2[(int64_t)i * NC + q], dl2[q], s);
+      const bool keep = kws_keep(row * (uint32_t)(2 * C) + (uint32_t)i, a.key2, a.thresh);
+      dfeat[i] = keep ? s * a.inv_keep : 0.f;
+    }
   }
   __syncthreads();
   // ---- pooling backward: reduce_max splits its gradient equally among ties -------------------
@@ -303,10 +383,10 @@ __global__ __launch_bounds__(256) void ts_tail_kernel(TailArgs a) {
     }
   }
   block_sum(dattl, T, scratch, datt);
-  if (tid == 0) {
-    float dot = 0.f;
-    for (int t = 0; t < T; ++t) dot += att[t] * datt[t];
-    for (int t = 0; t < T; ++t) dl1[t] = att[t] * (datt[t] - dot);
+  if (tid < 64) {
+    const float av = tid < T ? att[tid] : 0.f, dv = tid < T ? datt[tid] : 0.f;
+    const float dot = wave_all_sum(av * dv);
+    if (tid < T) dl1[tid] = av * (dv - dot);
   }
   __syncthreads();
   if (tid < T) a.dl1[(int64_t)b * T + tid] = dl1[tid];
@@ -341,18 +421,43 @@ __global__ __launch_bounds__(256) void ts_tail_kernel(TailArgs a) {
     __syncthreads();
   }
   float* gb = a.g + (int64_t)b * TC;
+  if (TT > 0) {
+    // as the generic loop below, the T pre-activations of a channel loaded in one batch (the sums keep their order in t)
+    constexpr int TV = TT > 0 ? TT : 1;
+    for (int c = tid; c < C; c += 256) {
+      float yv[TV];
+#pragma unroll
+      for (int t = 0; t < TV; ++t) yv[t] = yb[t * C + c];
+      const float sc = a.bn[c], sh = a.bn[C + c], mean = a.bn[2 * C + c], rstd = a.bn[3 * C + c];
+      float sg = 0.f, sgx = 0.f;
+#pragma unroll
+      for (int t = 0; t < TV; ++t) {
+        const int e = t * C + c;
+        const float pre = fmaf(yv[t], sc, sh);
+        const float gv = (pre > 0.f && pre <= 6.f) ? xs[e] : 0.f;
+        gb[e] = gv;
+        sg += gv;
+        sgx = fmaf(gv, (yv[t] - mean) * rstd, sgx);
+      }
+      float* pb = a.part + (int64_t)b * 5 * C;
+      pb[c] = sg;
+      pb[C + c] = sgx;
+      pb[2 * C + c] = 0.f;
+      pb[3 * C + c] = 0.f;
+      pb[4 * C + c] = 0.f;
+    }
+    return;
+  }
   for (int c = tid; c < C; c += 256) {
     const float sc = a.bn[c], sh = a.bn[C + c], mean = a.bn[2 * C + c], rstd = a.bn[3 * C + c];
     float sg = 0.f, sgx = 0.f;
     for (int t = 0; t < T; ++t) {
       const int e = t * C + c;
       float dx = xs[e];
-      if (TT == 0) {
-        float s = 0.f;
-        for (int q = 0; q < T; ++q) s = fmaf(a.W1[(int64_t)e * T + q], dl1[q], s);
-        const bool keep = kws_keep(row * (uint32_t)TC + (uint32_t)e, a.key1, a.thresh);
-        dx += keep ? s * a.inv_keep : 0.f;
-      }
+      float s = 0.f;
+      for (int q = 0; q < T; ++q) s = fmaf(a.W1[(int64_t)e * T + q], dl1[q], s);
+      const bool keep = kws_keep(row * (uint32_t)TC + (uint32_t)e, a.key1, a.thresh);
+      dx += keep ? s * a.inv_keep : 0.f;
       const float yv = yb[e];
       const float pre = fmaf(yv, sc, sh);
       const float gv = (pre > 0.f && pre <= 6.f) ? dx : 0.f;
@@ -491,7 +596,7 @@ int kws_ts_tail_launch(const kws_ts_tail_args* p, hipStream_t st) {
   KWS_REQUIRE(p->T > 0 && p->T <= MAXT && p->NC > 0 && p->NC <= MAXNC && p->C > 0, "ts_tail: bad shape T=%d NC=%d",
               p->T, p->NC);
   const int TC = p->T * p->C;
-  const size_t lds_floats = (size_t)TC + 4 * p->C + 4 * MAXNC + 4 * MAXT + 3 * MAXNC + 256;
+  const size_t lds_floats = (size_t)TC + 4 * p->C + 4 * MAXNC + 4 * MAXT + 3 * MAXNC + 256 + MAXNC + MAXT;
   KWS_REQUIRE(lds_floats * 4 <= 160 * 1024, "ts_tail: T*C=%d does not fit LDS", TC);
   TailArgs a{};
   a.y = p->y; a.bn = p->bn; a.W1 = p->W1; a.b1 = p->b1; a.W2 = p->W2; a.labels = p->labels; a.probs = p->probs;
@@ -508,7 +613,8 @@ int kws_ts_tail_launch(const kws_ts_tail_args* p, hipStream_t st) {
   KwsProfScope prof(p->train ? "tail_train" : "tail_infer", 4.0 * p->B * TC * p->T * (p->train ? 2 : 1), 4.0 * p->B * TC * (p->train ? 4 : 1), st);
   // T = 9 (16000-sample input) takes the vectorised W1 passes; W1 rows must then be 16-byte aligned in
   // groups of 4 (T*C % 4 == 0 and an aligned base, both true for the flat parameter buffer)
-  const bool fast9 = p->T == 9 && TC % 4 == 0 && (reinterpret_cast<uintptr_t>(p->W1) & 15) == 0;
+  const bool fast9 = p->T == 9 && p->C % 4 == 0 && ((reinterpret_cast<uintptr_t>(p->W1) | reinterpret_cast<uintptr_t>(p->y) |
+                                                     reinterpret_cast<uintptr_t>(p->bn) | reinterpret_cast<uintptr_t>(p->xd)) & 15) == 0;
   const void* fn = p->train ? (fast9 ? reinterpret_cast<const void*>(&ts_tail_kernel<true, 9>)
                                      : reinterpret_cast<const void*>(&ts_tail_kernel<true, 0>))
                             : (fast9 ? reinterpret_cast<const void*>(&ts_tail_kernel<false, 9>)
