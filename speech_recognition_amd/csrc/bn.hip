@@ -9,6 +9,10 @@ namespace {
 // finalise kernels: 256 threads = FIN_CG channels x FIN_RG row groups; up to 256 partial rows are summed
 // directly (<= 16 per thread; more rows with only C/16 workgroups is latency-bound: 2048 rows took 35 us), row group r takes rows r, r+FIN_RG, ... and the groups are combined in order
 constexpr int FIN_CG = 16, FIN_RG = 16;
+#ifndef KWS_FIN_U
+#define KWS_FIN_U 16
+#endif
+constexpr int FIN_U = KWS_FIN_U;   // rows per thread and trip
 
 __device__ float g_zero_fin[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
@@ -24,19 +28,20 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __r
   const int c = blockIdx.x * FIN_CG + cg;
   double s = 0.0, ss = 0.0;
   if (c < C) {
-    // four rows' loads in flight per trip (rows past the end read a zero buffer: address select, not a branch); the
-    // additions stay in ascending row order
-    for (int t = rg; t < n_tiles; t += 4 * FIN_RG) {
-      float a[4], b[4];
+    // FIN_U rows' loads in flight per trip - with <= 256 partial rows (the producers' caps) ONE trip: the kernel is a chain
+    // of memory round trips (the rows were just written by other XCDs) and little else.  Rows past the end read a zero
+    // buffer (address select, not a branch); the additions stay in ascending row order.
+    for (int t = rg; t < n_tiles; t += FIN_U * FIN_RG) {
+      float a[FIN_U], b[FIN_U];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < FIN_U; ++u) {
         const int tt = t + u * FIN_RG;
         const float* src = tt < n_tiles ? part + (int64_t)tt * 2 * C + c : g_zero_fin;
         a[u] = src[0];
         b[u] = src[tt < n_tiles ? C : 1];
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < FIN_U; ++u) {
         s += (double)a[u];
         ss += (double)b[u];
       }
@@ -129,10 +134,10 @@ __global__ __launch_bounds__(256) void dw_bwd_finalize_kernel(const float* __res
   const int c = blockIdx.x * FIN_CG + cg;
   double s[5] = {0, 0, 0, 0, 0};
   if (c < C) {
-    for (int t = rg; t < n_parts; t += 4 * FIN_RG) {   // as in bn_stats_finalize_kernel: 20 loads in flight per trip
-      float a[4][5];
+    for (int t = rg; t < n_parts; t += FIN_U * FIN_RG) {   // as in bn_stats_finalize_kernel: 5 FIN_U loads in flight per trip
+      float a[FIN_U][5];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < FIN_U; ++u) {
         const int tt = t + u * FIN_RG;
         const bool ok = tt < n_parts;
         const float* src = ok ? part + (int64_t)tt * 5 * C + c : g_zero_fin;
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(256) void dw_bwd_finalize_kernel(const float* __res
         for (int q = 0; q < 5; ++q) a[u][q] = src[ok ? q * C : q];
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < FIN_U; ++u)
 #pragma unroll
         for (int q = 0; q < 5; ++q) s[q] += (double)a[u][q];
     }
