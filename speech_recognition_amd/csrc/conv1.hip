@@ -34,6 +34,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int NOUT = 128;   // output channels (filter_mult 1)
 constexpr int FM = 64;      // forward row tile
 constexpr int UM = 32;      // weight-gradient row unit
+#ifndef KWS_C1W_OCC
+#define KWS_C1W_OCC 3      // weight-gradient workgroups per CU (one round: chunk = M / (256 x this))
+#endif
+#ifndef KWS_C1W_ABL
+#define KWS_C1W_ABL 0      // timing-only ablation (wrong results): 1 no MFMAs, 2 no global loads
+#endif
 
 struct Conv1Args {
   const float* x;
@@ -226,7 +232,7 @@ __global__ __launch_bounds__(256, 3) void conv1_fwd_kernel(Conv1Args p) {
 //                blocks (block cb = the columns of parity cb: 16 lanes read 128 contiguous bytes of a row);
 //   D            register v of block (rb, cb): dW[16 rb + 4 (lane / 16) + v][32 w + 2 j + cb] - the two blocks leave as 8-byte stores.
 template <int KF>
-__global__ __launch_bounds__(256, 3) void conv1_wgrad_kernel(Conv1Args p) {
+__global__ __launch_bounds__(256, KWS_C1W_OCC) void conv1_wgrad_kernel(Conv1Args p) {
   constexpr int PA = KF;            // row pitch of the staged rows: 80 = 16 mod 32 banks
   constexpr int TPR = 256 / UM;     // A-staging threads per row
   constexpr int QF = KF / TPR;      // floats per A-staging thread
@@ -251,6 +257,13 @@ __global__ __launch_bounds__(256, 3) void conv1_wgrad_kernel(Conv1Args p) {
     const int e0 = t * p.g.stride_t + p.g.base_off + aq * QF;
     const bool inside = row_ok && e0 >= 0 && e0 + QF <= p.g.x_len;
     const float* src = inside ? xb + e0 : g_zero64;
+    if (KWS_C1W_ABL & 2) {
+#pragma unroll
+      for (int i = 0; i < NL; ++i) ra[i] = make_float2((float)mb, (float)i);
+#pragma unroll
+      for (int s2 = 0; s2 < NS; ++s2) g_nxt[s2] = make_float2((float)(mb + s2), 1.f);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < NL; ++i) ra[i] = *reinterpret_cast<const float2*>(src + 2 * i);
     if (row_ok && !inside) {
@@ -302,6 +315,7 @@ __global__ __launch_bounds__(256, 3) void conv1_wgrad_kernel(Conv1Args p) {
       __builtin_amdgcn_sched_barrier(0);   // the reads above stay above the MFMAs below
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb) {
+        if (KWS_C1W_ABL & 1) { asm volatile("" :: "v"(a_cur[rb]), "v"(g_cur[s2].x), "v"(g_cur[s2].y)); continue; }
         acc[rb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[rb], g_cur[s2].x, acc[rb][0], 0, 0, 0);
         acc[rb][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[rb], g_cur[s2].y, acc[rb][1], 0, 0, 0);
       }
@@ -348,7 +362,7 @@ struct WgradPlan {
 };
 WgradPlan wgrad_plan(int64_t M) {
   WgradPlan pl;
-  int64_t chunk = ceil_div64(ceil_div64(M, 768), UM) * UM;   // three workgroups per CU, one round
+  int64_t chunk = ceil_div64(ceil_div64(M, 256 * KWS_C1W_OCC), UM) * UM;   // KWS_C1W_OCC workgroups per CU, one round
   if (chunk < UM) chunk = UM;
   pl.chunk = chunk;
   pl.S = (int)ceil_div64(M, chunk);
