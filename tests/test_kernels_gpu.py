@@ -138,12 +138,16 @@ def test_transpose():
 
 
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("Lin,stride,pad,C,with_bn", [(399, 1, (0, 0), 128, True), (397, 2, (1, 1), 128, True),
-                                                      (22, 2, (0, 1), 384, True), (11, 1, (0, 0), 512, True),
-                                                      (48, 1, (1, 1), 192, False), (97, 2, (1, 1), 256, True)])
-def test_dwconv_fwd_bwd(Lin, stride, pad, C, with_bn):
+# the last five: units shorter than / one past the 8-position batch of loads, channel counts whose workgroups hold 6 and
+# 32 units (C / 4 = 80, 16), and enough units (B = 300) that the capped grids of all three kernels take several strides
+@pytest.mark.parametrize("Lin,stride,pad,C,with_bn,B", [(399, 1, (0, 0), 128, True, 5), (397, 2, (1, 1), 128, True, 5),
+                                                        (22, 2, (0, 1), 384, True, 5), (11, 1, (0, 0), 512, True, 5),
+                                                        (48, 1, (1, 1), 192, False, 5), (97, 2, (1, 1), 256, True, 5),
+                                                        (7, 1, (1, 1), 64, True, 3), (8, 2, (0, 1), 320, True, 3),
+                                                        (9, 2, (1, 1), 64, False, 2), (40, 1, (0, 0), 512, True, 300),
+                                                        (41, 2, (1, 1), 512, True, 300)])
+def test_dwconv_fwd_bwd(Lin, stride, pad, C, with_bn, B):
     rng = np.random.RandomState(Lin * 7 + C)
-    B = 5
     y = rng.randn(B, Lin, C).astype(np.float32) * 2.0
     w = rng.randn(3, C).astype(np.float32)
     gamma = (1 + 0.1 * rng.randn(C)).astype(np.float32)
