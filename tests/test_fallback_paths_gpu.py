@@ -40,6 +40,23 @@ def test_train_step_on_fallback_shapes_matches_oracle(kw, B):
     assert abs(float(net.metrics.cpu().numpy()[0]) / B - loss) < 2e-5
 
 
+@pytest.mark.parametrize("nc", [30, 32])
+def test_train_step_with_other_class_counts_matches_oracle(nc):
+    """30 classes (the 30 words of the data set; rows of the classifier kernel are not whole 16-byte vectors) and 32 (more than
+    the 16 the vectorised classifier passes hold in registers): the tail kernel's generic classifier loops, and its one-wave
+    softmax / loss reductions with more lanes in use"""
+    B = 4
+    ora, net = _pair(num_classes=nc)
+    x, y = _batch(B, nc, 11 + nc)
+    probs = net.train_fwd_bwd(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(), seed=7, step=1)
+    torch.cuda.synchronize()
+    loss, p, grads, cache = _check_grads(ora, net, x, y, 7, 1, B, tol=1e-4)
+    got = probs.cpu().numpy()
+    assert np.abs(got - p).max() < 2e-5 and np.array_equal(got.argmax(1), p.argmax(1))
+    assert abs(float(net.metrics.cpu().numpy()[0]) / B - loss) < 2e-5
+    assert float(net.metrics.cpu().numpy()[1]) == float((p.argmax(1) == y.argmax(1)).sum())
+
+
 def _features(plan, dx, B, L, width):
     lib = _lib.load()
     F = lib.kws_stft_num_frames(plan, L)
