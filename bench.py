@@ -611,6 +611,7 @@ def main():
             sys.stderr.write("A/B leg failed: %r\n" % (ex,))
         finally:
             model.net.set_gemm_mode(0)
+            _lib.Profiler.detach()   # a leg that raised between attach() and detach() must not leave this thread recording
     enq.stop()
     if rank == 0 and stages:
         # the STFT stage ALONE (its in-situ time above is that of a low-priority stream filling the gaps of the training

@@ -25,6 +25,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* libkws_hip.so is built with -fvisibility=hidden: exactly the declarations of this header are exported
+ * (tests/test_abi.py compares `nm -D` with it) */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 #define KWS_OK 0
 #define KWS_E_INVALID (-1)   /* bad argument / unsupported shape */
@@ -49,7 +54,9 @@ int kws_stream_destroy(void* stream);
  * launch with a hipEvent pair on the launch stream and books the algorithmic FLOPs/bytes of the call.  Several threads
  * may attach the same handle (the batch generator thread and the training thread of bench.py do).
  * kws_profiler_collect() waits for the recorded events and returns the number of families, kws_profiler_get() reads one
- * (summed device ms, launches, FLOPs, bytes).  No process-wide switch: a thread that never attaches never records. */
+ * (summed device ms, launches, FLOPs, bytes).  No process-wide switch: a thread that never attaches never records.
+ * The handle counts its attached threads (a thread that exits detaches itself): kws_profiler_destroy() ends the calling
+ * thread's own attachment and returns KWS_E_INVALID, leaving the handle alive, while any OTHER thread is still attached. */
 typedef struct kws_profiler kws_profiler_t;
 int kws_profiler_create(kws_profiler_t** out);
 int kws_profiler_destroy(kws_profiler_t* p);
@@ -405,6 +412,9 @@ int kws_net_train_fwd_bwd_part(const kws_net_t* net, const float* params, float*
                                void* workspace, int64_t workspace_bytes, int part, int split_block,
                                void* stream);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -212,8 +212,8 @@ class OwnedStream(object):
     def close(self):
         h, self.handle = self.handle, None
         if h and _lib is not None:
-            import torch
             try:
+                import torch
                 with torch.cuda.device(self.device):
                     self.stream.synchronize()
                     _lib.kws_stream_destroy(ctypes.c_void_p(h))
@@ -256,9 +256,11 @@ class Profiler(object):
         return out
 
     def close(self):
-        h, self.handle = self.handle, None
+        """Destroys the handle.  Raises (and keeps the handle) while another thread is still attached to it."""
+        h = self.handle
         if h is not None and _lib is not None:
-            _lib.kws_profiler_destroy(h)
+            check(_lib.kws_profiler_destroy(h), "kws_profiler_destroy")
+        self.handle = None
 
     def __del__(self):
         try:

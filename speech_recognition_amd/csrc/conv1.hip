@@ -377,16 +377,16 @@ int kws_conv1_stats_rows(int64_t M) {
   return (int)(tiles < 768 ? tiles : 768);
 }
 
-bool kws_conv1_supported(const kws_gather_t* g, int N) {
-  // anything else (filter_mult = 2: 256 output channels) takes the generic gathered GEMMs of gemm.hip
-  return g && g->taps == 1 && g->cin == 80 && N == NOUT && g->stride_t % 2 == 0 && g->base_off % 2 == 0 &&
-         g->x_batch_stride % 2 == 0 && g->L_out > 0;
+bool kws_conv1_supported(const kws_gather_t* g, const kws_gather_t* unfolded, int N) {
+  // anything else (filter_mult = 2: 256 output channels; more than three taps folded into the 80 samples: the forward
+  // kernel's fold-on-load prologue has three tap candidates) takes the generic gathered GEMMs of gemm.hip
+  return g && unfolded && g->taps == 1 && g->cin == 80 && N == NOUT && g->stride_t % 2 == 0 && g->base_off % 2 == 0 &&
+         g->x_batch_stride % 2 == 0 && g->L_out > 0 && unfolded->taps >= 1 && unfolded->taps <= 3;
 }
 
 int kws_conv1_fwd(const float* x, const kws_gather_t* g, const kws_gather_t* unfolded, const float* W, float* y, int B, int N,
                   float* stats, hipStream_t st) {
-  KWS_REQUIRE(x && g && unfolded && W && y && B > 0 && kws_conv1_supported(g, N), "conv1_fwd: unsupported shape");
-  KWS_REQUIRE(unfolded->taps >= 1 && unfolded->taps <= 3, "conv1_fwd: %d taps (the fold-on-load prologue handles 1..3)", unfolded->taps);
+  KWS_REQUIRE(x && g && unfolded && W && y && B > 0 && kws_conv1_supported(g, unfolded, N), "conv1_fwd: unsupported shape");
   Conv1Args a{};
   a.x = x; a.W = W; a.y = y; a.stats = stats; a.g = *g; a.B = B; a.M = (int64_t)B * g->L_out;
   a.taps = unfolded->taps; a.cin = unfolded->cin; a.hop = unfolded->stride_j;
@@ -403,7 +403,7 @@ int64_t kws_conv1_wgrad_workspace_floats(int64_t M) { return (int64_t)wgrad_plan
 
 int kws_conv1_wgrad(const float* x, const kws_gather_t* g, const kws_gather_t* unfolded, const float* G, float* dW, int B,
                     int N, float* workspace, hipStream_t st) {
-  KWS_REQUIRE(x && g && unfolded && G && dW && workspace && B > 0 && kws_conv1_supported(g, N),
+  KWS_REQUIRE(x && g && unfolded && G && dW && workspace && B > 0 && kws_conv1_supported(g, unfolded, N),
               "conv1_wgrad: unsupported shape");
   Conv1Args a{};
   a.x = x; a.G = G; a.ws = workspace; a.g = *g; a.B = B; a.M = (int64_t)B * g->L_out;

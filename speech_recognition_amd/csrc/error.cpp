@@ -74,6 +74,7 @@ int kws_stream_destroy(void* stream) {
 
 // ---- profiler ----------------------------------------------------------------------------------------
 #include <map>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -92,6 +93,7 @@ struct ProfAgg {
 // A profiler is a handle (include/kws_hip.h); the calling thread's attachment is the only state outside it.
 struct kws_profiler {
   std::mutex mu;
+  std::atomic<int> attached{0};   // threads recording into this handle: destroy refuses while it is non-zero
   std::vector<ProfRec*> recs;
   std::vector<std::pair<std::string, ProfAgg>> out;
   void clear_locked() {
@@ -103,7 +105,15 @@ struct kws_profiler {
     recs.clear();
   }
 };
-static thread_local kws_profiler* t_prof = nullptr;
+// the calling thread's attachment; a thread that ends while attached detaches itself (its count must not pin the handle)
+struct ProfTls {
+  kws_profiler* p = nullptr;
+  ~ProfTls() {
+    if (p) p->attached.fetch_sub(1);
+  }
+};
+static thread_local ProfTls t_prof_tls;
+#define t_prof (t_prof_tls.p)
 static std::mutex g_roctx_mu;
 
 bool kws_prof_on() { return t_prof != nullptr; }
@@ -184,7 +194,14 @@ int kws_profiler_create(kws_profiler_t** out) {
 
 int kws_profiler_destroy(kws_profiler_t* p) {
   if (!p) return KWS_OK;
-  if (t_prof == p) t_prof = nullptr;     // other threads must have detached before the handle is destroyed
+  if (t_prof == p) {                     // the caller's own attachment ends with the handle
+    t_prof = nullptr;
+    p->attached.fetch_sub(1);
+  }
+  if (p->attached.load() != 0) {         // another thread would keep a dangling pointer (its next launch books into p)
+    kws_set_error("profiler_destroy: %d other thread(s) still attached (kws_profiler_attach(NULL) from each first)", p->attached.load());
+    return KWS_E_INVALID;
+  }
   {
     std::lock_guard<std::mutex> lk(p->mu);
     p->clear_locked();
@@ -195,6 +212,9 @@ int kws_profiler_destroy(kws_profiler_t* p) {
 
 // the CALLING THREAD records into p from now on (NULL: stops recording)
 int kws_profiler_attach(kws_profiler_t* p) {
+  if (t_prof == p) return KWS_OK;
+  if (t_prof) t_prof->attached.fetch_sub(1);
+  if (p) p->attached.fetch_add(1);
   t_prof = p;
   return KWS_OK;
 }

@@ -20,13 +20,16 @@
 #include "internal.h"
 
 #include <algorithm>
+#include <map>
+#include <mutex>
+#include <tuple>
 #include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #ifdef KWS_GEMM_STAMP
 __device__ unsigned long long g_stamps[8192][8];
-extern "C" int kws_debug_read_stamps(unsigned long long* out) {
+extern "C" __attribute__((visibility("default"))) int kws_debug_read_stamps(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(g_stamps));
 }
 #endif
@@ -1331,7 +1334,25 @@ int64_t tn_cost(int64_t M, int K, int N, int tiles, int U, int64_t chunk, int* S
   *S_out = (int)S;
   return worst + (int64_t)((double)S * K * N * 4.0 * 0.8e-3) + 6000;   // + slab sum: bytes at ~2.5 TB/s, one launch
 }
+TNPlan tn_plan_search(int64_t M, int K, int N, bool ws);
+// The search below walks s_lo * 15 + 64 candidates with an 8-XCD inner loop and is asked for the same few shapes ~33 times per
+// training step (launch, workspace size, layout): memoised per (M, K, N, ws) - a step's shapes are a dozen entries.
 TNPlan tn_plan(int64_t M, int K, int N, bool ws) {
+  static std::mutex mu;
+  static std::map<std::tuple<int64_t, int, int, bool>, TNPlan> cache;
+  const auto key = std::make_tuple(M, K, N, ws);
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    const auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+  }
+  const TNPlan pl = tn_plan_search(M, K, N, ws);
+  std::lock_guard<std::mutex> lk(mu);
+  if (cache.size() > 4096) cache.clear();           // (a caller sweeping shapes: keep the map bounded)
+  cache[key] = pl;
+  return pl;
+}
+TNPlan tn_plan_search(int64_t M, int K, int N, bool ws) {
   TNPlan pl;
   if (ws) {
     pl.bko = (K % 128 == 0) ? 128 : 64;

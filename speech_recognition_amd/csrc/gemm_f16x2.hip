@@ -44,7 +44,7 @@ __device__ __forceinline__ void split4h(const float4 v, const float s, f16x4& h1
 // products, [3] wait for the next slab + split + store, [4] barrier after the store, [5] epilogue, [6] cycles, [7] 100 MHz ticks
 #ifdef KWS_X3_STAMP
 __device__ unsigned long long g_h2_stamps[2048][8];
-extern "C" int kws_debug_read_h2_stamps(unsigned long long* out) {
+extern "C" __attribute__((visibility("default"))) int kws_debug_read_h2_stamps(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_h2_stamps), sizeof(g_h2_stamps));
 }
 #define X3_DECL unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_mark = __builtin_amdgcn_s_memtime(); \

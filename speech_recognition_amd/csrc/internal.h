@@ -14,8 +14,8 @@ int kws_small_wgrad_launch(const float* X, const float* D, float* out, float* ou
                            float* scratch, hipStream_t st);
 int kws_metrics_launch(const float* per_loss, const float* per_correct, int B, float* metrics, hipStream_t st);
 // conv1.hip: the raw-waveform net's folded first convolution as a Toeplitz GEMM (forward with BN statistics rows, weight
-// gradient with its own slab workspace); kws_conv1_supported() says whether a gather descriptor / width qualifies
-bool kws_conv1_supported(const kws_gather_t* g, int N);
+// gradient with its own slab workspace); kws_conv1_supported() says whether a (folded, unfolded) descriptor pair / width qualifies
+bool kws_conv1_supported(const kws_gather_t* g, const kws_gather_t* unfolded, int N);
 int kws_conv1_stats_rows(int64_t M);
 // g = the folded view (one tap of 80 samples), unfolded = the reference's view (taps x cin, taps `stride_j` apart); W and
 // dW are the UNFOLDED kernel / gradient [taps][cin][128]: the forward kernel folds W while loading it into registers, the

@@ -378,7 +378,7 @@ int kws_net_predict(const kws_net_t* net, const float* params, const float* stat
   };
   KWS_TRY(prep(net->bn1, 0));
   for (int i = 0; i < nb; ++i) KWS_TRY(prep(net->blocks[i].bn, i + 1));
-  if (kws_conv1_supported(&net->gather1f, net->C1)) {
+  if (kws_conv1_supported(&net->gather1f, &net->gather1, net->C1)) {
     KWS_TRY(kws_conv1_fwd(x, &net->gather1f, &net->gather1, params + net->conv1, ws + lo.y[0], B, net->C1, nullptr, st));
   } else {
     KWS_TRY(fold_conv1(net, params, ws + lo.w1f, st));
@@ -507,13 +507,13 @@ static int ts_train(const kws_net_t* net, const float* params, float* state, con
   // ---------------- forward ----------------
   {
     const int64_t M = (int64_t)B * net->L1;
-    if (kws_conv1_supported(&net->gather1f, net->C1)) {
+    if (kws_conv1_supported(&net->gather1f, &net->gather1, net->C1)) {
       KWS_TRY(kws_conv1_fwd(x, &net->gather1f, &net->gather1, params + net->conv1, ws + lo.y[0], B, net->C1, part, st));
     } else {
       KWS_TRY(fold_conv1(net, params, ws + lo.w1f, st));
       KWS_TRY(kws_gemm_gather_f32(x, &net->gather1f, ws + lo.w1f, ws + lo.y[0], B, net->C1, part, st));
     }
-    const int rows1 = kws_conv1_supported(&net->gather1f, net->C1) ? kws_conv1_stats_rows(M) : kws_gemm_gather_stats_rows(M);
+    const int rows1 = kws_conv1_supported(&net->gather1f, &net->gather1, net->C1) ? kws_conv1_stats_rows(M) : kws_gemm_gather_stats_rows(M);
     KWS_TRY(kws_bn_stats_finalize(part, rows1, M, net->C1, params + net->bn1.gamma,
                                   params + net->bn1.beta, BN_EPS, BN_MOMENTUM, state + net->bn1.mm, state + net->bn1.mv,
                                   bn_at(0), red, st));
@@ -602,7 +602,7 @@ static int ts_train(const kws_net_t* net, const float* params, float* state, con
   if (phase != 1) {
     const int64_t M = (int64_t)B * net->L1;
     (void)M;                                        // Gb[0] already holds dy of the first convolution
-    if (kws_conv1_supported(&net->gather1f, net->C1)) {
+    if (kws_conv1_supported(&net->gather1f, &net->gather1, net->C1)) {
       KWS_TRY(kws_conv1_wgrad(x, &net->gather1f, &net->gather1, Gb[0], grads + net->conv1, B, net->C1, ws + lo.tn, st));
     } else {
       KWS_TRY(kws_gemm_tn_gather_f32(x, &net->gather1f, Gb[0], ws + lo.g1f, B, net->C1, ws + lo.tn, st));

@@ -34,7 +34,7 @@ using namespace kws_fft;
 // [3] mel + log, [4] DCT + store, [5] passes, [6] total cycles, [7] total in 100 MHz ticks
 #ifdef KWS_STFT_STAMP
 __device__ unsigned long long g_stft_stamps[256][12];
-extern "C" int kws_debug_read_stft_stamps(unsigned long long* out) {
+extern "C" __attribute__((visibility("default"))) int kws_debug_read_stft_stamps(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stft_stamps), sizeof(g_stft_stamps));
 }
 #define ST_DECL unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_mark = __builtin_amdgcn_s_memtime(); \

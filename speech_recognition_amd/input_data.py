@@ -148,7 +148,7 @@ class AudioProcessor(object):
         # co-running with its MFMA kernels (round 2 measured low / normal / high: the step time does not move, the
         # generator's own kernels run 40 % shorter on the low one).  The handle is ours: close() destroys it.
         self._own_stream = _lib.OwnedStream(self.device, -1)
-        self._stream = self._own_stream.stream
+        self._stream_obj = self._own_stream.stream
         self.profiler = None            # a _lib.Profiler: get_data() attaches the calling (generator) thread to it
         self._plan = None
         self._synthetic = isinstance(data_dirs, dict)
@@ -174,9 +174,17 @@ class AudioProcessor(object):
         if getattr(self, '_plan', None):
             self.lib.kws_stft_plan_destroy(self._plan)
             self._plan = None
+        self._stream_obj = None          # a later get_data() fails cleanly instead of launching on a destroyed stream
         if own is not None:
             own.close()
             self._own_stream = None
+
+    @property
+    def _stream(self):
+        s = self.__dict__.get('_stream_obj')
+        if s is None:
+            raise _lib.KwsError("AudioProcessor is closed: its generator stream and STFT plan are gone")
+        return s
 
     def __del__(self):
         try:

@@ -119,6 +119,20 @@ def main():
         out.append(rec)
     with open(os.path.join(OUT, 'k8_callback.json'), 'w') as f:
         json.dump({'note': 'observed outputs of /root/reference/callbacks.py (see make_golden_callback.py)',
+                   # which code produced each stored value: the reference's own lines, or the
+                   # reference's lines fed by the pd.crosstab stand-in for pandas_ml.ConfusionMatrix
+                   'provenance': {
+                       'logs.val_loss': "reference only: callbacks.py log_loss (:6-10) on the concatenated batches (:46-56); no stand-in involved",
+                       'log_loss': "reference only: callbacks.py log_loss (:6-10) called directly",
+                       'logs.val_categorical_accuracy': "reference arithmetic (callbacks.py accuracy(): trace / sum of the confusion matrix, :37-43, used at :64) on the "
+                                                        "matrix built by the pd.crosstab STAND-IN for pandas_ml.ConfusionMatrix",
+                       'logs.val_mean_categorical_accuracy_all': "reference arithmetic (callbacks.py accuracies(): diag / row sum with 0 for empty rows, float32, used at :63; .mean() at :82) "
+                                                                 "on the STAND-IN's matrix",
+                       'logs.val_mean_categorical_accuracy_wanted': "reference arithmetic (callbacks.py:65-70, :83: wanted words, others folded into "
+                                                                    "_unknown_) on the STAND-IN's matrix",
+                       'acc_line': "reference format string (callbacks.py:71) over the two accuracies above, i.e. through the STAND-IN",
+                       'logs_dtype': "types of the values the reference injected into `logs`",
+                       'inputs (words, wanted, y_true, y_pred)': "seeded by this script; not reference outputs"},
                    'cases': out}, f)
     for r in out:
         print(r['name'], r['logs'], r['acc_line'])
