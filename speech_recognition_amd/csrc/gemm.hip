@@ -340,7 +340,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_persist_kernel(NNArgs p) {
 // Host-checked preconditions: K % 32 == 0, K >= 64, N % BN == 0, 32-bit byte offsets inside a tile view.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // -DKWS_WS_ABL=<bits> (timing only, wrong results): the kernel without 1 the storers' row moves, 2 the loaders' LDS writes,
-// 4 the loaders' global loads, 8 the MFMA waves' staging writes
+// 4 the loaders' global loads, 8 the MFMA waves' staging writes; 16 = WITH five dependent vector instructions per A element
+// in the loader waves (what a depthwise -> pointwise loader fusion would issue there: BN scale/shift + ReLU6 on the loaded
+// y element, three FIR taps)
 #ifndef KWS_WS_ABL
 #define KWS_WS_ABL 0
 #endif
@@ -669,6 +671,16 @@ __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNA
     };
     auto write_lds = [&](int slot) {
       if (KWS_WS_ABL & 2) { asm volatile("" :: "v"(ra[0].x), "v"(rb[0].x)); return; }
+      if (KWS_WS_ABL & 16) {
+#pragma unroll
+        for (int r = 0; r < A_F4; ++r) {
+          float* e = &ra[r].x;
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int o = 0; o < 5; ++o) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(e[c]) : "v"(rb[0].x));
+        }
+      }
       float* sA = smem + slot * STAGE + arow * PLDA + acol;
 #pragma unroll
       for (int r = 0; r < A_F4; ++r) *reinterpret_cast<float4*>(sA + AROWS * r * PLDA) = ra[r];

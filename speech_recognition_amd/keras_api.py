@@ -506,9 +506,11 @@ class Model(object):
                     for cb in cbs:
                         cb.on_batch_end(step, {'batch': step, 'size': _batch_len(x)})
                 m = self._ring[:steps_per_epoch].cpu().numpy().astype(np.float64)
-                n = float(sum(sizes))
-                logs = {'loss': m[:, 0].sum() / n + reg_sum / max(reg_n, 1),
-                        'categorical_accuracy': m[:, 1].sum() / n}
+                # data-parallel: the logged training metrics are the GLOBAL batch's (sums over every rank's clips), the
+                # same on all ranks - a rank-local value would differ per replica and mislead anything that reads `logs`
+                loss_sum, acc_sum, n = parallel.allreduce_sums([m[:, 0].sum(), m[:, 1].sum(), float(sum(sizes))], self.device)
+                logs = {'loss': loss_sum / n + reg_sum / max(reg_n, 1),
+                        'categorical_accuracy': acc_sum / n}
                 if parallel.active():
                     # rank 0's moving statistics become everyone's BEFORE validation: every rank then computes the
                     # same val_* logs, so ReduceLROnPlateau / early stopping decide alike on all replicas

@@ -69,6 +69,19 @@ def allreduce_wait(handle):
         handle.wait()           # NCCL/RCCL: the current stream waits for the collective; gloo: the host does
 
 
+def allreduce_sums(values, device=None):
+    """Sum a few host scalars over all ranks (float64); returns a list of floats.  Used for what is LOGGED: an epoch's
+    loss / accuracy numerators and its sample count, so that every rank reports the global batch's metric instead of its
+    own shard's (the training itself never needs it).  One small collective per epoch."""
+    vals = [float(v) for v in values]
+    if not active():
+        return vals
+    dev = device if (device is not None and dist.get_backend() == 'nccl') else 'cpu'
+    t = torch.tensor(vals, dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(v) for v in t.cpu().tolist()]
+
+
 def split_block_from_env():
     """Default of Model.allreduce_split: KWS_ALLREDUCE_SPLIT=<block> all-reduces the gradients of blocks >= <block> (+ tail)
     while the earlier blocks' backward still runs.  Unset / 0 = one buffer after the backward pass (the default until an

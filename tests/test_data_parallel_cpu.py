@@ -47,6 +47,8 @@ def _worker(rank, world, port, out_dir):
     parallel.allreduce_grads(flat2[:off])
     parallel.allreduce_wait(h)
     assert torch.equal(flat2, flat)
+    # what fit_generator LOGS per epoch: the global batch's sums, the same on every rank
+    assert parallel.allreduce_sums([1.5 + rank, 10.0 * (rank + 1), 2.0]) == [4.0, 30.0, 4.0]
     # optimizer step on the reduced gradient: replicas stay identical
     p0 = np.concatenate([v.reshape(-1).astype(np.float64) for v in net.params.values()])
     new_p, _ = OL.rmsprop_step(p0, flat.numpy(), np.zeros_like(p0), 1e-3)
@@ -74,3 +76,4 @@ def test_single_process_is_a_noop():
     from speech_recognition_amd import parallel
     t = torch.ones(4)
     assert parallel.allreduce_grads(t) is t and parallel.world_size() == 1 and parallel.shard_rows(8) == (0, 8)
+    assert parallel.allreduce_sums([1.0, 2.5]) == [1.0, 2.5]
