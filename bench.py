@@ -99,6 +99,29 @@ def _cpu_clip(OF, rng, bank, noise):
                       noise[rng.randint(0, 960000 - 16000):][:16000], rng.uniform(0, 0.15))
 
 
+def feature_error_vs_oracle(proc, n_clips=16):
+    """CHECKER leg (oracle/ is test infrastructure: it is only ever the yardstick here).  Max |device - float64 oracle| of the
+    STFT+mel stage on clips of this run's own generator: |X|, log-mel (input_data.py:367-378) and the MFCC rows the
+    generator hands out (input_data.py:379-381), plus the largest magnitudes, so the tolerances of tests/test_kernels_gpu.py
+    can be read against what the shipped kernel (fp16-split first radix-16 pass and DCT, v_log_f32) really does."""
+    from oracle import features as OF
+    X, _ = proc.get_data(n_clips, 0, 0.3, 0.15, 0.3, 0.15, 0.3, [-500, 0], 'training', None, pseudo_frequency=0.6)
+    raw = (X[1] if isinstance(X, (list, tuple)) else X).tensor
+    proc._stream.synchronize()
+    dev = {k: proc._features(raw, kind) for k, kind in (("mfcc", 0), ("spectrogram", 1), ("log_mel", 2))}
+    proc._stream.synchronize()
+    tables = OF.tables_path_b(480, proc._n_mel, proc._n_out)
+    x64 = raw.cpu().numpy().astype(np.float64)
+    mag, logmel, feat = OF.features(x64, tables, 160, dtype=np.float64, return_all=True)
+    ref = {"mfcc": feat, "spectrogram": mag, "log_mel": logmel}
+    out = {"clips": int(n_clips), "what": "max |device - float64 oracle| on %d clips of the run's own generator (M=%d, K=%d)"
+                                          % (n_clips, proc._n_mel, proc._n_out)}
+    for k in ("spectrogram", "log_mel", "mfcc"):
+        d = dev[k].cpu().numpy().astype(np.float64).reshape(ref[k].shape)
+        out[k] = {"max_abs_err_vs_f64": float(np.abs(d - ref[k]).max()), "max_abs_value": float(np.abs(ref[k]).max())}
+    return out
+
+
 def cpu_baselines(budget_s=30.0):
     """The CPU-baseline set of BASELINE.md section 2, timed on this box's host cores on bounded samples (the whole
     call is ~30 s).  All of it runs oracle/ code (kind "port": TensorFlow 1.4 cannot run here):
@@ -359,6 +382,91 @@ def visible_gpu_count():
     return n
 
 
+# ---- first contact of N > 1 ranks: RCCL has never joined more than one rank on this pool, so the very
+# first collectives run under a watchdog BEFORE the 4.3 GB clip bank is built.  The watchdog is a fresh CHILD process that
+# never touches the GPU (started before this process does): if the process group does not come up, or the all-reduce of
+# ones + one gradient-sized (4.77 MB) all-reduce do not complete within the limit, the child prints the ONE JSON line of the
+# run - with "error" and "stage" - on rank 0's stdout and kills rank 0 (the launcher then ends the other ranks and returns
+# non-zero).  A hung collective may hold the GIL or sit inside the runtime: a thread of the hung process could not report it.
+PREFLIGHT_WATCHDOG = r"""
+import json, os, select, signal, sys, time
+ppid, world, t_init, t_coll = int(sys.argv[1]), int(sys.argv[2]), float(sys.argv[3]), float(sys.argv[4])
+stage, limit = "init_process_group", t_init
+deadline = time.time() + limit
+buf = b""
+while True:
+    r, _, _ = select.select([0], [], [], max(0.0, deadline - time.time()))
+    if not r:
+        print(json.dumps({"metric": "1s 16kHz clips/sec training throughput", "value": None, "unit": "clips/s", "n_gpus": world,
+                          "error": "rank 0 did not get through '%s' within %.0f s (hung collective / rendezvous): killed by the "
+                                   "preflight watchdog" % (stage, limit), "stage": stage, "rccl_ranks": None}), flush=True)
+        try:
+            os.kill(ppid, signal.SIGKILL)
+        except OSError:
+            pass
+        sys.exit(3)
+    chunk = os.read(0, 256)
+    if not chunk:
+        sys.exit(0)          # rank 0 closed the pipe: it is past the preflight, or ended by itself and said why
+    buf += chunk
+    while b"\n" in buf:
+        line, buf = buf.split(b"\n", 1)
+        if line == b"start":
+            stage, limit = "preflight all-reduce", t_coll
+            deadline = time.time() + limit
+        elif line == b"ok":
+            sys.exit(0)
+"""
+
+
+class PreflightWatchdog(object):
+    def __init__(self, json_out, world):
+        import subprocess
+        t_coll = float(os.environ.get("KWS_BENCH_PREFLIGHT_TIMEOUT", "60"))
+        t_init = float(os.environ.get("KWS_BENCH_INIT_TIMEOUT", "600"))
+        self.p = subprocess.Popen([sys.executable, "-c", PREFLIGHT_WATCHDOG, str(os.getpid()), str(world), str(t_init), str(t_coll)],
+                                  stdin=subprocess.PIPE, stdout=json_out, close_fds=True)
+
+    def say(self, word):
+        try:
+            self.p.stdin.write(word.encode() + b"\n")
+            self.p.stdin.flush()
+        except (IOError, OSError, ValueError):
+            pass
+
+    def done(self):
+        self.say("ok")
+        try:
+            self.p.stdin.close()
+            self.p.wait(timeout=10)
+        except Exception:
+            pass
+
+
+def preflight_collectives(dist, device, world, rank, n_floats=1191436):
+    """The first two collectives of the run: an all-reduce of ones (how many ranks really joined) and ONE all-reduce of a
+    buffer the size of the flat gradient buffer (1,191,436 floats = 4.77 MB), checked element-wise at both ends and by its sum."""
+    t0 = time.time()
+    if os.environ.get("KWS_BENCH_PREFLIGHT_FAIL") == "hang" and rank == 0:      # test hook: a collective that never returns
+        time.sleep(3600)
+    if os.environ.get("KWS_BENCH_PREFLIGHT_FAIL") == "raise":
+        raise RuntimeError("KWS_BENCH_PREFLIGHT_FAIL=raise (test hook)")
+    ones = torch.ones(1, dtype=torch.float32, device=device)
+    dist.all_reduce(ones)
+    joined = int(round(float(ones.item())))
+    if joined != world:
+        raise RuntimeError("all-reduce of ones returned %d on a world of %d" % (joined, world))
+    buf = torch.full((n_floats,), float(rank + 1), dtype=torch.float32, device=device)
+    dist.all_reduce(buf)
+    torch.cuda.synchronize(device)
+    expect = world * (world + 1) / 2.0
+    got = (float(buf[0].item()), float(buf[-1].item()), float(buf.double().sum().item()) / n_floats)
+    if any(abs(g - expect) > 1e-6 for g in got):
+        raise RuntimeError("gradient-sized all-reduce returned %r, expected %r everywhere" % (got, expect))
+    return {"rccl_ranks": joined, "grad_allreduce_floats": n_floats, "grad_allreduce_ok": True,
+            "seconds": time.time() - t0, "watchdog_s": float(os.environ.get("KWS_BENCH_PREFLIGHT_TIMEOUT", "60"))}
+
+
 def launch_ranks(args, json_out):
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves.
 
@@ -417,6 +525,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("KWS_BENCH_ONE_DEVICE"):   # test hook: N ranks on ONE GPU over gloo (1-GPU boxes cannot run RCCL x N)
         local_rank = 0
+    dog = PreflightWatchdog(json_out, world) if (world > 1 and rank == 0) else None    # before anything touches the GPU
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback of the product path")
     torch.cuda.set_device(local_rank)
@@ -432,12 +541,23 @@ def main():
     if world != args.gpus:
         raise SystemExit("bench.py --gpus %d started with WORLD_SIZE=%d" % (args.gpus, world))
     rccl_ranks = 1
-    if dist:      # how many ranks the collective library really joined: an all-reduce of ones
-        ones = torch.ones(1, dtype=torch.float32, device=device)
-        dist.all_reduce(ones)
-        rccl_ranks = int(round(float(ones.item())))
-        if rccl_ranks != world:
-            raise SystemExit("all-reduce of ones returned %d on a world of %d" % (rccl_ranks, world))
+    preflight = None
+    if dist:      # first contact, under the watchdog, before the clip bank is built
+        if dog:
+            dog.say("start")
+        try:
+            preflight = preflight_collectives(dist, device, world, rank)
+        except Exception as ex:
+            if rank == 0:
+                print(json.dumps({"metric": "1s 16kHz clips/sec training throughput", "value": None, "unit": "clips/s", "n_gpus": world,
+                                  "error": repr(ex), "stage": "preflight all-reduce", "rccl_ranks": None}), file=json_out, flush=True)
+            sys.stderr.write("preflight collectives failed on rank %d: %r\n" % (rank, ex))
+            if dog:
+                dog.done()
+            raise SystemExit(3)
+        rccl_ranks = preflight["rccl_ranks"]
+        if dog:
+            dog.done()
 
     from speech_recognition_amd import _lib
     from speech_recognition_amd.input_data import AudioProcessor
@@ -461,7 +581,7 @@ def main():
     model.seed = 87654321            # one dropout stream for the global batch: rank r uses rows [r*B, (r+1)*B)
     model.allreduce_split = 0        # the headline step: ONE all-reduce of the flat gradient buffer after the backward pass
     ab_steps = min(args.steps, 50)
-    ring = torch.zeros((args.warmup + args.steps + 3 * args.profile_steps + 2 * (ab_steps + 8) + 8, 4), dtype=torch.float32, device=device)
+    ring = torch.zeros((args.warmup + args.steps + 3 * args.profile_steps + 2 * (ab_steps + 8) + 4 * (ab_steps + 14) + 8, 4), dtype=torch.float32, device=device)
     enq = GeneratorEnqueuer(gen, max_queue_size=10, device=device)
     enq.start()
 
@@ -612,7 +732,51 @@ def main():
         finally:
             model.net.set_gemm_mode(0)
             _lib.Profiler.detach()   # a leg that raised between attach() and detach() must not leave this thread recording
+    # ---- configs[1]'s own A/B: "HIP STFT+mel vs raw-wave path".  The headline step produces BOTH arms of every batch (the
+    # generator's 'mfcc_and_raw' output); here the same training step is timed with the generator switched between 'raw'
+    # (augment only) and 'mfcc_and_raw' (augment + STFT/mel/DCT(80,60)) at run time, two alternating rounds each, same process.
+    if world == 1 and not args.no_ab:
+        try:
+            def step_any(i):
+                X, y = enq.get()
+                if isinstance(X, (list, tuple)):
+                    X[0].wait()
+                    X = X[1]
+                model._train_step_async(X, y, ring[i])
+            arms = {"raw": [], "mfcc_and_raw": []}
+            for rnd in range(2):
+                for rep in ("raw", "mfcc_and_raw"):
+                    proc.output_representation = rep
+                    for i in range(14):                 # the queue (depth 10) still holds batches of the other kind: train through them
+                        step_any(used + i)
+                    used += 14
+                    barrier()
+                    t0 = time.time()
+                    for i in range(ab_steps):
+                        step_any(used + i)
+                    barrier()
+                    arms[rep].append((time.time() - t0) / ab_steps)
+                    used += ab_steps
+            proc.output_representation = 'mfcc_and_raw'
+            m_raw, m_both = 1e3 * min(arms["raw"]), 1e3 * min(arms["mfcc_and_raw"])
+            ab["ab_features"] = {"what": "the same training step fed by the generator's 'raw' output (augment only) vs its "
+                                         "'mfcc_and_raw' output (augment + STFT/mel/DCT(80,60) on the generator's low-priority stream); "
+                                         "best of two alternating rounds of %d steps each" % ab_steps,
+                                 "steps": ab_steps,
+                                 "raw": {"ms_per_step": m_raw, "value": B / m_raw * 1e3, "rounds_ms": [1e3 * v for v in arms["raw"]]},
+                                 "mfcc_and_raw": {"ms_per_step": m_both, "value": B / m_both * 1e3,
+                                                  "rounds_ms": [1e3 * v for v in arms["mfcc_and_raw"]]},
+                                 "stft_mel_cost_us_per_step": 1e3 * (m_both - m_raw), "unit": "clips/s"}
+        except Exception as ex:
+            ab["ab_features_error"] = repr(ex)
+            sys.stderr.write("A/B features leg failed: %r\n" % (ex,))
     enq.stop()
+    feature_err = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:                             # checker leg: the generator thread has stopped, this thread may draw from the processor
+            feature_err = feature_error_vs_oracle(proc)
+        except Exception as ex:
+            feature_err = {"error": repr(ex)}
     if rank == 0 and stages:
         # the STFT stage ALONE (its in-situ time above is that of a low-priority stream filling the gaps of the training
         # stream): 20 back-to-back launches on one batch, HIP events on the launch stream
@@ -668,7 +832,7 @@ def main():
                 c3["roofline"] = roofline_entry(kern, dom, {"gemm_nn": "gemm_nn_ws_kernel", "gemm_tn": "gemm_tn_ws_kernel"}.get(dom, dom + "_kernel"),
                                                 bound, "dominant kernel family of the C3 step by summed HIP-event time", None)
             configs["C3"] = c3
-            configs["C5"] = bench_configs.c5(speed_tta=False, n=10, warm=3)
+            configs["C5"] = bench_configs.c5(speed_tta=True, n=10, warm=3)   # x3 AND the six-term speed TTA BASELINE configs[4] names
         except Exception as ex:
             configs["error"] = repr(ex)
             sys.stderr.write("configs legs failed: %r\n" % (ex,))
@@ -687,6 +851,7 @@ def main():
                        "global_batch": B * world, "parallelism": "dp%d" % world,
                        "clip_bank": args.bank},
             "rccl_ranks": rccl_ranks,
+            "preflight": preflight,
             "collective_backend": (dist.get_backend() if dist else None),
             "per_rank_ms": per_rank_ms,
             "scaling_vs_n1": (clips / dt) / (world * args.n1_value) if args.n1_value else None,
@@ -697,6 +862,8 @@ def main():
             "roofline": roof,
             "roofline_stages": stages[1:],
             "ab_gemm_f16x2": ab.get("ab_gemm_f16x2"),
+            "ab_features": ab.get("ab_features"),
+            "stft_mel_error": feature_err,
             "ab_error": ab.get("error"),
             "configs": configs,
             "kernels": prof,

@@ -102,9 +102,21 @@ def c5(speed_tta=True, n=10, warm=3):
         # device inside the timed region (the reference reads them from the offline set of create_tta_set.py)
         ms_tta6 = timed(lambda: predict_tta(model, x, use_speed_tta=True), warm, n)
         ms_stretch = timed(lambda: time_stretch(x, 0.9), warm, n)
-        out["speed_tta"] = {"what": "x6 (identity, 1.2x, roll 1500, slow, clip(1.1 slow), 0.9 slow), phase-vocoder stretch on "
-                                    "the device", "ms_per_batch": ms_tta6, "clips_per_s": B / ms_tta6 * 1e3,
-                            "stretch_ms_per_batch": ms_stretch, "stretch_clips_per_s": B / ms_stretch * 1e3}
+        # the stretch kernel against both roofs: 64 kB in + 64 kB out per clip (f32 bank), ~8 MFLOP per clip (68 real
+        # 2048-point FFTs as 1024-point complex radix-4 transforms + phase vocoder)
+        by, fl = 128000.0 * B, 8.0e6 * B
+        out["speed_tta"] = {"what": "x6 (identity, 1.2x, roll 1500, slow, clip(1.1 slow), 0.9 slow; the sum divided by 10 as "
+                                    "make_submission.py:137-140 does), phase-vocoder stretch on the device",
+                            "ms_per_batch": ms_tta6, "clips_per_s": B / ms_tta6 * 1e3,
+                            "stretch_ms_per_batch": ms_stretch, "stretch_clips_per_s": B / ms_stretch * 1e3,
+                            "stretch_roofline": {"kernel": "stretch_kernel", "bound": "hbm",
+                                                 "achieved": by / (ms_stretch * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                                 "frac": by / (ms_stretch * 1e-3) / 1e9 / 8000.0,
+                                                 "frac_flops": fl / (ms_stretch * 1e-3) / 1e12 / 157.3,
+                                                 "algorithmic_bytes_per_launch": by, "algorithmic_flops_per_launch": fl,
+                                                 "avg_launch_us": ms_stretch * 1e3,
+                                                 "note": "latency / VALU bound (340 barrier-to-barrier passes per clip); timed by HIP "
+                                                         "events on the launch stream, %d launches" % n}}
     return out
 
 

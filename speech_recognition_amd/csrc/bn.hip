@@ -174,6 +174,57 @@ __global__ __launch_bounds__(256) void dw_bwd_finalize_kernel(const float* __res
   }
 }
 
+// The depthwise weight gradients of SEVERAL layers in one launch (round 4, net_logmfcc.hip): a block's FIRST depthwise
+// convolution reads a materialised activation, so its backward leaves only dw partial rows - nothing on the dependency chain
+// needs their fold.  Each layer keeps its rows in a region of its own until this launch.  Same summation order per channel as
+// dw_bwd_finalize_kernel (row groups r, r + FIN_RG, ...; groups combined in order; double): bit-identical gradients.
+struct DwFinBatch {
+  const float* part[KWS_DW_FIN_BATCH];
+  float* dw[KWS_DW_FIN_BATCH];
+  int n_parts[KWS_DW_FIN_BATCH], C[KWS_DW_FIN_BATCH], blk_end[KWS_DW_FIN_BATCH];
+  int n;
+};
+__global__ __launch_bounds__(256) void dw_grad_finalize_batch_kernel(DwFinBatch b) {
+  __shared__ double red[3][FIN_RG][FIN_CG];
+  int m = 0;
+  while (m + 1 < b.n && (int)blockIdx.x >= b.blk_end[m]) ++m;
+  const int blk = blockIdx.x - (m ? b.blk_end[m - 1] : 0);
+  const int C = b.C[m], n_parts = b.n_parts[m];
+  const float* part = b.part[m];
+  const int cg = threadIdx.x % FIN_CG, rg = threadIdx.x / FIN_CG;
+  const int c = blk * FIN_CG + cg;
+  double s[3] = {0, 0, 0};
+  if (c < C) {
+    for (int t = rg; t < n_parts; t += FIN_U * FIN_RG) {
+      float a[FIN_U][3];
+#pragma unroll
+      for (int u = 0; u < FIN_U; ++u) {
+        const int tt = t + u * FIN_RG;
+        const bool ok = tt < n_parts;
+        const float* src = ok ? part + (int64_t)tt * 5 * C + c : g_zero_fin;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) a[u][q] = src[ok ? (q + 2) * C : q];
+      }
+#pragma unroll
+      for (int u = 0; u < FIN_U; ++u)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) s[q] += (double)a[u][q];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 3; ++q) red[q][rg][cg] = s[q];
+  __syncthreads();
+  if (rg == 0 && c < C) {
+    float* dw = b.dw[m];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      double a = 0.0;
+      for (int r = 0; r < FIN_RG; ++r) a += red[q][r][cg];
+      dw[q * C + c] = (float)a;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ g, const float* __restrict__ y,
                                                            const float* __restrict__ bn, const float* __restrict__ gamma,
                                                            const float* __restrict__ coef, int64_t n4, int C,
@@ -215,6 +266,28 @@ int pre_reduce(const float* part, int n, int W, float* scratch, hipStream_t st, 
 }
 
 }  // namespace
+
+// internal (net_logmfcc.hip): dw[i][3][C_i] = column sums 2..4 of part[i][n_parts_i][5][C_i], count <= KWS_DW_FIN_BATCH layers, one launch
+int kws_dw_grad_finalize_batch(const float* const* part, const int* n_parts, const int* C, float* const* dw, int count,
+                               hipStream_t stream) {
+  KWS_REQUIRE(part && n_parts && C && dw && count > 0 && count <= KWS_DW_FIN_BATCH, "dw_grad_finalize_batch: bad arguments (count=%d)", count);
+  DwFinBatch b;
+  int blocks = 0;
+  double bytes = 0;
+  for (int i = 0; i < count; ++i) {
+    KWS_REQUIRE(part[i] && dw[i] && n_parts[i] > 0 && n_parts[i] <= 8 * KWS_REDUCE_SLICES && C[i] > 0,
+                "dw_grad_finalize_batch: bad entry %d (rows %d)", i, n_parts[i]);
+    b.part[i] = part[i]; b.dw[i] = dw[i]; b.n_parts[i] = n_parts[i]; b.C[i] = C[i];
+    blocks += ceil_div(C[i], FIN_CG);
+    b.blk_end[i] = blocks;
+    bytes += 12.0 * n_parts[i] * C[i];
+  }
+  b.n = count;
+  KwsProfScope prof("bn_finalize", 0.0, bytes, stream);
+  hipLaunchKernelGGL(dw_grad_finalize_batch_kernel, dim3((unsigned)blocks), dim3(FIN_CG * FIN_RG), 0, stream, b);
+  KWS_LAUNCH_CHECK("dw_grad_finalize_batch_kernel");
+  return KWS_OK;
+}
 
 extern "C" {
 

@@ -79,6 +79,10 @@ struct KwsSlabQueue {
     return 0;
   }
 };
+// bn.hip: the depthwise weight gradients of up to KWS_DW_FIN_BATCH layers folded in one launch (their partial rows kept apart)
+constexpr int KWS_DW_FIN_BATCH = 16;
+int kws_dw_grad_finalize_batch(const float* const* part, const int* n_parts, const int* C, float* const* dw, int count,
+                               hipStream_t stream);
 constexpr int KWS_TRANSPOSE_BATCH = 16;
 extern "C" int kws_transpose_batch_f32(const float* const* in, float* const* out, const int* rows, const int* cols, int n,
                                        hipStream_t stream);

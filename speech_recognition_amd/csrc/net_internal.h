@@ -82,6 +82,11 @@ int kws_block_out_fwd(const float* y, const float* bn, const float* res, const f
                       int L, int C, int pool, hipStream_t st);
 // g[b,u,c] = [u wins its pool window] * dO[b,u/P,c] * (relu ? relu6'(bn(y)) : 1); part = [blocks][5][C] sums of
 // (g, g*xhat, 0, 0, 0)
+// two-pass join backward + BatchNorm backward (resblock.hip block_join_bwd_kernel): pass 1 leaves kws_block_join_bwd_parts()
+// partial rows [5][C] (<= 256 per launch: no slice fold in front of kws_dw_bwd_finalize), pass 2 writes dy directly
+int kws_block_join_bwd_parts(int B, int L, int C, int pool);
+int kws_block_join_bwd(const float* dO, const float* y, const float* bn, const float* gamma, const float* coef, float* out,
+                       float* part, int pass, int B, int L, int C, int pool, int relu, hipStream_t st);
 int64_t kws_block_out_bwd_part_floats(int B, int L, int C, int pool);
 int kws_block_out_bwd(const float* dO, const float* y, const float* bn, float* g, float* part, int B, int L, int C,
                       int pool, int relu, hipStream_t st);

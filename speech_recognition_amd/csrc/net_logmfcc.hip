@@ -89,6 +89,7 @@ struct LmLayout {
   std::vector<int64_t> ys, z1, y1, z2, y2, o;
   int64_t bn = 0, bn_stride = 0, part = 0, red = 0, coef = 0, WT = 0, tn = 0, swg = 0;
   int64_t tnq = 0, tnq_floats = 0;         // slabs of the pointwise weight gradients of one backward pass (KwsSlabQueue)
+  int64_t dwq = 0, dwq_floats = 0;         // partial rows of the depthwise weight gradients folded by one launch (DwFinQueue)
   int64_t dOa = 0, dOb = 0, G = 0, DZ = 0, DXS = 0;
   int64_t u = 0, fd = 0, dl = 0, gu = 0, coef2 = 0, per_loss = 0, per_correct = 0, att = 0;
   int64_t xpad = 0, wpad = 0, gwpad = 0;  // only when Fp != F (style 0) / always (style 1: padded first kernel)
@@ -115,6 +116,8 @@ void lm_layout(const kws_net* n, int B, LmLayout* lo) {
     max_tn = std::max(max_tn, kws_gemm_tn_workspace_floats(M, K, N));
   };
   int64_t sum_tnq = 0;                     // the pointwise weight gradients keep their slabs until one batched sum
+  int64_t sum_dwq = 0;                     // depthwise backward kernels whose rows hold only a weight gradient: folded at the end
+  auto upd_dwq = [&](int L, int C) { sum_dwq += (kws_dwconv_bwd_part_floats(B, L, C) + 63) / 64 * 64; };
   auto upd_pw = [&](int64_t M, int K, int N) {
     upd_gemm(M, K, N);
     sum_tnq += (kws_gemm_tn_workspace_floats(M, K, N) + 63) / 64 * 64;
@@ -133,6 +136,7 @@ void lm_layout(const kws_net* n, int B, LmLayout* lo) {
     max_z = (int64_t)B * p.L0 * p.C0;
     upd_pw((int64_t)B * p.L0, p.C0, p.C0);
     max_part = std::max(max_part, kws_dwconv_bwd_part_floats(B, p.L0, p.C0));
+    upd_dwq(p.L0, p.C0);
   }
   for (int i = 0; i < nb; ++i) {
     const LmBlock& b = p.blocks[i];
@@ -150,6 +154,7 @@ void lm_layout(const kws_net* n, int B, LmLayout* lo) {
     upd_pw((int64_t)B * b.Lmid, b.nf, b.nf);
     if (b.has_short) upd_gemm((int64_t)B * b.Lout, b.cin, b.nf);
     max_part = std::max(max_part, kws_dwconv_bwd_part_floats(B, b.Lin, b.cin));
+    upd_dwq(b.Lin, b.cin);
     max_part = std::max(max_part, kws_dwconv_bwd_part_floats(B, b.Lmid, b.nf));
     max_part = std::max(max_part, b.pool3 ? kws_block_out3_bwd_part_floats(B, b.Lmid, b.nf)
                                           : kws_block_out_bwd_part_floats(B, b.Lmid, b.nf, b.pool));
@@ -165,6 +170,7 @@ void lm_layout(const kws_net* n, int B, LmLayout* lo) {
     max_o = std::max(max_o, std::max((int64_t)B * q.Lin * q.cin, (int64_t)B * q.Lout * q.cout));
     upd_pw((int64_t)B * q.Lout, q.cin, q.cout);
     max_part = std::max(max_part, kws_dwconv_bwd_part_floats(B, q.Lin, q.cin));
+    if (j == 0) upd_dwq(q.Lin, q.cin);
     max_part = std::max(max_part, kws_block_out_bwd_part_floats(B, q.Lout, q.cout, 1));
   }
   if (!p.plain.empty()) lo->alast = bp.take((int64_t)B * p.T * p.C);
@@ -188,6 +194,8 @@ void lm_layout(const kws_net* n, int B, LmLayout* lo) {
   lo->tn = bp.take(max_tn);
   lo->tnq_floats = sum_tnq;
   lo->tnq = bp.take(sum_tnq);
+  lo->dwq_floats = sum_dwq;
+  lo->dwq = bp.take(sum_dwq);
   lo->swg = bp.take((int64_t)KWS_SMALL_WGRAD_SLICES * feat * p.NC);
   lo->dOa = bp.take(max_o);
   lo->dOb = bp.take(max_o);
@@ -851,6 +859,48 @@ int lm_train(const kws_net* n, const float* params, float* state, const float* x
   float* dX = ws + lo.dOb;
   KwsSlabQueue sq;
   sq.base = ws + lo.tnq; sq.cap = lo.tnq_floats;
+  // Depthwise backward kernels that leave ONLY a weight gradient behind (a block's first depthwise convolution, the context
+  // block's, the first plain block's: their input is a materialised activation, no BatchNorm in front): nothing on the
+  // dependency chain needs the fold of their partial rows, so the rows stay in regions of their own and one launch folds up to
+  // KWS_DW_FIN_BATCH layers at the end of the pass (round 4: one small launch per block off the chain).
+  struct DwFinQueue {
+    const float* part[KWS_DW_FIN_BATCH];
+    float* dw[KWS_DW_FIN_BATCH];
+    int n_parts[KWS_DW_FIN_BATCH], C[KWS_DW_FIN_BATCH];
+    int count = 0;
+    float* base = nullptr;
+    int64_t used = 0, cap = 0;
+    hipStream_t st = nullptr;
+    int flush() {
+      if (count == 0) return KWS_OK;
+      const int rc = kws_dw_grad_finalize_batch(part, n_parts, C, dw, count, st);
+      count = 0;
+      used = 0;
+      return rc;
+    }
+    // a region for the rows of one depthwise backward launch (floats = kws_dwconv_bwd_part_floats) whose fold writes dW
+    int take(int64_t floats, int Cc, float* dW, float** out) {
+      const int64_t need = (floats + 63) / 64 * 64;
+      if (count == KWS_DW_FIN_BATCH || used + need > cap) KWS_TRY(flush());
+      if (need > cap) return KWS_E_WORKSPACE;
+      *out = base + used;
+      part[count] = base + used; dw[count] = dW; n_parts[count] = (int)(floats / (5 * Cc)); C[count] = Cc;
+      used += need;
+      ++count;
+      return KWS_OK;
+    }
+  } dq;
+  dq.base = ws + lo.dwq; dq.cap = lo.dwq_floats; dq.st = st;
+  // join backward + BatchNorm backward in two passes (round 4): reductions, fold (dgamma, dbeta, c1 | c2), then the masked /
+  // pool-routed gradient is recomputed and dy written directly - 5 tensor passes instead of the 6 of "kws_block_out_bwd,
+  // fold, kws_bn_bwd_apply", <= 256 partial rows (no slice fold), one launch less per join.  `outp` may be `dOin` (pool 1).
+  auto join_bwd = [&](const float* dOin, const float* yv, const BnRef& r, int bn_idx, float* outp, int L, int C, int pool,
+                      int relu) -> int {
+    KWS_TRY(kws_block_join_bwd(dOin, yv, c.bn_at(bn_idx), nullptr, nullptr, nullptr, part, 1, B, L, C, pool, relu, st));
+    KWS_TRY(kws_dw_bwd_finalize(part, kws_block_join_bwd_parts(B, L, C, pool), (int64_t)B * L, C, nullptr, grads + r.gamma,
+                                grads + r.beta, coef, red, st));
+    return kws_block_join_bwd(dOin, yv, c.bn_at(bn_idx), params + r.gamma, coef, outp, nullptr, 2, B, L, C, pool, relu, st);
+  };
   // ---- tail forward + backward ----
   if (p.style != 0) {
     kws_gp_tail_args g;
@@ -870,10 +920,7 @@ int lm_train(const kws_net* n, const float* params, float* state, const float* x
       const LmPlain& q = p.plain[j];
       const int64_t M = (int64_t)B * q.Lout;
       if (j == (int)p.plain.size() - 1) {
-        KWS_TRY(kws_block_out_bwd(dO, ws + lo.py[j], c.bn_at(q.bn_idx), G, part, B, q.Lout, q.cout, 1, 1, st));
-        const int np = (int)(kws_block_out_bwd_part_floats(B, q.Lout, q.cout, 1) / (5 * q.cout));
-        KWS_TRY(kws_dw_bwd_finalize(part, np, M, q.cout, nullptr, grads + q.bn.gamma, grads + q.bn.beta, coef, red, st));
-        KWS_TRY(kws_bn_bwd_apply(G, ws + lo.py[j], c.bn_at(q.bn_idx), params + q.bn.gamma, coef, M, q.cout, st));
+        KWS_TRY(join_bwd(dO, ws + lo.py[j], q.bn, q.bn_idx, G, q.Lout, q.cout, 1, 1));
       }  // else: G already holds dy of this block (pass 2 of the next block's depthwise backward)
       KWS_TRY(kws_gemm_nn_f32(G, ws + lo.wt_plain[j], DZ, M, q.cout, q.cin, nullptr, st));
       KWS_TRY(sq.gemm(ws + lo.pz[j], G, grads + q.pw, M, q.cin, q.cout, st));
@@ -888,8 +935,9 @@ int lm_train(const kws_net* n, const float* params, float* state, const float* x
                                       q.Lout, q.cin, q.stride, q.pad_l, st));
       } else {
         const float* xin = ws + lo.o[p.blocks.size() - 1];
-        KWS_TRY(kws_dwconv_bwd_f32(DZ, xin, nullptr, params + q.dw, dX, part, B, q.Lin, q.Lout, q.cin, q.stride, q.pad_l, st));
-        KWS_TRY(kws_dw_bwd_finalize(part, np, (int64_t)B * q.Lin, q.cin, grads + q.dw, nullptr, nullptr, nullptr, red, st));
+        float* dpart;
+        KWS_TRY(dq.take(kws_dwconv_bwd_part_floats(B, q.Lin, q.cin), q.cin, grads + q.dw, &dpart));
+        KWS_TRY(kws_dwconv_bwd_f32(DZ, xin, nullptr, params + q.dw, dX, dpart, B, q.Lin, q.Lout, q.cin, q.stride, q.pad_l, st));
         std::swap(dO, dX);
       }
     }
@@ -911,15 +959,14 @@ int lm_train(const kws_net* n, const float* params, float* state, const float* x
     const float* xin = i == 0 ? (p.style == 1 ? ws + lo.ac : ws + lo.a0) : ws + lo.o[i - 1];
     // main branch: join backward (maxpool routing + ReLU6 mask) -> BN2 -> pointwise 2
     int np;
-    if (b.pool3) {
+    if (b.pool3) {   // the 3-wide SAME join keeps the one-pass form (an input position collects up to three windows)
       KWS_TRY(kws_block_out3_bwd(dO, ws + lo.y2[i], c.bn_at(b.bn2_idx), G, part, B, b.Lmid, b.Lout, b.nf, b.stride, b.ppad, st));
       np = (int)(kws_block_out3_bwd_part_floats(B, b.Lmid, b.nf) / (5 * b.nf));
+      KWS_TRY(kws_dw_bwd_finalize(part, np, M, b.nf, nullptr, grads + b.bn2.gamma, grads + b.bn2.beta, coef, red, st));
+      KWS_TRY(kws_bn_bwd_apply(G, ws + lo.y2[i], c.bn_at(b.bn2_idx), params + b.bn2.gamma, coef, M, b.nf, st));
     } else {
-      KWS_TRY(kws_block_out_bwd(dO, ws + lo.y2[i], c.bn_at(b.bn2_idx), G, part, B, b.Lmid, b.nf, b.pool, 1, st));
-      np = (int)(kws_block_out_bwd_part_floats(B, b.Lmid, b.nf, b.pool) / (5 * b.nf));
+      KWS_TRY(join_bwd(dO, ws + lo.y2[i], b.bn2, b.bn2_idx, G, b.Lmid, b.nf, b.pool, 1));
     }
-    KWS_TRY(kws_dw_bwd_finalize(part, np, M, b.nf, nullptr, grads + b.bn2.gamma, grads + b.bn2.beta, coef, red, st));
-    KWS_TRY(kws_bn_bwd_apply(G, ws + lo.y2[i], c.bn_at(b.bn2_idx), params + b.bn2.gamma, coef, M, b.nf, st));
     KWS_TRY(kws_gemm_nn_f32(G, ws + lo.wt_pw2[i], DZ, M, b.nf, b.nf, nullptr, st));
     KWS_TRY(sq.gemm(ws + lo.z2[i], G, grads + b.pw2, M, b.nf, b.nf, st));
     // depthwise 2 -> BN1 -> pointwise 1
@@ -933,19 +980,16 @@ int lm_train(const kws_net* n, const float* params, float* state, const float* x
     KWS_TRY(kws_gemm_nn_f32(G, ws + lo.wt_pw1[i], DZ, M, b.nf, b.cin, nullptr, st));
     KWS_TRY(sq.gemm(ws + lo.z1[i], G, grads + b.pw1, M, b.cin, b.nf, st));
     // depthwise 1 on the (materialised) block input
+    float* dpart;      // only a weight gradient comes out of these rows: folded with the other blocks' at the end of the pass
+    KWS_TRY(dq.take(kws_dwconv_bwd_part_floats(B, b.Lin, b.cin), b.cin, grads + b.dw1, &dpart));
     if (!b.has_short)   // identity shortcut: the join's other gradient is added while the depthwise input gradient is written
-      KWS_TRY(kws_dwconv_bwd_acc_f32(DZ, xin, params + b.dw1, dO, dX, part, B, b.Lin, b.Lmid, b.cin, b.s1, b.pad1, st));
+      KWS_TRY(kws_dwconv_bwd_acc_f32(DZ, xin, params + b.dw1, dO, dX, dpart, B, b.Lin, b.Lmid, b.cin, b.s1, b.pad1, st));
     else
-      KWS_TRY(kws_dwconv_bwd_f32(DZ, xin, nullptr, params + b.dw1, dX, part, B, b.Lin, b.Lmid, b.cin, b.s1, b.pad1, st));
-    np = (int)(kws_dwconv_bwd_part_floats(B, b.Lin, b.cin) / (5 * b.cin));
-    KWS_TRY(kws_dw_bwd_finalize(part, np, (int64_t)B * b.Lin, b.cin, grads + b.dw1, nullptr, nullptr, nullptr, red, st));
+      KWS_TRY(kws_dwconv_bwd_f32(DZ, xin, nullptr, params + b.dw1, dX, dpart, B, b.Lin, b.Lmid, b.cin, b.s1, b.pad1, st));
     // residual branch
     if (b.has_short) {
       const int64_t Mo = (int64_t)B * b.Lout;
-      KWS_TRY(kws_block_out_bwd(dO, ws + lo.ys[i], c.bn_at(b.bns_idx), dO, part, B, b.Lout, b.nf, 1, 0, st));
-      np = (int)(kws_block_out_bwd_part_floats(B, b.Lout, b.nf, 1) / (5 * b.nf));
-      KWS_TRY(kws_dw_bwd_finalize(part, np, Mo, b.nf, nullptr, grads + b.bns.gamma, grads + b.bns.beta, coef, red, st));
-      KWS_TRY(kws_bn_bwd_apply(dO, ws + lo.ys[i], c.bn_at(b.bns_idx), params + b.bns.gamma, coef, Mo, b.nf, st));
+      KWS_TRY(join_bwd(dO, ws + lo.ys[i], b.bns, b.bns_idx, dO, b.Lout, b.nf, 1, 0));   // the shortcut's BN: no mask, in place
       KWS_TRY(kws_gemm_tn_gather_f32(xin, &b.gs, dO, grads + b.ws, B, b.nf, ws + lo.tn, st));
       KWS_TRY(kws_gemm_nn_f32(dO, ws + lo.wt_ws[i], ws + lo.DXS, Mo, b.nf, b.cin, nullptr, st));
       KWS_TRY(kws_add_strided_f32(dX, ws + lo.DXS, B, b.Lin, b.Lout, b.cin, b.stride, st));
@@ -954,15 +998,12 @@ int lm_train(const kws_net* n, const float* params, float* state, const float* x
   }
   if (p.style == 1) {  // ---- context block: dO is the gradient wrt its activated output ----
     const int64_t M = (int64_t)B * p.L0;
-    KWS_TRY(kws_block_out_bwd(dO, ws + lo.yc, c.bn_at(p.ctx_bn_idx), G, part, B, p.L0, p.C0, 1, 1, st));
-    int np = (int)(kws_block_out_bwd_part_floats(B, p.L0, p.C0, 1) / (5 * p.C0));
-    KWS_TRY(kws_dw_bwd_finalize(part, np, M, p.C0, nullptr, grads + p.ctx_bn.gamma, grads + p.ctx_bn.beta, coef, red, st));
-    KWS_TRY(kws_bn_bwd_apply(G, ws + lo.yc, c.bn_at(p.ctx_bn_idx), params + p.ctx_bn.gamma, coef, M, p.C0, st));
+    KWS_TRY(join_bwd(dO, ws + lo.yc, p.ctx_bn, p.ctx_bn_idx, G, p.L0, p.C0, 1, 1));
     KWS_TRY(kws_gemm_nn_f32(G, ws + lo.wt_ctx, DZ, M, p.C0, p.C0, nullptr, st));
     KWS_TRY(sq.gemm(ws + lo.zc, G, grads + p.ctx_pw, M, p.C0, p.C0, st));
-    KWS_TRY(kws_dwconv_bwd_f32(DZ, ws + lo.a0, nullptr, params + p.ctx_dw, dX, part, B, p.L0, p.L0, p.C0, 1, 1, st));
-    np = (int)(kws_dwconv_bwd_part_floats(B, p.L0, p.C0) / (5 * p.C0));
-    KWS_TRY(kws_dw_bwd_finalize(part, np, M, p.C0, grads + p.ctx_dw, nullptr, nullptr, nullptr, red, st));
+    float* dpart;
+    KWS_TRY(dq.take(kws_dwconv_bwd_part_floats(B, p.L0, p.C0), p.C0, grads + p.ctx_dw, &dpart));
+    KWS_TRY(kws_dwconv_bwd_f32(DZ, ws + lo.a0, nullptr, params + p.ctx_dw, dX, dpart, B, p.L0, p.L0, p.C0, 1, 1, st));
     std::swap(dO, dX);
   }
   if (p.style == 3) {  // ---- the two stems: split the gradient of the concatenation, then each like a first convolution
@@ -975,23 +1016,18 @@ int lm_train(const kws_net* n, const float* params, float* state, const float* x
     const Stem stems[2] = {{dOm, ws + lo.y0, 1, p.Cm, &p.bn0, &p.g0, p.conv1},
                            {dOr, ws + lo.y0 + M * p.Cm, 2, p.Cr, &p.bn0r, &p.g0r, p.conv1r}};
     for (const Stem& sm : stems) {
-      KWS_TRY(kws_block_out_bwd(sm.d, sm.y, c.bn_at(sm.idx), G, part, B, p.L0, sm.C, 1, 1, st));
-      const int np = (int)(kws_block_out_bwd_part_floats(B, p.L0, sm.C, 1) / (5 * sm.C));
-      KWS_TRY(kws_dw_bwd_finalize(part, np, M, sm.C, nullptr, grads + sm.bn->gamma, grads + sm.bn->beta, coef, red, st));
-      KWS_TRY(kws_bn_bwd_apply(G, sm.y, c.bn_at(sm.idx), params + sm.bn->gamma, coef, M, sm.C, st));
+      KWS_TRY(join_bwd(sm.d, sm.y, *sm.bn, sm.idx, G, p.L0, sm.C, 1, 1));
       KWS_TRY(kws_gemm_tn_gather_f32(x, sm.g, G, grads + sm.w, B, sm.C, ws + lo.tn, st));
     }
     KWS_TRY(sq.flush(st));
+    KWS_TRY(dq.flush());
     return KWS_OK;
   }
   KWS_TRY(sq.flush(st));   // the pointwise weight gradients of the whole pass: one sum (two past 16 layers)
+  KWS_TRY(dq.flush());     // ... and the depthwise weight gradients whose rows were parked
   // ---- first convolution ----
   {
-    const int64_t M = (int64_t)B * p.L0;
-    KWS_TRY(kws_block_out_bwd(dO, ws + lo.y0, c.bn_at(1), G, part, B, p.L0, p.C0, 1, 1, st));
-    const int np = (int)(kws_block_out_bwd_part_floats(B, p.L0, p.C0, 1) / (5 * p.C0));
-    KWS_TRY(kws_dw_bwd_finalize(part, np, M, p.C0, nullptr, grads + p.bn0.gamma, grads + p.bn0.beta, coef, red, st));
-    KWS_TRY(kws_bn_bwd_apply(G, ws + lo.y0, c.bn_at(1), params + p.bn0.gamma, coef, M, p.C0, st));
+    KWS_TRY(join_bwd(dO, ws + lo.y0, p.bn0, 1, G, p.L0, p.C0, 1, 1));
     if (p.style == 1) {  // gradient of the zero-padded [76, C0] kernel; its first 75 rows are the kernel's
       float* gw = ws + lo.gwpad;
       KWS_TRY(kws_gemm_tn_gather_f32(x, &p.g0, G, gw, B, p.C0, ws + lo.tn, st));

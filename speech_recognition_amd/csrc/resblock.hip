@@ -116,6 +116,116 @@ __global__ __launch_bounds__(256) void block_out_bwd_kernel(const float* __restr
   }
 }
 
+// Two-pass form of the join backward + BatchNorm backward (round 4; what kws_dwconv_bwd_bn_f32 is for the depthwise blocks):
+//   PASS 1  the reductions only - sums of g and g * xhat over (batch, time), g = the masked / max-pool-routed gradient, which is
+//           NOT stored; a grid-stride walk by at most 256 workgroups, so the partial rows go straight to kws_dw_bwd_finalize
+//           (the one-pass kernel above leaves one row per 256-thread workgroup: 1,536 rows for the first block of config C3 and a
+//           slice_reduce launch in front of every finalise);
+//   PASS 2  g recomputed from dO and y and dy = gamma rstd (g - c1 - xhat c2) written directly (kws_bn_bwd_apply's expression,
+//           the same operation order: bit-identical to "store g, then kws_bn_bwd_apply").
+// 5 tensor passes per join instead of 6, and no launch between the finalise and the next GEMM but this one.  All loads of a
+// unit (TT steps x {dO, y0, y1}) are issued before the first is used - from clamped addresses - as in dwconv.hip.
+template <int P, bool RELU, int PASS>
+__global__ __launch_bounds__(512) void block_join_bwd_kernel(const float* __restrict__ dO, const float* __restrict__ y,
+                                                             const float* __restrict__ bn, const float* __restrict__ gamma,
+                                                             const float* __restrict__ coef, float* __restrict__ out,
+                                                             float* __restrict__ part, int L, int Lo, int C, int nchunks, int R,
+                                                             int Cb, int64_t units) {
+  __shared__ float red[2][512 * 4];
+  const int C4 = Cb >> 2;
+  const int tid = threadIdx.x;
+  const int r = tid / C4, c4 = tid - r * C4;
+  const int c = blockIdx.y * Cb + c4 * 4;
+  const float4 sc = ld4(bn + c), sh = ld4(bn + C + c), mean = ld4(bn + 2 * C + c), rstd = ld4(bn + 3 * C + c);
+  float4 ga = sc, c1 = sc, c2 = sc;
+  if (PASS == 2) {
+    ga = ld4(gamma + c);
+    c1 = ld4(coef + c);
+    c2 = ld4(coef + C + c);
+  }
+  float4 sg = make_float4(0.f, 0.f, 0.f, 0.f), sgx = sg;
+  for (int64_t unit = (int64_t)blockIdx.x * R + r; unit < units; unit += (int64_t)gridDim.x * R) {
+    const int64_t b = unit / nchunks;
+    const int chunk = (int)(unit - b * nchunks);
+    float4 d[TT], y0[TT], y1[P == 2 ? TT : 1];
+#pragma unroll
+    for (int i = 0; i < TT; ++i) {
+      const int t = chunk * TT + i;
+      const int tc = t < Lo ? t : Lo - 1;
+      d[i] = ld4(dO + (b * Lo + tc) * (int64_t)C + c);
+      y0[i] = ld4(y + (b * L + (int64_t)tc * P) * C + c);
+      if (P == 2) {
+        const int u1 = 2 * tc + 1 < L ? 2 * tc + 1 : L - 1;
+        y1[i] = ld4(y + (b * L + u1) * (int64_t)C + c);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < TT; ++i) {
+      const int t = chunk * TT + i;
+      if (t >= Lo) break;
+      const int64_t u0 = b * L + (int64_t)t * P;
+      const bool two = P == 2 && 2 * t + 1 < L;     // an odd L: the last window has one element
+      const float4 dd = d[i], a0 = y0[i];
+      const float4 p0 = bn4(a0, sc, sh);
+      float4 g0, g1 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = g1;
+      if (P == 1) {
+        g0 = RELU ? make_float4(dd.x * mk(p0.x), dd.y * mk(p0.y), dd.z * mk(p0.z), dd.w * mk(p0.w)) : dd;
+      } else if (!two) {
+        g0 = make_float4(dd.x * mk(p0.x), dd.y * mk(p0.y), dd.z * mk(p0.z), dd.w * mk(p0.w));
+      } else {
+        a1 = y1[i];
+        const float4 p1 = bn4(a1, sc, sh);
+        const bool w1x = relu6f(p1.x) > relu6f(p0.x), w1y = relu6f(p1.y) > relu6f(p0.y);
+        const bool w1z = relu6f(p1.z) > relu6f(p0.z), w1w = relu6f(p1.w) > relu6f(p0.w);
+        g0 = make_float4(w1x ? 0.f : dd.x * mk(p0.x), w1y ? 0.f : dd.y * mk(p0.y), w1z ? 0.f : dd.z * mk(p0.z),
+                         w1w ? 0.f : dd.w * mk(p0.w));
+        g1 = make_float4(w1x ? dd.x * mk(p1.x) : 0.f, w1y ? dd.y * mk(p1.y) : 0.f, w1z ? dd.z * mk(p1.z) : 0.f,
+                         w1w ? dd.w * mk(p1.w) : 0.f);
+      }
+      if (PASS == 1) {
+        sg.x += g0.x; sg.y += g0.y; sg.z += g0.z; sg.w += g0.w;
+        sgx.x = fmaf(g0.x, (a0.x - mean.x) * rstd.x, sgx.x);
+        sgx.y = fmaf(g0.y, (a0.y - mean.y) * rstd.y, sgx.y);
+        sgx.z = fmaf(g0.z, (a0.z - mean.z) * rstd.z, sgx.z);
+        sgx.w = fmaf(g0.w, (a0.w - mean.w) * rstd.w, sgx.w);
+        if (two) {
+          sg.x += g1.x; sg.y += g1.y; sg.z += g1.z; sg.w += g1.w;
+          sgx.x = fmaf(g1.x, (a1.x - mean.x) * rstd.x, sgx.x);
+          sgx.y = fmaf(g1.y, (a1.y - mean.y) * rstd.y, sgx.y);
+          sgx.z = fmaf(g1.z, (a1.z - mean.z) * rstd.z, sgx.z);
+          sgx.w = fmaf(g1.w, (a1.w - mean.w) * rstd.w, sgx.w);
+        }
+      } else {
+        float4 o;
+        o.x = ga.x * rstd.x * (g0.x - c1.x - (a0.x - mean.x) * rstd.x * c2.x);
+        o.y = ga.y * rstd.y * (g0.y - c1.y - (a0.y - mean.y) * rstd.y * c2.y);
+        o.z = ga.z * rstd.z * (g0.z - c1.z - (a0.z - mean.z) * rstd.z * c2.z);
+        o.w = ga.w * rstd.w * (g0.w - c1.w - (a0.w - mean.w) * rstd.w * c2.w);
+        *reinterpret_cast<float4*>(out + u0 * C + c) = o;
+        if (two) {
+          o.x = ga.x * rstd.x * (g1.x - c1.x - (a1.x - mean.x) * rstd.x * c2.x);
+          o.y = ga.y * rstd.y * (g1.y - c1.y - (a1.y - mean.y) * rstd.y * c2.y);
+          o.z = ga.z * rstd.z * (g1.z - c1.z - (a1.z - mean.z) * rstd.z * c2.z);
+          o.w = ga.w * rstd.w * (g1.w - c1.w - (a1.w - mean.w) * rstd.w * c2.w);
+          *reinterpret_cast<float4*>(out + (u0 + 1) * C + c) = o;
+        }
+      }
+    }
+  }
+  if (PASS == 1) {
+    *reinterpret_cast<float4*>(&red[0][tid * 4]) = sg;
+    *reinterpret_cast<float4*>(&red[1][tid * 4]) = sgx;
+    __syncthreads();
+    for (int o = tid; o < 5 * Cb; o += blockDim.x) {
+      const int q = o / Cb, ch = o - q * Cb;
+      float s = 0.f;
+      if (q < 2)
+        for (int rr = 0; rr < R; ++rr) s += red[q][rr * Cb + ch];
+      part[((int64_t)blockIdx.x * 5 + q) * C + blockIdx.y * Cb + ch] = s;
+    }
+  }
+}
+
 // ---- 3-wide SAME max-pool join (conv_1d_residual, model.py:874-875): window of output t = inputs
 // t*S - PL .. t*S - PL + 2 (positions outside [0, L) are -inf), the FIRST maximum wins --------------------------
 __device__ __forceinline__ float4 act_or_ninf(const float* y, int64_t row0, int u, int L, int C, int c, float4 sc, float4 sh) {
@@ -761,6 +871,54 @@ int kws_block_out_bwd(const float* dO, const float* y, const float* bn, float* g
 }
 
 // 3-wide SAME max-pool join: L inputs -> Lo = ceil(L / stride) outputs, window of output t starts at t*stride - pad_l
+// two-pass join backward (block_join_bwd_kernel): geometry, partial rows (<= 256 per channel slice) and the launcher
+struct JoinGeom {
+  int nchunks, R, block, ny, Cb, grid;
+  int64_t units;
+};
+static JoinGeom join_geom(int B, int Lo, int C) {
+  JoinGeom g;
+  g.ny = ceil_div(C / 4, 256);
+  g.Cb = C / g.ny;
+  const int C4 = g.Cb / 4;
+  g.nchunks = ceil_div(Lo, TT);
+  g.R = 512 / C4 < 1 ? 1 : 512 / C4;
+  g.block = g.R * C4;
+  g.units = (int64_t)B * g.nchunks;
+  const int64_t wgs = ceil_div64(g.units, g.R);
+  g.grid = (int)(wgs < 256 ? wgs : 256);             // one 512-thread workgroup per CU; the rows go straight to the finaliser
+  return g;
+}
+int kws_block_join_bwd_parts(int B, int L, int C, int pool) {
+  if (B <= 0 || L <= 0 || !geom_ok(C) || pool < 1) return 0;
+  return join_geom(B, (L + pool - 1) / pool, C).grid;
+}
+int kws_block_join_bwd(const float* dO, const float* y, const float* bn, const float* gamma, const float* coef, float* out,
+                       float* part, int pass, int B, int L, int C, int pool, int relu, hipStream_t st) {
+  KWS_REQUIRE(dO && y && bn && B > 0 && L > 0 && geom_ok(C) && (pool == 1 || pool == 2) && (relu || pool == 1) &&
+                  ((pass == 1 && part) || (pass == 2 && gamma && coef && out)),
+              "block_join_bwd: bad arguments (L=%d C=%d pool=%d relu=%d pass=%d)", L, C, pool, relu, pass);
+  const int Lo = (L + pool - 1) / pool;
+  const JoinGeom ge = join_geom(B, Lo, C);
+  KwsProfScope prof("block_join", 6.0 * B * L * C, 4.0 * ((pass == 1 ? 1.0 : 2.0) * B * L * C + (double)B * Lo * C), st);
+  dim3 gr((unsigned)ge.grid, (unsigned)ge.ny), b((unsigned)ge.block);
+#define KWS_JOIN_LAUNCH(P_, RELU_)                                                                                              \
+  do {                                                                                                                          \
+    if (pass == 1)                                                                                                              \
+      hipLaunchKernelGGL((block_join_bwd_kernel<P_, RELU_, 1>), gr, b, 0, st, dO, y, bn, gamma, coef, out, part, L, Lo, C,       \
+                         ge.nchunks, ge.R, ge.Cb, ge.units);                                                                    \
+    else                                                                                                                        \
+      hipLaunchKernelGGL((block_join_bwd_kernel<P_, RELU_, 2>), gr, b, 0, st, dO, y, bn, gamma, coef, out, part, L, Lo, C,       \
+                         ge.nchunks, ge.R, ge.Cb, ge.units);                                                                    \
+  } while (0)
+  if (pool == 2) KWS_JOIN_LAUNCH(2, true);
+  else if (relu) KWS_JOIN_LAUNCH(1, true);
+  else KWS_JOIN_LAUNCH(1, false);
+#undef KWS_JOIN_LAUNCH
+  KWS_LAUNCH_CHECK("block_join_bwd_kernel");
+  return KWS_OK;
+}
+
 int kws_block_out3_fwd(const float* y, const float* bn, const float* res, const float* res_bn, float* o, int B, int L,
                        int Lo, int C, int stride, int pad_l, hipStream_t st) {
   KWS_REQUIRE(y && bn && res && o && B > 0 && L > 0 && Lo > 0 && C % 4 == 0 && (stride == 1 || stride == 2) &&

@@ -31,6 +31,8 @@ def test_bench_two_ranks_print_one_json_line():
     assert out["n_gpus"] == 2 and out["steps"] == 6 and out["warmup"] == 2 and out["scaling"] == "weak"
     assert out["config"]["global_batch"] == 512 and out["config"]["parallelism"] == "dp2"
     assert out["value"] > 0 and out["roofline"] is not None and out["rccl_ranks"] == 2
+    pf = out["preflight"]                               # first contact: ones + one gradient-sized all-reduce, under the watchdog
+    assert pf["rccl_ranks"] == 2 and pf["grad_allreduce_ok"] is True and pf["grad_allreduce_floats"] == 1191436 and pf["seconds"] < 60
     assert out["cpu_baseline"]["value"] > 0 and out["cpu_baseline"]["kind"] == "port"      # N>1 lines carry it too
     assert out["train_loss_first_last"][0] == out["train_loss_first_last"][0]      # finite
     # the N > 1 line diagnoses itself: the gradient exchange alone, the split-overlap form of the same step, every rank's time
@@ -62,6 +64,7 @@ def test_bench_launches_its_own_ranks():
     assert len(lines) == 1, lines
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["config"]["global_batch"] == 512
+    assert out["preflight"]["grad_allreduce_ok"] is True
     assert out["ab_allreduce_split"]["split_block"] == 3 and out["ab_allreduce_split"]["value"] > 0     # the argument, not the environment
     assert out["allreduce_only"]["us_per_allreduce"] > 0 and len(out["per_rank_ms"]) == 2
     assert abs(out["scaling_vs_n1"] - out["value"] / (2 * 100000.0)) < 1e-9
@@ -117,3 +120,45 @@ def test_tta_inference_sharded_over_two_ranks_matches_one_rank(tmp_path):
         outs[world] = np.load(out)
     assert outs[1].shape == (5003, 12)
     assert np.array_equal(outs[1], outs[2])                 # inference is per clip: the split cannot change a bit
+
+
+@pytest.mark.parametrize("mode", ["hang", "raise"])
+def test_bench_preflight_failure_prints_one_error_line_and_fails(mode):
+    """the first collectives of an N > 1 run go under a watchdog, before the clip bank is built.  A
+    collective that never returns ('hang': the fresh watchdog child reports and kills rank 0) or that raises ('raise': rank 0
+    reports itself) must leave exactly ONE JSON line carrying "error" on stdout and a non-zero exit status."""
+    env = dict(os.environ, KWS_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", KWS_BENCH_PREFLIGHT_FAIL=mode,
+               KWS_BENCH_PREFLIGHT_TIMEOUT="5")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29543" if mode == "hang" else "29545", os.path.join(ROOT, "bench.py"), "--gpus", "2",
+           "--steps", "2", "--warmup", "1", "--bank", "8192", "--batch", "256", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=400)
+    assert res.returncode != 0
+    json_lines = [l for l in res.stdout.decode().splitlines() if l.lstrip().startswith("{")]
+    assert len(json_lines) == 1, res.stdout.decode()[-2000:] + res.stderr.decode()[-2000:]
+    out = json.loads(json_lines[0])
+    assert out["value"] is None and out["n_gpus"] == 2 and out["stage"] == "preflight all-reduce"
+    assert ("watchdog" in out["error"]) == (mode == "hang")
+
+
+def test_bench_single_gpu_line_carries_the_round4_keys():
+    """The N = 1 line: configs[1]'s own A/B (generator 'raw' vs 'mfcc_and_raw'), and the measured error of the STFT+mel stage
+    against the float64 oracle on the run's own clips (VERDICT r3 item 4 ii / iii)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "KWS_BENCH_ONE_DEVICE"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "3", "--bank", "8192", "--batch", "256",
+           "--no-val-acc", "--no-configs", "--profile-steps", "1"]
+    res = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    lines = [l for l in res.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["preflight"] is None and out["value"] > 0
+    ab = out["ab_features"]
+    assert ab["raw"]["value"] > 0 and ab["mfcc_and_raw"]["value"] > 0 and len(ab["raw"]["rounds_ms"]) == 2
+    assert abs(ab["stft_mel_cost_us_per_step"] - 1e3 * (ab["mfcc_and_raw"]["ms_per_step"] - ab["raw"]["ms_per_step"])) < 1e-6
+    err = out["stft_mel_error"]
+    assert err["clips"] == 16
+    assert err["log_mel"]["max_abs_err_vs_f64"] < 1e-3 and err["mfcc"]["max_abs_err_vs_f64"] < 2e-3     # the test-suite bars
+    assert err["spectrogram"]["max_abs_err_vs_f64"] < 2e-5 * max(1.0, err["spectrogram"]["max_abs_value"])
