@@ -212,6 +212,16 @@ int kws_stft_mel_f32(const kws_stft_plan_t* plan, const float* x, int B, int L, 
  * that produce a GEMM operand leave its maximum behind.  The largest magnitude lands in [2^14, 2^15) (fp16 overflows at
  * 65504) and results are multiplied by the two inverse scales on the way out (exact: powers of two). */
 int kws_absmax_batch_f32(const float* const* in, const int64_t* n, unsigned* slots, int count, void* stream);
+/* The producers of a GEMM operand that leave the operand's |x| maximum behind on the way (what the network programs call for this
+ * arm; `amax` = a slot group of 256 words zeroed by the caller, or NULL = the plain kernel): kws_dwconv_fwd_f32 / pass 2 of
+ * kws_dwconv_bwd_bn_f32 / kws_bn_bwd_apply with one more argument.  The tensors they write are bit-identical to the plain calls'. */
+int kws_dwconv_fwd_amax_f32(const float* y, const float* bn, const float* w, float* z, int B, int L_in, int L_out,
+                            int C, int stride, int pad_l, unsigned* amax, void* stream);
+int kws_dwconv_bwd_bn_amax_f32(const float* dz, const float* y, const float* bn, const float* w, const float* coef,
+                               float* dy, float* part, int pass, int B, int L_in, int L_out, int C, int stride, int pad_l,
+                               unsigned* amax, void* stream);
+int kws_bn_bwd_apply_amax(float* g, const float* y, const float* bn, const float* gamma, const float* coef, int64_t rows,
+                          int C, unsigned* amax, void* stream);
 int kws_f16x2_split_batch(const float* const* in, void* const* out, const int* rows, const int* cols,
                           const int* transpose, const unsigned* const* slots, int count, void* stream);
 /* shapes the arm's kernels take (K granule, 32-bit offsets inside a 2 GB buffer view); the network programs fall back

@@ -21,3 +21,7 @@ g = t[:, 3]
 print("TN M=%d K=%d N=%d: %d work items, %.1f stages each | per stage (cycles): MFMA wave 0 issue %.0f, barrier wait %.0f | loader wave 0: work %.0f, barrier wait %.0f | loop %.0f cycles per stage, epilogue %.0f cycles per item" % (
     M, K, N, len(t), g.mean(), np.median(t[:, 0] / g), np.median(t[:, 1] / g), np.median(t[:, 6] / g), np.median(t[:, 7] / g),
     np.median(t[:, 4] / g), np.median(t[:, 5])))
+if t[:, 2].max() > 0:
+    tot = t[:, 4] + t[:, 5]
+    print("   item lifetime %.0f k cycles = %.1f us (median; min %.1f max %.1f us) -> clock %.2f GHz" % (
+        np.median(tot) / 1e3, np.median(t[:, 2]) / 100.0, t[:, 2].min() / 100.0, t[:, 2].max() / 100.0, np.median(tot / t[:, 2]) * 0.1))

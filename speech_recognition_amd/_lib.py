@@ -113,6 +113,9 @@ SIGNATURES = {
     "kws_gemm_tn_f16x2_supported": (_I, [_I64, _I, _I]),
     "kws_gemm_nn_f16x2_stats_rows": (_I, [_I64]),
     "kws_absmax_batch_f32": (_I, [_P, _P, _P, _I, _P]),
+    "kws_dwconv_fwd_amax_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "kws_dwconv_bwd_bn_amax_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "kws_bn_bwd_apply_amax": (_I, [_P, _P, _P, _P, _P, _I64, _I, _P, _P]),
     "kws_f16x2_split_batch": (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),
     "kws_gemm_nn_f16x2_f32": (_I, [_P, _P, _P, _I64, _I, _I, _P, _P, _P, _P]),
     "kws_gemm_tn_f16x2_workspace_floats": (_I64, [_I64, _I, _I]),

@@ -342,7 +342,8 @@ int kws_bn_bwd_apply(float* g, const float* y, const float* bn, const float* gam
 
 // internal: as kws_bn_bwd_apply, and the |dy| maximum into amax (may be NULL)
 int kws_bn_bwd_apply_amax(float* g, const float* y, const float* bn, const float* gamma, const float* coef, int64_t rows,
-                          int C, unsigned* amax, hipStream_t stream) {
+                          int C, unsigned* amax, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
   KWS_REQUIRE(g && y && bn && gamma && coef && rows > 0 && C > 0 && C % 4 == 0, "bn_bwd_apply: bad arguments");
   const int64_t n4 = rows * C / 4;
   KwsProfScope prof("bn_bwd_apply", 6.0 * rows * C, 12.0 * rows * C, (hipStream_t)stream);

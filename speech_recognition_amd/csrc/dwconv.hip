@@ -336,7 +336,8 @@ int kws_dwconv_fwd_f32(const float* y, const float* bn, const float* w, float* z
 
 // internal: as kws_dwconv_fwd_f32, and the |z| maximum into amax (KWS_ABSMAX_WORDS words, may be NULL)
 int kws_dwconv_fwd_amax_f32(const float* y, const float* bn, const float* w, float* z, int B, int L_in, int L_out,
-                            int C, int stride, int pad_l, unsigned* amax, hipStream_t stream) {
+                            int C, int stride, int pad_l, unsigned* amax, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
   KWS_REQUIRE(y && w && z, "dwconv_fwd: NULL pointer");
   KWS_REQUIRE(B > 0 && L_in > 0 && L_out > 0 && C > 0 && C % 4 == 0, "dwconv_fwd: bad shape B=%d L=%d->%d C=%d",
               B, L_in, L_out, C);
@@ -397,7 +398,8 @@ int kws_dwconv_bwd_bn_f32(const float* dz, const float* y, const float* bn, cons
 // internal: as kws_dwconv_bwd_bn_f32; pass 2 also leaves the |dy| maximum in amax (may be NULL)
 int kws_dwconv_bwd_bn_amax_f32(const float* dz, const float* y, const float* bn, const float* w, const float* coef,
                                float* dy, float* part, int pass, int B, int L_in, int L_out, int C, int stride, int pad_l,
-                               unsigned* amax, hipStream_t stream) {
+                               unsigned* amax, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
   KWS_REQUIRE(dz && y && bn && w, "dwconv_bwd_bn: NULL pointer");
   KWS_REQUIRE(pass == 1 ? part != nullptr : (pass == 2 && coef != nullptr && dy != nullptr),
               "dwconv_bwd_bn: pass %d needs %s", pass, pass == 1 ? "part" : "coef and dy");

@@ -346,6 +346,17 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #ifndef KWS_WS_ABL
 #define KWS_WS_ABL 0
 #endif
+// -DKWS_WS_PRIO_MMA=<0..3> / -DKWS_WS_PRIO_LD=<0..3> / -DKWS_WS_PRIO_ST=<0..3>: s_setprio of the MFMA / loader / storer waves
+// (round 4 experiment: a SIMD hosts one MFMA wave and one mover; the default leaves all at 0)
+#ifndef KWS_WS_PRIO_MMA
+#define KWS_WS_PRIO_MMA 0
+#endif
+#ifndef KWS_WS_PRIO_LD
+#define KWS_WS_PRIO_LD 0
+#endif
+#ifndef KWS_WS_PRIO_ST
+#define KWS_WS_PRIO_ST 0
+#endif
 constexpr int KWS_WS_MAX_N = 1024;                  // widest N the per-workgroup statistics row supports
 constexpr int KWS_BUFFER_RSRC_FLAGS = 0x00020000;   // raw buffer, 32-bit data format (gfx9 family)
 
@@ -431,6 +442,7 @@ __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNA
 
   if (tid < NCT) {
     // ------------------------------------------------------------------ MFMA waves
+    if (KWS_WS_PRIO_MMA) __builtin_amdgcn_s_setprio(KWS_WS_PRIO_MMA);
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, lh = lane >> 5;
@@ -634,6 +646,7 @@ __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNA
     }
   } else if (tid < NCT + NLT) {
     // ------------------------------------------------------------------ loader waves
+    if (KWS_WS_PRIO_LD) __builtin_amdgcn_s_setprio(KWS_WS_PRIO_LD);
     const int lane = tid & 63;
     const int lw = __builtin_amdgcn_readfirstlane((tid - NCT) >> 6);   // my slabs: s = lw (mod NLW)
     constexpr int AROWS = 64 / PBK4;                // A rows covered by one wave instruction: 8 or 4
@@ -727,6 +740,7 @@ __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNA
     // ------------------------------------------------------------------ storer waves
     // pure data movers (LDS read + buffer store, one address add per pass): the tile staged at kt = 0 is
     // moved out in nk-1 equal chunks at kt = 1..nk-1
+    if (KWS_WS_PRIO_ST) __builtin_amdgcn_s_setprio(KWS_WS_PRIO_ST);
     const int stt = tid - NCT - NLT;
     const int c4 = stt % BN4, r_in = stt / BN4;
     const int c_voff = (r_in * N + c4 * 4) * 4;
@@ -1016,7 +1030,7 @@ __global__ __launch_bounds__((4 + ((128 / BKO) * (128 / BNO) > 2 ? 4 : 2)) * 64,
     __syncthreads();
 #ifdef KWS_GEMM_STAMP
     unsigned long long tn_mma = 0, tn_bar = 0, tn_mark = __builtin_amdgcn_s_memtime();
-    const unsigned long long tn_begin = tn_mark;
+    const unsigned long long tn_begin = tn_mark, tn_rbegin = __builtin_amdgcn_s_memrealtime();
 #define TNT(acc_) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc_ += now_ - tn_mark; tn_mark = now_; } while (0)
 #else
 #define TNT(acc_)
@@ -1115,6 +1129,7 @@ __global__ __launch_bounds__((4 + ((128 / BKO) * (128 / BNO) > 2 ? 4 : 2)) * 64,
 #ifdef KWS_GEMM_STAMP
     if (tid == 0 && blockIdx.x < 4096) {
       g_stamps[blockIdx.x][0] = tn_mma; g_stamps[blockIdx.x][1] = tn_bar; g_stamps[blockIdx.x][3] = (unsigned long long)G;
+      g_stamps[blockIdx.x][2] = __builtin_amdgcn_s_memrealtime() - tn_rbegin;   // 100 MHz ticks of the whole item (clock = cycles / ticks)
       g_stamps[blockIdx.x][4] = tn_loop_end - tn_begin; g_stamps[blockIdx.x][5] = __builtin_amdgcn_s_memtime() - tn_loop_end;
     }
 #endif
@@ -1332,6 +1347,12 @@ bool tn_ws_eligible(int K, int N, bool gather) { return !gather && K % 64 == 0 &
 // 91 us; in-kernel stamps and rocprofv3 agree, profiles/r03_tn_plan.txt).  The split size is now searched: every candidate
 // (whole stages of the tile shape) is priced as the busiest XCD's items per CU x (stages x cycles per stage + the fixed
 // cost of an item: first loads, epilogue) + the slab sum's traffic, and the cheapest wins.
+#ifndef KWS_TN_MAX_S
+#define KWS_TN_MAX_S 256
+#endif
+#ifndef KWS_TN_PAIR_PCT
+#define KWS_TN_PAIR_PCT 0     // experiment (round 4): price two co-resident 128 x 128 items (64 KB of LDS each) at this % of two in a row
+#endif
 int64_t tn_cost(int64_t M, int K, int N, int tiles, int U, int64_t chunk, int* S_out) {
   const int64_t S = ceil_div64(M, chunk);
   const int64_t stages = ceil_div64(chunk, 32 * U);
@@ -1340,7 +1361,11 @@ int64_t tn_cost(int64_t M, int K, int N, int tiles, int U, int64_t chunk, int* S
   for (int x = 0; x < NXCD; ++x) {
     const int64_t cnt = x < S ? (S - x + NXCD - 1) / NXCD : 0;
     const int64_t per_cu = ceil_div64(tiles * cnt, 32);
-    const int64_t t = per_cu * (stages * t_stage + 4500);
+    int64_t t = per_cu * (stages * t_stage + 4500);
+    if (KWS_TN_PAIR_PCT && U == 1) {      // the CU holds two such workgroups at once
+      const int64_t pairs = per_cu / 2, single = per_cu % 2;
+      t = pairs * (2 * (stages * t_stage + 4500) * KWS_TN_PAIR_PCT / 100) + single * (stages * t_stage + 4500);
+    }
     if (t > worst) worst = t;
   }
   *S_out = (int)S;
@@ -1389,7 +1414,7 @@ TNPlan tn_plan_search(int64_t M, int K, int N, bool ws) {
   }
   const int U = 4 / ((pl.bko / 64) * (pl.bno / 64));   // 32-row units per stage of the wave-specialised kernel
   const int64_t g = 32 * U;
-  const int64_t s_lo = std::max<int64_t>(1, ceil_div64(M, 256 * g));   // S <= 256: bounds the slab traffic
+  const int64_t s_lo = std::max<int64_t>(1, ceil_div64(M, KWS_TN_MAX_S * g));   // S <= 256: bounds the slab traffic
   int64_t best = -1, best_chunk = s_lo * g;
   const int64_t max_chunk = ((1ll << 31) - 1) / (4ll * (K > N ? K : N));   // 32-bit byte offsets inside a split's buffer views
   for (int64_t st = s_lo; st < s_lo * 16 + 64; ++st) {

@@ -29,14 +29,7 @@ int kws_conv1_wgrad(const float* x, const kws_gather_t* g, const kws_gather_t* u
 extern "C" int kws_reduce_slab_groups_f32(float* ws, int64_t n, int S, int per_group, hipStream_t st);
 // gemm.hip: out[i] = sum over S slabs of ws[s][i], fixed order (n % 4 == 0)
 extern "C" int kws_reduce_slabs_f32(const float* ws, float* out, int64_t n, int S, hipStream_t st);
-// producers of GEMM operands that also leave the operand's |x| maximum (fp16 x 2 arm; amax may be NULL)
-extern "C" int kws_dwconv_fwd_amax_f32(const float* y, const float* bn, const float* w, float* z, int B, int L_in, int L_out,
-                                       int C, int stride, int pad_l, unsigned* amax, hipStream_t stream);
-extern "C" int kws_dwconv_bwd_bn_amax_f32(const float* dz, const float* y, const float* bn, const float* w, const float* coef,
-                                          float* dy, float* part, int pass, int B, int L_in, int L_out, int C, int stride,
-                                          int pad_l, unsigned* amax, hipStream_t stream);
-extern "C" int kws_bn_bwd_apply_amax(float* g, const float* y, const float* bn, const float* gamma, const float* coef,
-                                     int64_t rows, int C, unsigned* amax, hipStream_t stream);
+// (the |x|-maximum producers kws_dwconv_fwd_amax_f32 / kws_dwconv_bwd_bn_amax_f32 / kws_bn_bwd_apply_amax are public: include/kws_hip.h)
 extern "C" int kws_dwconv_bwd_acc_f32(const float* dz, const float* y, const float* w, const float* add, float* g, float* part,
                                       int B, int L_in, int L_out, int C, int stride, int pad_l, hipStream_t st);
 // gemm.hip: the weight-gradient GEMM without its slab sum, and the slab sums of several of them in one launch

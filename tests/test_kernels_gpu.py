@@ -328,14 +328,17 @@ def test_stft_mel_features(path, n_mel, n_out, win, step):
     dx = dev(x)
     mag = torch.full((B, F, 257), float("nan"), device="cuda")
     _lib.call("kws_stft_mel_f32", plan, _lib.ptr(dx), B, L, _lib.ptr(mag), 1, S())
-    assert np.abs(mag.cpu().numpy() - mag_ref).max() < 2e-5 * max(1.0, mag_ref.max())
+    # Tolerances = 2 x the error MEASURED on these very inputs (scripts/measure_feature_error.py, round 4: spectrogram
+    # 0.96 - 1.12e-6 at magnitudes up to 8, log-mel 1.2 - 2.3e-6, MFCC 2.5 - 5.3e-5 at values up to 247, on all four plan shapes) -
+    # the shipped kernel runs its first radix-16 pass and the DCT as 2-way fp16-split f16 MFMA products and its log as
+    # v_log_f32 * ln 2, and this is what that costs against float64.  (Rounds 1-3 allowed 2e-5 * max, 1e-3 and 2e-3.)
+    assert np.abs(mag.cpu().numpy() - mag_ref).max() < 2.3e-6
     lm = torch.full((B, F, n_mel), float("nan"), device="cuda")
     _lib.call("kws_stft_mel_f32", plan, _lib.ptr(dx), B, L, _lib.ptr(lm), 2, S())
-    # tolerance 1e-3 absolute on log-mel (f32 FFT noise floor under a log at near-silent bins)
-    assert np.abs(lm.cpu().numpy() - logmel_ref).max() < 1e-3
+    assert np.abs(lm.cpu().numpy() - logmel_ref).max() < 5e-6       # SURVEY section 7 asked <= 1e-4 relative on log-mel
     out = torch.full((B, F, n_out), float("nan"), device="cuda")
     _lib.call("kws_stft_mel_f32", plan, _lib.ptr(dx), B, L, _lib.ptr(out), 0, S())
-    assert np.abs(out.cpu().numpy() - feat_ref).max() < 2e-3
+    assert np.abs(out.cpu().numpy() - feat_ref).max() < 1.1e-4      # MFCC rows reach |175| - |247|: 4.5e-7 relative
     lib.kws_stft_plan_destroy(plan)
 
 
