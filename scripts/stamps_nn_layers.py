@@ -37,7 +37,7 @@ def stamps(kb):
     return dict(wgs=len(t), iters=it.mean(), mma=np.median(t[:, 0] / it), bar=np.median(t[:, 1] / it), stage=np.median(t[:, 2] / it),
                 lwrite=np.median(t[:, 6] / it), lissue=np.median(t[:, 7] / it), total=np.median(t[:, 4] / it),
                 ghz=np.median(t[:, 4] / t[:, 5]) * 0.1, wave_bar=[np.median(wb[:, w] / it) for w in range(8)],
-                kernel_cycles=np.median(t[:, 4]))
+                kernel_cycles=np.median(t[:, 4]), life_us=(t[:, 5].min() / 100.0, np.median(t[:, 5]) / 100.0, t[:, 5].max() / 100.0))
 
 
 tot = {"fwd": 0.0, "dgrad": 0.0}
@@ -60,6 +60,7 @@ for li, (L, K, N) in enumerate(shapes):
             line += " | wgs %3d iters/wg %5.1f | mma %5.0f bar %4.0f epi %4.0f | ld write %4.0f issue %4.0f | iter %5.0f cyc | %.2f GHz | %s" % (
                 s["wgs"], s["iters"], s["mma"], s["bar"], s["stage"], s["lwrite"], s["lissue"], s["total"], s["ghz"],
                 " ".join("%.0f" % v for v in s["wave_bar"]))
+            line += " | MFMA-wave lifetime of a workgroup min/median/max %.1f/%.1f/%.1f us" % s["life_us"]
         print(line, flush=True)
     fl += 2.0 * M * K * N
 print("total fwd %.3f ms (%.1f TF)  dgrad %.3f ms (%.1f TF)" % (tot["fwd"] / 1e3, fl / tot["fwd"] / 1e6, tot["dgrad"] / 1e3, fl / tot["dgrad"] / 1e6))
