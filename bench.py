@@ -267,8 +267,11 @@ def cpu_baselines(budget_s=30.0):
 
 # (profiler family, device kernel, bound, what it is) - the dominant kernel first; each becomes one roofline object
 ROOFLINE_KERNELS = [
-    ("gemm_nn", "gemm_nn_ws_kernel", "mfma", "pointwise 1x1 convolutions: forward + input gradient"),
-    ("gemm_tn", "gemm_tn_ws_kernel", "mfma", "pointwise 1x1 convolutions: weight gradient"),
+    # round 4: a layer's input-gradient and weight-gradient GEMMs are ONE launch (gemm_dgrad_wgrad_kernel); the forward GEMMs
+    # (and whatever the fused kernel does not take) stay gemm_nn_ws_kernel / gemm_tn_ws_kernel launches
+    ("gemm_bwd_pair", "gemm_dgrad_wgrad_kernel", "mfma", "pointwise 1x1 convolutions: input gradient + weight gradient of a layer in one launch"),
+    ("gemm_nn", "gemm_nn_ws_kernel", "mfma", "pointwise 1x1 convolutions: forward (+ input gradient where not paired)"),
+    ("gemm_tn", "gemm_tn_ws_kernel", "mfma", "pointwise 1x1 convolutions: weight gradient (where not paired)"),
     ("conv1_fwd", "conv1_fwd_kernel", "mfma", "first convolution (frames of 40 hop 20, k3 s2) as a Toeplitz GEMM"),
     ("conv1_wgrad", "conv1_wgrad_kernel", "mfma", "first convolution, weight gradient"),
     ("stft_mel", "stft4_kernel", "hbm", "STFT 480/160/512 -> |X| -> mel 80 -> log -> DCT 60 (generator stream, low priority)"),
@@ -581,7 +584,7 @@ def main():
     model.seed = 87654321            # one dropout stream for the global batch: rank r uses rows [r*B, (r+1)*B)
     model.allreduce_split = 0        # the headline step: ONE all-reduce of the flat gradient buffer after the backward pass
     ab_steps = min(args.steps, 50)
-    ring = torch.zeros((args.warmup + args.steps + 3 * args.profile_steps + 2 * (ab_steps + 8) + 4 * (ab_steps + 14) + 8, 4), dtype=torch.float32, device=device)
+    ring = torch.zeros((args.warmup + args.steps + 3 * args.profile_steps + 2 * (ab_steps + 8) + 4 * (ab_steps + 14) + 4 * (ab_steps + 4) + 8, 4), dtype=torch.float32, device=device)
     enq = GeneratorEnqueuer(gen, max_queue_size=10, device=device)
     enq.start()
 
@@ -646,11 +649,13 @@ def main():
                 e = roofline_entry(prof, family, kernel, bound, what, pmc)
                 if e is not None:
                     stages.append(e)
-            roof = stages[0] if stages and stages[0]["family"] == "gemm_nn" else None
+            # the line's `roofline` = the dominant kernel of the step: the GEMM family with the largest summed HIP-event time
+            gemm_stages = [e for e in stages if e["family"] in ("gemm_bwd_pair", "gemm_nn")]
+            roof = max(gemm_stages, key=lambda e: e["launches"] * e["avg_launch_us"]) if gemm_stages else None
             # the weight-gradient GEMMs' slab sums run as ONE batched launch per step ("slab_sum"): priced into their family
             ss = prof.get("slab_sum")
             for e in stages:
-                if e["family"] == "gemm_tn" and ss and ss["count"] > 0:
+                if e["family"] in ("gemm_tn", "gemm_bwd_pair") and ss and ss["count"] > 0:
                     us = e["avg_launch_us"] + 1e3 * ss["ms"] / e["launches"]
                     e["slab_sum_us_per_step"] = 1e3 * ss["ms"] / ss["count"]
                     e["avg_launch_us_incl_slab_sum"] = us
@@ -732,6 +737,29 @@ def main():
         finally:
             model.net.set_gemm_mode(0)
             _lib.Profiler.detach()   # a leg that raised between attach() and detach() must not leave this thread recording
+    # ---- round 4 A/B: the backward GEMMs of a layer as ONE launch (gemm mode 0, the default) vs the two launches of rounds
+    # 1 - 3 (mode 1); bit-identical results (tests/test_net_gpu.py), two alternating rounds each, same process
+    if world == 1 and not args.no_ab and gemm_mode == 0:
+        try:
+            arms = {0: [], 1: []}
+            for rnd in range(2):
+                for mode in (1, 0):
+                    model.net.set_gemm_mode(mode)
+                    for i in range(4):
+                        step(used + i)
+                    dt_m, _ = timed_steps(used + 4, ab_steps)
+                    used += 4 + ab_steps
+                    arms[mode].append(1e3 * dt_m / ab_steps)
+            ab["ab_bwd_pair"] = {"what": "input-gradient + weight-gradient GEMM of a layer as one launch (gemm_dgrad_wgrad_kernel, the default) "
+                                         "vs two launches (gemm mode 1, the schedule of rounds 1 - 3); best of two alternating rounds of %d steps" % ab_steps,
+                                 "steps": ab_steps, "paired": {"ms_per_step": min(arms[0]), "value": B / min(arms[0]) * 1e3, "rounds_ms": arms[0]},
+                                 "separate": {"ms_per_step": min(arms[1]), "value": B / min(arms[1]) * 1e3, "rounds_ms": arms[1]},
+                                 "gain_us_per_step": 1e3 * (min(arms[1]) - min(arms[0])), "unit": "clips/s"}
+        except Exception as ex:
+            ab["ab_bwd_pair_error"] = repr(ex)
+            sys.stderr.write("A/B backward-pair leg failed: %r\n" % (ex,))
+        finally:
+            model.net.set_gemm_mode(0)
     # ---- configs[1]'s own A/B: "HIP STFT+mel vs raw-wave path".  The headline step produces BOTH arms of every batch (the
     # generator's 'mfcc_and_raw' output); here the same training step is timed with the generator switched between 'raw'
     # (augment only) and 'mfcc_and_raw' (augment + STFT/mel/DCT(80,60)) at run time, two alternating rounds each, same process.
@@ -844,7 +872,7 @@ def main():
             "value": clips / dt, "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": {0: "f32", 2: "f32 (pointwise GEMMs as scaled 2-way fp16 splits, f32 accumulate)"}[gemm_mode],
+            "dtype": {0: "f32", 1: "f32", 2: "f32 (pointwise GEMMs as scaled 2-way fp16 splits, f32 accumulate)"}[gemm_mode],
             "data": "synthetic",
             "config": {"workload": "configs[1]: 12-class conv_1d_time_sliced_with_attention, batch %d/GPU synthetic "
                                    "16000-sample fp32 clips, sampler+augment+STFT/mel(80,60)+raw fwd/bwd+RMSprop" % B,
@@ -860,9 +888,10 @@ def main():
             "train_loss_first_last": [float(ms[0, 0] / B), float(ms[-1, 0] / B)],
             "train_acc_last": float(ms[-1, 1] / B),
             "roofline": roof,
-            "roofline_stages": stages[1:],
+            "roofline_stages": [e for e in stages if e is not roof],
             "ab_gemm_f16x2": ab.get("ab_gemm_f16x2"),
             "ab_features": ab.get("ab_features"),
+            "ab_bwd_pair": ab.get("ab_bwd_pair"),
             "stft_mel_error": feature_err,
             "ab_error": ab.get("error"),
             "configs": configs,

@@ -6,7 +6,7 @@ import collections, csv, hashlib, json, os, re, sys
 
 CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "speech_recognition_amd", "csrc")
 # kernel -> the source file that defines it: bench.py drops a traffic figure once that file has changed
-SOURCE_OF = {"gemm_nn_ws_kernel": "gemm.hip", "gemm_tn_ws_kernel": "gemm.hip", "gemm_nn_persist_kernel": "gemm.hip",
+SOURCE_OF = {"gemm_nn_ws_kernel": "gemm.hip", "gemm_dgrad_wgrad_kernel": "gemm.hip", "gemm_tn_ws_kernel": "gemm.hip", "gemm_nn_persist_kernel": "gemm.hip",
              "gemm_tn_kernel": "gemm.hip", "reduce_slabs_kernel": "gemm.hip", "conv1_fwd_kernel": "conv1.hip",
              "conv1_wgrad_kernel": "conv1.hip", "reduce_slabs_batch_kernel": "gemm.hip",
              "stft4_kernel": "stft4.hip", "augment_kernel": "augment.hip", "dwconv_fwd_kernel": "dwconv.hip",

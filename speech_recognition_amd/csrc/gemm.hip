@@ -367,8 +367,15 @@ __device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, int voff, in
 
 // KB = K-slab depth per barrier: 32 for the 128-wide column tiles; the 64-wide tiles (N = 192, 320) take 64 so
 // that an MFMA wave still issues 64 MFMAs per barrier (LDS: 2 x 50.8 KB slots + 34.8 KB staging).
+// LDS floats of the kernel below (the same arithmetic as its layout constants)
+template <int BN, int KB, bool STATS>
+constexpr int nn_ws_smem_floats() {
+  return 2 * (128 * (KB + 4) + KB * BN) + 128 * (BN + 4) + (256 / (BN / 4)) * 2 * BN + (STATS ? 2 * KWS_WS_MAX_N : 0);
+}
+// The kernel as a device function of (block id, number of blocks): gemm_nn_ws_kernel runs it on its own grid,
+// gemm_dgrad_wgrad_kernel (further down) on the first blocks of a grid that also holds a weight-gradient GEMM.
 template <int BN, int KB, int NLW, int NSW, bool STATS>
-__global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNArgs p) {
+__device__ __forceinline__ void nn_ws_body(const NNArgs& p, float* const smem, const int bid, const int nblk) {
   constexpr int PBK = KB, PLDA = KB + 4;            // shadow the 32-deep constants of the 4-wave kernels
   constexpr int NQ = KB / 8;                        // 8-deep k-groups per slab
   constexpr int BM = 128, WM = 2, WN = 2;
@@ -390,15 +397,15 @@ __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNA
   constexpr int WACC_OFF = RED_OFF + (NCT / BN4) * 2 * BN;   // [2][KWS_WS_MAX_N] column sums of ALL my tiles
   constexpr int SMEM = WACC_OFF + (STATS ? 2 * KWS_WS_MAX_N : 0);
   static_assert(SMEM * 4 <= 160 * 1024, "LDS budget");
-  __shared__ __attribute__((aligned(16))) float smem[SMEM];
+  static_assert(SMEM == nn_ws_smem_floats<BN, KB, STATS>(), "nn_ws_smem_floats out of step with the layout");
 
   const int tid = threadIdx.x;
   const int K = p.K, N = p.N;
   const int nk = K / PBK;                           // >= 2
 
-  const int xcd = blockIdx.x % NXCD;
-  const int wg_in_xcd = blockIdx.x / NXCD;
-  const int wgs_per_xcd = gridDim.x / NXCD;
+  const int xcd = bid % NXCD;
+  const int wg_in_xcd = bid / NXCD;
+  const int wgs_per_xcd = nblk / NXCD;
   const int panels = (p.m_tiles - xcd + NXCD - 1) / NXCD;
   const int local_tiles = panels * p.n_tiles;
   // The walk of an XCD's workgroups over its tiles ends with a partial round: e_x of the wgs_per_xcd workgroups would
@@ -414,7 +421,7 @@ __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNA
   const int local_count = halves ? first_half + 2 * e_x : local_tiles;
   if (wg_in_xcd >= local_count) {                   // (only when local_tiles < wgs_per_xcd: unreachable with halves)
     if (STATS)
-      for (int c = tid; c < 2 * N; c += blockDim.x) p.stats[(int64_t)blockIdx.x * 2 * N + c] = 0.f;
+      for (int c = tid; c < 2 * N; c += (4 + NLW + NSW) * 64) p.stats[(int64_t)bid * 2 * N + c] = 0.f;
     return;
   }
   // local item -> tile view: row tile, first row inside it (0 / 64), rows it holds, first column.  Everything here is 32-bit
@@ -625,12 +632,12 @@ __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNA
     if (n_my & 1) stage(accA); else stage(accB);
     set_staged_tile(n_my - 1);
 #ifdef KWS_GEMM_STAMP
-    if ((tid & 63) == 0 && blockIdx.x < 256) g_stamps[blockIdx.x + 512][tid >> 6] = t_bar;   // every wave's barrier wait
-    if (tid == 0 && blockIdx.x < 8192) {
-      g_stamps[blockIdx.x][0] = t_mma; g_stamps[blockIdx.x][1] = t_bar; g_stamps[blockIdx.x][2] = t_stage;
-      g_stamps[blockIdx.x][3] = (unsigned long long)G;
-      g_stamps[blockIdx.x][4] = __builtin_amdgcn_s_memtime() - t_begin;
-      g_stamps[blockIdx.x][5] = __builtin_amdgcn_s_memrealtime() - r_begin;
+    if ((tid & 63) == 0 && bid < 256) g_stamps[bid + 512][tid >> 6] = t_bar;   // every wave's barrier wait
+    if (tid == 0 && bid < 8192) {
+      g_stamps[bid][0] = t_mma; g_stamps[bid][1] = t_bar; g_stamps[bid][2] = t_stage;
+      g_stamps[bid][3] = (unsigned long long)G;
+      g_stamps[bid][4] = __builtin_amdgcn_s_memtime() - t_begin;
+      g_stamps[bid][5] = __builtin_amdgcn_s_memrealtime() - r_begin;
     }
 #endif
     __syncthreads();   // last tile staged
@@ -640,8 +647,8 @@ __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNA
       stats_finish();
       __syncthreads();
       for (int c = tid; c < N; c += NCT) {
-        p.stats[((int64_t)blockIdx.x * 2 + 0) * N + c] = smem[WACC_OFF + c];
-        p.stats[((int64_t)blockIdx.x * 2 + 1) * N + c] = smem[WACC_OFF + KWS_WS_MAX_N + c];
+        p.stats[((int64_t)bid * 2 + 0) * N + c] = smem[WACC_OFF + c];
+        p.stats[((int64_t)bid * 2 + 1) * N + c] = smem[WACC_OFF + KWS_WS_MAX_N + c];
       }
     }
   } else if (tid < NCT + NLT) {
@@ -727,11 +734,11 @@ __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNA
       WT(t_lbar);
     }
 #ifdef KWS_GEMM_STAMP
-    if (tid == NCT && blockIdx.x < 8192) {
-      g_stamps[blockIdx.x][6] = t_write; g_stamps[blockIdx.x][7] = t_issue;
-      g_stamps[blockIdx.x + 256][2] = t_lbar;
+    if (tid == NCT && bid < 8192) {
+      g_stamps[bid][6] = t_write; g_stamps[bid][7] = t_issue;
+      g_stamps[bid + 256][2] = t_lbar;
     }
-    if ((tid & 63) == 0 && blockIdx.x < 256) g_stamps[blockIdx.x + 512][tid >> 6] = t_lbar;
+    if ((tid & 63) == 0 && bid < 256) g_stamps[bid + 512][tid >> 6] = t_lbar;
 #endif
     __syncthreads();
     __syncthreads();
@@ -800,11 +807,11 @@ __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNA
       WT(t_sbar);
     }
 #ifdef KWS_GEMM_STAMP
-    if (stt == 0 && blockIdx.x < 8192) {
-      g_stamps[blockIdx.x + 256][0] = t_store;
-      g_stamps[blockIdx.x + 256][1] = t_sbar;
+    if (stt == 0 && bid < 8192) {
+      g_stamps[bid + 256][0] = t_store;
+      g_stamps[bid + 256][1] = t_sbar;
     }
-    if ((tid & 63) == 0 && blockIdx.x < 256) g_stamps[blockIdx.x + 512][tid >> 6] = t_sbar;
+    if ((tid & 63) == 0 && bid < 256) g_stamps[bid + 512][tid >> 6] = t_sbar;
 #endif
     begin_tile();
     __syncthreads();   // last tile staged
@@ -812,6 +819,12 @@ __global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNA
     __syncthreads();
     if (STATS) __syncthreads();
   }
+}
+
+template <int BN, int KB, int NLW, int NSW, bool STATS>
+__global__ __launch_bounds__((4 + NLW + NSW) * 64, 1) void gemm_nn_ws_kernel(NNArgs p) {
+  __shared__ __attribute__((aligned(16))) float smem[nn_ws_smem_floats<BN, KB, STATS>()];
+  nn_ws_body<BN, KB, NLW, NSW, STATS>(p, smem, blockIdx.x, gridDim.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -986,7 +999,16 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs p) {
 //              right after, so each load has about a full stage to land.
 // Host-checked: K % BKO == 0, N % BNO == 0, chunk = whole stages (32 U rows), 32-bit byte offsets inside a split.
 template <int BKO, int BNO>
-__global__ __launch_bounds__((4 + ((128 / BKO) * (128 / BNO) > 2 ? 4 : 2)) * 64, 1) void gemm_tn_ws_kernel(TNArgs p) {
+constexpr int tn_ws_smem_floats() {
+  constexpr int U = 4 / ((BKO / 64) * (BNO / 64));
+  return 2 * U * 32 * (BKO + BNO) > (U > 1 ? 4 * 64 * 64 : 0) ? 2 * U * 32 * (BKO + BNO) : 4 * 64 * 64;
+}
+template <int BKO, int BNO>
+constexpr int tn_ws_threads() { return (4 + ((128 / BKO) * (128 / BNO) > 2 ? 4 : 2)) * 64; }
+// As for the NN kernel: a device function of the block id; NTHREADS = threads of the launching kernel (waves past the
+// kernel's own 4 + NLW only keep the barrier count).
+template <int BKO, int BNO, int NTHREADS>
+__device__ __forceinline__ void tn_ws_body(const TNArgs& p, float* const smem, const int bid) {
   constexpr int WK = BKO / 64, WN = BNO / 64, WS = 4 / (WK * WN);
   constexpr int U = WS;                             // 32-row units per stage
   constexpr bool IL = WS != 2;                      // interleaved column blocks (see the fragment reads)
@@ -998,10 +1020,11 @@ __global__ __launch_bounds__((4 + ((128 / BKO) * (128 / BNO) > 2 ? 4 : 2)) * 64,
   constexpr int RED = WS > 1 ? 4 * 64 * 64 : 0;
   constexpr int SMEM = 2 * SLOT > RED ? 2 * SLOT : RED;
   static_assert(SMEM * 4 <= 160 * 1024, "LDS budget");
-  __shared__ __attribute__((aligned(16))) float smem[SMEM];
+  static_assert(SMEM == tn_ws_smem_floats<BKO, BNO>(), "tn_ws_smem_floats out of step with the layout");
+  static_assert(NTHREADS >= (4 + NLW) * 64, "the launching kernel must bring the kernel's own waves");
 
   const int n_out_tiles = p.k_tiles * p.n_tiles;
-  const int xcd = blockIdx.x % NXCD, slot_id = blockIdx.x / NXCD;
+  const int xcd = bid % NXCD, slot_id = bid / NXCD;
   const int tile = slot_id % n_out_tiles;
   const int split = (slot_id / n_out_tiles) * NXCD + xcd;
   if (split >= p.S) return;
@@ -1127,13 +1150,13 @@ __global__ __launch_bounds__((4 + ((128 / BKO) * (128 / BNO) > 2 ? 4 : 2)) * 64,
       }
     }
 #ifdef KWS_GEMM_STAMP
-    if (tid == 0 && blockIdx.x < 4096) {
-      g_stamps[blockIdx.x][0] = tn_mma; g_stamps[blockIdx.x][1] = tn_bar; g_stamps[blockIdx.x][3] = (unsigned long long)G;
-      g_stamps[blockIdx.x][2] = __builtin_amdgcn_s_memrealtime() - tn_rbegin;   // 100 MHz ticks of the whole item (clock = cycles / ticks)
-      g_stamps[blockIdx.x][4] = tn_loop_end - tn_begin; g_stamps[blockIdx.x][5] = __builtin_amdgcn_s_memtime() - tn_loop_end;
+    if (tid == 0 && bid < 4096) {
+      g_stamps[bid][0] = tn_mma; g_stamps[bid][1] = tn_bar; g_stamps[bid][3] = (unsigned long long)G;
+      g_stamps[bid][2] = __builtin_amdgcn_s_memrealtime() - tn_rbegin;   // 100 MHz ticks of the whole item (clock = cycles / ticks)
+      g_stamps[bid][4] = tn_loop_end - tn_begin; g_stamps[bid][5] = __builtin_amdgcn_s_memtime() - tn_loop_end;
     }
 #endif
-  } else {
+  } else if (tid < NCT + NLW * 64) {
     // ------------------------------------------------------------------ loader waves
     const int lane = tid & 63;
     const int lw = __builtin_amdgcn_readfirstlane((tid - NCT) >> 6);
@@ -1191,10 +1214,36 @@ __global__ __launch_bounds__((4 + ((128 / BKO) * (128 / BNO) > 2 ? 4 : 2)) * 64,
       TLT(tl_bar);
     }
 #ifdef KWS_GEMM_STAMP
-    if ((tid & 63) == 0 && lw == 0 && blockIdx.x < 4096) { g_stamps[blockIdx.x][6] = tl_work; g_stamps[blockIdx.x][7] = tl_bar; }
+    if ((tid & 63) == 0 && lw == 0 && bid < 4096) { g_stamps[bid][6] = tl_work; g_stamps[bid][7] = tl_bar; }
 #endif
     if (WS > 1) __syncthreads();
+  } else {
+    // ------------------------------------------------------------------ spare waves of a wider launching kernel: the barriers only
+    __syncthreads();
+    for (int g = 0; g < G; ++g) __syncthreads();
+    if (WS > 1) __syncthreads();
   }
+}
+
+template <int BKO, int BNO>
+__global__ __launch_bounds__((4 + ((128 / BKO) * (128 / BNO) > 2 ? 4 : 2)) * 64, 1) void gemm_tn_ws_kernel(TNArgs p) {
+  __shared__ __attribute__((aligned(16))) float smem[tn_ws_smem_floats<BKO, BNO>()];
+  constexpr int NT = tn_ws_threads<BKO, BNO>();
+  tn_ws_body<BKO, BNO, NT>(p, smem, blockIdx.x);
+}
+
+// One launch = the input-gradient GEMM (dZ = dY W^T: the first nn_grid blocks, the persistent NN walk) AND the weight-gradient
+// GEMM of the same layer (dW slabs = Z^T dY: one block per work item behind them).  The two are independent; in one grid the
+// hardware starts weight-gradient workgroups on a CU the moment its NN workgroup has ended - the NN kernel's last partial
+// round (stamps, round 4: 1 - 12 us of idle CUs per launch) and the second launch's ramp-up are filled without an event
+// (two streams cost 30 us per layer in events, profiles/r04_dgrad_wgrad_two_streams.txt).  Same code paths, same per-element
+// arithmetic as the two separate launches: bit-identical dZ and slabs.
+template <int BN, int KB, int BKO, int BNO>
+__global__ __launch_bounds__(512, 1) void gemm_dgrad_wgrad_kernel(NNArgs a, TNArgs t, int nn_grid) {
+  constexpr int SM_NN = nn_ws_smem_floats<BN, KB, false>(), SM_TN = tn_ws_smem_floats<BKO, BNO>();
+  __shared__ __attribute__((aligned(16))) float smem[SM_NN > SM_TN ? SM_NN : SM_TN];
+  if ((int)blockIdx.x < nn_grid) nn_ws_body<BN, KB, 2, 2, false>(a, smem, blockIdx.x, nn_grid);
+  else tn_ws_body<BKO, BNO, 512>(t, smem, (int)blockIdx.x - nn_grid);
 }
 
 // out[i] = sum_k ws[k][i], k ascending within 4 interleaved groups that are combined in a fixed order
@@ -1554,6 +1603,40 @@ int launch_tn(TNArgs a, float* dW, hipStream_t st, int* S_out = nullptr) {
   return KWS_OK;
 }
 
+// The fused launch of a layer's input-gradient and weight-gradient GEMMs (gemm_dgrad_wgrad_kernel).  Returns 1 when the pair is
+// not eligible (either plan falls to a 4-wave kernel, or a split would need 64-bit offsets): the caller then launches the two
+// GEMMs separately, exactly as before.
+template <int BN, int KB>
+void launch_pair_tn(const NNArgs& a, const TNArgs& t, const TNPlan& tp, int nn_grid, unsigned grid, hipStream_t st) {
+  if (tp.bko == 128 && tp.bno == 128) hipLaunchKernelGGL((gemm_dgrad_wgrad_kernel<BN, KB, 128, 128>), dim3(grid), dim3(512), 0, st, a, t, nn_grid);
+  else if (tp.bko == 128) hipLaunchKernelGGL((gemm_dgrad_wgrad_kernel<BN, KB, 128, 64>), dim3(grid), dim3(512), 0, st, a, t, nn_grid);
+  else if (tp.bno == 128) hipLaunchKernelGGL((gemm_dgrad_wgrad_kernel<BN, KB, 64, 128>), dim3(grid), dim3(512), 0, st, a, t, nn_grid);
+  else hipLaunchKernelGGL((gemm_dgrad_wgrad_kernel<BN, KB, 64, 64>), dim3(grid), dim3(512), 0, st, a, t, nn_grid);
+}
+int launch_dgrad_wgrad(NNArgs a, TNArgs t, hipStream_t st, int* S_out) {
+  const NNPlan np = nn_plan(a.M, a.K, a.N, false);
+  if (!np.ws || a.stats != nullptr) return 1;
+  if (!tn_ws_eligible(t.K, t.N, false)) return 1;
+  const TNPlan tp = tn_plan(t.M, t.K, t.N, true);
+  if (tp.chunk * (int64_t)(t.K > t.N ? t.K : t.N) * 4 >= (1ll << 31)) return 1;
+  a.m_tiles = (int)ceil_div64(a.M, 128);
+  a.n_tiles = ceil_div(a.N, np.bn);
+  a.half_tail = nn_half_tail() ? 1 : 0;
+  a.last_rows = (int)(a.M - (int64_t)(a.m_tiles - 1) * 128);
+  a.inv_n_tiles = a.n_tiles > 1 ? (unsigned)(((1ull << 32) + a.n_tiles - 1) / a.n_tiles) : 0u;
+  t.chunk = tp.chunk; t.k_tiles = tp.k_tiles; t.n_tiles = tp.n_tiles; t.S = tp.S;
+  const int nn_grid = np.wgs;
+  const int64_t tn_grid = (int64_t)tp.k_tiles * tp.n_tiles * ceil_div(tp.S, NXCD) * NXCD;
+  if (nn_grid % NXCD != 0 || tn_grid + nn_grid > 0x7FFFFFFF) return 1;   // (the weight-gradient blocks keep their XCD: nn_grid is 8 x per-XCD)
+  const unsigned grid = (unsigned)(nn_grid + tn_grid);
+  if (np.bn == 128) launch_pair_tn<128, 32>(a, t, tp, nn_grid, grid, st);
+  else if (np.kb == 64) launch_pair_tn<64, 64>(a, t, tp, nn_grid, grid, st);
+  else launch_pair_tn<64, 32>(a, t, tp, nn_grid, grid, st);
+  KWS_LAUNCH_CHECK("gemm_dgrad_wgrad_kernel");
+  if (S_out) *S_out = tp.S;
+  return KWS_OK;
+}
+
 int check_gather(const kws_gather_t* g, int B, int N) {
   KWS_REQUIRE(g != nullptr, "gather descriptor is NULL");
   KWS_REQUIRE(g->L_out > 0 && g->cin > 0 && g->taps > 0 && g->cin % 4 == 0,
@@ -1629,6 +1712,22 @@ int kws_gemm_tn_slabs_f32(const float* A, const float* G, int64_t M, int K, int 
   a.A = A; a.G = G; a.ws = workspace; a.M = M; a.K = K; a.N = N;
   KwsProfScope prof("gemm_tn", 2.0 * M * K * N, 4.0 * ((double)M * K + (double)M * N + (double)K * N), stream);
   return launch_tn<false>(a, nullptr, stream, S);
+}
+
+// internal (net.hip): dZ[M, cin] = dY[M, cout] * WT[cout, cin] and the slabs of dW[cin, cout] = Z^T dY in ONE launch
+// (gemm_dgrad_wgrad_kernel); workspace / *S as for kws_gemm_tn_slabs_f32.  Returns 1 (nothing launched) when the shapes are not
+// eligible for the fused kernel: the caller then makes the two calls.
+int kws_gemm_dgrad_wgrad_f32(const float* dY, const float* WT, float* dZ, const float* Z, int64_t M, int cin, int cout,
+                             float* workspace, int* S, hipStream_t stream) {
+  KWS_REQUIRE(dY && WT && dZ && Z && workspace && S, "gemm_dgrad_wgrad: NULL pointer");
+  KWS_REQUIRE(M > 0 && cin > 0 && cout > 0 && cin % 4 == 0 && cout % 4 == 0, "gemm_dgrad_wgrad: M=%lld cin=%d cout=%d", (long long)M, cin, cout);
+  NNArgs a{};
+  a.A = dY; a.W = WT; a.C = dZ; a.M = M; a.K = cout; a.N = cin; a.stats = nullptr;
+  TNArgs t{};
+  t.A = Z; t.G = dY; t.ws = workspace; t.M = M; t.K = cin; t.N = cout;
+  const double fl = 2.0 * M * cin * cout;
+  KwsProfScope prof("gemm_bwd_pair", 2.0 * fl, 4.0 * (3.0 * M * cout + 2.0 * M * cin + 2.0 * (double)cin * cout) , stream);
+  return launch_dgrad_wgrad(a, t, stream, S);
 }
 
 int kws_reduce_slabs_batch(const float* const* ws, float* const* out, const int64_t* n, const int* S, int count, hipStream_t stream) {

@@ -36,6 +36,9 @@ extern "C" int kws_dwconv_bwd_acc_f32(const float* dz, const float* y, const flo
 constexpr int KWS_SLAB_BATCH = 16;
 extern "C" int kws_gemm_tn_slabs_f32(const float* A, const float* G, int64_t M, int K, int N, float* workspace, int* S,
                                      hipStream_t stream);
+// gemm.hip: a layer's input-gradient GEMM and the slabs of its weight-gradient GEMM in one launch (returns 1 = not eligible, nothing launched)
+extern "C" int kws_gemm_dgrad_wgrad_f32(const float* dY, const float* WT, float* dZ, const float* Z, int64_t M, int cin, int cout,
+                                        float* workspace, int* S, hipStream_t stream);
 extern "C" int kws_reduce_slabs_batch(const float* const* ws, float* const* out, const int64_t* n, const int* S, int count,
                                       hipStream_t stream);
 extern "C" int64_t kws_gemm_tn_workspace_floats(int64_t M, int K, int N);
@@ -70,6 +73,27 @@ struct KwsSlabQueue {
     used += need;
     ++count;
     return 0;
+  }
+  // the input-gradient GEMM dZ = dY WT and the weight-gradient slabs of dW = Z^T dY of one layer: ONE launch where the fused kernel
+  // takes the shapes (kws_gemm_dgrad_wgrad_f32), the two launches otherwise
+  int pair(const float* dY, const float* WT, float* dZ, const float* Z, float* dW, int64_t M, int cin, int cout, hipStream_t st) {
+    const int64_t need = (kws_gemm_tn_workspace_floats(M, cin, cout) + 63) / 64 * 64;
+    if (count == KWS_SLAB_BATCH || used + need > cap) {
+      const int rc = flush(st);
+      if (rc) return rc;
+    }
+    if (need > cap) return KWS_E_WORKSPACE;
+    const int rc = kws_gemm_dgrad_wgrad_f32(dY, WT, dZ, Z, M, cin, cout, base + used, &S[count], st);
+    if (rc < 0) return rc;
+    if (rc == 0) {
+      ws[count] = base + used; out[count] = dW; n[count] = (int64_t)cin * cout;
+      used += need;
+      ++count;
+      return 0;
+    }
+    const int rc2 = kws_gemm_nn_f32(dY, WT, dZ, M, cout, cin, nullptr, st);
+    if (rc2) return rc2;
+    return gemm(Z, dY, dW, M, cin, cout, st);
   }
 };
 // bn.hip: the depthwise weight gradients of up to KWS_DW_FIN_BATCH layers folded in one launch (their partial rows kept apart)

@@ -429,7 +429,8 @@ int kws_net_predict(const kws_net_t* net, const float* params, const float* stat
 extern "C" int kws_net_get_gemm_mode(const kws_net_t* net) { return net ? net->gemm_mode.load(std::memory_order_relaxed) : 0; }
 extern "C" int kws_net_set_gemm_mode(kws_net_t* net, int mode) {
   KWS_REQUIRE(net != nullptr, "net_set_gemm_mode: NULL net");
-  KWS_REQUIRE(mode == 0 || mode == 2, "net_set_gemm_mode: mode %d (0 = f32 MFMA, 2 = fp16 x 2 split)", mode);
+  KWS_REQUIRE(mode == 0 || mode == 1 || mode == 2,
+              "net_set_gemm_mode: mode %d (0 = f32 MFMA, 1 = f32 MFMA with separate input- / weight-gradient launches, 2 = fp16 x 2 split)", mode);
   net->gemm_mode.store(mode, std::memory_order_relaxed);
   return KWS_OK;
 }
@@ -461,6 +462,7 @@ static int ts_train(const kws_net_t* net, const float* params, float* state, con
   // GEMMs run as three f16 MFMA products of scaled two-way operand splits; the first convolution stays f32, and so does any
   // GEMM whose shape the arm's kernels cannot take (kws_gemm_*_f16x2_supported: K granule, 2 GB buffer views)
   const bool h2 = kws_net_get_gemm_mode(net) == 2;
+  const bool pair_bwd = kws_net_get_gemm_mode(net) == 0;     // mode 1: f32 MFMA with separate dgrad / wgrad launches
   // fp16 x 2 arm: slot groups of the operands' |x| maxima (common.h): W of block i, z of block i, dy of block i's output
   unsigned* amax0 = reinterpret_cast<unsigned*>(ws + lo.amax);
   auto w_slots = [&](int i) { return amax0 + (int64_t)i * KWS_ABSMAX_WORDS; };
@@ -576,6 +578,21 @@ static int ts_train(const kws_net_t* net, const float* params, float* state, con
     if (i == nb - 1)
       KWS_TRY(kws_bn_bwd_apply_amax(Gcur, ws + lo.y[i + 1], bn_at(i + 1), params + b.bn.gamma, coef, M, b.cout,
                                     h2 ? g_slots(i) : nullptr, st));
+    // f32 arm, gemm mode 0 (default): the input-gradient GEMM and the weight-gradient GEMM of the layer - independent of each
+    // other - go out as ONE launch whose weight-gradient workgroups start on a CU as soon as its input-gradient workgroup has
+    // ended (gemm.hip gemm_dgrad_wgrad_kernel; same code, bit-identical dZ and slabs).  Mode 1 keeps the two launches of
+    // rounds 1 - 3 (the A/B reference), and so does any shape the fused kernel does not take (rc 1).
+    bool paired = false;
+    if (pair_bwd) {
+      const int rc = kws_gemm_dgrad_wgrad_f32(Gcur, ws + lo.WT[i], DZ, ws + lo.z[i], M, b.cin, b.cout, ws + lo.tns[i], &sl_S[n_sl], st);
+      if (rc < 0) return rc;
+      if (rc == 0) {
+        sl_ws[n_sl] = ws + lo.tns[i]; sl_out[n_sl] = grads + b.pw; sl_n[n_sl] = (int64_t)b.cin * b.cout;
+        ++n_sl;
+        paired = true;
+      }
+    }
+    if (!paired) {
     if (h2 && kws_gemm_nn_f16x2_supported(M, b.cout, b.cin))
       KWS_TRY(kws_gemm_nn_f16x2_f32(Gcur, ws + lo.WPd[i], DZ, M, b.cout, b.cin, g_slots(i), w_slots(i), nullptr, st));
     else
@@ -586,6 +603,7 @@ static int ts_train(const kws_net_t* net, const float* params, float* state, con
       sl_ws[n_sl] = ws + lo.tns[i]; sl_out[n_sl] = grads + b.pw; sl_n[n_sl] = (int64_t)b.cin * b.cout;
       KWS_TRY(kws_gemm_tn_slabs_f32(ws + lo.z[i], Gcur, M, b.cin, b.cout, ws + lo.tns[i], &sl_S[n_sl], st));
       ++n_sl;
+    }
     }
     const BnRef& prev = (i == 0) ? net->bn1 : net->blocks[i - 1].bn;
     // depthwise backward + BatchNorm backward of this block's input without materialising the masked

@@ -922,8 +922,7 @@ int lm_train(const kws_net* n, const float* params, float* state, const float* x
       if (j == (int)p.plain.size() - 1) {
         KWS_TRY(join_bwd(dO, ws + lo.py[j], q.bn, q.bn_idx, G, q.Lout, q.cout, 1, 1));
       }  // else: G already holds dy of this block (pass 2 of the next block's depthwise backward)
-      KWS_TRY(kws_gemm_nn_f32(G, ws + lo.wt_plain[j], DZ, M, q.cout, q.cin, nullptr, st));
-      KWS_TRY(sq.gemm(ws + lo.pz[j], G, grads + q.pw, M, q.cin, q.cout, st));
+      KWS_TRY(sq.pair(G, ws + lo.wt_plain[j], DZ, ws + lo.pz[j], grads + q.pw, M, q.cin, q.cout, st));   // dgrad + wgrad: one launch
       const int np = (int)(kws_dwconv_bwd_part_floats(B, q.Lin, q.cin) / (5 * q.cin));
       if (j > 0) {
         const LmPlain& r = p.plain[j - 1];
@@ -967,8 +966,7 @@ int lm_train(const kws_net* n, const float* params, float* state, const float* x
     } else {
       KWS_TRY(join_bwd(dO, ws + lo.y2[i], b.bn2, b.bn2_idx, G, b.Lmid, b.nf, b.pool, 1));
     }
-    KWS_TRY(kws_gemm_nn_f32(G, ws + lo.wt_pw2[i], DZ, M, b.nf, b.nf, nullptr, st));
-    KWS_TRY(sq.gemm(ws + lo.z2[i], G, grads + b.pw2, M, b.nf, b.nf, st));
+    KWS_TRY(sq.pair(G, ws + lo.wt_pw2[i], DZ, ws + lo.z2[i], grads + b.pw2, M, b.nf, b.nf, st));   // dgrad + wgrad: one launch where eligible
     // depthwise 2 -> BN1 -> pointwise 1
     // (two passes over dz and y1 instead of "store g, then kws_bn_bwd_apply": the masked gradient is never stored)
     KWS_TRY(kws_dwconv_bwd_bn_f32(DZ, ws + lo.y1[i], c.bn_at(b.bn1_idx), params + b.dw2, nullptr, nullptr, part, 1, B,
@@ -977,8 +975,7 @@ int lm_train(const kws_net* n, const float* params, float* state, const float* x
     KWS_TRY(kws_dw_bwd_finalize(part, np, M, b.nf, grads + b.dw2, grads + b.bn1.gamma, grads + b.bn1.beta, coef, red, st));
     KWS_TRY(kws_dwconv_bwd_bn_f32(DZ, ws + lo.y1[i], c.bn_at(b.bn1_idx), params + b.dw2, coef, G, nullptr, 2, B, b.Lmid,
                                   b.Lmid, b.nf, 1, 1, st));
-    KWS_TRY(kws_gemm_nn_f32(G, ws + lo.wt_pw1[i], DZ, M, b.nf, b.cin, nullptr, st));
-    KWS_TRY(sq.gemm(ws + lo.z1[i], G, grads + b.pw1, M, b.cin, b.nf, st));
+    KWS_TRY(sq.pair(G, ws + lo.wt_pw1[i], DZ, ws + lo.z1[i], grads + b.pw1, M, b.cin, b.nf, st));
     // depthwise 1 on the (materialised) block input
     float* dpart;      // only a weight gradient comes out of these rows: folded with the other blocks' at the end of the pass
     KWS_TRY(dq.take(kws_dwconv_bwd_part_floats(B, b.Lin, b.cin), b.cin, grads + b.dw1, &dpart));
@@ -999,8 +996,7 @@ int lm_train(const kws_net* n, const float* params, float* state, const float* x
   if (p.style == 1) {  // ---- context block: dO is the gradient wrt its activated output ----
     const int64_t M = (int64_t)B * p.L0;
     KWS_TRY(join_bwd(dO, ws + lo.yc, p.ctx_bn, p.ctx_bn_idx, G, p.L0, p.C0, 1, 1));
-    KWS_TRY(kws_gemm_nn_f32(G, ws + lo.wt_ctx, DZ, M, p.C0, p.C0, nullptr, st));
-    KWS_TRY(sq.gemm(ws + lo.zc, G, grads + p.ctx_pw, M, p.C0, p.C0, st));
+    KWS_TRY(sq.pair(G, ws + lo.wt_ctx, DZ, ws + lo.zc, grads + p.ctx_pw, M, p.C0, p.C0, st));
     float* dpart;
     KWS_TRY(dq.take(kws_dwconv_bwd_part_floats(B, p.L0, p.C0), p.C0, grads + p.ctx_dw, &dpart));
     KWS_TRY(kws_dwconv_bwd_f32(DZ, ws + lo.a0, nullptr, params + p.ctx_dw, dX, dpart, B, p.L0, p.L0, p.C0, 1, 1, st));

@@ -158,6 +158,9 @@ def test_bench_single_gpu_line_carries_the_round4_keys():
     ab = out["ab_features"]
     assert ab["raw"]["value"] > 0 and ab["mfcc_and_raw"]["value"] > 0 and len(ab["raw"]["rounds_ms"]) == 2
     assert abs(ab["stft_mel_cost_us_per_step"] - 1e3 * (ab["mfcc_and_raw"]["ms_per_step"] - ab["raw"]["ms_per_step"])) < 1e-6
+    bp = out["ab_bwd_pair"]                              # one launch for a layer's two backward GEMMs vs two (mode 1)
+    assert bp["paired"]["value"] > 0 and bp["separate"]["value"] > 0 and len(bp["paired"]["rounds_ms"]) == 2
+    assert out["roofline"]["family"] in ("gemm_bwd_pair", "gemm_nn") and out["roofline"]["frac"] > 0
     err = out["stft_mel_error"]
     assert err["clips"] == 16
     assert err["log_mel"]["max_abs_err_vs_f64"] < 1e-3 and err["mfcc"]["max_abs_err_vs_f64"] < 2e-3     # the test-suite bars

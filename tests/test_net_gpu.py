@@ -272,3 +272,28 @@ def test_split_step_is_bit_identical_to_the_whole_step(split):
         net.train_fwd_bwd_part(1, 11, dx, dy, seed=9, step=2)
     with pytest.raises(_lib.KwsError):
         net.grad_ready_offset(0)
+
+
+@pytest.mark.parametrize("B", [6, 70])
+def test_paired_backward_launch_is_bit_identical_to_separate_launches(B):
+    """Round 4: in gemm mode 0 a layer's input-gradient and weight-gradient GEMMs go out as ONE launch (gemm.hip
+    gemm_dgrad_wgrad_kernel: the NN walk on the first blocks, one weight-gradient work item per block behind them); mode 1 is
+    the schedule of rounds 1 - 3 (two launches).  Same code paths, same per-element arithmetic: every gradient, the
+    probabilities, the metrics and the BatchNorm state must agree bit for bit.  (B = 70: several row tiles and a ragged last
+    one in every layer, more than one M-split in the early ones.)"""
+    ora, net = _pair()
+    x, y = _batch(B, 12, 43)
+    dx, dy = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    assert net.gemm_mode == 0
+    p0 = net.train_fwd_bwd(dx, dy, seed=5, step=1).clone()
+    g0, m0, st0 = net.grads.clone(), net.metrics.clone(), net.state.clone()
+    net.set_weights(dict(ora.params, **ora.state))
+    net.set_gemm_mode(1)
+    try:
+        p1 = net.train_fwd_bwd(dx, dy, seed=5, step=1)
+        torch.cuda.synchronize()
+        assert torch.equal(p1, p0) and torch.equal(net.metrics, m0) and torch.equal(net.state, st0)
+        assert torch.equal(net.grads, g0)
+    finally:
+        net.set_gemm_mode(0)
+    assert float(g0.abs().max()) > 0
