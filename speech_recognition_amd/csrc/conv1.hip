@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256, 3) void conv1_fwd_kernel(Conv1Args p) {
 //                blocks (block cb = the columns of parity cb: 16 lanes read 128 contiguous bytes of a row);
 //   D            register v of block (rb, cb): dW[16 rb + 4 (lane / 16) + v][32 w + 2 j + cb] - the two blocks leave as 8-byte stores.
 template <int KF>
-__global__ __launch_bounds__(256, KWS_C1W_OCC) void conv1_wgrad_kernel(Conv1Args p) {
+__device__ __forceinline__ void conv1_wgrad_body(const Conv1Args& p, float (*sA)[UM * KF], const int bid) {
   constexpr int PA = KF;            // row pitch of the staged rows: 80 = 16 mod 32 banks
   constexpr int TPR = 256 / UM;     // A-staging threads per row
   constexpr int QF = KF / TPR;      // floats per A-staging thread
@@ -241,9 +241,8 @@ __global__ __launch_bounds__(256, KWS_C1W_OCC) void conv1_wgrad_kernel(Conv1Args
   static_assert(KF % 16 == 0 && KF % (2 * TPR) == 0, "whole 16-row blocks, 8-byte staging loads");
   constexpr int NL = QF / 2;
   typedef float f32x4 __attribute__((ext_vector_type(4)));
-  __shared__ float sA[2][UM * PA];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l16 = lane & 15, lk = lane >> 4;
-  const int64_t m_begin = (int64_t)blockIdx.x * p.chunk;
+  const int64_t m_begin = (int64_t)bid * p.chunk;
   const int64_t m_end = m_begin + p.chunk < p.M ? m_begin + p.chunk : p.M;
   const int arow = tid / TPR, aq = tid % TPR;
   float2 ra[NL];
@@ -329,7 +328,7 @@ __global__ __launch_bounds__(256, KWS_C1W_OCC) void conv1_wgrad_kernel(Conv1Args
     __syncthreads();
     buf ^= 1;
   }
-  float* slab = p.ws + (int64_t)blockIdx.x * KF * NOUT;
+  float* slab = p.ws + (int64_t)bid * KF * NOUT;
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
@@ -337,6 +336,23 @@ __global__ __launch_bounds__(256, KWS_C1W_OCC) void conv1_wgrad_kernel(Conv1Args
       const int k = 16 * rb + 4 * lk + v;
       *reinterpret_cast<float2*>(slab + k * NOUT + wave * 32 + 2 * l16) = make_float2(acc[rb][0][v], acc[rb][1][v]);
     }
+}
+
+template <int KF>
+__global__ __launch_bounds__(256, KWS_C1W_OCC) void conv1_wgrad_kernel(Conv1Args p) {
+  __shared__ float sA[2][UM * KF];
+  conv1_wgrad_body<KF>(p, sA, blockIdx.x);
+}
+
+// Round 4: the first convolution's weight gradient AND the batched slab sum of the pointwise weight gradients (independent of each
+// other: one MFMA / memory bound, one HBM bound) as ONE grid - blocks [0, n_conv) are the weight-gradient slabs, the blocks behind
+// them the slab-sum columns (internal.h kws_reduce_slabs_batch_body); no event between them, the hardware co-schedules the two.
+template <int KF>
+__global__ __launch_bounds__(256, KWS_C1W_OCC) void conv1_wgrad_slabsum_kernel(Conv1Args p, SlabBatch b, int n_conv) {
+  __shared__ float sA[2][UM * KF];
+  __shared__ float4 red[4][64];
+  if ((int)blockIdx.x < n_conv) conv1_wgrad_body<KF>(p, sA, blockIdx.x);
+  else kws_reduce_slabs_batch_body(b, (int)blockIdx.x - n_conv, red);
 }
 
 // dW[j][c][n] = sum over slab groups of ws[group][hop j + c][n]: the second stage of the slab sum writes the three taps
@@ -403,15 +419,33 @@ int64_t kws_conv1_wgrad_workspace_floats(int64_t M) { return (int64_t)wgrad_plan
 
 int kws_conv1_wgrad(const float* x, const kws_gather_t* g, const kws_gather_t* unfolded, const float* G, float* dW, int B,
                     int N, float* workspace, hipStream_t st) {
+  return kws_conv1_wgrad_slabs(x, g, unfolded, G, dW, B, N, workspace, nullptr, nullptr, nullptr, nullptr, 0, st);
+}
+
+// as kws_conv1_wgrad; with n_sl > 0 the same launch also sums the slabs of n_sl pointwise weight-gradient GEMMs (the arguments of
+// kws_reduce_slabs_batch) - conv1_wgrad_slabsum_kernel
+int kws_conv1_wgrad_slabs(const float* x, const kws_gather_t* g, const kws_gather_t* unfolded, const float* G, float* dW, int B,
+                          int N, float* workspace, const float* const* sl_ws, float* const* sl_out, const int64_t* sl_n,
+                          const int* sl_S, int n_sl, hipStream_t st) {
   KWS_REQUIRE(x && g && unfolded && G && dW && workspace && B > 0 && kws_conv1_supported(g, unfolded, N),
               "conv1_wgrad: unsupported shape");
   Conv1Args a{};
   a.x = x; a.G = G; a.ws = workspace; a.g = *g; a.B = B; a.M = (int64_t)B * g->L_out;
   const WgradPlan pl = wgrad_plan(a.M);
   a.S = pl.S; a.chunk = pl.chunk;
+  if (n_sl > 0) {
+    SlabBatch sb;
+    int blocks = 0;
+    double bytes = 0;
+    KWS_TRY(kws_slab_batch_fill(&sb, sl_ws, sl_out, sl_n, sl_S, n_sl, &blocks, &bytes));
+    KwsProfScope prof("conv1_wgrad", 2.0 * a.M * 80 * N, 4.0 * ((double)B * g->x_len + (double)a.M * N + 80.0 * N) + bytes, st);
+    hipLaunchKernelGGL((conv1_wgrad_slabsum_kernel<80>), dim3(pl.S + blocks), dim3(256), 0, st, a, sb, pl.S);
+    KWS_LAUNCH_CHECK("conv1_wgrad_slabsum_kernel");
+  } else {
   KwsProfScope prof("conv1_wgrad", 2.0 * a.M * 80 * N, 4.0 * ((double)B * g->x_len + (double)a.M * N + 80.0 * N), st);
   hipLaunchKernelGGL((conv1_wgrad_kernel<80>), dim3(pl.S), dim3(256), 0, st, a);
   KWS_LAUNCH_CHECK("conv1_wgrad_kernel");
+  }
   // slab sum in two stages: groups of 32 slabs in place (over each group's first slab), then the group sums straight into
   // the three taps of dW
   const int per_group = 32, groups = ceil_div(pl.S, per_group);

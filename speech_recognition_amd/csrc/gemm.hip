@@ -1343,42 +1343,9 @@ __global__ __launch_bounds__(256) void transpose_batch_kernel(TransposeBatch b) 
 // their slabs into regions of their own; summing them per layer cost fourteen 5 - 10 us launches on the dependency chain).
 // One workgroup = 64 float4 columns of one GEMM; 4 slab groups (k = grp, grp + 4, ...) with four loads in flight each,
 // combined in a fixed order: bit-reproducible.
-struct SlabBatch {
-  const float* ws[KWS_SLAB_BATCH];
-  float* out[KWS_SLAB_BATCH];
-  int64_t n4[KWS_SLAB_BATCH];
-  int S[KWS_SLAB_BATCH], blk_end[KWS_SLAB_BATCH];
-  int n;
-};
-__device__ __forceinline__ void add4(float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
 __global__ __launch_bounds__(256) void reduce_slabs_batch_kernel(SlabBatch b) {
   __shared__ float4 red[4][64];
-  int m = 0;
-  while (m + 1 < b.n && (int)blockIdx.x >= b.blk_end[m]) ++m;
-  const int t = blockIdx.x - (m ? b.blk_end[m - 1] : 0);
-  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int64_t n4 = b.n4[m];
-  const int S = b.S[m];
-  const int64_t i = (int64_t)t * 64 + col;
-  const float4* w = reinterpret_cast<const float4*>(b.ws[m]);
-  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
-  if (i < n4) {
-    int k = grp;
-    for (; k + 12 < S; k += 16) {
-      const float4 v0 = w[(int64_t)k * n4 + i], v1 = w[(int64_t)(k + 4) * n4 + i];
-      const float4 v2 = w[(int64_t)(k + 8) * n4 + i], v3 = w[(int64_t)(k + 12) * n4 + i];
-      add4(s0, v0); add4(s1, v1); add4(s2, v2); add4(s3, v3);
-    }
-    for (; k < S; k += 4) add4(s0, w[(int64_t)k * n4 + i]);
-    add4(s0, s1); add4(s2, s3); add4(s0, s2);
-  }
-  red[grp][col] = s0;
-  __syncthreads();
-  if (grp == 0 && i < n4) {
-    float4 r = red[0][col];
-    add4(r, red[1][col]); add4(r, red[2][col]); add4(r, red[3][col]);
-    reinterpret_cast<float4*>(b.out[m])[i] = r;
-  }
+  kws_reduce_slabs_batch_body(b, blockIdx.x, red);
 }
 
 // split heuristic of the TN kernel: enough workgroups to fill 256 CUs, slabs no larger than needed
@@ -1730,19 +1697,30 @@ int kws_gemm_dgrad_wgrad_f32(const float* dY, const float* WT, float* dZ, const 
   return launch_dgrad_wgrad(a, t, stream, S);
 }
 
-int kws_reduce_slabs_batch(const float* const* ws, float* const* out, const int64_t* n, const int* S, int count, hipStream_t stream) {
-  KWS_REQUIRE(ws && out && n && S && count > 0 && count <= KWS_SLAB_BATCH, "reduce_slabs_batch: bad arguments (count=%d)", count);
-  SlabBatch b;
+int kws_slab_batch_fill(SlabBatch* b, const float* const* ws, float* const* out, const int64_t* n, const int* S, int count, int* blocks_out,
+                        double* bytes_out) {
+  KWS_REQUIRE(b && ws && out && n && S && count > 0 && count <= KWS_SLAB_BATCH, "reduce_slabs_batch: bad arguments (count=%d)", count);
   int blocks = 0;
   double bytes = 0;
   for (int i = 0; i < count; ++i) {
-    KWS_REQUIRE(ws[i] && out[i] && n[i] > 0 && n[i] % 4 == 0 && S[i] > 0, "reduce_slabs_batch: bad entry %d", i);
-    b.ws[i] = ws[i]; b.out[i] = out[i]; b.n4[i] = n[i] / 4; b.S[i] = S[i];
+    KWS_REQUIRE(ws[i] && out[i] && n[i] > 0 && n[i] % 4 == 0 && S[i] != 0, "reduce_slabs_batch: bad entry %d", i);
+    b->ws[i] = ws[i]; b->out[i] = out[i]; b->n4[i] = n[i] / 4; b->S[i] = S[i] < 0 ? -S[i] : S[i];
+    b->order[i] = S[i] < 0 ? 1 : 0;
     blocks += (int)ceil_div64(n[i] / 4, 64);
-    b.blk_end[i] = blocks;
-    bytes += 4.0 * n[i] * (S[i] + 1);
+    b->blk_end[i] = blocks;
+    bytes += 4.0 * n[i] * (b->S[i] + 1);
   }
-  b.n = count;
+  b->n = count;
+  *blocks_out = blocks;
+  *bytes_out = bytes;
+  return KWS_OK;
+}
+
+int kws_reduce_slabs_batch(const float* const* ws, float* const* out, const int64_t* n, const int* S, int count, hipStream_t stream) {
+  SlabBatch b;
+  int blocks = 0;
+  double bytes = 0;
+  KWS_TRY(kws_slab_batch_fill(&b, ws, out, n, S, count, &blocks, &bytes));
   KwsProfScope prof("slab_sum", 0.0, bytes, stream);
   hipLaunchKernelGGL(reduce_slabs_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, b);
   KWS_LAUNCH_CHECK("reduce_slabs_batch_kernel");

@@ -13,6 +13,19 @@ constexpr int KWS_SMALL_WGRAD_SLICES = 32;  // scratch: KWS_SMALL_WGRAD_SLICES *
 int kws_small_wgrad_launch(const float* X, const float* D, float* out, float* out_bias, int B, int K, int N,
                            float* scratch, hipStream_t st);
 int kws_metrics_launch(const float* per_loss, const float* per_correct, int B, float* metrics, hipStream_t st);
+// tail.hip (round 4): what follows the tail kernel off the dependency chain - the SLICES of the two dense layers' weight
+// gradients (X2 [B, K2] x D2 [B, N2] and X1 x D1, KWS_SMALL_WGRAD_SLICES slices each into ws2 / ws1), the bias gradient of the
+// first (column sums of D1, may be NULL) and the batch metrics - as ONE launch instead of six.  The slices are NOT summed here:
+// the caller adds (ws, out, K N, -S) to a slab batch (negative S: kws_small_wgrad_launch's summation order, bit-identical).
+// Returns 1 (nothing launched) for shapes the fused kernel does not take.
+struct kws_tail_post_args {
+  const float* X2; const float* D2; float* ws2; int K2, N2;
+  const float* X1; const float* D1; float* ws1; int K1, N1;
+  float* bias1;
+  const float* per_loss; const float* per_correct; float* metrics;
+  int B;
+};
+int kws_tail_post_launch(const kws_tail_post_args* a, int* S_out, hipStream_t st);
 // conv1.hip: the raw-waveform net's folded first convolution as a Toeplitz GEMM (forward with BN statistics rows, weight
 // gradient with its own slab workspace); kws_conv1_supported() says whether a (folded, unfolded) descriptor pair / width qualifies
 bool kws_conv1_supported(const kws_gather_t* g, const kws_gather_t* unfolded, int N);
@@ -25,6 +38,9 @@ int kws_conv1_fwd(const float* x, const kws_gather_t* g, const kws_gather_t* unf
 int64_t kws_conv1_wgrad_workspace_floats(int64_t M);
 int kws_conv1_wgrad(const float* x, const kws_gather_t* g, const kws_gather_t* unfolded, const float* G, float* dW, int B,
                     int N, float* workspace, hipStream_t st);
+int kws_conv1_wgrad_slabs(const float* x, const kws_gather_t* g, const kws_gather_t* unfolded, const float* G, float* dW, int B,
+                          int N, float* workspace, const float* const* sl_ws, float* const* sl_out, const int64_t* sl_n,
+                          const int* sl_S, int n_sl, hipStream_t st);
 // gemm.hip: first stage of a two-stage slab sum: every group of `per_group` slabs is summed over the group's first slab
 extern "C" int kws_reduce_slab_groups_f32(float* ws, int64_t n, int S, int per_group, hipStream_t st);
 // gemm.hip: out[i] = sum over S slabs of ws[s][i], fixed order (n % 4 == 0)
@@ -42,6 +58,60 @@ extern "C" int kws_gemm_dgrad_wgrad_f32(const float* dY, const float* WT, float*
 extern "C" int kws_reduce_slabs_batch(const float* const* ws, float* const* out, const int64_t* n, const int* S, int count,
                                       hipStream_t stream);
 extern "C" int64_t kws_gemm_tn_workspace_floats(int64_t M, int K, int N);
+// (kws_slab_batch_fill: an entry with S[i] < 0 holds |S[i]| slabs and is summed in the order of reduce_slabs_kernel: `order` below.)
+// The slab sums of several weight-gradient GEMMs as one grid (gemm.hip reduce_slabs_batch_kernel; since round 4 also the tail blocks
+// of conv1.hip's conv1_wgrad_slabsum_kernel): one workgroup of 256 threads = 64 float4 columns of one GEMM; 4 slab groups
+// (k = grp, grp + 4, ...) with four loads in flight each, combined in a fixed order: bit-reproducible.
+struct SlabBatch {
+  const float* ws[KWS_SLAB_BATCH];
+  float* out[KWS_SLAB_BATCH];
+  int64_t n4[KWS_SLAB_BATCH];
+  int S[KWS_SLAB_BATCH], blk_end[KWS_SLAB_BATCH];
+  int order[KWS_SLAB_BATCH];   // 0: four accumulators per slab group (k, k+4, k+8, k+12); 1: the two of reduce_slabs_kernel (k, k+4) -
+  int n;                       // what kws_small_wgrad_launch's own slab sum uses, so that its slices can join a batch bit for bit
+};
+extern "C" int kws_slab_batch_fill(SlabBatch* b, const float* const* ws, float* const* out, const int64_t* n, const int* S, int count,
+                                   int* blocks_out, double* bytes_out);
+#ifdef __HIPCC__
+__device__ __forceinline__ void kws_add4(float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+__device__ __forceinline__ void kws_reduce_slabs_batch_body(const SlabBatch& b, int bid, float4 (*red)[64]) {
+  int m = 0;
+  while (m + 1 < b.n && bid >= b.blk_end[m]) ++m;
+  const int t = bid - (m ? b.blk_end[m - 1] : 0);
+  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int64_t n4 = b.n4[m];
+  const int S = b.S[m];
+  const int64_t i = (int64_t)t * 64 + col;
+  const float4* w = reinterpret_cast<const float4*>(b.ws[m]);
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+  if (i < n4 && b.order[m]) {
+    float4 t2 = s0;
+    int k = grp;
+    for (; k + 4 < S; k += 8) {
+      const float4 v = w[(int64_t)k * n4 + i], u = w[(int64_t)(k + 4) * n4 + i];
+      kws_add4(s0, v); kws_add4(t2, u);
+    }
+    if (k < S) kws_add4(s0, w[(int64_t)k * n4 + i]);
+    kws_add4(s0, t2);
+  } else if (i < n4) {
+    int k = grp;
+    for (; k + 12 < S; k += 16) {
+      const float4 v0 = w[(int64_t)k * n4 + i], v1 = w[(int64_t)(k + 4) * n4 + i];
+      const float4 v2 = w[(int64_t)(k + 8) * n4 + i], v3 = w[(int64_t)(k + 12) * n4 + i];
+      kws_add4(s0, v0); kws_add4(s1, v1); kws_add4(s2, v2); kws_add4(s3, v3);
+    }
+    for (; k < S; k += 4) kws_add4(s0, w[(int64_t)k * n4 + i]);
+    kws_add4(s0, s1); kws_add4(s2, s3); kws_add4(s0, s2);
+  }
+  red[grp][col] = s0;
+  __syncthreads();
+  if (grp == 0 && i < n4) {
+    float4 r = red[0][col];
+    kws_add4(r, red[1][col]); kws_add4(r, red[2][col]); kws_add4(r, red[3][col]);
+    reinterpret_cast<float4*>(b.out[m])[i] = r;
+  }
+}
+#endif
 // The weight-gradient GEMMs of one backward pass, their slab sums deferred: gemm() launches the GEMM into the next piece of
 // `base` (cap floats: the sum of the calls' kws_gemm_tn_workspace_floats, each rounded up to 64) and flush() sums the slabs
 // of up to KWS_SLAB_BATCH of them in one launch.  A gradient is final only after the flush that follows its gemm().

@@ -173,7 +173,7 @@ struct Layout {
   int64_t total = 0;  // bytes
   std::vector<int64_t> y;   // y[l], l = 0..11 (float offsets)
   std::vector<int64_t> z;   // z[i], i = 0..10
-  int64_t G = 0, G2 = 0, DZ = 0, bn = 0, part = 0, coef = 0, tn = 0, red = 0, swg = 0;
+  int64_t G = 0, G2 = 0, DZ = 0, bn = 0, part = 0, coef = 0, tn = 0, red = 0, swg = 0, swg1 = 0;
   std::vector<int64_t> WT;  // transposed pointwise kernel of block i (dgrad GEMM operand)
   std::vector<int64_t> tns; // weight-gradient slabs of block i: a region of its own, summed for all blocks in ONE launch
   std::vector<int64_t> WPf, WPd;  // fp16 x 2 arm: fp16 planes [2][cout][cin] (forward) / [2][cin][cout] (input gradient)
@@ -224,6 +224,8 @@ void make_layout(const kws_net* n, int B, bool training, Layout* lo) {
     lo->red = bp.take((int64_t)KWS_REDUCE_SLICES * 5 * maxC);
     lo->swg = bp.take((int64_t)KWS_SMALL_WGRAD_SLICES *
                       std::max((int64_t)n->T * n->C * n->T, (int64_t)2 * n->C * n->NC));
+    // round 4: the attention dense layer's slices keep a region of their own (both dense layers' slices wait for the call's slab sum)
+    lo->swg1 = bp.take((int64_t)KWS_SMALL_WGRAD_SLICES * n->T * n->C * n->T);
     lo->WT.assign(nb, 0);
     for (int i = 0; i < nb; ++i) lo->WT[i] = bp.take((int64_t)n->blocks[i].cin * n->blocks[i].cout);
     lo->WPf.assign(nb, 0);
@@ -482,6 +484,7 @@ static int ts_train(const kws_net_t* net, const float* params, float* state, con
   };
   kws_ts_tail_args t;
   memset(&t, 0, sizeof(t));
+  int tail_S = 0;                                     // > 0: the tail's dense weight gradients wait as slices for this call's slab sum
   if (run_head) {
   KWS_HIP(hipMemsetAsync(grads, 0, (size_t)net->n_params * 4, st));
   if (h2) {                                         // maxima of the pointwise kernels (this also zeroes their groups), then
@@ -544,10 +547,30 @@ static int ts_train(const kws_net_t* net, const float* params, float* state, con
   t.step = step; t.keep_prob = DROP_KEEP; t.label_smoothing = LABEL_SMOOTH; t.loss_batch = loss_batch;
   t.row_offset = row_offset; t.train = 1;
   KWS_TRY(kws_ts_tail_launch(&t, st));
+  // off the dependency chain: metrics, the two dense layers' weight gradients, the attention bias gradient.  Gemm mode 0: ONE
+  // launch writes the metrics, the bias gradient and the weight gradients' SLICES (tail.hip tail_post_kernel); the slices are
+  // summed with the pointwise layers' slabs at the end of this call (in kws_small_wgrad_launch's own order: bit-identical).
+  // Mode 1 / shapes the fused kernel does not take: the six launches of rounds 1 - 3.
+  bool tail_fused = false;
+  if (pair_bwd) {
+    kws_tail_post_args tp;
+    tp.X2 = t.fd; tp.D2 = t.dl2; tp.ws2 = ws + lo.swg; tp.K2 = 2 * net->C; tp.N2 = net->NC;
+    tp.X1 = t.xd; tp.D1 = t.dl1; tp.ws1 = ws + lo.swg1; tp.K1 = net->T * net->C; tp.N1 = net->T;
+    tp.bias1 = grads + net->d1b; tp.per_loss = t.per_loss; tp.per_correct = t.per_correct; tp.metrics = metrics; tp.B = B;
+    int S_tail = 0;
+    const int rc = kws_tail_post_launch(&tp, &S_tail, st);
+    if (rc < 0) return rc;
+    if (rc == 0) {
+      tail_fused = true;
+      tail_S = S_tail;
+    }
+  }
+  if (!tail_fused) {
   KWS_TRY(kws_metrics_launch(t.per_loss, t.per_correct, B, metrics, st));
   KWS_TRY(kws_small_wgrad_launch(t.fd, t.dl2, grads + net->d2k, nullptr, B, 2 * net->C, net->NC, ws + lo.swg, st));
   KWS_TRY(kws_small_wgrad_launch(t.xd, t.dl1, grads + net->d1k, grads + net->d1b, B, net->T * net->C, net->T,
                                  ws + lo.swg, st));
+  }
   {
     const BnRef& r = net->blocks[nb - 1].bn;
     KWS_TRY(kws_dw_bwd_finalize(part, B, (int64_t)B * net->T, r.C, nullptr, grads + r.gamma,
@@ -566,7 +589,11 @@ static int ts_train(const kws_net_t* net, const float* params, float* state, con
   float* sl_out[KWS_SLAB_BATCH];
   int64_t sl_n[KWS_SLAB_BATCH];
   int sl_S[KWS_SLAB_BATCH], n_sl = 0;
-  KWS_REQUIRE(nb <= KWS_SLAB_BATCH, "net: %d blocks exceed the slab batch", nb);
+  KWS_REQUIRE(nb + 2 <= KWS_SLAB_BATCH, "net: %d blocks exceed the slab batch", nb);
+  if (tail_S > 0) {   // (negative S: kws_small_wgrad_launch's summation order)
+    sl_ws[n_sl] = ws + lo.swg; sl_out[n_sl] = grads + net->d2k; sl_n[n_sl] = (int64_t)2 * net->C * net->NC; sl_S[n_sl] = -tail_S; ++n_sl;
+    sl_ws[n_sl] = ws + lo.swg1; sl_out[n_sl] = grads + net->d1k; sl_n[n_sl] = (int64_t)net->T * net->C * net->T; sl_S[n_sl] = -tail_S; ++n_sl;
+  }
   const int i_hi = phase == 2 ? split - 1 : nb - 1, i_lo = phase == 1 ? split : 0;
   for (int i = i_hi; i >= i_lo; --i) {
     const Block& b = net->blocks[i];
@@ -616,12 +643,18 @@ static int ts_train(const kws_net_t* net, const float* params, float* state, con
     KWS_TRY(kws_dwconv_bwd_bn_amax_f32(DZ, ws + lo.y[i], bn_at(i), params + b.dw, coef, Gnext, nullptr, 2, B, b.Lin, b.Lout,
                                        b.cin, b.stride, b.pad_l, (h2 && i > 0) ? g_slots(i - 1) : nullptr, st));
   }
-  if (n_sl > 0) KWS_TRY(kws_reduce_slabs_batch(sl_ws, sl_out, sl_n, sl_S, n_sl, st));   // (a part's gradients are final when it returns)
+  // the slab sums of this call's pointwise weight gradients: beside the first convolution's weight gradient in ONE launch when
+  // that kernel runs in this call (round 4: conv1_wgrad_slabsum_kernel - the two are independent, one is MFMA / memory bound, the
+  // other HBM bound), their own launch otherwise (a part's gradients are final when it returns)
+  const bool sum_with_conv1 = n_sl > 0 && phase != 1 && kws_conv1_supported(&net->gather1f, &net->gather1, net->C1) &&
+                              kws_net_get_gemm_mode(net) != 1;
+  if (n_sl > 0 && !sum_with_conv1) KWS_TRY(kws_reduce_slabs_batch(sl_ws, sl_out, sl_n, sl_S, n_sl, st));
   if (phase != 1) {
     const int64_t M = (int64_t)B * net->L1;
     (void)M;                                        // Gb[0] already holds dy of the first convolution
     if (kws_conv1_supported(&net->gather1f, &net->gather1, net->C1)) {
-      KWS_TRY(kws_conv1_wgrad(x, &net->gather1f, &net->gather1, Gb[0], grads + net->conv1, B, net->C1, ws + lo.tn, st));
+      KWS_TRY(kws_conv1_wgrad_slabs(x, &net->gather1f, &net->gather1, Gb[0], grads + net->conv1, B, net->C1, ws + lo.tn,
+                                    sl_ws, sl_out, sl_n, sl_S, sum_with_conv1 ? n_sl : 0, st));
     } else {
       KWS_TRY(kws_gemm_tn_gather_f32(x, &net->gather1f, Gb[0], ws + lo.g1f, B, net->C1, ws + lo.tn, st));
       KWS_TRY(unfold_conv1(net, ws + lo.g1f, grads, st));

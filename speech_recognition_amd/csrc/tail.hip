@@ -494,11 +494,11 @@ __global__ __launch_bounds__(256) void small_wgrad_kernel(const float* __restric
 // across the workgroup.  Same summation order per output as the generic kernel (ascending b inside a slice).
 constexpr int KWS_SMALL_WGRAD_ROWS = 64;   // most rows a slice may hold (B / KWS_SMALL_WGRAD_SLICES, checked by the launcher)
 template <int NMAX>
-__global__ __launch_bounds__(256) void small_wgrad_rows_kernel(const float* __restrict__ X, const float* __restrict__ D,
-                                                               float* __restrict__ out, int B, int K, int N,
-                                                               int rows_per) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  const int b0 = blockIdx.y * rows_per;
+__device__ __forceinline__ void small_wgrad_rows_body(const float* __restrict__ X, const float* __restrict__ D,
+                                                      float* __restrict__ out, int B, int K, int N, int rows_per, const int bx,
+                                                      const int by) {
+  const int i = bx * 256 + threadIdx.x;
+  const int b0 = by * rows_per;
   int b1 = b0 + rows_per;
   if (b1 > B) b1 = B;
   __shared__ float sD[KWS_SMALL_WGRAD_ROWS * NMAX];   // this slice's D rows, zero padded to NMAX columns
@@ -522,11 +522,17 @@ __global__ __launch_bounds__(256) void small_wgrad_rows_kernel(const float* __re
 #pragma unroll
         for (int k = 0; k < NMAX; ++k) acc[k] = fmaf(x[u], sD[(r0 + u) * NMAX + k], acc[k]);
     }
-    float* o = out + (int64_t)blockIdx.y * K * N + (int64_t)i * N;
+    float* o = out + (int64_t)by * K * N + (int64_t)i * N;
 #pragma unroll
     for (int k = 0; k < NMAX; ++k)
       if (k < N) o[k] = acc[k];
   }
+}
+template <int NMAX>
+__global__ __launch_bounds__(256) void small_wgrad_rows_kernel(const float* __restrict__ X, const float* __restrict__ D,
+                                                               float* __restrict__ out, int B, int K, int N,
+                                                               int rows_per) {
+  small_wgrad_rows_body<NMAX>(X, D, out, B, K, N, rows_per, blockIdx.x, blockIdx.y);
 }
 __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t n,
                                                        int S) {
@@ -539,7 +545,7 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__
 // out[k] = sum_b D[b, k]: KP columns x 256/KP row groups, each group sums its rows b = g, g+G, ... in
 // ascending order, the groups are combined in ascending order (fixed order, one workgroup).
 template <int KP>
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ D, float* __restrict__ out, int B, int N) {
+__device__ __forceinline__ void colsum_body(const float* __restrict__ D, float* __restrict__ out, int B, int N) {
   constexpr int G = 256 / KP;
   __shared__ float red[G][KP];
   const int k = threadIdx.x % KP, g = threadIdx.x / KP;
@@ -560,10 +566,13 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ D
     out[k] = s;
   }
 }
+template <int KP>
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ D, float* __restrict__ out, int B, int N) {
+  colsum_body<KP>(D, out, B, N);
+}
 // metrics[0] = sum per_loss (double accumulation), metrics[1] = sum per_correct: thread t sums elements
 // t, t+256, ... and the 256 partials are combined in ascending order (fixed order, one workgroup).
-__global__ __launch_bounds__(256) void metrics_kernel(const float* per_loss, const float* per_correct, int B,
-                                                      float* metrics) {
+__device__ __forceinline__ void metrics_body(const float* per_loss, const float* per_correct, int B, float* metrics) {
   __shared__ double rl[256];
   __shared__ float rc[256];
   double sl = 0.0;
@@ -588,6 +597,33 @@ __global__ __launch_bounds__(256) void metrics_kernel(const float* per_loss, con
     metrics[2] = 0.f;
     metrics[3] = 0.f;
   }
+}
+__global__ __launch_bounds__(256) void metrics_kernel(const float* per_loss, const float* per_correct, int B,
+                                                      float* metrics) {
+  metrics_body(per_loss, per_correct, B, metrics);
+}
+
+// Round 4: the six small launches that follow the tail kernel off the dependency chain as ONE grid - slices of the classifier's
+// weight gradient (blocks [0, gx2 S)), slices of the attention dense layer's (the next gx1 S), its bias gradient (one block),
+// the batch metrics (one block).  Each part is the body of the kernel that did it alone: same arithmetic, same order.
+struct TailPost {
+  kws_tail_post_args a;
+  int rows_per, S, gx2, gx1;
+};
+__global__ __launch_bounds__(256) void tail_post_kernel(TailPost p) {
+  int b = blockIdx.x;
+  if (b < p.gx2 * p.S) {
+    small_wgrad_rows_body<16>(p.a.X2, p.a.D2, p.a.ws2, p.a.B, p.a.K2, p.a.N2, p.rows_per, b % p.gx2, b / p.gx2);
+    return;
+  }
+  b -= p.gx2 * p.S;
+  if (b < p.gx1 * p.S) {
+    small_wgrad_rows_body<16>(p.a.X1, p.a.D1, p.a.ws1, p.a.B, p.a.K1, p.a.N1, p.rows_per, b % p.gx1, b / p.gx1);
+    return;
+  }
+  b -= p.gx1 * p.S;
+  if (b == 0) metrics_body(p.a.per_loss, p.a.per_correct, p.a.B, p.a.metrics);
+  else colsum_body<16>(p.a.D1, p.a.bias1, p.a.B, p.a.N1);
 }
 
 }  // namespace
@@ -662,6 +698,28 @@ int kws_small_wgrad_launch(const float* X, const float* D, float* out, float* ou
     else hipLaunchKernelGGL(colsum_kernel<64>, dim3(1), dim3(256), 0, st, D, out_bias, B, N);
     KWS_LAUNCH_CHECK("colsum_kernel");
   }
+  return KWS_OK;
+}
+
+int kws_tail_post_launch(const kws_tail_post_args* a, int* S_out, hipStream_t st) {
+  KWS_REQUIRE(a && S_out && a->X2 && a->D2 && a->ws2 && a->X1 && a->D1 && a->ws1 && a->per_loss && a->per_correct && a->metrics && a->B > 0,
+              "tail_post: bad arguments");
+  int S = KWS_SMALL_WGRAD_SLICES;
+  if (S > a->B) S = a->B;
+  const int rows_per = ceil_div(a->B, S);
+  S = ceil_div(a->B, rows_per);
+  // the slices of kws_small_wgrad_launch's fast kernel, summed later by a slab batch (16-byte columns): anything else takes the six launches
+  if (S <= 1 || a->N1 > 16 || a->N2 > 16 || rows_per > KWS_SMALL_WGRAD_ROWS || ((int64_t)a->K1 * a->N1) % 4 != 0 ||
+      ((int64_t)a->K2 * a->N2) % 4 != 0)
+    return 1;
+  TailPost p;
+  p.a = *a; p.rows_per = rows_per; p.S = S; p.gx2 = ceil_div(a->K2, 256); p.gx1 = ceil_div(a->K1, 256);
+  const int blocks = (p.gx2 + p.gx1) * S + 1 + (a->bias1 ? 1 : 0);
+  KwsProfScope prof("small_wgrad", 2.0 * a->B * ((double)a->K1 * a->N1 + (double)a->K2 * a->N2),
+                    4.0 * ((double)a->B * (a->K1 + a->K2 + a->N1 + a->N2) + (double)S * ((double)a->K1 * a->N1 + (double)a->K2 * a->N2)), st);
+  hipLaunchKernelGGL(tail_post_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
+  KWS_LAUNCH_CHECK("tail_post_kernel");
+  *S_out = S;
   return KWS_OK;
 }
 
