@@ -273,7 +273,8 @@ ROOFLINE_KERNELS = [
     ("gemm_nn", "gemm_nn_ws_kernel", "mfma", "pointwise 1x1 convolutions: forward (+ input gradient where not paired)"),
     ("gemm_tn", "gemm_tn_ws_kernel", "mfma", "pointwise 1x1 convolutions: weight gradient (where not paired)"),
     ("conv1_fwd", "conv1_fwd_kernel", "mfma", "first convolution (frames of 40 hop 20, k3 s2) as a Toeplitz GEMM"),
-    ("conv1_wgrad", "conv1_wgrad_kernel", "mfma", "first convolution, weight gradient"),
+    ("conv1_wgrad", "conv1_wgrad_slabsum_kernel", "mfma", "first convolution, weight gradient; since round 4 the same launch also sums the "
+                                                          "slabs of the eleven pointwise weight gradients (137 MB, HBM bound) beside it"),
     ("stft_mel", "stft4_kernel", "hbm", "STFT 480/160/512 -> |X| -> mel 80 -> log -> DCT 60 (generator stream, low priority)"),
     ("augment", "augment_kernel", "hbm", "gather x foreground volume, circular roll, + noise x volume (generator stream)"),
     ("dwconv_fwd", "dwconv_fwd_kernel", "hbm", "depthwise k3 forward with BN+ReLU6 applied on load"),

@@ -8,7 +8,7 @@ CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
 # kernel -> the source file that defines it: bench.py drops a traffic figure once that file has changed
 SOURCE_OF = {"gemm_nn_ws_kernel": "gemm.hip", "gemm_dgrad_wgrad_kernel": "gemm.hip", "gemm_tn_ws_kernel": "gemm.hip", "gemm_nn_persist_kernel": "gemm.hip",
              "gemm_tn_kernel": "gemm.hip", "reduce_slabs_kernel": "gemm.hip", "conv1_fwd_kernel": "conv1.hip",
-             "conv1_wgrad_kernel": "conv1.hip", "reduce_slabs_batch_kernel": "gemm.hip",
+             "conv1_wgrad_kernel": "conv1.hip", "conv1_wgrad_slabsum_kernel": "conv1.hip", "tail_post_kernel": "tail.hip", "reduce_slabs_batch_kernel": "gemm.hip",
              "stft4_kernel": "stft4.hip", "augment_kernel": "augment.hip", "dwconv_fwd_kernel": "dwconv.hip",
              "dwconv_bwd_kernel": "dwconv.hip", "dwconv_bwd_bn_kernel": "dwconv.hip", "ts_tail_kernel": "tail.hip",
              "gemm_nn_f16x2_kernel": "gemm_f16x2.hip", "gemm_tn_f16x2_kernel": "gemm_f16x2.hip"}
