@@ -284,16 +284,17 @@ def test_paired_backward_launch_is_bit_identical_to_separate_launches(B):
     ora, net = _pair()
     x, y = _batch(B, 12, 43)
     dx, dy = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
-    assert net.gemm_mode == 0
-    p0 = net.train_fwd_bwd(dx, dy, seed=5, step=1).clone()
-    g0, m0, st0 = net.grads.clone(), net.metrics.clone(), net.state.clone()
-    net.set_weights(dict(ora.params, **ora.state))
-    net.set_gemm_mode(1)
+    mode0 = net.gemm_mode                      # (the fp16 x 2 re-run of this file starts every net in mode 2)
+    net.set_gemm_mode(0)
     try:
+        p0 = net.train_fwd_bwd(dx, dy, seed=5, step=1).clone()
+        g0, m0, st0 = net.grads.clone(), net.metrics.clone(), net.state.clone()
+        net.set_weights(dict(ora.params, **ora.state))
+        net.set_gemm_mode(1)
         p1 = net.train_fwd_bwd(dx, dy, seed=5, step=1)
         torch.cuda.synchronize()
         assert torch.equal(p1, p0) and torch.equal(net.metrics, m0) and torch.equal(net.state, st0)
         assert torch.equal(net.grads, g0)
     finally:
-        net.set_gemm_mode(0)
+        net.set_gemm_mode(mode0)
     assert float(g0.abs().max()) > 0
