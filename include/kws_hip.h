@@ -380,7 +380,7 @@ int kws_net_create(const kws_net_config_t* cfg, kws_net_t** net);
 int kws_net_destroy(kws_net_t* net);
 /* arithmetic / launch schedule of this handle's pointwise GEMMs: 0 = f32 MFMA (default, the product path; since round 4 a
  * layer's input-gradient and weight-gradient GEMMs go out as ONE launch), 1 = f32 MFMA with the two as separate launches (the
- * schedule of rounds 1 - 3, kept as the A/B reference: bit-identical results), 2 = the fp16 x 2 A/B arm (raw-waveform
+ * schedule of rounds 1 - 3, kept as the A/B reference: bit-identical results; every net kind), 2 = the fp16 x 2 A/B arm (raw-waveform
  * attention net; other kinds ignore it).  State of the handle, not of the process. */
 int kws_net_get_gemm_mode(const kws_net_t* net);
 int kws_net_set_gemm_mode(kws_net_t* net, int mode);

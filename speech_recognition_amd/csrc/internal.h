@@ -123,6 +123,7 @@ struct KwsSlabQueue {
   int count = 0;
   float* base = nullptr;
   int64_t used = 0, cap = 0;
+  bool allow_pair = true;      // false (gemm mode 1): pair() makes the two launches of rounds 1 - 3
   int flush(hipStream_t st) {
     if (count == 0) return 0;
     const int rc = kws_reduce_slabs_batch(ws, out, n, S, count, st);
@@ -153,7 +154,7 @@ struct KwsSlabQueue {
       if (rc) return rc;
     }
     if (need > cap) return KWS_E_WORKSPACE;
-    const int rc = kws_gemm_dgrad_wgrad_f32(dY, WT, dZ, Z, M, cin, cout, base + used, &S[count], st);
+    const int rc = allow_pair ? kws_gemm_dgrad_wgrad_f32(dY, WT, dZ, Z, M, cin, cout, base + used, &S[count], st) : 1;
     if (rc < 0) return rc;
     if (rc == 0) {
       ws[count] = base + used; out[count] = dW; n[count] = (int64_t)cin * cout;

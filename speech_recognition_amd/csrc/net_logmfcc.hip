@@ -859,6 +859,7 @@ int lm_train(const kws_net* n, const float* params, float* state, const float* x
   float* dX = ws + lo.dOb;
   KwsSlabQueue sq;
   sq.base = ws + lo.tnq; sq.cap = lo.tnq_floats;
+  sq.allow_pair = kws_net_get_gemm_mode(n) != 1;    // mode 1: the A/B reference schedule (separate input- / weight-gradient launches)
   // Depthwise backward kernels that leave ONLY a weight gradient behind (a block's first depthwise convolution, the context
   // block's, the first plain block's: their input is a materialised activation, no BatchNorm in front): nothing on the
   // dependency chain needs the fold of their partial rows, so the rows stay in regions of their own and one launch folds up to

@@ -342,3 +342,32 @@ def test_config_c3_train_step_full_batch_matches_oracle():
     probs2 = net.train_fwd_bwd(dx, dy, seed=31337, step=4)
     torch.cuda.synchronize()
     assert torch.equal(probs2, probs) and torch.equal(net.grads, g_first)
+
+
+def test_one_grid_launches_are_bit_identical_at_the_benchmark_batch():
+    """Round 4, at configs[1]'s full size (batch 1024: the split counts, half tiles and slab numbers of the benchmark):
+    gemm mode 0 (a layer's input-gradient + weight-gradient GEMM as one launch, the slab sum beside the first convolution's
+    weight gradient, the tail's post-kernels as one launch) against mode 1 (the launches of rounds 1 - 3).  Same code paths and
+    summation orders: probabilities, metrics, every gradient and the BatchNorm state agree bit for bit."""
+    B = B_FULL
+    net = DeviceNet(_lib.KWS_NET_TS_ATTENTION, 12)
+    net.initialize(seed=11)
+    w0 = net.params.clone()
+    s0 = net.state.clone()
+    x, lab = _clips(B, 78)
+    y = torch.eye(12, device="cuda")[lab.long()].contiguous()
+    mode0 = net.gemm_mode
+    out = {}
+    try:
+        for mode in (0, 1):
+            net.set_gemm_mode(mode)
+            net.params.copy_(w0)
+            net.state.copy_(s0)
+            p = net.train_fwd_bwd(x, y, seed=31, step=3).clone()
+            torch.cuda.synchronize()
+            out[mode] = (p, net.grads.clone(), net.metrics.clone(), net.state.clone())
+    finally:
+        net.set_gemm_mode(mode0)
+    for a, b in zip(out[0], out[1]):
+        assert torch.equal(a, b)
+    assert float(out[0][1].abs().max()) > 0 and bool(torch.isfinite(out[0][1]).all())

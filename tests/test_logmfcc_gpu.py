@@ -219,3 +219,31 @@ def test_odd_lengths_pool_in_ceil_mode(T):
             ref = ref - 2e-5 * ora.params[k].astype(np.float64)
         ref = ref.reshape(g[k].shape)
         assert np.abs(g[k] - ref).max() / max(np.abs(ref).max(), 1e-7) < 1e-4, k
+
+
+def test_paired_backward_launches_are_bit_identical_for_the_residual_program():
+    """Round 4: conv_1d_log_mfcc's 21 input-gradient / weight-gradient pairs go out as single launches (gemm mode 0); mode 1
+    makes the two launches of rounds 1 - 3.  Same kernels' code paths: every gradient agrees bit for bit."""
+    net = DeviceNet(_lib.KWS_NET_LOG_MFCC, 32, input_size=98 * 40, spectrogram_length=98, num_features=40)
+    net.initialize(seed=5)
+    w0, s0 = net.params.clone(), net.state.clone()
+    g = torch.Generator(device="cuda")
+    g.manual_seed(8)
+    B = 96
+    x = (torch.randn((B, 98 * 40), generator=g, device="cuda") * 3.0).contiguous()
+    y = torch.eye(32, device="cuda")[torch.randint(0, 32, (B,), generator=g, device="cuda")].contiguous()
+    mode0 = net.gemm_mode
+    out = {}
+    try:
+        for mode in (0, 1):
+            net.set_gemm_mode(mode)
+            net.params.copy_(w0)
+            net.state.copy_(s0)
+            p = net.train_fwd_bwd(x, y, seed=3, step=1).clone()
+            torch.cuda.synchronize()
+            out[mode] = (p, net.grads.clone(), net.metrics.clone(), net.state.clone())
+    finally:
+        net.set_gemm_mode(mode0)
+    for a, b in zip(out[0], out[1]):
+        assert torch.equal(a, b)
+    assert float(out[0][1].abs().max()) > 0
