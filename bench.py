@@ -538,10 +538,21 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if os.environ.get("KWS_BENCH_ONE_DEVICE"):
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        try:
+            if os.environ.get("KWS_BENCH_PREFLIGHT_FAIL") == "init":          # test hook: a rendezvous / communicator that raises
+                raise RuntimeError("KWS_BENCH_PREFLIGHT_FAIL=init (test hook)")
+            if os.environ.get("KWS_BENCH_ONE_DEVICE"):
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        except Exception as ex:          # first contact can fail right here (no xGMI, IPC mode, ports): one JSON line, non-zero exit
+            if rank == 0:
+                print(json.dumps({"metric": "1s 16kHz clips/sec training throughput", "value": None, "unit": "clips/s", "n_gpus": world,
+                                  "error": repr(ex), "stage": "init_process_group", "rccl_ranks": None}), file=json_out, flush=True)
+            sys.stderr.write("init_process_group failed on rank %d: %r\n" % (rank, ex))
+            if dog:
+                dog.done()
+            raise SystemExit(3)
     if world != args.gpus:
         raise SystemExit("bench.py --gpus %d started with WORLD_SIZE=%d" % (args.gpus, world))
     rccl_ranks = 1

@@ -122,7 +122,7 @@ def test_tta_inference_sharded_over_two_ranks_matches_one_rank(tmp_path):
     assert np.array_equal(outs[1], outs[2])                 # inference is per clip: the split cannot change a bit
 
 
-@pytest.mark.parametrize("mode", ["hang", "raise"])
+@pytest.mark.parametrize("mode", ["hang", "raise", "init"])
 def test_bench_preflight_failure_prints_one_error_line_and_fails(mode):
     """the first collectives of an N > 1 run go under a watchdog, before the clip bank is built.  A
     collective that never returns ('hang': the fresh watchdog child reports and kills rank 0) or that raises ('raise': rank 0
@@ -130,14 +130,15 @@ def test_bench_preflight_failure_prints_one_error_line_and_fails(mode):
     env = dict(os.environ, KWS_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", KWS_BENCH_PREFLIGHT_FAIL=mode,
                KWS_BENCH_PREFLIGHT_TIMEOUT="5")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29543" if mode == "hang" else "29545", os.path.join(ROOT, "bench.py"), "--gpus", "2",
+           "127.0.0.1", "--master-port", {"hang": "29543", "raise": "29545", "init": "29547"}[mode], os.path.join(ROOT, "bench.py"), "--gpus", "2",
            "--steps", "2", "--warmup", "1", "--bank", "8192", "--batch", "256", "--no-cpu-baseline"]
     res = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=400)
     assert res.returncode != 0
     json_lines = [l for l in res.stdout.decode().splitlines() if l.lstrip().startswith("{")]
     assert len(json_lines) == 1, res.stdout.decode()[-2000:] + res.stderr.decode()[-2000:]
     out = json.loads(json_lines[0])
-    assert out["value"] is None and out["n_gpus"] == 2 and out["stage"] == "preflight all-reduce"
+    assert out["value"] is None and out["n_gpus"] == 2
+    assert out["stage"] == ("init_process_group" if mode == "init" else "preflight all-reduce")
     assert ("watchdog" in out["error"]) == (mode == "hang")
 
 
