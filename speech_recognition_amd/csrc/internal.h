@@ -171,6 +171,10 @@ struct KwsSlabQueue {
 constexpr int KWS_DW_FIN_BATCH = 16;
 int kws_dw_grad_finalize_batch(const float* const* part, const int* n_parts, const int* C, float* const* dw, int count,
                                hipStream_t stream);
+// bn.hip: inference BatchNorm tables of up to KWS_BN_INFER_BATCH layers in one launch
+constexpr int KWS_BN_INFER_BATCH = 16;
+extern "C" int kws_bn_infer_prepare_batch(const float* const* gamma, const float* const* beta, const float* const* mm, const float* const* mv,
+                               float eps, const int* C, float* const* bn, int count, hipStream_t stream);
 constexpr int KWS_TRANSPOSE_BATCH = 16;
 extern "C" int kws_transpose_batch_f32(const float* const* in, float* const* out, const int* rows, const int* cols, int n,
                                        hipStream_t stream);

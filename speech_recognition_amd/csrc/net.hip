@@ -374,12 +374,18 @@ int kws_net_predict(const kws_net_t* net, const float* params, const float* stat
   hipStream_t st = (hipStream_t)stream;
   const int nb = (int)net->blocks.size();
   auto bn_at = [&](int l) { return ws + lo.bn + lo.bn_stride * l; };
-  auto prep = [&](const BnRef& r, int l) {
-    return kws_bn_infer_prepare(params + r.gamma, params + r.beta, state + r.mm, state + r.mv, BN_EPS, r.C, bn_at(l),
-                                st);
-  };
-  KWS_TRY(prep(net->bn1, 0));
-  for (int i = 0; i < nb; ++i) KWS_TRY(prep(net->blocks[i].bn, i + 1));
+  {  // the twelve inference tables in one launch (round 4: twelve 4.5 us launches per predict call before)
+    KWS_REQUIRE(nb + 1 <= KWS_BN_INFER_BATCH, "net: %d blocks exceed the BatchNorm table batch", nb);
+    const float *ga[KWS_BN_INFER_BATCH], *be[KWS_BN_INFER_BATCH], *mm[KWS_BN_INFER_BATCH], *mv[KWS_BN_INFER_BATCH];
+    float* tb[KWS_BN_INFER_BATCH];
+    int Cs[KWS_BN_INFER_BATCH];
+    auto put = [&](const BnRef& r, int l) {
+      ga[l] = params + r.gamma; be[l] = params + r.beta; mm[l] = state + r.mm; mv[l] = state + r.mv; tb[l] = bn_at(l); Cs[l] = r.C;
+    };
+    put(net->bn1, 0);
+    for (int i = 0; i < nb; ++i) put(net->blocks[i].bn, i + 1);
+    KWS_TRY(kws_bn_infer_prepare_batch(ga, be, mm, mv, BN_EPS, Cs, tb, nb + 1, st));
+  }
   if (kws_conv1_supported(&net->gather1f, &net->gather1, net->C1)) {
     KWS_TRY(kws_conv1_fwd(x, &net->gather1f, &net->gather1, params + net->conv1, ws + lo.y[0], B, net->C1, nullptr, st));
   } else {
