@@ -270,6 +270,8 @@ ROOFLINE_KERNELS = [
     # round 4: a layer's input-gradient and weight-gradient GEMMs are ONE launch (gemm_dgrad_wgrad_kernel); the forward GEMMs
     # (and whatever the fused kernel does not take) stay gemm_nn_ws_kernel / gemm_tn_ws_kernel launches
     ("gemm_bwd_pair", "gemm_dgrad_wgrad_kernel", "mfma", "pointwise 1x1 convolutions: input gradient + weight gradient of a layer in one launch"),
+    ("dwbwd_wgrad", "dwbwd_wgrad_kernel", "hbm", "gemm mode 3 only (round 5's experiment): a depthwise-backward pass and weight-gradient work items of the "
+                                                 "same layer in one CU-partitioned grid; both fractions are of the whole chip's roofs"),
     ("gemm_nn", "gemm_nn_ws_kernel", "mfma", "pointwise 1x1 convolutions: forward (+ input gradient where not paired)"),
     ("gemm_tn", "gemm_tn_ws_kernel", "mfma", "pointwise 1x1 convolutions: weight gradient (where not paired)"),
     ("conv1_fwd", "conv1_fwd_kernel", "mfma", "first convolution (frames of 40 hop 20, k3 s2) as a Toeplitz GEMM"),
@@ -596,7 +598,7 @@ def main():
     model.seed = 87654321            # one dropout stream for the global batch: rank r uses rows [r*B, (r+1)*B)
     model.allreduce_split = 0        # the headline step: ONE all-reduce of the flat gradient buffer after the backward pass
     ab_steps = min(args.steps, 50)
-    ring = torch.zeros((args.warmup + args.steps + 3 * args.profile_steps + 2 * (ab_steps + 8) + 4 * (ab_steps + 14) + 4 * (ab_steps + 4) + 8, 4), dtype=torch.float32, device=device)
+    ring = torch.zeros((args.warmup + args.steps + 3 * args.profile_steps + 2 * (ab_steps + 8) + 4 * (ab_steps + 14) + 6 * (ab_steps + 4) + 8, 4), dtype=torch.float32, device=device)
     enq = GeneratorEnqueuer(gen, max_queue_size=10, device=device)
     enq.start()
 
@@ -749,27 +751,40 @@ def main():
         finally:
             model.net.set_gemm_mode(0)
             _lib.Profiler.detach()   # a leg that raised between attach() and detach() must not leave this thread recording
-    # ---- round 4 A/B: the backward GEMMs of a layer as ONE launch (gemm mode 0, the default) vs the two launches of rounds
-    # 1 - 3 (mode 1); bit-identical results (tests/test_net_gpu.py), two alternating rounds each, same process
+    # ---- A/B of the backward schedules, same process, two alternating rounds each, all bit-identical (tests/test_net_gpu.py,
+    # tests/test_fullsize_gpu.py).  gemm mode 1: the launches of rounds 1 - 3; mode 0 (the default): round 4's one-grid launches (a
+    # layer's input-gradient + weight-gradient GEMM, slab sum beside the first convolution's weight gradient, the tail's post-kernels);
+    # mode 3: round 5's experiment - on top of mode 0, the weight-gradient GEMM of a layer cut into work items and stage windows that
+    # run BESIDE the layer's two depthwise-backward passes (CUs partitioned), the remainder in the next layer's input-gradient launch.
+    # Measured a LOSS (profiles/r05_wgrad_beside_dwbwd*.txt): the line carries the same-run number so nobody has to take that on trust
     if world == 1 and not args.no_ab and gemm_mode == 0:
         try:
-            arms = {0: [], 1: []}
+            arms = {0: [], 1: [], 3: []}
             for rnd in range(2):
-                for mode in (1, 0):
+                for mode in (1, 3, 0):
                     model.net.set_gemm_mode(mode)
                     for i in range(4):
                         step(used + i)
                     dt_m, _ = timed_steps(used + 4, ab_steps)
                     used += 4 + ab_steps
                     arms[mode].append(1e3 * dt_m / ab_steps)
-            ab["ab_bwd_pair"] = {"what": "input-gradient + weight-gradient GEMM of a layer as one launch (gemm_dgrad_wgrad_kernel, the default) "
-                                         "vs two launches (gemm mode 1, the schedule of rounds 1 - 3); best of two alternating rounds of %d steps" % ab_steps,
+            ab["ab_bwd_pair"] = {"what": "all one-grid launches of gemm mode 0 (the default since round 4: input-gradient + weight-gradient GEMM of a layer, slab sum "
+                                         "beside the first convolution's weight gradient, the tail's post-kernels) vs gemm mode 1 (the separate launches of "
+                                         "rounds 1 - 3); best of two alternating rounds of %d steps" % ab_steps,
                                  "steps": ab_steps, "paired": {"ms_per_step": min(arms[0]), "value": B / min(arms[0]) * 1e3, "rounds_ms": arms[0]},
                                  "separate": {"ms_per_step": min(arms[1]), "value": B / min(arms[1]) * 1e3, "rounds_ms": arms[1]},
                                  "gain_us_per_step": 1e3 * (min(arms[1]) - min(arms[0])), "unit": "clips/s"}
+            ab["ab_wgrad_beside_dwbwd"] = {
+                "what": "gemm mode 3 (round 5's experiment, NOT the default: a layer's weight-gradient work items beside its two depthwise-backward "
+                        "passes in one CU-partitioned grid, dwbwd_wgrad_kernel; the remainder in the next layer's input-gradient launch) vs gemm mode 0 "
+                        "(the default: the depthwise passes alone on the whole chip, the whole weight gradient in the layer's own input-gradient launch); "
+                        "best of two alternating rounds of %d steps; bit-identical results" % ab_steps,
+                "steps": ab_steps, "beside": {"ms_per_step": min(arms[3]), "value": B / min(arms[3]) * 1e3, "rounds_ms": arms[3]},
+                "in_series": {"ms_per_step": min(arms[0]), "value": B / min(arms[0]) * 1e3, "rounds_ms": arms[0]},
+                "gain_us_per_step": 1e3 * (min(arms[0]) - min(arms[3])), "unit": "clips/s"}
         except Exception as ex:
             ab["ab_bwd_pair_error"] = repr(ex)
-            sys.stderr.write("A/B backward-pair leg failed: %r\n" % (ex,))
+            sys.stderr.write("A/B backward-schedule leg failed: %r\n" % (ex,))
         finally:
             model.net.set_gemm_mode(0)
     # ---- configs[1]'s own A/B: "HIP STFT+mel vs raw-wave path".  The headline step produces BOTH arms of every batch (the
@@ -869,7 +884,7 @@ def main():
             if fams:
                 dom = fams[0]
                 bound = "mfma" if dom.startswith("gemm") or dom.startswith("conv1") else "hbm"
-                c3["roofline"] = roofline_entry(kern, dom, {"gemm_nn": "gemm_nn_ws_kernel", "gemm_tn": "gemm_tn_ws_kernel"}.get(dom, dom + "_kernel"),
+                c3["roofline"] = roofline_entry(kern, dom, {"gemm_nn": "gemm_nn_ws_kernel", "gemm_tn": "gemm_tn_ws_kernel", "gemm_bwd_pair": "gemm_dgrad_wgrad_kernel"}.get(dom, dom + "_kernel"),
                                                 bound, "dominant kernel family of the C3 step by summed HIP-event time", None)
             configs["C3"] = c3
             configs["C5"] = bench_configs.c5(speed_tta=True, n=10, warm=3)   # x3 AND the six-term speed TTA BASELINE configs[4] names
@@ -884,7 +899,7 @@ def main():
             "value": clips / dt, "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": {0: "f32", 1: "f32", 2: "f32 (pointwise GEMMs as scaled 2-way fp16 splits, f32 accumulate)"}[gemm_mode],
+            "dtype": {0: "f32", 1: "f32", 3: "f32", 2: "f32 (pointwise GEMMs as scaled 2-way fp16 splits, f32 accumulate)"}[gemm_mode],
             "data": "synthetic",
             "config": {"workload": "configs[1]: 12-class conv_1d_time_sliced_with_attention, batch %d/GPU synthetic "
                                    "16000-sample fp32 clips, sampler+augment+STFT/mel(80,60)+raw fwd/bwd+RMSprop" % B,

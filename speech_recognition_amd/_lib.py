@@ -45,6 +45,13 @@ class SamplerArgs(ctypes.Structure):
                 ("silence_volume_range", ctypes.c_double)]
 
 
+class WgradItems(ctypes.Structure):
+    _fields_ = [("Z", ctypes.c_void_p), ("dY", ctypes.c_void_p), ("M", ctypes.c_int64), ("K", ctypes.c_int), ("N", ctypes.c_int),
+                ("slabs", ctypes.c_void_p), ("ckpt", ctypes.c_void_p), ("item_lo", ctypes.c_int), ("item_hi", ctypes.c_int),
+                ("f0", ctypes.c_int), ("f1", ctypes.c_int), ("n_resume", ctypes.c_int), ("resume_lo", ctypes.c_int * 4),
+                ("resume_hi", ctypes.c_int * 4), ("resume_f", ctypes.c_int * 4)]
+
+
 class NetConfig(ctypes.Structure):
     _fields_ = [("kind", ctypes.c_int), ("num_classes", ctypes.c_int), ("filter_mult", ctypes.c_int),
                 ("input_size", ctypes.c_int), ("spectrogram_length", ctypes.c_int),
@@ -132,6 +139,10 @@ SIGNATURES = {
     "kws_dwconv_bwd_part_floats": (_I64, [_I, _I, _I]),
     "kws_dwconv_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "kws_dwconv_bwd_bn_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "kws_gemm_tn_items": (_I, [_I64, _I, _I, ctypes.POINTER(_I)]),
+    "kws_gemm_tn_ckpt_floats": (_I64, [_I64, _I, _I]),
+    "kws_dwconv_bwd_bn_wgrad_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, ctypes.POINTER(WgradItems), _I,
+                                        ctypes.POINTER(_I), _P]),
     "kws_dw_bwd_finalize": (_I, [_P, _I, _I64, _I, _P, _P, _P, _P, _P, _P]),
     "kws_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _I64, _I, _P]),
     "kws_rmsprop_step": (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _P]),

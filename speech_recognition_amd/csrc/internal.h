@@ -55,6 +55,9 @@ extern "C" int kws_gemm_tn_slabs_f32(const float* A, const float* G, int64_t M, 
 // gemm.hip: a layer's input-gradient GEMM and the slabs of its weight-gradient GEMM in one launch (returns 1 = not eligible, nothing launched)
 extern "C" int kws_gemm_dgrad_wgrad_f32(const float* dY, const float* WT, float* dZ, const float* Z, int64_t M, int cin, int cout,
                                         float* workspace, int* S, hipStream_t stream);
+// gemm.hip (round 5): an NN GEMM (no statistics) and weight-gradient work items of any layer in one launch (1 = not eligible)
+extern "C" int kws_gemm_nn_wgrad_items_f32(const float* A, const float* W, float* C, int64_t M, int K, int N, const kws_wgrad_items_t* wi,
+                                           int* S, hipStream_t stream);
 extern "C" int kws_reduce_slabs_batch(const float* const* ws, float* const* out, const int64_t* n, const int* S, int count,
                                       hipStream_t stream);
 extern "C" int64_t kws_gemm_tn_workspace_floats(int64_t M, int K, int N);

@@ -274,7 +274,7 @@ def test_split_step_is_bit_identical_to_the_whole_step(split):
         net.grad_ready_offset(0)
 
 
-@pytest.mark.parametrize("B", [6, 70])
+@pytest.mark.parametrize("B", [6, 70, 200])
 def test_paired_backward_launch_is_bit_identical_to_separate_launches(B):
     """Round 4: in gemm mode 0 a layer's input-gradient and weight-gradient GEMMs go out as ONE launch (gemm.hip
     gemm_dgrad_wgrad_kernel: the NN walk on the first blocks, one weight-gradient work item per block behind them); mode 1 is
@@ -289,12 +289,13 @@ def test_paired_backward_launch_is_bit_identical_to_separate_launches(B):
     try:
         p0 = net.train_fwd_bwd(dx, dy, seed=5, step=1).clone()
         g0, m0, st0 = net.grads.clone(), net.metrics.clone(), net.state.clone()
-        net.set_weights(dict(ora.params, **ora.state))
-        net.set_gemm_mode(1)
-        p1 = net.train_fwd_bwd(dx, dy, seed=5, step=1)
-        torch.cuda.synchronize()
-        assert torch.equal(p1, p0) and torch.equal(net.metrics, m0) and torch.equal(net.state, st0)
-        assert torch.equal(net.grads, g0)
+        for mode in (1, 3):                    # 3: round 4's paired launches without round 5's work beside the depthwise passes
+            net.set_weights(dict(ora.params, **ora.state))
+            net.set_gemm_mode(mode)
+            p1 = net.train_fwd_bwd(dx, dy, seed=5, step=1)
+            torch.cuda.synchronize()
+            assert torch.equal(p1, p0) and torch.equal(net.metrics, m0) and torch.equal(net.state, st0), mode
+            assert torch.equal(net.grads, g0), mode
     finally:
         net.set_gemm_mode(mode0)
     assert float(g0.abs().max()) > 0
