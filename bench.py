@@ -36,9 +36,12 @@ ALL30 = ('sheila nine stop bed four six down bird marvin cat off right seven eig
          'wow dog yes five one tree house two left no').split()
 
 
-def build_synthetic(device, n_bank, seed, L=16000):
+def build_synthetic(device, n_bank, seed, L=16000, tone_amp=0.05, tone_step_hz=None, label_noise=0.0):
     """SURVEY 8d synthetic inputs: x = 0.0774*N(0,1) clipped to [-1,1] + 0.05 sin(2 pi f_c t), f_c = 200(1+c) Hz;
-    6 x 60 s noise recordings; label mix silence 13 % / unknown 60 % (train.py:40-45); a 'pseudo' partition."""
+    6 x 60 s noise recordings; label mix silence 13 % / unknown 60 % (train.py:40-45); a 'pseudo' partition.
+    The val-acc parity run (scripts/val_acc_parity.py) asks for a task that does not saturate: a weaker tone (tone_amp), class
+    frequencies tone_step_hz apart (f_c = 400 + step * c) and a share label_noise of ALL index entries (training, pseudo and
+    validation) relabelled with a random word."""
     from speech_recognition_amd.input_data import ClipBank, SILENCE_LABEL
     g = torch.Generator(device=device)
     g.manual_seed(seed)
@@ -58,8 +61,8 @@ def build_synthetic(device, n_bank, seed, L=16000):
     for s in range(0, n_bank, 4096):
         e = min(s + 4096, n_bank)
         x = torch.randn((e - s, L), generator=g, device=device) * 0.0774
-        f = 200.0 * (1.0 + cls_t[s:e].float())
-        x += 0.05 * torch.sin(2.0 * math.pi * f[:, None] * t[None, :])
+        f = 200.0 * (1.0 + cls_t[s:e].float()) if tone_step_hz is None else 400.0 + float(tone_step_hz) * cls_t[s:e].float()
+        x += float(tone_amp) * torch.sin(2.0 * math.pi * f[:, None] * t[None, :])
         bank[s:e] = x.clamp_(-1.0, 1.0)
     rng = np.random.RandomState(59185)
     noise = [(rng.randn(960000) * 0.1).astype(np.float32) for _ in range(6)]
@@ -82,6 +85,13 @@ def build_synthetic(device, n_bank, seed, L=16000):
         'validation': [(r, word_of_row[r]) for r in val_rows],
         'testing': [],
     }
+    if label_noise > 0.0:
+        lrng = np.random.RandomState(seed ^ 0x5EED)
+        for part in ('training', 'pseudo', 'validation'):
+            ent = index[part]
+            for k in np.nonzero(lrng.rand(len(ent)) < label_noise)[0]:
+                if ent[k][1] != SILENCE_LABEL:
+                    ent[k] = (ent[k][0], ALL30[lrng.randint(len(ALL30))])
     return {'bank': cb, 'index': index}
 
 

@@ -55,8 +55,9 @@ int kws_stream_destroy(void* stream);
  * may attach the same handle (the batch generator thread and the training thread of bench.py do).
  * kws_profiler_collect() waits for the recorded events and returns the number of families, kws_profiler_get() reads one
  * (summed device ms, launches, FLOPs, bytes).  No process-wide switch: a thread that never attaches never records.
- * The handle counts its attached threads (a thread that exits detaches itself): kws_profiler_destroy() ends the calling
- * thread's own attachment and returns KWS_E_INVALID, leaving the handle alive, while any OTHER thread is still attached. */
+ * The handle counts its attached threads (a thread that exits detaches itself): kws_profiler_destroy() returns KWS_E_INVALID
+ * and changes NOTHING - the handle stays alive, the calling thread stays attached - while any OTHER thread is still attached;
+ * when it succeeds it ends the calling thread's own attachment with the handle. */
 typedef struct kws_profiler kws_profiler_t;
 int kws_profiler_create(kws_profiler_t** out);
 int kws_profiler_destroy(kws_profiler_t* p);

@@ -194,13 +194,14 @@ int kws_profiler_create(kws_profiler_t** out) {
 
 int kws_profiler_destroy(kws_profiler_t* p) {
   if (!p) return KWS_OK;
+  const int others = p->attached.load() - (t_prof == p ? 1 : 0);
+  if (others != 0) {                     // another thread would keep a dangling pointer (its next launch books into p);
+    kws_set_error("profiler_destroy: %d other thread(s) still attached (kws_profiler_attach(NULL) from each first)", others);
+    return KWS_E_INVALID;                // a refused destroy changes nothing: the caller stays attached and keeps recording
+  }
   if (t_prof == p) {                     // the caller's own attachment ends with the handle
     t_prof = nullptr;
     p->attached.fetch_sub(1);
-  }
-  if (p->attached.load() != 0) {         // another thread would keep a dangling pointer (its next launch books into p)
-    kws_set_error("profiler_destroy: %d other thread(s) still attached (kws_profiler_attach(NULL) from each first)", p->attached.load());
-    return KWS_E_INVALID;
   }
   {
     std::lock_guard<std::mutex> lk(p->mu);

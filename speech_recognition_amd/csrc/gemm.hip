@@ -1569,6 +1569,9 @@ NNPlan nn_plan(int64_t M, int K, int N, bool gather) {
   }
   pl.bn = BN;
   pl.kb = (BN == 64 && K % 64 == 0 && K >= 128) ? 64 : 32;
+#ifdef KWS_NN_KB32_K128   // experiment (round 5): a 64-wide tile of K = 128 is TWO 64-deep iterations long and carries its staging + statistics
+  if (BN == 64 && K == 128) pl.kb = 32;   // epilogue in both; four 32-deep iterations spread it (profiles/r05_nn_fwd_l1.txt)
+#endif
   const int64_t slots = ceil_div64(pl.m_tiles, NXCD) * ceil_div(N, BN);
   // wave-specialised kernel (default): needs whole K-slabs and column tiles, and 32-bit byte offsets
   // inside one tile's buffer views (128 rows of A / C, all of W); everything else (the gathered first

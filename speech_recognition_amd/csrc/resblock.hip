@@ -126,9 +126,11 @@ __global__ __launch_bounds__(256) void block_out_bwd_kernel(const float* __restr
 // 5 tensor passes per join instead of 6, and no launch between the finalise and the next GEMM but this one.  All loads of a
 // unit (TT steps x {dO, y0, y1}) are issued before the first is used - from clamped addresses - as in dwconv.hip.
 template <int P, bool RELU, int PASS>
-__global__ __launch_bounds__(512) void block_join_bwd_kernel(const float* __restrict__ dO, const float* __restrict__ y,
+// (dO and out carry no __restrict__: the shortcut BatchNorm's pass 2 runs in place, out == dO with P == 1 - every thread loads its
+// own rows of a unit before it stores them, which is only defined behaviour while the compiler may not assume the two apart)
+__global__ __launch_bounds__(512) void block_join_bwd_kernel(const float* dO, const float* __restrict__ y,
                                                              const float* __restrict__ bn, const float* __restrict__ gamma,
-                                                             const float* __restrict__ coef, float* __restrict__ out,
+                                                             const float* __restrict__ coef, float* out,
                                                              float* __restrict__ part, int L, int Lo, int C, int nchunks, int R,
                                                              int Cb, int64_t units) {
   __shared__ float red[2][512 * 4];

@@ -1,8 +1,11 @@
 """Val-acc parity (BASELINE.json metric: "...; val-acc parity"): the reference's train/validate loop (train.py:56-75,
-callbacks.py:45-83) on the device and on the oracle's CPU twin over the same batches - scripts/val_acc_parity.py."""
+callbacks.py:45-83) on the device and on the oracle's CPU twin over the same batches - scripts/val_acc_parity.py.
+Round 5: on a task that does not saturate (weak tone under the noise, classes 25 Hz apart, 10 % label noise) and two sampler
+seeds, so that "both sides reached the same accuracy" says something about the gradients."""
 import os
 import sys
 
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -13,15 +16,23 @@ def test_val_acc_parity_device_vs_cpu_oracle(repo_root):
     import val_acc_parity
     res = val_acc_parity.run(epochs=12, steps=100, batch=64, val_batches=8, quiet=True)
     par = res["val_acc_parity"]
-    print(par["device"], par["cpu"])
-    # the bar: the SETTLED accuracy (median of the last three epochs) and the best epoch agree within the tolerance.  The
-    # last epoch alone is reported (val_acc / val_acc_cpu) but not asserted: with Keras' BatchNorm momentum of 0.99 one late
-    # epoch of either side can sit a class lower, and the torch-CPU twin is not run-to-run deterministic (1.000 / 0.980 /
-    # 0.879 measured for the same batches)
-    assert par["tolerance"] == 0.05 and par["validation_rows_disjoint_from_training"]
-    assert abs(res["val_acc_settled"] - res["val_acc_cpu_settled"]) <= par["tolerance"], (par["device"]["val_acc"], par["cpu"]["val_acc"])
-    assert abs(res["val_acc_best"] - res["val_acc_cpu_best"]) <= par["tolerance"]
-    # both learned the 12-class tone task (chance = the largest class share, ~0.3 with 60 % 'unknown' draws folded in)
-    assert res["val_acc_settled"] > 0.6 and res["val_acc_cpu_settled"] > 0.6
-    # the training-side accuracies (same batches, same dropout masks) track each other as well
-    assert abs(par["device"]["train_acc"][-1] - par["cpu"]["train_acc"][-1]) < 0.08
+    for r in par["per_seed"]:
+        print(r["seed"], r["device"]["val_acc"], r["cpu"]["val_acc"], r["device"]["val_loss"], r["cpu"]["val_loss"])
+    assert par["validation_rows_disjoint_from_training"] and len(par["per_seed"]) >= 2
+    assert par["tolerance_mean_settled"] == 0.02 and par["tolerance"] == 0.05
+    # the bar: the SETTLED accuracy (median of the last three epochs) agrees within 0.02 on the mean over the seeds and within 0.05
+    # for every seed; the best epoch agrees within 0.05.  The last epoch alone is reported but not asserted: with Keras' BatchNorm
+    # momentum of 0.99 one late epoch of either side can sit lower, and the torch-CPU twin is not run-to-run deterministic
+    assert par["mean_abs_settled_difference"] <= par["tolerance_mean_settled"], par["settled_device_minus_cpu"]
+    for r in par["per_seed"]:
+        assert abs(r["val_acc_settled"] - r["val_acc_cpu_settled"]) <= par["tolerance"], (r["device"]["val_acc"], r["cpu"]["val_acc"])
+        assert abs(r["val_acc_best"] - r["val_acc_cpu_best"]) <= par["tolerance"]
+        # the task does NOT saturate (10 % of the labels are wrong) and both sides learned it (chance = the largest class share, ~0.35)
+        assert 0.6 < r["val_acc_settled"] < 0.97 and 0.6 < r["val_acc_cpu_settled"] < 0.97, (r["val_acc_settled"], r["val_acc_cpu_settled"])
+        # the training-side accuracies (same batches, same dropout masks) track each other
+        assert abs(r["device"]["train_acc"][-1] - r["cpu"]["train_acc"][-1]) < 0.05
+        # the validation loss of the settled epochs agrees as well (cross-entropy against the noisy labels: ~0.5 at the ceiling)
+        assert abs(np.median(r["device"]["val_loss"][-3:]) - np.median(r["cpu"]["val_loss"][-3:])) < 0.15
+        # the reference's ReduceLROnPlateau replayed on either side's own series halves the rate about as often
+        fd, fc = r["device"]["lr_replay"]["fired_after_epochs"], r["cpu"]["lr_replay"]["fired_after_epochs"]
+        assert abs(len(fd) - len(fc)) <= 1, (fd, fc)
