@@ -12,18 +12,19 @@ the validation partition at every epoch end (callbacks.py:45-83).  Here that loo
           clips.
 
 Data (round 5): the tone dataset of SURVEY 8d made HARD enough not to saturate - class c = 0.0774 N(0,1) + TONE_AMP sin(2 pi
-(400 + 25 c) t) with TONE_AMP = 0.015 (the reference-statistics task used 0.05 and frequencies 200 Hz apart: both sides reached
+(400 + 25 c) t) with TONE_AMP = 0.010 (the reference-statistics task used 0.05 and frequencies 200 Hz apart: both sides reached
 1.000 on it, which a net with a modest gradient bug would also have done - VERDICT r4), and 10 % of ALL index entries (training,
-pseudo, validation) relabelled with a random word, so the accuracy that can be reached is ~0.9 and how fast a run gets there
-depends on the gradients being right.  Built on the device by bench.build_synthetic with a fixed seed; TWO sampler seeds.
+pseudo, validation) relabelled with a random word, so the validation accuracy that can be reached is 0.937 (measured: both sides
+settle there for tone amplitudes 0.007 ... 0.015) and how fast the TRAINING accuracy climbs under the same batches and dropout
+masks (0.51, 0.79, 0.85, 0.87, 0.90 ... per epoch at 0.010; 0.59, 0.84, 0.88 ... at 0.015) depends on the gradients being right.  Built on the device by bench.build_synthetic with a fixed seed; TWO sampler seeds.
 Training is chaotic across ReLU6 kinks, so the two runs are not expected to agree weight by weight after hundreds of steps; what
 must agree is the SETTLED validation accuracy (median of the last three epochs; tolerance TOL_SETTLED on the mean over seeds) -
 and both must have learned the task.  Validation runs in inference mode on the BatchNorm MOVING statistics (momentum 0.99,
 SURVEY D.2), which lag the batch statistics for the first few hundred steps: both sides validate at chance until then.
 Both sides take the same FIXED schedule (1e-3, then one halving per epoch over the last three epochs: ReduceLROnPlateau's
-factor) - a 12-epoch run never waits out the reference's patience of 4 (train.py:62-63) - and each side's own validation-
+factor) - a 10-epoch run never waits out the reference's patience of 4 (train.py:62-63) - and each side's own validation-
 accuracy series is then REPLAYED through the product's ReduceLROnPlateau (keras_api.py: Keras 2.1.2's rule, pinned by fixture K3;
-monitor val_categorical_accuracy, mode max, factor 0.5, patience 2 so that a 12-epoch series can fire) to show where the
+monitor val_categorical_accuracy, mode max, factor 0.5, patience 2 so that a 10-epoch series can fire) to show where the
 reference's schedule would have fired on either side (`lr_replay`).
 
 The oracle is used here as the CHECKER (this script is measurement / test infrastructure, like bench.cpu_baseline).
@@ -47,7 +48,7 @@ import torch  # noqa: E402
 
 TOL_VAL_ACC = 0.05      # per seed: |settled val_acc(device) - settled val_acc(cpu)|
 TOL_SETTLED = 0.02      # mean over the seeds of the same difference
-TONE_AMP, TONE_STEP_HZ, LABEL_NOISE = 0.015, 25.0, 0.10
+TONE_AMP, TONE_STEP_HZ, LABEL_NOISE = 0.010, 25.0, 0.10
 SEEDS = (4321, 97)
 
 
@@ -100,20 +101,14 @@ def replay_reduce_lr(series, patience=2, factor=0.5, base_lr=1e-3, min_lr=1e-5):
     return {"fired_after_epochs": fired, "lr": lrs}
 
 
-def run_one(device, spec, seed, epochs, steps, batch, val_batches, quiet, cpu_threads):
+def run_one(device, proc, settings, words, seed, epochs, steps, batch, val_batches, quiet, cpu_threads):
     import bench
     from speech_recognition_amd.keras_api import Callback
     from oracle.net import TimeSlicedAttentionNet
     from oracle.torch_net import TorchTimeSlicedNet
     from speech_recognition_amd.callbacks import ConfusionMatrixCallback
-    from speech_recognition_amd.input_data import AudioProcessor, prepare_words_list
-    from speech_recognition_amd.model import prepare_model_settings, speech_model
+    from speech_recognition_amd.model import speech_model
     from speech_recognition_amd.utils import data_gen
-    words = prepare_words_list(bench.WANTED)
-    settings = prepare_model_settings(label_count=len(words), sample_rate=16000, clip_duration_ms=1000,
-                                      window_size_ms=30.0, window_stride_ms=10.0, dct_coefficient_count=80,
-                                      num_log_mel_features=60, output_representation='raw')
-    proc = AudioProcessor(spec, 13.0, 60.0, bench.WANTED, 10.0, 0.0, settings, output_representation='raw', device=device)
     np.random.seed(seed)
     out_stream = sys.stderr if quiet else sys.stdout
     old_stdout, cwd = sys.stdout, os.getcwd()
@@ -140,7 +135,6 @@ def run_one(device, spec, seed, epochs, steps, batch, val_batches, quiet, cpu_th
     finally:
         os.chdir(cwd)
         sys.stdout = old_stdout
-        proc.close()
     dev_acc = [float(v) for v in hist.history['val_categorical_accuracy']]
     dev_loss = [float(v) for v in hist.history['val_loss']]
     dev_train_acc = [float(v) for v in hist.history['categorical_accuracy']]
@@ -179,12 +173,25 @@ def run_one(device, spec, seed, epochs, steps, batch, val_batches, quiet, cpu_th
                     "what": "oracle/torch_net.py (torch-CPU f32), same batches, same dropout masks, same RMSprop"}}
 
 
-def run(device=None, epochs=12, steps=100, batch=64, val_batches=8, bank=16384, quiet=False, cpu_threads=None, seeds=SEEDS,
+def run(device=None, epochs=10, steps=100, batch=64, val_batches=None, bank=16384, quiet=False, cpu_threads=None, seeds=SEEDS,
         tone_amp=TONE_AMP, tone_step_hz=TONE_STEP_HZ, label_noise=LABEL_NOISE):
     import bench
     device = device if device is not None else torch.device("cuda", 0)
     spec = bench.build_synthetic(device, bank, seed=59185, tone_amp=tone_amp, tone_step_hz=tone_step_hz, label_noise=label_noise)
-    per_seed = [run_one(device, spec, sd, epochs, steps, batch, val_batches, quiet, cpu_threads) for sd in seeds]
+    # every epoch scores the WHOLE validation partition (the generator walks it in index order, wanted words first: a part of it
+    # per epoch makes the series a function of which part was scored - measured: 0.96 / 0.97 on the unknown-word quarters, 0.2 - 0.9 on
+    # the others, period 4)
+    if val_batches is None:
+        val_batches = len(spec['index']['validation']) // batch
+    from speech_recognition_amd.input_data import AudioProcessor, prepare_words_list
+    from speech_recognition_amd.model import prepare_model_settings
+    words = prepare_words_list(bench.WANTED)
+    settings = prepare_model_settings(label_count=len(words), sample_rate=16000, clip_duration_ms=1000,
+                                      window_size_ms=30.0, window_stride_ms=10.0, dct_coefficient_count=80,
+                                      num_log_mel_features=60, output_representation='raw')
+    # ONE processor (clip bank, generator stream) for all seeds: a seed is the sampler's RNG state and fresh generators
+    proc = AudioProcessor(spec, 13.0, 60.0, bench.WANTED, 10.0, 0.0, settings, output_representation='raw', device=device)
+    per_seed = [run_one(device, proc, settings, words, sd, epochs, steps, batch, val_batches, quiet, cpu_threads) for sd in seeds]
     mean = lambda k: float(np.mean([r[k] for r in per_seed]))
     d_settled = [r["val_acc_settled"] - r["val_acc_cpu_settled"] for r in per_seed]
     res = {"val_acc": mean("val_acc_last"), "val_acc_cpu": mean("val_acc_cpu_last"), "val_acc_best": mean("val_acc_best"),
@@ -212,10 +219,10 @@ def run(device=None, epochs=12, steps=100, batch=64, val_batches=8, bank=16384, 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--epochs", type=int, default=12)
+    ap.add_argument("--epochs", type=int, default=10)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--batch", type=int, default=64)
-    ap.add_argument("--val-batches", type=int, default=8)
+    ap.add_argument("--val-batches", type=int, default=None)
     ap.add_argument("--tone-amp", type=float, default=TONE_AMP)
     ap.add_argument("--seeds", default=",".join(str(v) for v in SEEDS))
     ap.add_argument("--json", default=None)

@@ -169,6 +169,11 @@ class AudioProcessor(object):
         if own is not None and own.stream is not None:
             try:
                 own.stream.synchronize()
+                # torch's pinned-memory cache holds events recorded on this stream (the non_blocking parameter uploads of
+                # _augment): let it retire them while the stream still exists - a later query of an event whose stream is gone,
+                # or whose handle a NEW stream got, fails ("event last recorded in a capturing stream", round 5)
+                import torch
+                torch.empty(16).pin_memory()
             except Exception:
                 pass
         if getattr(self, '_plan', None):

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 def test_val_acc_parity_device_vs_cpu_oracle(repo_root):
     sys.path.insert(0, os.path.join(repo_root, "scripts"))
     import val_acc_parity
-    res = val_acc_parity.run(epochs=12, steps=100, batch=64, val_batches=8, quiet=True)
+    res = val_acc_parity.run(epochs=10, steps=100, batch=64, quiet=True)
     par = res["val_acc_parity"]
     for r in par["per_seed"]:
         print(r["seed"], r["device"]["val_acc"], r["cpu"]["val_acc"], r["device"]["val_loss"], r["cpu"]["val_loss"])
@@ -29,10 +29,15 @@ def test_val_acc_parity_device_vs_cpu_oracle(repo_root):
         assert abs(r["val_acc_best"] - r["val_acc_cpu_best"]) <= par["tolerance"]
         # the task does NOT saturate (10 % of the labels are wrong) and both sides learned it (chance = the largest class share, ~0.35)
         assert 0.6 < r["val_acc_settled"] < 0.97 and 0.6 < r["val_acc_cpu_settled"] < 0.97, (r["val_acc_settled"], r["val_acc_cpu_settled"])
-        # the training-side accuracies (same batches, same dropout masks) track each other
-        assert abs(r["device"]["train_acc"][-1] - r["cpu"]["train_acc"][-1]) < 0.05
-        # the validation loss of the settled epochs agrees as well (cross-entropy against the noisy labels: ~0.5 at the ceiling)
-        assert abs(np.median(r["device"]["val_loss"][-3:]) - np.median(r["cpu"]["val_loss"][-3:])) < 0.15
+        # the LEARNING CURVES track each other: training accuracy per epoch under the same batches and dropout masks (it climbs
+        # 0.51 -> 0.95 over the run: a gradient that is off would bend this curve long before it shows in the settled accuracy;
+        # measured differences <= 0.021 at any epoch)
+        for e, (a, b) in enumerate(zip(r["device"]["train_acc"], r["cpu"]["train_acc"])):
+            assert abs(a - b) < 0.04, (e, a, b)
+        assert r["device"]["train_acc"][1] - r["device"]["train_acc"][0] > 0.1 and r["device"]["train_acc"][-1] > 0.9
+        # the validation loss of the settled epochs agrees as well (cross-entropy against the noisy labels: ~0.4 at the ceiling;
+        # measured differences <= 0.02)
+        assert abs(np.median(r["device"]["val_loss"][-3:]) - np.median(r["cpu"]["val_loss"][-3:])) < 0.06
         # the reference's ReduceLROnPlateau replayed on either side's own series halves the rate about as often
         fd, fc = r["device"]["lr_replay"]["fired_after_epochs"], r["cpu"]["lr_replay"]["fired_after_epochs"]
         assert abs(len(fd) - len(fc)) <= 1, (fd, fc)
