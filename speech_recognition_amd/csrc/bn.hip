@@ -323,6 +323,9 @@ int kws_bn_stats_finalize(const float* stats_part, int n_tiles, int64_t count, i
   KWS_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), "bn_stats_finalize: moving stats must both be set");
   const float omm = (float)(1.0 - (double)momentum);
   KwsProfScope prof("bn_finalize", 0.0, 8.0 * n_tiles * C, (hipStream_t)stream);
+#ifdef KWS_ABL_NO_FIN   // timing-only ablation (wrong results): what the fold launches on the dependency chain cost the step
+  return KWS_OK;       // (round 5: 4.414 -> 4.233 ms, 181 us for 25 launches; profiles/r05_ablation_no_fold_launches.txt)
+#endif
   KWS_TRY(pre_reduce(stats_part, n_tiles, 2 * C, scratch, (hipStream_t)stream, &stats_part, &n_tiles));
   hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((unsigned)ceil_div(C, FIN_CG)), dim3(FIN_CG * FIN_RG), 0, (hipStream_t)stream,
                      stats_part, n_tiles, 1.0 / (double)count, C, gamma, beta, eps, omm, moving_mean, moving_var, bn);
@@ -369,6 +372,9 @@ int kws_dw_bwd_finalize(const float* part, int n_parts, int64_t count, int C, fl
                         float* coef, float* scratch, void* stream) {
   KWS_REQUIRE(part && n_parts > 0 && count > 0 && C > 0, "dw_bwd_finalize: bad arguments");
   KwsProfScope prof("bn_finalize", 0.0, 20.0 * n_parts * C, (hipStream_t)stream);
+#ifdef KWS_ABL_NO_FIN
+  return KWS_OK;
+#endif
   KWS_TRY(pre_reduce(part, n_parts, 5 * C, scratch, (hipStream_t)stream, &part, &n_parts));
   hipLaunchKernelGGL(dw_bwd_finalize_kernel, dim3((unsigned)ceil_div(C, FIN_CG)), dim3(FIN_CG * FIN_RG), 0, (hipStream_t)stream, part,
                      n_parts, 1.0 / (double)count, C, dw, dgamma, dbeta, coef);
