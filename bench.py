@@ -929,6 +929,8 @@ def main():
             "ab_gemm_f16x2": ab.get("ab_gemm_f16x2"),
             "ab_features": ab.get("ab_features"),
             "ab_bwd_pair": ab.get("ab_bwd_pair"),
+            "ab_wgrad_beside_dwbwd": ab.get("ab_wgrad_beside_dwbwd"),
+            "ab_bwd_pair_error": ab.get("ab_bwd_pair_error"),
             "stft_mel_error": feature_err,
             "ab_error": ab.get("error"),
             "configs": configs,
