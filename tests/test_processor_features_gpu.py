@@ -137,3 +137,26 @@ def test_whole_partition_larger_than_one_launch():
     torch.cuda.synchronize()
     assert tuple(Xt.shape) == (n, L)
     assert torch.equal(Xt, bank[torch.from_numpy(rows).to(dev)])
+
+
+def test_processor_closed_and_replaced_keeps_generating():
+    """Round 5: a second AudioProcessor built after the first was closed (val-acc parity's seeds, a driver that re-creates its
+    generator) failed in its first parameter upload with 'operation not permitted on an event last recorded in a capturing
+    stream': torch's pinned-memory cache still held events recorded on the closed processor's stream, whose handle the new
+    stream had taken.  close() now lets the cache retire them first; a closed processor refuses get_data cleanly."""
+    from speech_recognition_amd import _lib
+    from speech_recognition_amd.utils import data_gen
+    first = None
+    for round_ in range(4):
+        proc, settings, spec = _processor('raw', 80, 60, n_bank=1024)
+        gen = data_gen(proc, None, batch_size=64, mode='training', pseudo_frequency=0.6)
+        for _ in range(3):
+            X, y = next(gen)
+        X = np.asarray(X)
+        assert X.shape == (64, 16000) and np.isfinite(X).all() and np.abs(X).max() > 0
+        if first is None:
+            first = X.shape
+        proc.close()
+        with pytest.raises(_lib.KwsError):
+            proc.get_data(4, 0, 0.0, 0.0, 0.0, 0.0, 0.0, [0, 0], 'validation', None)
+        proc.close()                                     # idempotent
