@@ -2010,6 +2010,20 @@ int kws_gemm_tn_gather_f32(const float* X, const kws_gather_t* g, const float* G
   return launch_tn<true>(a, dW, (hipStream_t)stream);
 }
 
+// internal (net_logmfcc.hip, round 5): the gathered weight-gradient GEMM WITHOUT its slab sum - *S slabs of [taps * cin, N] into
+// workspace (kws_gemm_tn_workspace_floats of (B * L_out, taps * cin, N)); the caller queues them for kws_reduce_slabs_batch with
+// a NEGATIVE count (the summation order of this kernel's own reduce_slabs_kernel launch: bit-identical to kws_gemm_tn_gather_f32)
+int kws_gemm_tn_gather_slabs_f32(const float* X, const kws_gather_t* g, const float* G, int B, int N, float* workspace, int* S,
+                                 hipStream_t stream) {
+  KWS_REQUIRE(X && G && workspace && S, "gemm_tn_gather_slabs: NULL pointer");
+  KWS_TRY(check_gather(g, B, N));
+  TNArgs a{};
+  a.A = X; a.G = G; a.ws = workspace; a.M = (int64_t)B * g->L_out; a.K = g->taps * g->cin; a.N = N;
+  a.g = *g;
+  KwsProfScope prof("gemm_tn", 2.0 * a.M * a.K * N, 4.0 * ((double)B * g->x_len + (double)a.M * N + (double)a.K * N), stream);
+  return launch_tn<true>(a, nullptr, stream, S);
+}
+
 int kws_transpose_f32(const float* in, float* out, int rows, int cols, void* stream) {
   KWS_REQUIRE(in && out && rows > 0 && cols > 0, "transpose: bad arguments");
   KwsProfScope prof("transpose", 0.0, 8.0 * rows * cols, (hipStream_t)stream);

@@ -58,6 +58,9 @@ extern "C" int kws_gemm_dgrad_wgrad_f32(const float* dY, const float* WT, float*
 // gemm.hip (round 5): an NN GEMM (no statistics) and weight-gradient work items of any layer in one launch (1 = not eligible)
 extern "C" int kws_gemm_nn_wgrad_items_f32(const float* A, const float* W, float* C, int64_t M, int K, int N, const kws_wgrad_items_t* wi,
                                            int* S, hipStream_t stream);
+// gemm.hip (round 5): the gathered weight-gradient GEMM without its slab sum (queue the slabs with a NEGATIVE count)
+extern "C" int kws_gemm_tn_gather_slabs_f32(const float* X, const kws_gather_t* g, const float* G, int B, int N, float* workspace, int* S,
+                                            hipStream_t stream);
 extern "C" int kws_reduce_slabs_batch(const float* const* ws, float* const* out, const int64_t* n, const int* S, int count,
                                       hipStream_t stream);
 extern "C" int64_t kws_gemm_tn_workspace_floats(int64_t M, int K, int N);
@@ -144,6 +147,26 @@ struct KwsSlabQueue {
     ws[count] = base + used; out[count] = dW; n[count] = (int64_t)K * N;
     const int rc = kws_gemm_tn_slabs_f32(A, G, M, K, N, base + used, &S[count], st);
     if (rc) return rc;
+    used += need;
+    ++count;
+    return 0;
+  }
+  // a GATHERED weight-gradient GEMM (first / shortcut convolutions of the residual families): its slabs join the batch in the
+  // summation order of its own slab-sum launch (negative count), which they replace - one small launch less per call
+  int gemm_gather(const float* X, const kws_gather_t* g, const float* G, float* dW, int B, int N, hipStream_t st) {
+    const int64_t M = (int64_t)B * g->L_out;
+    const int K = g->taps * g->cin;
+    const int64_t need = (kws_gemm_tn_workspace_floats(M, K, N) + 63) / 64 * 64;
+    if (count == KWS_SLAB_BATCH || used + need > cap) {
+      const int rc = flush(st);
+      if (rc) return rc;
+    }
+    if (need > cap) return KWS_E_WORKSPACE;
+    ws[count] = base + used; out[count] = dW; n[count] = (int64_t)K * N;
+    int S_ = 0;
+    const int rc = kws_gemm_tn_gather_slabs_f32(X, g, G, B, N, base + used, &S_, st);
+    if (rc) return rc;
+    S[count] = -S_;
     used += need;
     ++count;
     return 0;

@@ -122,9 +122,9 @@ void lm_layout(const kws_net* n, int B, LmLayout* lo) {
     upd_gemm(M, K, N);
     sum_tnq += (kws_gemm_tn_workspace_floats(M, K, N) + 63) / 64 * 64;
   };
-  upd_gemm((int64_t)B * p.L0, p.style == 1 ? p.K0p : 3 * p.Fp, p.C0);
+  upd_pw((int64_t)B * p.L0, p.style == 1 ? p.K0p : 3 * p.Fp, p.C0);     // (gathered weight gradients queue their slabs too: round 5)
   if (p.style == 3) {
-    upd_gemm((int64_t)B * p.L0, p.g0r.taps * p.g0r.cin, p.Cr);
+    upd_pw((int64_t)B * p.L0, p.g0r.taps * p.g0r.cin, p.Cr);
     lo->a0m = bp.take((int64_t)B * p.L0 * p.Cm);
     lo->a0r = bp.take((int64_t)B * p.L0 * p.Cr);
   }
@@ -152,7 +152,7 @@ void lm_layout(const kws_net* n, int B, LmLayout* lo) {
     max_xs = std::max(max_xs, (int64_t)B * b.Lout * b.cin);
     upd_pw((int64_t)B * b.Lmid, b.cin, b.nf);
     upd_pw((int64_t)B * b.Lmid, b.nf, b.nf);
-    if (b.has_short) upd_gemm((int64_t)B * b.Lout, b.cin, b.nf);
+    if (b.has_short) upd_pw((int64_t)B * b.Lout, b.cin, b.nf);
     max_part = std::max(max_part, kws_dwconv_bwd_part_floats(B, b.Lin, b.cin));
     upd_dwq(b.Lin, b.cin);
     max_part = std::max(max_part, kws_dwconv_bwd_part_floats(B, b.Lmid, b.nf));
@@ -988,7 +988,7 @@ int lm_train(const kws_net* n, const float* params, float* state, const float* x
     if (b.has_short) {
       const int64_t Mo = (int64_t)B * b.Lout;
       KWS_TRY(join_bwd(dO, ws + lo.ys[i], b.bns, b.bns_idx, dO, b.Lout, b.nf, 1, 0));   // the shortcut's BN: no mask, in place
-      KWS_TRY(kws_gemm_tn_gather_f32(xin, &b.gs, dO, grads + b.ws, B, b.nf, ws + lo.tn, st));
+      KWS_TRY(sq.gemm_gather(xin, &b.gs, dO, grads + b.ws, B, b.nf, st));   // slabs queued: summed with the pass's other weight gradients
       KWS_TRY(kws_gemm_nn_f32(dO, ws + lo.wt_ws[i], ws + lo.DXS, Mo, b.nf, b.cin, nullptr, st));
       KWS_TRY(kws_add_strided_f32(dX, ws + lo.DXS, B, b.Lin, b.Lout, b.cin, b.stride, st));
     }
@@ -1014,17 +1014,21 @@ int lm_train(const kws_net* n, const float* params, float* state, const float* x
                            {dOr, ws + lo.y0 + M * p.Cm, 2, p.Cr, &p.bn0r, &p.g0r, p.conv1r}};
     for (const Stem& sm : stems) {
       KWS_TRY(join_bwd(sm.d, sm.y, *sm.bn, sm.idx, G, p.L0, sm.C, 1, 1));
-      KWS_TRY(kws_gemm_tn_gather_f32(x, sm.g, G, grads + sm.w, B, sm.C, ws + lo.tn, st));
+      KWS_TRY(sq.gemm_gather(x, sm.g, G, grads + sm.w, B, sm.C, st));
     }
     KWS_TRY(sq.flush(st));
     KWS_TRY(dq.flush());
     return KWS_OK;
   }
-  KWS_TRY(sq.flush(st));   // the pointwise weight gradients of the whole pass: one sum (two past 16 layers)
-  KWS_TRY(dq.flush());     // ... and the depthwise weight gradients whose rows were parked
+  KWS_TRY(dq.flush());     // the depthwise weight gradients whose rows were parked
   // ---- first convolution ----
   {
     KWS_TRY(join_bwd(dO, ws + lo.y0, p.bn0, 1, G, p.L0, p.C0, 1, 1));
+    if (p.style != 1 && p.Fp == p.F) {   // its gradient is written in place: the slabs join the pass's batched sum
+      KWS_TRY(sq.gemm_gather(x, &p.g0, G, grads + p.conv1, B, p.C0, st));
+      return sq.flush(st);
+    }
+    KWS_TRY(sq.flush(st));   // the pointwise weight gradients of the whole pass: one sum (two past 16 layers)
     if (p.style == 1) {  // gradient of the zero-padded [76, C0] kernel; its first 75 rows are the kernel's
       float* gw = ws + lo.gwpad;
       KWS_TRY(kws_gemm_tn_gather_f32(x, &p.g0, G, gw, B, p.C0, ws + lo.tn, st));
