@@ -31,9 +31,9 @@ def test_val_acc_parity_device_vs_cpu_oracle(repo_root):
         assert 0.6 < r["val_acc_settled"] < 0.97 and 0.6 < r["val_acc_cpu_settled"] < 0.97, (r["val_acc_settled"], r["val_acc_cpu_settled"])
         # the LEARNING CURVES track each other: training accuracy per epoch under the same batches and dropout masks (it climbs
         # 0.51 -> 0.95 over the run: a gradient that is off would bend this curve long before it shows in the settled accuracy;
-        # measured differences <= 0.021 at any epoch)
+        # measured differences <= 0.021 in the first three epochs, <= 0.009 after)
         for e, (a, b) in enumerate(zip(r["device"]["train_acc"], r["cpu"]["train_acc"])):
-            assert abs(a - b) < 0.04, (e, a, b)
+            assert abs(a - b) < (0.05 if e < 3 else 0.03), (e, a, b)      # (the steep first epochs: 0.51 -> 0.79 -> 0.85)
         assert r["device"]["train_acc"][1] - r["device"]["train_acc"][0] > 0.1 and r["device"]["train_acc"][-1] > 0.9
         # the validation loss of the settled epochs agrees as well (cross-entropy against the noisy labels: ~0.4 at the ceiling;
         # measured differences <= 0.02)
