@@ -36,7 +36,7 @@ extern "C" {
 #define KWS_E_HIP (-2)       /* a HIP runtime call failed */
 #define KWS_E_WORKSPACE (-3) /* caller workspace too small */
 
-#define KWS_ABI_VERSION 3   /* round 4: hidden visibility (exports = this header), the three |x|-maximum producers, gemm mode 1, profiler_destroy may refuse; round 3 (2): profiler / gemm-mode state moved onto handles */
+#define KWS_ABI_VERSION 4   /* round 5: kws_wgrad_items_t + kws_dwconv_bwd_bn_wgrad_f32 / kws_gemm_tn_items / kws_gemm_tn_ckpt_floats, gemm mode 3, a refused profiler_destroy changes nothing; round 4 (3): hidden visibility (exports = this header), the three |x|-maximum producers, gemm mode 1, profiler_destroy may refuse; round 3 (2): profiler / gemm-mode state moved onto handles */
 
 int kws_abi_version(void);
 const char* kws_last_error(void);

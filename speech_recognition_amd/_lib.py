@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KWS_LIB_PATH") or os.path.join(_HERE, "libkws_hip.so")  # override: kernel A/B experiments
 
-ABI_VERSION = 3    # include/kws_hip.h: KWS_ABI_VERSION
+ABI_VERSION = 4    # include/kws_hip.h: KWS_ABI_VERSION
 
 KWS_NET_TS_ATTENTION = 1
 KWS_NET_LOG_MFCC = 2
