@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 def test_val_acc_parity_device_vs_cpu_oracle(repo_root):
     sys.path.insert(0, os.path.join(repo_root, "scripts"))
     import val_acc_parity
-    res = val_acc_parity.run(epochs=10, steps=100, batch=64, quiet=True)
+    res = val_acc_parity.run(epochs=9, steps=100, batch=64, quiet=True)      # (9 x 100 steps x 2 seeds: ~ 170 s, the CPU twin is 150 of them)
     par = res["val_acc_parity"]
     for r in par["per_seed"]:
         print(r["seed"], r["device"]["val_acc"], r["cpu"]["val_acc"], r["device"]["val_loss"], r["cpu"]["val_loss"])
