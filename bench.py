@@ -280,8 +280,6 @@ ROOFLINE_KERNELS = [
     # round 4: a layer's input-gradient and weight-gradient GEMMs are ONE launch (gemm_dgrad_wgrad_kernel); the forward GEMMs
     # (and whatever the fused kernel does not take) stay gemm_nn_ws_kernel / gemm_tn_ws_kernel launches
     ("gemm_bwd_pair", "gemm_dgrad_wgrad_kernel", "mfma", "pointwise 1x1 convolutions: input gradient + weight gradient of a layer in one launch"),
-    ("dwbwd_wgrad", "dwbwd_wgrad_kernel", "hbm", "gemm mode 3 only (round 5's experiment): a depthwise-backward pass and weight-gradient work items of the "
-                                                 "same layer in one CU-partitioned grid; both fractions are of the whole chip's roofs"),
     ("gemm_nn", "gemm_nn_ws_kernel", "mfma", "pointwise 1x1 convolutions: forward (+ input gradient where not paired)"),
     ("gemm_tn", "gemm_tn_ws_kernel", "mfma", "pointwise 1x1 convolutions: weight gradient (where not paired)"),
     ("conv1_fwd", "conv1_fwd_kernel", "mfma", "first convolution (frames of 40 hop 20, k3 s2) as a Toeplitz GEMM"),
@@ -763,15 +761,14 @@ def main():
             _lib.Profiler.detach()   # a leg that raised between attach() and detach() must not leave this thread recording
     # ---- A/B of the backward schedules, same process, two alternating rounds each, all bit-identical (tests/test_net_gpu.py,
     # tests/test_fullsize_gpu.py).  gemm mode 1: the launches of rounds 1 - 3; mode 0 (the default): round 4's one-grid launches (a
-    # layer's input-gradient + weight-gradient GEMM, slab sum beside the first convolution's weight gradient, the tail's post-kernels);
-    # mode 3: round 5's experiment - on top of mode 0, the weight-gradient GEMM of a layer cut into work items and stage windows that
-    # run BESIDE the layer's two depthwise-backward passes (CUs partitioned), the remainder in the next layer's input-gradient launch.
-    # Measured a LOSS (profiles/r05_wgrad_beside_dwbwd*.txt): the line carries the same-run number so nobody has to take that on trust
+    # layer's input-gradient + weight-gradient GEMM, slab sum beside the first convolution's weight gradient, the tail's post-kernels).
+    # (Round 5's third schedule - weight-gradient work items beside the depthwise passes, a measured loss - left the library in round 6:
+    # profiles/r05_wgrad_beside_dwbwd*.txt are its record, scripts/probes/wgrad_beside_dwbwd/ its code.)
     if world == 1 and not args.no_ab and gemm_mode == 0:
         try:
-            arms = {0: [], 1: [], 3: []}
+            arms = {0: [], 1: []}
             for rnd in range(2):
-                for mode in (1, 3, 0):
+                for mode in (1, 0):
                     model.net.set_gemm_mode(mode)
                     for i in range(4):
                         step(used + i)
@@ -784,14 +781,6 @@ def main():
                                  "steps": ab_steps, "paired": {"ms_per_step": min(arms[0]), "value": B / min(arms[0]) * 1e3, "rounds_ms": arms[0]},
                                  "separate": {"ms_per_step": min(arms[1]), "value": B / min(arms[1]) * 1e3, "rounds_ms": arms[1]},
                                  "gain_us_per_step": 1e3 * (min(arms[1]) - min(arms[0])), "unit": "clips/s"}
-            ab["ab_wgrad_beside_dwbwd"] = {
-                "what": "gemm mode 3 (round 5's experiment, NOT the default: a layer's weight-gradient work items beside its two depthwise-backward "
-                        "passes in one CU-partitioned grid, dwbwd_wgrad_kernel; the remainder in the next layer's input-gradient launch) vs gemm mode 0 "
-                        "(the default: the depthwise passes alone on the whole chip, the whole weight gradient in the layer's own input-gradient launch); "
-                        "best of two alternating rounds of %d steps; bit-identical results" % ab_steps,
-                "steps": ab_steps, "beside": {"ms_per_step": min(arms[3]), "value": B / min(arms[3]) * 1e3, "rounds_ms": arms[3]},
-                "in_series": {"ms_per_step": min(arms[0]), "value": B / min(arms[0]) * 1e3, "rounds_ms": arms[0]},
-                "gain_us_per_step": 1e3 * (min(arms[0]) - min(arms[3])), "unit": "clips/s"}
         except Exception as ex:
             ab["ab_bwd_pair_error"] = repr(ex)
             sys.stderr.write("A/B backward-schedule leg failed: %r\n" % (ex,))
@@ -929,7 +918,6 @@ def main():
             "ab_gemm_f16x2": ab.get("ab_gemm_f16x2"),
             "ab_features": ab.get("ab_features"),
             "ab_bwd_pair": ab.get("ab_bwd_pair"),
-            "ab_wgrad_beside_dwbwd": ab.get("ab_wgrad_beside_dwbwd"),
             "ab_bwd_pair_error": ab.get("ab_bwd_pair_error"),
             "stft_mel_error": feature_err,
             "ab_error": ab.get("error"),

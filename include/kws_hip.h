@@ -36,7 +36,7 @@ extern "C" {
 #define KWS_E_HIP (-2)       /* a HIP runtime call failed */
 #define KWS_E_WORKSPACE (-3) /* caller workspace too small */
 
-#define KWS_ABI_VERSION 4   /* round 5: kws_wgrad_items_t + kws_dwconv_bwd_bn_wgrad_f32 / kws_gemm_tn_items / kws_gemm_tn_ckpt_floats, gemm mode 3, a refused profiler_destroy changes nothing; round 4 (3): hidden visibility (exports = this header), the three |x|-maximum producers, gemm mode 1, profiler_destroy may refuse; round 3 (2): profiler / gemm-mode state moved onto handles */
+#define KWS_ABI_VERSION 5   /* round 6: round 5's measured loss (kws_wgrad_items_t, kws_dwconv_bwd_bn_wgrad_f32, kws_gemm_tn_items, kws_gemm_tn_ckpt_floats, gemm mode 3) retired from the ABI - kept as scripts/probes/wgrad_beside_dwbwd/mode3.patch; round 5 (4): a refused profiler_destroy changes nothing; round 4 (3): hidden visibility (exports = this header), the three |x|-maximum producers, gemm mode 1, profiler_destroy may refuse; round 3 (2): profiler / gemm-mode state moved onto handles */
 
 int kws_abi_version(void);
 const char* kws_last_error(void);
@@ -317,36 +317,6 @@ int kws_dwconv_bwd_f32(const float* dz, const float* y, const float* bn, const f
 int kws_dwconv_bwd_bn_f32(const float* dz, const float* y, const float* bn, const float* w,
                           const float* coef, float* dy, float* part, int pass, int B, int L_in,
                           int L_out, int C, int stride, int pad_l, void* stream);
-/* Round 5: a pass of kws_dwconv_bwd_bn_f32 and PART of the same layer's weight-gradient GEMM (the slabs of
- * dW[K,N] = Z[M,K]^T dY[M,N], reference: the Conv2DBackpropFilter of the pointwise Conv1D, model.py:48-49) in ONE grid.
- * The weight gradient of a layer hangs off the backward chain dgrad -> pass 1 -> fold -> pass 2 and is bound by the matrix
- * pipe where the passes are bound by HBM: `dw_blocks` workgroups (a multiple of 8, <= 256: CUs) stream the pass while the
- * others take weight-gradient work.  That work is cut two ways: by ITEM (kws_gemm_tn_items(M,K,N) items = output tile x split
- * of M; ranges are multiples of 8, *granule = the items of one round of splits) and by STAGE WINDOW [f0, f1) in 1/1024ths
- * of an item's rows: an item that stops short of its last stage parks its accumulators in `ckpt`
- * (kws_gemm_tn_ckpt_floats(M,K,N) floats) and a later launch that lists it in a resume range continues the same MFMA chain.
- * Every item must have reached its end - in any number of launches - before the *S slabs in `slabs`
- * (kws_gemm_tn_workspace_floats) are summed; however the work is cut, every result is bit-identical to the separate calls'.
- * pass 0 = the items alone.  Returns 1 (nothing launched) for shapes the fused kernel does not take; kws_gemm_tn_items
- * returns 0 for those. */
-typedef struct kws_wgrad_items {
-  const float* Z;          /* [M, K] */
-  const float* dY;         /* [M, N] */
-  int64_t M;
-  int K, N;
-  float* slabs;            /* kws_gemm_tn_workspace_floats(M,K,N) */
-  float* ckpt;             /* kws_gemm_tn_ckpt_floats(M,K,N), or NULL when no window of any launch is cut */
-  int item_lo, item_hi;    /* the items of this launch */
-  int f0, f1;              /* their stage window, 1/1024ths (0, 1024 = whole items) */
-  int n_resume;            /* <= 4 ranges of items that start at resume_f instead of f0 (what earlier launches did) */
-  int resume_lo[4], resume_hi[4], resume_f[4];
-} kws_wgrad_items_t;
-int kws_gemm_tn_items(int64_t M, int K, int N, int* granule);
-int64_t kws_gemm_tn_ckpt_floats(int64_t M, int K, int N);
-int kws_dwconv_bwd_bn_wgrad_f32(const float* dz, const float* y, const float* bn, const float* w,
-                                const float* coef, float* dy, float* part, int pass, int B, int L_in,
-                                int L_out, int C, int stride, int pad_l, const kws_wgrad_items_t* items,
-                                int dw_blocks, int* S, void* stream);
 /* reduces part -> dw[3,C] (may be NULL), dgamma[C], dbeta[C], and coef[2*C] = (c1, c2) used by
  * kws_bn_bwd_apply; n_parts = part floats / (5*C) */
 int kws_dw_bwd_finalize(const float* part, int n_parts, int64_t count, int C, float* dw,

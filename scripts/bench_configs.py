@@ -46,7 +46,7 @@ def clips(B, seed):
     return (torch.randn((B, 16000), generator=g, device="cuda") * 0.0774).clamp_(-1, 1).contiguous()
 
 
-def c3(steps=30, warm=5, profile_steps=5):
+def c3(steps=30, warm=5, profile_steps=5, ab=True):
     B = 2048
     lib = _lib.load()
     t = path_b_tables(480, 40, 40)
@@ -67,14 +67,18 @@ def c3(steps=30, warm=5, profile_steps=5):
         model._train_step_async(feats, y, row)
 
     ms = timed(step, warm, steps)
-    net.set_gemm_mode(1)             # A/B reference: the input- / weight-gradient GEMMs as separate launches (rounds 1 - 3)
-    ms_sep = timed(step, 3, steps)
-    net.set_gemm_mode(0)
+    ms_sep = None
+    if ab:                           # A/B reference: the input- / weight-gradient GEMMs as separate launches (rounds 1 - 3);
+        net.set_gemm_mode(1)         # never inside a profiled process (ab=False there: the stats must be ONE schedule)
+        ms_sep = timed(step, 3, steps)
+        net.set_gemm_mode(0)
     out = {"config": "C3 (configs[2]): 32-class conv_1d_log_mfcc, log-mel 40x98 from raw clips, batch 2048, "
                      "STFT/mel + fwd + bwd + RMSprop",
            "batch": B, "steps": steps, "ms_per_step": ms, "clips_per_s": B / ms * 1e3, "n_gpus": 1, "dtype": "f32",
            "gemm_arm": ARM[net.gemm_mode], "data": "synthetic",
-           "ab_bwd_pair": {"paired_ms_per_step": ms, "separate_ms_per_step": ms_sep, "gain_us_per_step": 1e3 * (ms_sep - ms)}}
+           }
+    if ab:
+        out["ab_bwd_pair"] = {"paired_ms_per_step": ms, "separate_ms_per_step": ms_sep, "gain_us_per_step": 1e3 * (ms_sep - ms)}
     if profile_steps > 0:        # per-family HIP-event times of the same step (the caller turns the largest into a roofline object)
         prof = _lib.Profiler()
         prof.attach()

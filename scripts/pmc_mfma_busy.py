@@ -18,7 +18,7 @@ for r in csv.DictReader(open(sys.argv[1])):
         act[k] += float(r["Counter_Value"])
 out = {k: {"launches": n[k], "mfma_busy_cycles": busy[k], "gui_active_cycles": act[k],
            "busy_per_simd": busy[k] / (act[k] * 128.0) if act[k] else None} for k in sorted(busy)}
-json.dump({"note": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE (own pass), bench.py --batch 1024; "
+json.dump({"note": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE (own pass), " + (sys.argv[3] if len(sys.argv) > 3 else "bench.py --batch 1024") + "; "
                    "busy_per_simd = sum(busy over SIMDs) / (sum(active over XCDs) * 128 SIMDs per XCD)",
            "kernels": out}, open(sys.argv[2], "w"), indent=1, sort_keys=True)
 for k, v in out.items():

@@ -11,7 +11,12 @@ SOURCE_OF = {"gemm_nn_ws_kernel": "gemm.hip", "gemm_dgrad_wgrad_kernel": "gemm.h
              "conv1_wgrad_kernel": "conv1.hip", "conv1_wgrad_slabsum_kernel": "conv1.hip", "tail_post_kernel": "tail.hip", "reduce_slabs_batch_kernel": "gemm.hip",
              "stft4_kernel": "stft4.hip", "augment_kernel": "augment.hip", "dwconv_fwd_kernel": "dwconv.hip",
              "dwconv_bwd_kernel": "dwconv.hip", "dwconv_bwd_bn_kernel": "dwconv.hip", "ts_tail_kernel": "tail.hip",
-             "gemm_nn_f16x2_kernel": "gemm_f16x2.hip", "gemm_tn_f16x2_kernel": "gemm_f16x2.hip"}
+             "gemm_nn_f16x2_kernel": "gemm_f16x2.hip", "gemm_tn_f16x2_kernel": "gemm_f16x2.hip",
+             # C3 (conv_1d_log_mfcc) families
+             "block_out_fwd_kernel": "resblock.hip", "block_out_bwd_kernel": "resblock.hip", "block_join_bwd_kernel": "resblock.hip",
+             "add_strided_kernel": "resblock.hip", "lm_tail_kernel": "resblock.hip", "lm_att_bn_kernel": "resblock.hip",
+             "lm_att_bn_bwd_kernel": "resblock.hip", "lm_att_logits_kernel": "resblock.hip", "lm_att_bwd_kernel": "resblock.hip",
+             "colsum_kernel": "tail.hip", "small_wgrad_kernel": "tail.hip", "bn_relu6_apply_kernel": "bn.hip"}
 
 
 def load(path, counter):
@@ -31,13 +36,15 @@ for k in sorted(set(f) | set(w)):
     fk = sum(f.get(k, [0])) / max(len(f.get(k, [])), 1)
     wk = sum(w.get(k, [0])) / max(len(w.get(k, [])), 1)
     out[k] = {"launches_seen": len(f.get(k, [])), "fetch_kib_avg_raw": fk, "write_kib_avg": wk,
-              "hbm_bytes_per_launch": (2.0 * fk + wk) * 1024.0, "source": SOURCE_OF.get(k)}
+              "hbm_bytes_per_launch": (2.0 * fk + wk) * 1024.0, "source": SOURCE_OF.get(k),
+              # the family's bytes summed over every launch the pass saw (the step's traffic = this / steps profiled)
+              "hbm_bytes_total": (2.0 * sum(f.get(k, [0])) + sum(w.get(k, [0]))) * 1024.0}
 sources = {}
 for src in sorted(set(v for v in SOURCE_OF.values())):
     path = os.path.join(CSRC, src)
     if os.path.exists(path):
         sources[src] = hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
-json.dump({"note": "FETCH_SIZE doubled (gfx950 correction), separate --pmc passes, bench.py --batch 1024",
+json.dump({"note": "FETCH_SIZE doubled (gfx950 correction), separate --pmc passes, " + (sys.argv[4] if len(sys.argv) > 4 else "bench.py --batch 1024"),
            "sources": sources, "kernels": out}, open(sys.argv[3], "w"), indent=1, sort_keys=True)
 for k, v in out.items():
     if v["hbm_bytes_per_launch"] > 1e6:

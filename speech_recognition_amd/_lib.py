@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KWS_LIB_PATH") or os.path.join(_HERE, "libkws_hip.so")  # override: kernel A/B experiments
 
-ABI_VERSION = 4    # include/kws_hip.h: KWS_ABI_VERSION
+ABI_VERSION = 5    # include/kws_hip.h: KWS_ABI_VERSION
 
 KWS_NET_TS_ATTENTION = 1
 KWS_NET_LOG_MFCC = 2
@@ -43,13 +43,6 @@ class SamplerArgs(ctypes.Structure):
                 ("foreground_volume_range", ctypes.c_double), ("time_shift_frequency", ctypes.c_double),
                 ("pseudo_frequency", ctypes.c_double), ("flip_frequency", ctypes.c_double),
                 ("silence_volume_range", ctypes.c_double)]
-
-
-class WgradItems(ctypes.Structure):
-    _fields_ = [("Z", ctypes.c_void_p), ("dY", ctypes.c_void_p), ("M", ctypes.c_int64), ("K", ctypes.c_int), ("N", ctypes.c_int),
-                ("slabs", ctypes.c_void_p), ("ckpt", ctypes.c_void_p), ("item_lo", ctypes.c_int), ("item_hi", ctypes.c_int),
-                ("f0", ctypes.c_int), ("f1", ctypes.c_int), ("n_resume", ctypes.c_int), ("resume_lo", ctypes.c_int * 4),
-                ("resume_hi", ctypes.c_int * 4), ("resume_f", ctypes.c_int * 4)]
 
 
 class NetConfig(ctypes.Structure):
@@ -139,10 +132,6 @@ SIGNATURES = {
     "kws_dwconv_bwd_part_floats": (_I64, [_I, _I, _I]),
     "kws_dwconv_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "kws_dwconv_bwd_bn_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
-    "kws_gemm_tn_items": (_I, [_I64, _I, _I, ctypes.POINTER(_I)]),
-    "kws_gemm_tn_ckpt_floats": (_I64, [_I64, _I, _I]),
-    "kws_dwconv_bwd_bn_wgrad_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, ctypes.POINTER(WgradItems), _I,
-                                        ctypes.POINTER(_I), _P]),
     "kws_dw_bwd_finalize": (_I, [_P, _I, _I64, _I, _P, _P, _P, _P, _P, _P]),
     "kws_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _I64, _I, _P]),
     "kws_rmsprop_step": (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _P]),

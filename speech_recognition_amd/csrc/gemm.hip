@@ -18,7 +18,6 @@
 // -DKWS_GEMM_STAMP builds add s_memtime stamps to the wave-specialised NN kernel (scripts/stamps_ws.py).
 #include "common.h"
 #include "internal.h"
-#include "dw_bwd_body.h"
 
 #include <algorithm>
 #include <map>
@@ -838,16 +837,7 @@ struct TNArgs {
   int64_t chunk;    // rows per split (multiple of 32)
   int k_tiles, n_tiles, S;
   kws_gather_t g;
-  // Round 5 (wave-specialised kernel only): an item's stages can be cut across launches.  This launch runs the window
-  // [f0, f1) (1/1024ths of the item's stages) of its items; an item whose window does not reach its last stage parks its
-  // accumulators in ckpt (KWS_TN_CKPT_FLOATS per item) and a later launch resumes from them - the same MFMA chain, so the slab
-  // is bit-identical to an uncut item's.  resume: items [r_lo, r_hi) start at r_f instead of f0 (what earlier launches did).
-  int f0 = 0, f1 = 1024;
-  float* ckpt = nullptr;
-  int nr = 0;
-  int r_lo[4] = {0, 0, 0, 0}, r_hi[4] = {0, 0, 0, 0}, r_f[4] = {0, 0, 0, 0};
 };
-constexpr int KWS_TN_CKPT_FLOATS = 4 * 64 * 64;   // four MFMA waves x 64 lanes x 64 accumulator registers
 
 constexpr int MS = 32;  // rows of M per LDS stage
 
@@ -1042,21 +1032,10 @@ __device__ __forceinline__ void tn_ws_body(const TNArgs& p, float* const smem, c
   const int tid = threadIdx.x;
   const int k0 = tile_k * BKO, n0 = tile_n * BNO;
   const int K = p.K, N = p.N;
-  const int64_t m_begin0 = (int64_t)split * p.chunk;
-  const int64_t m_end0 = (m_begin0 + p.chunk < p.M) ? m_begin0 + p.chunk : p.M;
-  const int rows0 = (int)(m_end0 - m_begin0);
-  const int G_all = (rows0 + 32 * U - 1) / (32 * U);   // stages of the whole item
-  // this launch's window of the item's stages (uniform over the workgroup); the default [0, 1024) is the whole item
-  int fs = p.f0;
-  for (int i = 0; i < p.nr; ++i)
-    if (bid >= p.r_lo[i] && bid < p.r_hi[i]) fs = p.r_f[i];
-  const int g_first = (int)(((int64_t)G_all * fs) >> 10), g_last = (int)(((int64_t)G_all * p.f1) >> 10);
-  if (g_last <= g_first) return;
-  const bool resume = g_first > 0, finish = g_last == G_all;
-  const int64_t m_begin = m_begin0 + (int64_t)g_first * (32 * U);
-  const int rows = (g_last * (32 * U) < rows0 ? g_last * (32 * U) : rows0) - g_first * (32 * U);
-  const int G = g_last - g_first;                   // stages of this launch; barriers per wave: 1 + G (+ 1 when WS > 1 and finish)
-  float* const ck = p.ckpt + (int64_t)bid * KWS_TN_CKPT_FLOATS;
+  const int64_t m_begin = (int64_t)split * p.chunk;
+  const int64_t m_end = (m_begin + p.chunk < p.M) ? m_begin + p.chunk : p.M;
+  const int rows = (int)(m_end - m_begin);
+  const int G = (rows + 32 * U - 1) / (32 * U);     // stages; barriers per wave: 1 + G (+ 1 when WS > 1)
 
   if (tid < NCT) {
     // ------------------------------------------------------------------ MFMA waves
@@ -1071,17 +1050,6 @@ __device__ __forceinline__ void tn_ws_body(const TNArgs& p, float* const smem, c
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
-    if (resume) {                                   // the accumulators an earlier launch parked: [wave][i][j][quad][lane] float4
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const float4 c = *reinterpret_cast<const float4*>(ck + ((((wave * 2 + i) * 2 + j) * 4 + q) * 64 + lane) * 4);
-            acc[i][j][4 * q] = c.x; acc[i][j][4 * q + 1] = c.y; acc[i][j][4 * q + 2] = c.z; acc[i][j][4 * q + 3] = c.w;
-          }
-    }
     __syncthreads();
 #ifdef KWS_GEMM_STAMP
     unsigned long long tn_mma = 0, tn_bar = 0, tn_mark = __builtin_amdgcn_s_memtime();
@@ -1144,16 +1112,7 @@ __device__ __forceinline__ void tn_ws_body(const TNArgs& p, float* const smem, c
     const unsigned long long tn_loop_end = __builtin_amdgcn_s_memtime();
 #endif
     float* out = p.ws + (int64_t)split * K * N;
-    if (!finish) {                                  // park the accumulators; a later launch resumes the chain
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<float4*>(ck + ((((wave * 2 + i) * 2 + j) * 4 + q) * 64 + lane) * 4) =
-                make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
-    } else if (WS == 1) {
+    if (WS == 1) {
       // accumulator (i, j) register v of lane (li, lh) is dW[k0 + wk 64 + 2 r + i][n0 + wn 64 + 2 li + j], r = the MFMA's row of
       // register v: the two column blocks of a row leave as one 8-byte store (256 contiguous bytes per row and wave)
 #pragma unroll
@@ -1257,12 +1216,12 @@ __device__ __forceinline__ void tn_ws_body(const TNArgs& p, float* const smem, c
 #ifdef KWS_GEMM_STAMP
     if ((tid & 63) == 0 && lw == 0 && bid < 4096) { g_stamps[bid][6] = tl_work; g_stamps[bid][7] = tl_bar; }
 #endif
-    if (WS > 1 && finish) __syncthreads();
+    if (WS > 1) __syncthreads();
   } else {
     // ------------------------------------------------------------------ spare waves of a wider launching kernel: the barriers only
     __syncthreads();
     for (int g = 0; g < G; ++g) __syncthreads();
-    if (WS > 1 && finish) __syncthreads();
+    if (WS > 1) __syncthreads();
   }
 }
 
@@ -1286,58 +1245,6 @@ __global__ __launch_bounds__(512, 1) void gemm_dgrad_wgrad_kernel(NNArgs a, TNAr
   if ((int)blockIdx.x < nn_grid) nn_ws_body<BN, KB, 2, 2, false>(a, smem, blockIdx.x, nn_grid);
   else tn_ws_body<BKO, BNO, 512>(t, smem, (int)blockIdx.x - nn_grid);
 }
-
-// Round 5: weight-gradient work items BESIDE a depthwise-backward pass of the same layer, one grid, the CUs partitioned.  The
-// step's backward chain is dgrad_l -> depthwise pass 1 -> fold -> pass 2 -> dgrad_(l-1); the weight-gradient GEMM of layer l
-// (dW = Z^T dY) hangs off that chain and is bound by the matrix pipe, the two depthwise passes by HBM.  Blocks [0, dw_grid)
-// run the pass (kws_dw::bwd_body), the blocks behind them one weight-gradient item each (tn_ws_body, items item_lo ...):
-// 512 threads and the LDS of the larger layout, i.e. ONE workgroup per CU, so the first 256 blocks of the grid are a
-// partition of the CUs (dw_grid of them stream, the others multiply) and a CU whose pass block has ended takes items.
-// Bit-identical to the separate launches: pass 1 walks the VIRTUAL blocks v = block, block + dw_grid, ... < vblocks of the
-// stand-alone launch one after the other (same units, same sums, same partial row v), pass 2 is elementwise, and an item
-// writes its own slab tile whatever runs beside it.
-template <int S, int MODE, int BKO, int BNO>
-__global__ __launch_bounds__(512, 1) void dwbwd_wgrad_kernel(kws_dw::BwdArgs d, TNArgs t, int dw_grid, int vblocks, int item_lo) {
-  constexpr int SM_TN = tn_ws_smem_floats<BKO, BNO>(), SM_DW = kws_dw::bwd_smem_floats(MODE, DW_BWD_THREADS);
-  __shared__ __attribute__((aligned(16))) float smem[SM_TN > SM_DW ? SM_TN : SM_DW];
-  if ((int)blockIdx.x < dw_grid) {
-    if (MODE == 1) {
-      for (int v = blockIdx.x; v < vblocks; v += dw_grid) {
-        kws_dw::bwd_body<S, true, 1, true>(d, smem, v, vblocks, 0);
-        __syncthreads();                            // the next virtual block's sums overwrite `smem`
-      }
-    } else {
-      kws_dw::bwd_body<S, true, 2, true>(d, smem, (int)blockIdx.x, dw_grid, 0);
-    }
-  } else {
-    tn_ws_body<BKO, BNO, 512>(t, smem, (int)blockIdx.x - dw_grid + item_lo);
-  }
-}
-
-#if DW_BWD_THREADS == 384
-// EXPERIMENT (round 5, variant builds with -DDW_BWD_THREADS=384): the same two kinds of workgroup SHARING a CU instead of
-// partitioning the chip - 384 threads, <= 168 registers (three waves per SIMD), 64 KB of LDS: two workgroups per CU, one of
-// each kind when the dispatcher deals the first n_items blocks (one item each) one per CU and the dw_grid blocks behind them
-// on top.  128 x 128 weight-gradient tiles only (the 64-wide forms need 96 / 128 KB).
-template <int S, int MODE>
-__global__ __launch_bounds__(384, 3) void dwbwd_wgrad_share_kernel(kws_dw::BwdArgs d, TNArgs t, int dw_grid, int vblocks, int item_lo, int n_items) {
-  constexpr int SM_TN = tn_ws_smem_floats<128, 128>(), SM_DW = kws_dw::bwd_smem_floats(MODE, DW_BWD_THREADS);
-  __shared__ __attribute__((aligned(16))) float smem[SM_TN > SM_DW ? SM_TN : SM_DW];
-  if ((int)blockIdx.x >= n_items) {
-    const int b = (int)blockIdx.x - n_items;
-    if (MODE == 1) {
-      for (int v = b; v < vblocks; v += dw_grid) {
-        kws_dw::bwd_body<S, true, 1, true>(d, smem, v, vblocks, 0);
-        __syncthreads();
-      }
-    } else {
-      kws_dw::bwd_body<S, true, 2, true>(d, smem, b, dw_grid, 0);
-    }
-  } else {
-    tn_ws_body<128, 128, 384>(t, smem, (int)blockIdx.x + item_lo);
-  }
-}
-#endif
 
 // out[i] = sum_k ws[k][i], k ascending within 4 interleaved groups that are combined in a fixed order
 // (bit-reproducible).  64 float4 columns x 4 slab groups per workgroup so that the S slabs of the small
@@ -1708,25 +1615,6 @@ int launch_dgrad_wgrad(const NNArgs& a, TNArgs t, const NNPlan& np, const TNPlan
   return KWS_OK;
 }
 
-// The fused launch of a depthwise-backward pass and a range of the layer's weight-gradient work items (dwbwd_wgrad_kernel).
-template <int S, int MODE>
-void launch_dwbwd_tn(const kws_dw::BwdArgs& d, const TNArgs& t, const TNPlan& tp, int dw_grid, int vblocks, int item_lo, unsigned grid,
-                     hipStream_t st) {
-  if (tp.bko == 128 && tp.bno == 128) hipLaunchKernelGGL((dwbwd_wgrad_kernel<S, MODE, 128, 128>), dim3(grid), dim3(512), 0, st, d, t, dw_grid, vblocks, item_lo);
-  else if (tp.bko == 128) hipLaunchKernelGGL((dwbwd_wgrad_kernel<S, MODE, 128, 64>), dim3(grid), dim3(512), 0, st, d, t, dw_grid, vblocks, item_lo);
-  else if (tp.bno == 128) hipLaunchKernelGGL((dwbwd_wgrad_kernel<S, MODE, 64, 128>), dim3(grid), dim3(512), 0, st, d, t, dw_grid, vblocks, item_lo);
-  else hipLaunchKernelGGL((dwbwd_wgrad_kernel<S, MODE, 64, 64>), dim3(grid), dim3(512), 0, st, d, t, dw_grid, vblocks, item_lo);
-}
-// the weight-gradient plan's work items: blocks of the TN grid (8 x per-XCD slots: a multiple of NXCD)
-bool tn_items(int64_t M, int K, int N, TNPlan* tp_out, int64_t* items) {
-  if (!tn_ws_eligible(K, N, false)) return false;
-  const TNPlan tp = tn_plan(M, K, N, true);
-  if (tp.chunk * (int64_t)(K > N ? K : N) * 4 >= (1ll << 31)) return false;
-  *tp_out = tp;
-  *items = (int64_t)tp.k_tiles * tp.n_tiles * ceil_div(tp.S, NXCD) * NXCD;
-  return *items <= 0x3FFFFFFF;
-}
-
 int check_gather(const kws_gather_t* g, int B, int N) {
   KWS_REQUIRE(g != nullptr, "gather descriptor is NULL");
   KWS_REQUIRE(g->L_out > 0 && g->cin > 0 && g->taps > 0 && g->cin % 4 == 0,
@@ -1822,151 +1710,6 @@ int kws_gemm_dgrad_wgrad_f32(const float* dY, const float* WT, float* dZ, const 
   const double fl = 2.0 * M * cin * cout;
   KwsProfScope prof("gemm_bwd_pair", 2.0 * fl, 4.0 * (3.0 * M * cout + 2.0 * M * cin + 2.0 * (double)cin * cout) , stream);
   return launch_dgrad_wgrad(a, t, np, tp, tn_grid, stream, S);
-}
-
-int kws_gemm_tn_items(int64_t M, int K, int N, int* granule) {
-  TNPlan tp;
-  int64_t items = 0;
-  if (M <= 0 || K <= 0 || N <= 0 || !tn_items(M, K, N, &tp, &items)) return 0;
-  if (granule) *granule = tp.k_tiles * tp.n_tiles * NXCD;
-  return (int)items;
-}
-
-int64_t kws_gemm_tn_ckpt_floats(int64_t M, int K, int N) { return (int64_t)kws_gemm_tn_items(M, K, N, nullptr) * KWS_TN_CKPT_FLOATS; }
-
-namespace {
-// validates a work-item description against the plan of its shape and fills the kernel's arguments; 1 = shape not eligible
-int fill_wgrad_items(const kws_wgrad_items_t* w, TNArgs* t, TNPlan* tp, int64_t* items_out) {
-  KWS_REQUIRE(w && w->Z && w->dY && w->slabs, "wgrad items: NULL pointer");
-  KWS_REQUIRE(w->M > 0 && w->K > 0 && w->N > 0 && w->K % 4 == 0 && w->N % 4 == 0, "wgrad items: M=%lld K=%d N=%d", (long long)w->M, w->K, w->N);
-  int64_t items = 0;
-  if (!tn_items(w->M, w->K, w->N, tp, &items)) return 1;
-  KWS_REQUIRE(w->item_lo >= 0 && w->item_lo <= w->item_hi && w->item_hi <= items && w->item_lo % NXCD == 0 && w->item_hi % NXCD == 0,
-              "wgrad items: [%d, %d) of %lld (multiples of %d)", w->item_lo, w->item_hi, (long long)items, NXCD);
-  KWS_REQUIRE(w->f0 >= 0 && w->f0 <= w->f1 && w->f1 <= 1024, "wgrad items: stage window [%d, %d) of 1024", w->f0, w->f1);
-  KWS_REQUIRE(w->n_resume >= 0 && w->n_resume <= 4, "wgrad items: %d resume ranges (at most 4)", w->n_resume);
-  bool cut = w->f0 != 0 || w->f1 != 1024;
-  for (int i = 0; i < w->n_resume; ++i) {
-    KWS_REQUIRE(w->resume_lo[i] >= 0 && w->resume_lo[i] <= w->resume_hi[i] && w->resume_hi[i] <= items && w->resume_f[i] >= 0 &&
-                    w->resume_f[i] <= 1024,
-                "wgrad items: resume range %d = [%d, %d) from %d", i, w->resume_lo[i], w->resume_hi[i], w->resume_f[i]);
-    cut = cut || w->resume_f[i] != 0;
-  }
-  KWS_REQUIRE(!cut || w->ckpt != nullptr, "wgrad items: a cut stage window needs the checkpoint buffer (kws_gemm_tn_ckpt_floats)");
-  *t = TNArgs{};
-  t->A = w->Z; t->G = w->dY; t->ws = w->slabs; t->M = w->M; t->K = w->K; t->N = w->N;
-  t->chunk = tp->chunk; t->k_tiles = tp->k_tiles; t->n_tiles = tp->n_tiles; t->S = tp->S;
-  t->f0 = w->f0; t->f1 = w->f1; t->ckpt = w->ckpt; t->nr = w->n_resume;
-  for (int i = 0; i < w->n_resume; ++i) { t->r_lo[i] = w->resume_lo[i]; t->r_hi[i] = w->resume_hi[i]; t->r_f[i] = w->resume_f[i]; }
-  *items_out = items;
-  return KWS_OK;
-}
-// the share of the GEMM's FLOPs / bytes a launch of these items carries (for the profiler's books; resume ranges ignored)
-double wgrad_items_share(const kws_wgrad_items_t* w, int64_t items) {
-  return items > 0 ? (double)(w->item_hi - w->item_lo) / (double)items * (double)(w->f1 - w->f0) / 1024.0 : 0.0;
-}
-}  // namespace
-
-// One launch = pass `pass` (1 or 2) of kws_dwconv_bwd_bn_f32 on `dw_blocks` workgroups (a multiple of 8, <= 256) AND the
-// weight-gradient work items `wi` describes (include/kws_hip.h).  pass 0 = the items alone.  Returns 1 (nothing launched)
-// when the shapes are not eligible: the caller then makes the separate calls.
-int kws_dwconv_bwd_bn_wgrad_f32(const float* dz, const float* y, const float* bn, const float* w, const float* coef, float* dy,
-                                float* part, int pass, int B, int L_in, int L_out, int C, int stride, int pad_l,
-                                const kws_wgrad_items_t* wi, int dw_blocks, int* S, void* stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  KWS_REQUIRE(pass >= 0 && pass <= 2, "dwconv_bwd_bn_wgrad: pass %d", pass);
-  TNArgs t;
-  TNPlan tp;
-  int64_t items = 0;
-  const int rc = fill_wgrad_items(wi, &t, &tp, &items);
-  if (rc != 0) return rc;
-  kws_dw::BwdArgs d{};
-  int vblocks = 0;
-  double dw_flops = 0, dw_bytes = 0;
-  bool share = false;
-  (void)share;
-#if DW_BWD_THREADS == 384
-  if (pass != 0 && dw_blocks < 0 && tp.bko == 128 && tp.bno == 128) {   // experiment: negative = the CU-sharing form
-    share = true;
-    dw_blocks = -dw_blocks;
-  }
-#endif
-  if (pass != 0) {
-    KWS_REQUIRE(dz && y && bn && w, "dwconv_bwd_bn_wgrad: NULL pointer");
-    KWS_REQUIRE(pass == 1 ? part != nullptr : (coef != nullptr && dy != nullptr), "dwconv_bwd_bn_wgrad: pass %d needs %s", pass,
-                pass == 1 ? "part" : "coef and dy");
-    KWS_REQUIRE(B > 0 && L_in > 0 && L_out > 0 && kws_dw::bwd_geom_ok(C), "dwconv_bwd_bn_wgrad: bad shape B=%d L=%d->%d C=%d", B, L_in,
-                L_out, C);
-    KWS_REQUIRE(stride == 1 || stride == 2, "dwconv_bwd_bn_wgrad: stride %d unsupported", stride);
-    KWS_REQUIRE(dw_blocks > 0 && dw_blocks <= 256 && dw_blocks % NXCD == 0, "dwconv_bwd_bn_wgrad: dw_blocks %d (8 .. 256, multiple of 8)",
-                dw_blocks);
-    const kws_dw::BwdGeom ge = kws_dw::bwd_geom(B, L_in, C, pass == 1);
-    if (ge.ny != 1 || ge.block > 512) return 1;
-    d.dz = dz; d.y = y; d.bn = bn; d.w = w; d.coef = coef; d.g = dy; d.part = part;
-    d.B = B; d.Lin = L_in; d.Lout = L_out; d.C = C; d.pad_l = pad_l; d.nchunks = ge.nchunks; d.R = ge.R; d.Cb = ge.Cb; d.amax = nullptr;
-    vblocks = (int)ge.grid;
-    dw_flops = 12.0 * B * L_in * C;
-    dw_bytes = 4.0 * ((pass == 2 ? 2.0 : 1.0) * B * L_in * C + (double)B * L_out * C);
-  } else {
-    dw_blocks = 0;
-  }
-  const unsigned grid = (unsigned)(dw_blocks + (wi->item_hi - wi->item_lo));
-  if (S) *S = tp.S;
-  if (grid == 0) return KWS_OK;
-  const double frac = wgrad_items_share(wi, items);
-  KwsProfScope prof("dwbwd_wgrad", dw_flops + frac * 2.0 * t.M * t.K * t.N,
-                    dw_bytes + frac * 4.0 * ((double)t.M * t.K + (double)t.M * t.N + (double)t.K * t.N), stream);
-#if DW_BWD_THREADS == 384
-  if (share) {
-    const int n_items = wi->item_hi - wi->item_lo;
-    if (pass == 2) {
-      if (stride == 1) hipLaunchKernelGGL((dwbwd_wgrad_share_kernel<1, 2>), dim3(grid), dim3(384), 0, stream, d, t, dw_blocks, vblocks, wi->item_lo, n_items);
-      else hipLaunchKernelGGL((dwbwd_wgrad_share_kernel<2, 2>), dim3(grid), dim3(384), 0, stream, d, t, dw_blocks, vblocks, wi->item_lo, n_items);
-    } else {
-      if (stride == 1) hipLaunchKernelGGL((dwbwd_wgrad_share_kernel<1, 1>), dim3(grid), dim3(384), 0, stream, d, t, dw_blocks, vblocks, wi->item_lo, n_items);
-      else hipLaunchKernelGGL((dwbwd_wgrad_share_kernel<2, 1>), dim3(grid), dim3(384), 0, stream, d, t, dw_blocks, vblocks, wi->item_lo, n_items);
-    }
-    KWS_LAUNCH_CHECK("dwbwd_wgrad_share_kernel");
-    return KWS_OK;
-  }
-#endif
-  if (pass == 2) {
-    if (stride == 1) launch_dwbwd_tn<1, 2>(d, t, tp, dw_blocks, vblocks, wi->item_lo, grid, stream);
-    else launch_dwbwd_tn<2, 2>(d, t, tp, dw_blocks, vblocks, wi->item_lo, grid, stream);
-  } else {
-    if (pass == 0 || stride == 1) launch_dwbwd_tn<1, 1>(d, t, tp, dw_blocks, vblocks, wi->item_lo, grid, stream);
-    else launch_dwbwd_tn<2, 1>(d, t, tp, dw_blocks, vblocks, wi->item_lo, grid, stream);
-  }
-  KWS_LAUNCH_CHECK("dwbwd_wgrad_kernel");
-  return KWS_OK;
-}
-
-// internal (net.hip): C[M, N] = A[M, K] W[K, N] (the persistent NN walk, no statistics) and the weight-gradient work items `wi`
-// - of ANY layer: the schedule pairs a layer's input-gradient GEMM with what is left of the layer above's weight gradient - in
-// ONE launch (gemm_dgrad_wgrad_kernel; the items must be the plan's whole range [0, items): every block behind the NN blocks is
-// one item, and an item with an empty stage window returns at once).  Returns 1 (nothing launched) when either shape is not eligible.
-int kws_gemm_nn_wgrad_items_f32(const float* A, const float* W, float* C, int64_t M, int K, int N, const kws_wgrad_items_t* wi, int* S,
-                                hipStream_t stream) {
-  KWS_REQUIRE(A && W && C, "gemm_nn_wgrad_items: NULL pointer");
-  KWS_REQUIRE(M > 0 && K > 0 && N > 0 && K % 4 == 0 && N % 4 == 0, "gemm_nn_wgrad_items: M=%lld K=%d N=%d", (long long)M, K, N);
-  TNArgs t;
-  TNPlan tp;
-  int64_t items = 0;
-  const int rc = fill_wgrad_items(wi, &t, &tp, &items);
-  if (rc != 0) return rc;
-  KWS_REQUIRE(wi->item_lo == 0 && wi->item_hi == items, "gemm_nn_wgrad_items: the items must be the whole range [0, %lld)", (long long)items);
-  NNArgs a{};
-  a.A = A; a.W = W; a.C = C; a.M = M; a.K = K; a.N = N; a.stats = nullptr;
-  const NNPlan np = nn_plan(M, K, N, false);
-  if (!np.ws || np.wgs % NXCD != 0 || items + np.wgs > 0x7FFFFFFF) return 1;
-  const double frac = wgrad_items_share(wi, items);
-  KwsProfScope prof("gemm_bwd_pair", 2.0 * M * K * N + frac * 2.0 * t.M * t.K * t.N,
-                    4.0 * ((double)M * K + (double)K * N + (double)M * N) + frac * 4.0 * ((double)t.M * t.K + (double)t.M * t.N + (double)t.K * t.N),
-                    stream);
-  launch_pair(a, np, t, tp, (unsigned)(np.wgs + items), stream);
-  KWS_LAUNCH_CHECK("gemm_dgrad_wgrad_kernel");
-  if (S) *S = tp.S;
-  return KWS_OK;
 }
 
 int kws_slab_batch_fill(SlabBatch* b, const float* const* ws, float* const* out, const int64_t* n, const int* S, int count, int* blocks_out,

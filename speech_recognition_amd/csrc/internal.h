@@ -55,9 +55,6 @@ extern "C" int kws_gemm_tn_slabs_f32(const float* A, const float* G, int64_t M, 
 // gemm.hip: a layer's input-gradient GEMM and the slabs of its weight-gradient GEMM in one launch (returns 1 = not eligible, nothing launched)
 extern "C" int kws_gemm_dgrad_wgrad_f32(const float* dY, const float* WT, float* dZ, const float* Z, int64_t M, int cin, int cout,
                                         float* workspace, int* S, hipStream_t stream);
-// gemm.hip (round 5): an NN GEMM (no statistics) and weight-gradient work items of any layer in one launch (1 = not eligible)
-extern "C" int kws_gemm_nn_wgrad_items_f32(const float* A, const float* W, float* C, int64_t M, int K, int N, const kws_wgrad_items_t* wi,
-                                           int* S, hipStream_t stream);
 // gemm.hip (round 5): the gathered weight-gradient GEMM without its slab sum (queue the slabs with a NEGATIVE count)
 extern "C" int kws_gemm_tn_gather_slabs_f32(const float* X, const kws_gather_t* g, const float* G, int B, int N, float* workspace, int* S,
                                             hipStream_t stream);

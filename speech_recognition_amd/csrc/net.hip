@@ -176,7 +176,6 @@ struct Layout {
   std::vector<int64_t> y;   // y[l], l = 0..11 (float offsets)
   std::vector<int64_t> z;   // z[i], i = 0..10
   int64_t G = 0, G2 = 0, DZ = 0, bn = 0, part = 0, coef = 0, tn = 0, red = 0, swg = 0, swg1 = 0;
-  int64_t ckpt = 0;         // round 5: parked accumulators of weight-gradient items cut across launches (the largest layer's)
   std::vector<int64_t> WT;  // transposed pointwise kernel of block i (dgrad GEMM operand)
   std::vector<int64_t> tns; // weight-gradient slabs of block i: a region of its own, summed for all blocks in ONE launch
   std::vector<int64_t> WPf, WPd;  // fp16 x 2 arm: fp16 planes [2][cout][cin] (forward) / [2][cin][cout] (input gradient)
@@ -240,12 +239,8 @@ void make_layout(const kws_net* n, int B, bool training, Layout* lo) {
     lo->amax = bp.take((int64_t)3 * nb * KWS_ABSMAX_WORDS);
     lo->tn = bp.take(max_tn);
     lo->tns.assign(nb, 0);
-    int64_t max_ckpt = 0;
-    for (int i = 0; i < nb; ++i) {
+    for (int i = 0; i < nb; ++i)
       lo->tns[i] = bp.take(kws_gemm_tn_workspace_floats((int64_t)B * n->blocks[i].Lout, n->blocks[i].cin, n->blocks[i].cout));
-      max_ckpt = std::max(max_ckpt, kws_gemm_tn_ckpt_floats((int64_t)B * n->blocks[i].Lout, n->blocks[i].cin, n->blocks[i].cout));
-    }
-    lo->ckpt = bp.take(max_ckpt);
     lo->xd = bp.take((int64_t)B * n->T * n->C);
     lo->fd = bp.take((int64_t)B * 2 * n->C);
     lo->dl1 = bp.take((int64_t)B * n->T);
@@ -444,95 +439,10 @@ int kws_net_predict(const kws_net_t* net, const float* params, const float* stat
 extern "C" int kws_net_get_gemm_mode(const kws_net_t* net) { return net ? net->gemm_mode.load(std::memory_order_relaxed) : 0; }
 extern "C" int kws_net_set_gemm_mode(kws_net_t* net, int mode) {
   KWS_REQUIRE(net != nullptr, "net_set_gemm_mode: NULL net");
-  KWS_REQUIRE(mode >= 0 && mode <= 3,
-              "net_set_gemm_mode: mode %d (0 = f32 MFMA, 1 = f32 MFMA with separate input- / weight-gradient launches, 2 = fp16 x 2 split, "
-              "3 = f32 MFMA with a layer's weight-gradient work items beside its depthwise-backward passes: round 5's experiment)", mode);
+  KWS_REQUIRE(mode >= 0 && mode <= 2,
+              "net_set_gemm_mode: mode %d (0 = f32 MFMA, 1 = f32 MFMA with separate input- / weight-gradient launches, 2 = fp16 x 2 split)", mode);
   net->gemm_mode.store(mode, std::memory_order_relaxed);
   return KWS_OK;
-}
-
-// Round 5's EXPERIMENT (gemm mode 3, not the default) - the weight gradient of block i beside its two depthwise-backward passes
-// (gemm.hip dwbwd_wgrad_kernel): how the CUs and the weight-gradient work are cut.  The passes stream on G workgroups (one per CU)
-// while the other 256 - G CUs work through weight-gradient items; an item runs as far as the pass leaves it time for (stage window
-// [0, f), accumulators parked) and what is left of all items rides in the launch of the NEXT layer's input-gradient GEMM.  Times are
-// estimates - the cut only moves work between launches, every result is bit-identical whatever the estimates are.
-// MEASURED: A LOSS at every G (profiles/r05_wgrad_beside_dwbwd*.txt, r05_probe_share.txt, r05_ovl_sweep.txt; 4.37 -> 4.54 ms per step
-// at G = 128, worse elsewhere).  A CU alone streams only 30 - 40 GB/s in pass 1 (45 - 70 in pass 2): the passes are bound by the
-// vector ALUs and load slots of MANY CUs, not by a few CUs' latency, so every CU taken from a pass costs about what its matrix work
-// gains; two workgroups of the two kinds SHARING a CU take the SUM of their times (the weight-gradient loaders queue behind the
-// pass's loads); and pass 1's partial rows are 256 virtual blocks, so only G = 128 / 256 deal them evenly.  Kept as an A/B arm.
-#ifndef KWS_OVL_G
-#define KWS_OVL_G 128           // workgroups (CUs) of a depthwise pass
-#endif
-#ifndef KWS_OVL_R1
-#define KWS_OVL_R1 36.0         // GB/s one CU streams in pass 1 / pass 2
-#endif
-#ifndef KWS_OVL_R2
-#define KWS_OVL_R2 50.0
-#endif
-#ifndef KWS_OVL_HBM
-#define KWS_OVL_HBM 5800.0      // GB/s the passes reach with the whole chip
-#endif
-#ifndef KWS_OVL_CU_TF
-#define KWS_OVL_CU_TF 0.41      // TFLOP/s of weight-gradient work per CU (105 / 256)
-#endif
-#ifndef KWS_OVL_ALPHA
-#define KWS_OVL_ALPHA 0.9       // share of a pass's estimated time given to the items beside it
-#endif
-struct OverlapPlan {
-  bool on = false;
-  int items = 0;
-  int G1 = 0, nA = 0, fA = 0;   // pass 1: workgroups, items [0, nA) run the window [0, fA)
-  int G2 = 0, nB = 0, fB = 0;   // pass 2: items [nA, nA + nB) run [0, fB)
-};
-struct OverlapKnobs { int G; double alpha; bool off; };
-static OverlapKnobs overlap_knobs(int block) {
-  OverlapKnobs k{KWS_OVL_G, KWS_OVL_ALPHA, false};
-#ifdef KWS_OVL_ENV   // variant builds only (scripts/build_variant.sh): per-block sweeps without a rebuild per point
-  auto pick = [&](const char* name, double dflt) {
-    const char* e = getenv(name);
-    if (!e || !*e) return dflt;
-    std::vector<double> v;
-    for (const char* q = e; *q;) { char* end; v.push_back(strtod(q, &end)); q = (*end == ',') ? end + 1 : end; if (end == q && *q) break; }
-    if (v.empty()) return dflt;
-    return v[(size_t)block < v.size() ? block : v.size() - 1];
-  };
-  k.G = (int)pick("KWS_OVL_G", KWS_OVL_G);
-  k.alpha = pick("KWS_OVL_ALPHA", KWS_OVL_ALPHA);
-  k.off = pick("KWS_OVL_OFF", 0) != 0;
-#endif
-  return k;
-}
-static OverlapPlan overlap_plan(int B, const Block& b, int block) {
-  OverlapPlan pl;
-  const OverlapKnobs kn = overlap_knobs(block);
-  const int64_t M = (int64_t)B * b.Lout;
-  int gran = 0;
-  const int items = kws_gemm_tn_items(M, b.cin, b.cout, &gran);
-  if (kn.off || items <= 0 || b.cin > 1024 || kn.G < 8 || kn.G > 248) return pl;
-  pl.items = items;
-  int G = kn.G / 8 * 8;
-  if (items < 2 * (256 - G)) G = 256 - (items / 2) / 8 * 8;     // few items: more CUs to the pass, every item in one of the two launches
-  const int cus = 256 - G;
-  const double t_item = 2.0 * M * b.cin * b.cout / items / (KWS_OVL_CU_TF * 1e6);                       // us of one CU
-  const double by1 = 4.0 * B * b.cin * ((double)b.Lin + b.Lout), by2 = 4.0 * B * b.cin * (2.0 * b.Lin + b.Lout);
-  const double t1 = by1 / (std::min(KWS_OVL_HBM, G * KWS_OVL_R1) * 1e3), t2 = by2 / (std::min(KWS_OVL_HBM, G * KWS_OVL_R2) * 1e3);   // us
-  auto cut = [&](double t_pass, int avail, int* n, int* f) {
-    int rounds = (int)ceil(t_pass / t_item);
-    if (rounds < 1) rounds = 1;
-    int cnt = std::min(avail, cus * rounds) / 8 * 8;
-    if (cnt <= 0) { *n = 0; *f = 0; return; }
-    double fr = kn.alpha * t_pass * cus / (cnt * t_item);
-    int fi = (int)(fr * 1024.0);
-    if (fi >= 940) fi = 1024;          // nearly whole: finish the item, no checkpoint for a sliver
-    if (fi < 32) { *n = 0; *f = 0; return; }
-    *n = cnt; *f = fi;
-  };
-  pl.G1 = pl.G2 = G;
-  cut(t1, items, &pl.nA, &pl.fA);
-  cut(t2, items - pl.nA, &pl.nB, &pl.fB);
-  pl.on = true;
-  return pl;
 }
 
 // part 0: the whole step.  part 1: forward, tail and the backward pass down to block `split` (inclusive); part 2: the rest
@@ -563,12 +473,7 @@ static int ts_train(const kws_net_t* net, const float* params, float* state, con
   // GEMM whose shape the arm's kernels cannot take (kws_gemm_*_f16x2_supported: K granule, 2 GB buffer views)
   const bool h2 = kws_net_get_gemm_mode(net) == 2;
   const int gmode = kws_net_get_gemm_mode(net);
-  const bool pair_bwd = gmode == 0 || gmode == 3;            // mode 1: f32 MFMA with separate dgrad / wgrad launches
-  // mode 3: round 5's experiment - weight-gradient work beside the depthwise passes (measured: a loss, profiles/r05_wgrad_beside_dwbwd*.txt)
-  bool overlap_bwd = gmode == 3;
-#ifdef KWS_OVL_ENV
-  if (gmode == 0 && getenv("KWS_OVL_ON")) overlap_bwd = true;   // variant builds: sweeps through the unmodified bench
-#endif
+  const bool pair_bwd = gmode == 0;                          // mode 1: f32 MFMA with separate dgrad / wgrad launches
   // fp16 x 2 arm: slot groups of the operands' |x| maxima (common.h): W of block i, z of block i, dy of block i's output
   unsigned* amax0 = reinterpret_cast<unsigned*>(ws + lo.amax);
   auto w_slots = [&](int i) { return amax0 + (int64_t)i * KWS_ABSMAX_WORDS; };
@@ -699,22 +604,6 @@ static int ts_train(const kws_net_t* net, const float* params, float* state, con
     sl_ws[n_sl] = ws + lo.swg1; sl_out[n_sl] = grads + net->d1k; sl_n[n_sl] = (int64_t)net->T * net->C * net->T; sl_S[n_sl] = -tail_S; ++n_sl;
   }
   const int i_hi = phase == 2 ? split - 1 : nb - 1, i_lo = phase == 1 ? split : 0;
-  // Round 5 (gemm mode 0): the weight-gradient GEMM of block i is cut into work items and stage windows (overlap_plan): some of
-  // it runs BESIDE the block's two depthwise-backward passes (HBM bound, on the chain) on the CUs those leave free, the rest
-  // - `pend` - rides in the launch of block i - 1's input-gradient GEMM (or goes out alone when the call ends).  Same items,
-  // same MFMA chains, same slabs: bit-identical to modes 1 and 3.
-  kws_wgrad_items_t pend;
-  bool pend_on = false;
-  auto flush_pending = [&]() -> int {
-    if (!pend_on) return KWS_OK;
-    pend_on = false;
-    const int rc = kws_dwconv_bwd_bn_wgrad_f32(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 1, 0, &pend, 0, nullptr, st);
-    if (rc > 0) {
-      kws_set_error("net_train_fwd_bwd: pending weight-gradient items became ineligible");
-      return KWS_E_INVALID;
-    }
-    return rc;
-  };
   for (int i = i_hi; i >= i_lo; --i) {
     const Block& b = net->blocks[i];
     const int64_t M = (int64_t)B * b.Lout;
@@ -725,46 +614,6 @@ static int ts_train(const kws_net_t* net, const float* params, float* state, con
     if (i == nb - 1)
       KWS_TRY(kws_bn_bwd_apply_amax(Gcur, ws + lo.y[i + 1], bn_at(i + 1), params + b.bn.gamma, coef, M, b.cout,
                                     h2 ? g_slots(i) : nullptr, st));
-    const OverlapPlan op = overlap_bwd ? overlap_plan(B, b, i) : OverlapPlan();
-    if (op.on) {
-      // input gradient of block i, with what is left of block i + 1's weight gradient in the same launch
-      bool nn_done = false;
-      if (pend_on) {
-        const int rc = kws_gemm_nn_wgrad_items_f32(Gcur, ws + lo.WT[i], DZ, M, b.cout, b.cin, &pend, nullptr, st);
-        if (rc < 0) return rc;
-        if (rc == 0) { nn_done = true; pend_on = false; }
-        else KWS_TRY(flush_pending());
-      }
-      if (!nn_done) KWS_TRY(kws_gemm_nn_f32(Gcur, ws + lo.WT[i], DZ, M, b.cout, b.cin, nullptr, st));
-      kws_wgrad_items_t wi;
-      memset(&wi, 0, sizeof(wi));
-      wi.Z = ws + lo.z[i]; wi.dY = Gcur; wi.M = M; wi.K = b.cin; wi.N = b.cout; wi.slabs = ws + lo.tns[i]; wi.ckpt = ws + lo.ckpt;
-      const BnRef& prev = (i == 0) ? net->bn1 : net->blocks[i - 1].bn;
-      int S_i = 0;
-      wi.item_lo = 0; wi.item_hi = op.nA; wi.f0 = 0; wi.f1 = op.fA;
-      int rc = kws_dwconv_bwd_bn_wgrad_f32(DZ, ws + lo.y[i], bn_at(i), params + b.dw, nullptr, nullptr, part, 1, B, b.Lin, b.Lout, b.cin,
-                                           b.stride, b.pad_l, &wi, op.G1, &S_i, st);
-      if (rc > 0) { kws_set_error("net_train_fwd_bwd: block %d planned for the fused depthwise / weight-gradient launch is not eligible", i); return KWS_E_INVALID; }
-      if (rc < 0) return rc;
-      const int n_parts = (int)(kws_dwconv_bwd_part_floats(B, b.Lin, b.cin) / (5 * b.cin));
-      KWS_TRY(kws_dw_bwd_finalize(part, n_parts, (int64_t)B * b.Lin, b.cin, grads + b.dw, grads + prev.gamma, grads + prev.beta, coef, red, st));
-      wi.item_lo = op.nA; wi.item_hi = op.nA + op.nB; wi.f0 = 0; wi.f1 = op.fB;
-      rc = kws_dwconv_bwd_bn_wgrad_f32(DZ, ws + lo.y[i], bn_at(i), params + b.dw, coef, Gnext, nullptr, 2, B, b.Lin, b.Lout, b.cin, b.stride,
-                                       b.pad_l, &wi, op.G2, &S_i, st);
-      if (rc > 0) { kws_set_error("net_train_fwd_bwd: block %d planned for the fused depthwise / weight-gradient launch is not eligible", i); return KWS_E_INVALID; }
-      if (rc < 0) return rc;
-      // what is left: every item from where the two launches stopped (untouched items from 0)
-      pend = wi;
-      pend.item_lo = 0; pend.item_hi = op.items; pend.f0 = 0; pend.f1 = 1024;
-      pend.n_resume = 2;
-      pend.resume_lo[0] = 0; pend.resume_hi[0] = op.nA; pend.resume_f[0] = op.nA > 0 ? op.fA : 0;
-      pend.resume_lo[1] = op.nA; pend.resume_hi[1] = op.nA + op.nB; pend.resume_f[1] = op.nB > 0 ? op.fB : 0;
-      pend_on = true;
-      sl_ws[n_sl] = ws + lo.tns[i]; sl_out[n_sl] = grads + b.pw; sl_n[n_sl] = (int64_t)b.cin * b.cout; sl_S[n_sl] = S_i;
-      ++n_sl;
-      continue;
-    }
-    KWS_TRY(flush_pending());
     // f32 arm, gemm mode 0 (default): the input-gradient GEMM and the weight-gradient GEMM of the layer - independent of each
     // other - go out as ONE launch whose weight-gradient workgroups start on a CU as soon as its input-gradient workgroup has
     // ended (gemm.hip gemm_dgrad_wgrad_kernel; same code, bit-identical dZ and slabs).  Mode 1 keeps the two launches of
@@ -803,7 +652,6 @@ static int ts_train(const kws_net_t* net, const float* params, float* state, con
     KWS_TRY(kws_dwconv_bwd_bn_amax_f32(DZ, ws + lo.y[i], bn_at(i), params + b.dw, coef, Gnext, nullptr, 2, B, b.Lin, b.Lout,
                                        b.cin, b.stride, b.pad_l, (h2 && i > 0) ? g_slots(i - 1) : nullptr, st));
   }
-  KWS_TRY(flush_pending());   // the last block's remaining weight-gradient items (every slab complete before the sums below)
   // the slab sums of this call's pointwise weight gradients: beside the first convolution's weight gradient in ONE launch when
   // that kernel runs in this call (round 4: conv1_wgrad_slabsum_kernel - the two are independent, one is MFMA / memory bound, the
   // other HBM bound), their own launch otherwise (a part's gradients are final when it returns)

@@ -35,7 +35,7 @@ def test_library_loads_and_exports_every_symbol(repo_root):
     out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
     exported = sorted(line.split()[-1] for line in out.splitlines() if line.split()[-1].startswith("kws_"))
     assert exported == names, sorted(set(exported) ^ set(names))
-    assert _lib.load().kws_abi_version() == _lib.ABI_VERSION == 4
+    assert _lib.load().kws_abi_version() == _lib.ABI_VERSION == 5
 
 
 def test_product_path_fails_loudly_without_gpu():

@@ -161,9 +161,7 @@ def test_bench_single_gpu_line_carries_the_round4_keys():
     assert abs(ab["stft_mel_cost_us_per_step"] - 1e3 * (ab["mfcc_and_raw"]["ms_per_step"] - ab["raw"]["ms_per_step"])) < 1e-6
     bp = out["ab_bwd_pair"]                              # one launch for a layer's two backward GEMMs vs two (mode 1)
     assert bp["paired"]["value"] > 0 and bp["separate"]["value"] > 0 and len(bp["paired"]["rounds_ms"]) == 2
-    ov = out["ab_wgrad_beside_dwbwd"]                    # round 5's experiment (gemm mode 3) against the default, same run
-    assert out["ab_bwd_pair_error"] is None and ov["beside"]["value"] > 0 and ov["in_series"]["value"] > 0
-    assert abs(ov["gain_us_per_step"] - 1e3 * (ov["in_series"]["ms_per_step"] - ov["beside"]["ms_per_step"])) < 1e-6
+    assert out["ab_bwd_pair_error"] is None and "ab_wgrad_beside_dwbwd" not in out      # round 5's third schedule left the library
     assert out["roofline"]["family"] in ("gemm_bwd_pair", "gemm_nn") and out["roofline"]["frac"] > 0
     err = out["stft_mel_error"]
     assert err["clips"] == 16

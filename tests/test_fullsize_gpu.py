@@ -345,13 +345,11 @@ def test_config_c3_train_step_full_batch_matches_oracle():
 
 
 def test_one_grid_launches_are_bit_identical_at_the_benchmark_batch():
-    """Rounds 4 and 5, at configs[1]'s full size (batch 1024: the split counts, half tiles, slab numbers, work items and stage
-    windows of the benchmark): gemm mode 3 (round 4: a layer's input-gradient + weight-gradient GEMM as one launch, the slab
-    sum beside the first convolution's weight gradient, the tail's post-kernels as one launch) and mode 0 (round 5, the default:
-    on top of that, a layer's weight-gradient work items beside its two depthwise-backward passes in one CU-partitioned grid,
-    items cut by stage window and resumed from parked accumulators in the next layer's input-gradient launch) against mode 1
-    (the launches of rounds 1 - 3).  Same code paths, MFMA chains and summation orders: probabilities, metrics, every gradient
-    and the BatchNorm state agree bit for bit."""
+    """At configs[1]'s full size (batch 1024: the split counts, half tiles, slab numbers and work items of the benchmark): gemm
+    mode 0 (the default since round 4: a layer's input-gradient + weight-gradient GEMM as one launch, the slab sum beside the
+    first convolution's weight gradient, the tail's post-kernels as one launch) against mode 1 (the separate launches of rounds
+    1 - 3).  Same code paths, MFMA chains and summation orders: probabilities, metrics, every gradient and the BatchNorm state
+    agree bit for bit."""
     B = B_FULL
     net = DeviceNet(_lib.KWS_NET_TS_ATTENTION, 12)
     net.initialize(seed=11)
@@ -362,7 +360,7 @@ def test_one_grid_launches_are_bit_identical_at_the_benchmark_batch():
     mode0 = net.gemm_mode
     out = {}
     try:
-        for mode in (0, 1, 3):
+        for mode in (0, 1):
             net.set_gemm_mode(mode)
             net.params.copy_(w0)
             net.state.copy_(s0)
@@ -371,7 +369,6 @@ def test_one_grid_launches_are_bit_identical_at_the_benchmark_batch():
             out[mode] = (p, net.grads.clone(), net.metrics.clone(), net.state.clone())
     finally:
         net.set_gemm_mode(mode0)
-    for mode in (0, 3):
-        for a, b in zip(out[mode], out[1]):
-            assert torch.equal(a, b), mode
+    for a, b in zip(out[0], out[1]):
+        assert torch.equal(a, b)
     assert float(out[0][1].abs().max()) > 0 and bool(torch.isfinite(out[0][1]).all())
