@@ -36,7 +36,7 @@ ALL30 = ('sheila nine stop bed four six down bird marvin cat off right seven eig
          'wow dog yes five one tree house two left no').split()
 
 
-def build_synthetic(device, n_bank, seed, L=16000, tone_amp=0.05, tone_step_hz=None, label_noise=0.0):
+def build_synthetic(device, n_bank, seed, L=16000, tone_amp=0.05, tone_step_hz=None, label_noise=0.0, n_val=4096):
     """SURVEY 8d synthetic inputs: x = 0.0774*N(0,1) clipped to [-1,1] + 0.05 sin(2 pi f_c t), f_c = 200(1+c) Hz;
     6 x 60 s noise recordings; label mix silence 13 % / unknown 60 % (train.py:40-45); a 'pseudo' partition.
     The val-acc parity run (scripts/val_acc_parity.py) asks for a task that does not saturate: a weaker tone (tone_amp), class
@@ -70,7 +70,7 @@ def build_synthetic(device, n_bank, seed, L=16000, tone_amp=0.05, tone_step_hz=N
     # Partitions are DISJOINT row ranges, as the reference's which_set hash split makes them (input_data.py:61-114,
     # train.py:40-45): validation never scores a clip the training or pseudo partition draws.
     n_pseudo = n_bank // 8
-    n_val = min(4096, n_bank // 8)
+    n_val = min(n_val, n_bank // 8)
     n_val_w = n_val // 2                                             # half wanted words, half unknown words
     val_rows = list(range(n_wanted - n_val_w, n_wanted)) + list(range(n_bank - (n_val - n_val_w), n_bank))
     pseudo_rows = list(range(n_wanted - n_val_w - n_pseudo // 2, n_wanted - n_val_w))
@@ -363,6 +363,9 @@ def parse_args(argv=None):
                     help="clips/s of the N=1 run of the same build: fills scaling_vs_n1 = value / (N x n1-value)")
     ap.add_argument("--no-configs", action="store_true",
                     help="skip the `configs` legs (BASELINE configs[2] C3 and configs[4] C5 on this one GPU; N=1 only)")
+    ap.add_argument("--wall-budget", type=float, default=360.0,
+                    help="seconds after which the remaining CHECKER legs (A/B arms, configs, epoch anchor, val-acc parity) report "
+                         "{'skipped': 'budget'} instead of starting; the timed region, its roofline and cpu_baseline always run")
     ap.add_argument("--no-val-acc", action="store_true",
                     help="skip the short val-acc parity run (scripts/val_acc_parity.py: the same batches trained on the "
                          "device and on the oracle's torch-CPU twin, val_acc next to val_acc_cpu); N=1 only")
@@ -457,6 +460,88 @@ class PreflightWatchdog(object):
             pass
 
 
+def epoch_anchor(device, epochs=4, bank=65536):
+    """BASELINE.md section 1's one comparable anchor, through the product path: the epoch of exp-195 (the model train.py builds at HEAD) -
+    batch 384 (train.py:33), 95 training steps + 11 validation steps inside ConfusionMatrixCallback (4,224 clips; train.py:56-61,
+    callbacks.py:45-83), ReduceLROnPlateau + TensorBoard + ModelCheckpoint(save_best_only) attached (train.py:62-68), driven by
+    model.fit_generator (train.py:69-71).  logs_195 holds the wall time between consecutive epoch ends: 193.7 s median over 100 epochs on
+    host "apple2" (GPU unknown), real speech_commands wavs decoded per clip by the reference's generator.  Here: the same loop on a
+    synthetic, HBM-resident clip bank; seconds per epoch = the median difference between consecutive epoch ends (the first epoch, with its
+    first-launch costs, reported separately)."""
+    import shutil
+    import tempfile
+    from speech_recognition_amd.callbacks import ConfusionMatrixCallback
+    from speech_recognition_amd.input_data import AudioProcessor, prepare_words_list
+    from speech_recognition_amd.keras_api import Callback, ModelCheckpoint, ReduceLROnPlateau, TensorBoard
+    from speech_recognition_amd.model import prepare_model_settings, speech_model
+    from speech_recognition_amd.utils import data_gen
+    B, steps, val_steps = 384, 95, 11
+    spec = build_synthetic(device, bank, seed=195, n_val=val_steps * B)
+    words = prepare_words_list(WANTED)
+    settings = prepare_model_settings(label_count=len(words), sample_rate=16000, clip_duration_ms=1000, window_size_ms=30.0,
+                                      window_stride_ms=10.0, dct_coefficient_count=80, num_log_mel_features=60,
+                                      output_representation='raw')
+    proc = AudioProcessor(spec, 13.0, 60.0, WANTED, 10.0, 0.0, settings, output_representation='raw', device=device)
+    np.random.seed(195)
+    train_gen = data_gen(proc, None, batch_size=B, mode='training', pseudo_frequency=0.6)
+    val_gen = data_gen(proc, None, batch_size=B, mode='validation', pseudo_frequency=0.0)
+    model = speech_model('conv_1d_time_sliced_with_attention', settings['desired_samples'], num_classes=settings['label_count'])
+
+    class EpochEnds(Callback):            # LAST in the list: its on_epoch_end runs after the validation pass and the checkpoint write
+        def __init__(self):
+            Callback.__init__(self)
+            self.t = []
+
+        def on_train_begin(self, logs=None):
+            torch.cuda.synchronize()
+            self.t.append(time.time())
+
+        def on_epoch_end(self, epoch, logs=None):
+            torch.cuda.synchronize()
+            self.t.append(time.time())
+    ends = EpochEnds()
+    tmp, cwd, old_stdout = tempfile.mkdtemp(prefix="kws_anchor_"), os.getcwd(), sys.stdout
+    os.chdir(tmp)                         # ConfusionMatrixCallback writes its two text files into the cwd (callbacks.py:76-83)
+    try:
+        callbacks = [ConfusionMatrixCallback(val_gen, val_steps, wanted_words=words, all_words=words, label2int=proc.word_to_index),
+                     ReduceLROnPlateau(monitor='val_categorical_accuracy', mode='max', factor=0.5, patience=4, verbose=0, min_lr=1e-5),
+                     TensorBoard(log_dir='logs_210'),
+                     ModelCheckpoint('checkpoints_210/ep-{epoch:03d}-vl-{val_loss:.4f}.hdf5', save_best_only=True,
+                                     monitor='val_categorical_accuracy', mode='max'),
+                     ends]
+        hist = model.fit_generator(train_gen, steps_per_epoch=steps, epochs=epochs, verbose=0, callbacks=callbacks)
+        files = sorted(os.listdir('checkpoints_210')) if os.path.isdir('checkpoints_210') else []
+    finally:
+        os.chdir(cwd)
+        sys.stdout = old_stdout
+        shutil.rmtree(tmp, ignore_errors=True)
+        proc.close()
+    d = [b - a for a, b in zip(ends.t[:-1], ends.t[1:])]
+    steady = float(np.median(d[1:])) if len(d) > 1 else float(d[0])
+    clips_epoch = (steps + val_steps) * B
+    return {"what": "exp-195's epoch through the product path: batch 384, 95 training steps + 11 validation steps inside "
+                    "ConfusionMatrixCallback, ReduceLROnPlateau + TensorBoard + ModelCheckpoint attached, model.fit_generator "
+                    "(train.py:33,56-71); synthetic HBM-resident bank of %d clips" % bank,
+            "epochs": epochs, "seconds_per_epoch": steady, "first_epoch_seconds": float(d[0]), "epoch_seconds": [float(v) for v in d],
+            "clips_per_epoch": clips_epoch, "clips_per_s": clips_epoch / steady,
+            "checkpoints_written": len(files), "val_categorical_accuracy": [float(v) for v in hist.history.get('val_categorical_accuracy', [])],
+            "hardware": "1x MI355X, product path",
+            "reference": {"seconds_per_epoch": 193.7, "source": "logs_195 wall time between epoch ends (median of 100 epochs), host apple2, GPU unknown; "
+                                                                   "real speech_commands v0.01 wavs read and augmented per clip by the reference's "
+                                                                   "Python generator (BASELINE.md section 1)",
+                          "clips_per_s_derived": clips_epoch / 193.7},
+            "epochs_per_s_ratio": 193.7 / steady}
+
+
+def gather_per_rank(dist, value, world, device):
+    """one float per rank -> the list of all ranks' values, in rank order, on every rank (dist None: a single rank)"""
+    if not dist:
+        return [float(value)]
+    gathered = [torch.zeros(1, dtype=torch.float64, device=device) for _ in range(world)]
+    dist.all_gather(gathered, torch.tensor([float(value)], dtype=torch.float64, device=device))
+    return [float(g.item()) for g in gathered]
+
+
 def preflight_collectives(dist, device, world, rank, n_floats=1191436):
     """The first two collectives of the run: an all-reduce of ones (how many ranks really joined) and ONE all-reduce of a
     buffer the size of the flat gradient buffer (1,191,436 floats = 4.77 MB), checked element-wise at both ends and by its sum."""
@@ -533,6 +618,17 @@ def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args, json_out)
+    t_start = time.time()
+    skipped = []
+
+    def in_budget(leg):
+        """a checker leg starts only inside the wall budget (a slow host must not turn the checkers into a lost measurement at the
+        driver's limit); what was skipped is listed in the line"""
+        if time.time() - t_start < args.wall_budget:
+            return True
+        skipped.append(leg)
+        sys.stderr.write("leg %s skipped: %.0f s wall budget spent\n" % (leg, args.wall_budget))
+        return False
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -639,11 +735,10 @@ def main():
     dt, dt_own = timed_steps(args.warmup, args.steps)
     clips = B * world * args.steps
     ms = ring[args.warmup:args.warmup + args.steps].cpu().numpy()
-    per_rank_ms = [1e3 * dt_own / args.steps]
-    if dist:                             # every rank's own wall time per step: a straggler shows here
-        gathered = [torch.zeros(1, dtype=torch.float64, device=device) for _ in range(world)]
-        dist.all_gather(gathered, torch.tensor([1e3 * dt_own / args.steps], dtype=torch.float64, device=device))
-        per_rank_ms = [float(g.item()) for g in gathered]
+    # every rank's own wall time per step (a straggler shows here) and the seed its sampler drew from (ranks must not train on
+    # the same clips)
+    per_rank_ms = gather_per_rank(dist, 1e3 * dt_own / args.steps, world, device)
+    sampler_seeds = [int(v) for v in gather_per_rank(dist, float(1234 + rank), world, device)]
 
     # ---- per-kernel durations of the same step, HIP events on the launch stream -------------------
     prof = None
@@ -764,7 +859,7 @@ def main():
     # layer's input-gradient + weight-gradient GEMM, slab sum beside the first convolution's weight gradient, the tail's post-kernels).
     # (Round 5's third schedule - weight-gradient work items beside the depthwise passes, a measured loss - left the library in round 6:
     # profiles/r05_wgrad_beside_dwbwd*.txt are its record, scripts/probes/wgrad_beside_dwbwd/ its code.)
-    if world == 1 and not args.no_ab and gemm_mode == 0:
+    if world == 1 and not args.no_ab and gemm_mode == 0 and in_budget("ab_bwd_pair"):
         try:
             arms = {0: [], 1: []}
             for rnd in range(2):
@@ -789,7 +884,7 @@ def main():
     # ---- configs[1]'s own A/B: "HIP STFT+mel vs raw-wave path".  The headline step produces BOTH arms of every batch (the
     # generator's 'mfcc_and_raw' output); here the same training step is timed with the generator switched between 'raw'
     # (augment only) and 'mfcc_and_raw' (augment + STFT/mel/DCT(80,60)) at run time, two alternating rounds each, same process.
-    if world == 1 and not args.no_ab:
+    if world == 1 and not args.no_ab and in_budget("ab_features"):
         try:
             def step_any(i):
                 X, y = enq.get()
@@ -825,6 +920,50 @@ def main():
             ab["ab_features_error"] = repr(ex)
             sys.stderr.write("A/B features leg failed: %r\n" % (ex,))
     enq.stop()
+    # ---- the surface north_star names: Model.fit_generator.  The headline loop above calls Model._train_step_async itself; here the
+    # SAME generator and model are driven by model.fit_generator(gen, steps_per_epoch=100, epochs=1) - its own enqueuer thread, callback
+    # dispatch, the L2-loss read every 16 steps (a host sync) and the per-epoch metric copy - against this file's loop over the same
+    # number of steps from a fresh enqueuer, two alternating rounds.  Both arms are timed from "enqueuer not started" to "device idle".
+    if world == 1 and not args.no_ab and in_budget("ab_fit_generator"):
+        try:
+            from speech_recognition_amd.device_array import DeviceArray
+
+            def raw_after_features(g):
+                # the headline step trains on `raw` once the STFT arm of the batch exists too (mfcc.wait()): the features' ready event is
+                # recorded after raw's on the generator's stream, so it stands for both
+                for (mfcc, raw), y in g:
+                    yield DeviceArray(raw.tensor, mfcc.ready_event), y
+            fit_steps = 100
+            feed = raw_after_features(gen)
+            ring_fg = torch.zeros((fit_steps, 4), dtype=torch.float32, device=device)
+            arms = {"own_loop": [], "fit_generator": []}
+            for rnd in range(2):
+                barrier()
+                t0 = time.time()
+                e2 = GeneratorEnqueuer(feed, max_queue_size=10, device=device)
+                e2.start()
+                for i in range(fit_steps):
+                    X, y = e2.get()
+                    model._train_step_async(X, y, ring_fg[i])
+                barrier()
+                arms["own_loop"].append((time.time() - t0) / fit_steps)
+                e2.stop()
+                barrier()
+                t0 = time.time()
+                model.fit_generator(feed, steps_per_epoch=fit_steps, epochs=1, verbose=0, max_queue_size=10)
+                barrier()
+                arms["fit_generator"].append((time.time() - t0) / fit_steps)
+            m_own, m_fit = 1e3 * min(arms["own_loop"]), 1e3 * min(arms["fit_generator"])
+            ab["ab_fit_generator"] = {
+                "what": "model.fit_generator(gen, steps_per_epoch=%d, epochs=1) - the surface train.py:69-71 calls - vs this file's own loop over "
+                        "Model._train_step_async, same generator, same model, a fresh enqueuer (depth 10) each; best of two alternating rounds; "
+                        "both timed from before the enqueuer starts until the device is idle" % fit_steps,
+                "steps": fit_steps, "own_loop": {"ms_per_step": m_own, "value": B / m_own * 1e3, "rounds_ms": [1e3 * v for v in arms["own_loop"]]},
+                "fit_generator": {"ms_per_step": m_fit, "value": B / m_fit * 1e3, "rounds_ms": [1e3 * v for v in arms["fit_generator"]]},
+                "fit_generator_over_own_loop": m_fit / m_own, "unit": "clips/s"}
+        except Exception as ex:
+            ab["ab_fit_generator_error"] = repr(ex)
+            sys.stderr.write("A/B fit_generator leg failed: %r\n" % (ex,))
     feature_err = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:                             # checker leg: the generator thread has stopped, this thread may draw from the processor
@@ -868,7 +1007,9 @@ def main():
     # conv_1d_log_mfcc net at batch 2048 (freeze_graph_32_classes.py:55-69), configs[4] = C5 on this one GPU, TTA inference
     # (make_submission.py:120-146) at batch 4096.  Their rocprofv3 summaries: profiles/r03_kernel_stats_c3.csv / _c5.csv.
     configs = None
-    if world == 1 and not args.no_configs:
+    if world == 1 and not args.no_configs and not in_budget("configs"):
+        configs = {"skipped": "budget"}
+    elif world == 1 and not args.no_configs:
         configs = {}
         try:
             sys.path.insert(0, os.path.join(ROOT, "scripts"))
@@ -891,13 +1032,26 @@ def main():
             configs["error"] = repr(ex)
             sys.stderr.write("configs legs failed: %r\n" % (ex,))
 
+    anchor = None
+    if rank == 0 and world == 1 and not args.no_configs and in_budget("epoch_anchor"):
+        try:
+            anchor = epoch_anchor(device)
+        except Exception as ex:
+            anchor = {"error": repr(ex)}
+            sys.stderr.write("epoch anchor leg failed: %r\n" % (ex,))
+
     out = None
     if rank == 0:
         out = {
             "metric": "1s 16kHz clips/sec training throughput",
             "value": clips / dt, "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None,
+            # BASELINE.md publishes no clips/s; its one comparable anchor is exp-195's logged wall time per epoch (193.7 s), re-run here
+            # through fit_generator with the same epoch shape: vs_baseline = that ratio of epochs per second
+            "vs_baseline": (anchor or {}).get("epochs_per_s_ratio"),
+            "baseline": "logs_195 wall time per epoch (193.7 s: 95 x 384 training clips + 4,224 validation clips), host apple2, GPU unknown, real "
+                        "wavs - vs epoch_anchor.seconds_per_epoch on this MI355X, synthetic HBM-resident bank; a ratio of epochs/s, not of `value`",
+            "epoch_anchor": anchor,
             "dtype": {0: "f32", 1: "f32", 3: "f32", 2: "f32 (pointwise GEMMs as scaled 2-way fp16 splits, f32 accumulate)"}[gemm_mode],
             "data": "synthetic",
             "config": {"workload": "configs[1]: 12-class conv_1d_time_sliced_with_attention, batch %d/GPU synthetic "
@@ -909,6 +1063,7 @@ def main():
             "collective_backend": (dist.get_backend() if dist else None),
             "per_rank_ms": per_rank_ms,
             "scaling_vs_n1": (clips / dt) / (world * args.n1_value) if args.n1_value else None,
+            "sampler_seeds": sampler_seeds,
             "allreduce_only": exchange,
             "ab_allreduce_split": ab.get("ab_allreduce_split"),
             "train_loss_first_last": [float(ms[0, 0] / B), float(ms[-1, 0] / B)],
@@ -917,31 +1072,40 @@ def main():
             "roofline_stages": [e for e in stages if e is not roof],
             "ab_gemm_f16x2": ab.get("ab_gemm_f16x2"),
             "ab_features": ab.get("ab_features"),
+            "ab_fit_generator": ab.get("ab_fit_generator"),
+            "ab_fit_generator_error": ab.get("ab_fit_generator_error"),
             "ab_bwd_pair": ab.get("ab_bwd_pair"),
             "ab_bwd_pair_error": ab.get("ab_bwd_pair_error"),
             "stft_mel_error": feature_err,
             "ab_error": ab.get("error"),
             "configs": configs,
             "kernels": prof,
+            "skipped_legs": skipped,
         }
     if dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        if not args.no_val_acc and world == 1:
-            try:
-                sys.path.insert(0, os.path.join(ROOT, "scripts"))
-                import val_acc_parity
-                out.update(val_acc_parity.run(device, quiet=True))
-            except Exception as e:
-                out["val_acc_error"] = repr(e)
         # the host-core baseline of the same run: after the timed region and after the process group is gone, so no
-        # rank waits in a collective for it (under bench.py's own launcher the parent process measures it instead)
+        # rank waits in a collective for it (under bench.py's own launcher the parent process measures it instead).  The contract's
+        # object: it runs whatever the wall budget says, and BEFORE the longest checker leg
         if not args.no_cpu_baseline and not os.environ.get("KWS_BENCH_CHILD"):
             try:
                 out["cpu_baseline"] = cpu_baselines()
             except Exception as e:
                 out["cpu_baseline"] = {"error": repr(e)}
+        if not args.no_val_acc and world == 1:
+            if in_budget("val_acc_parity"):
+                try:
+                    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+                    import val_acc_parity
+                    out.update(val_acc_parity.run(device, quiet=True, negative_controls=("bn_c2",)))
+                except Exception as e:
+                    out["val_acc_error"] = repr(e)
+            else:
+                out["val_acc_parity"] = {"skipped": "budget"}
+        out["skipped_legs"] = skipped
+        out["bench_wall_s"] = time.time() - t_start
         print(json.dumps(out), file=json_out, flush=True)
 
 

@@ -21,8 +21,56 @@ import torch.nn.functional as F
 
 from . import layers as L
 
+# NEGATIVE CONTROLS (round 6; scripts/val_acc_parity.py, tests/test_val_acc_gpu.py): deliberately WRONG backward passes of this twin,
+# to show that the parity bars would catch a wrong gradient.  Never the default; the product knows nothing of them.
+#   'bn_c2'   BatchNorm backward without its xhat * mean(g xhat) term (every BatchNorm layer)
+#   'dw_flip' depthwise convolution: the input gradient uses the taps in reverse order (a correlation / convolution mix-up)
+#   'pw_half' the weight gradient of ONE pointwise layer (conv1d_6) x 0.5 - invisible to RMSprop by construction (the update
+#             g / sqrt(mean g^2) does not change when a tensor's gradient is scaled); caught by the one-step gradient bars instead
+#   'l2_off'  the L2 term dropped from the gradient (1e-5 |w|^2: ~1e-6 of a typical gradient entry - caught by the total-loss and
+#             the updated-weights bars of the step tests)
+MUTATIONS = ('bn_c2', 'dw_flip', 'pw_half', 'l2_off')
 
-def forward(net, params, x, y, seed, step, training=True, state=None, dropout='oracle', batch_stats=None):
+
+class _BNNoC2(torch.autograd.Function):
+    """training-mode BatchNorm whose backward drops the xhat * mean(g * xhat) term (mutation 'bn_c2')"""
+
+    @staticmethod
+    def forward(ctx, h, g, b):
+        mean = h.mean(dim=(0, 2), keepdim=True)
+        var = h.var(dim=(0, 2), unbiased=False, keepdim=True)
+        rstd = torch.rsqrt(var + 1e-3)
+        xhat = (h - mean) * rstd
+        ctx.save_for_backward(xhat, rstd, g)
+        return xhat * g[None, :, None] + b[None, :, None]
+
+    @staticmethod
+    def backward(ctx, dout):
+        xhat, rstd, g = ctx.saved_tensors
+        dg = (dout * xhat).sum(dim=(0, 2))
+        db = dout.sum(dim=(0, 2))
+        dx = g[None, :, None] * rstd * (dout - dout.mean(dim=(0, 2), keepdim=True))        # ... - xhat * mean(dout * xhat): dropped
+        return dx, dg, db
+
+
+class _DWFlip(torch.autograd.Function):
+    """depthwise conv1d (already padded input) whose INPUT gradient is computed with the taps reversed (mutation 'dw_flip')"""
+
+    @staticmethod
+    def forward(ctx, h, w, stride):
+        ctx.save_for_backward(h, w)
+        ctx.stride = stride
+        return F.conv1d(h, w, stride=stride, groups=w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dout):
+        h, w = ctx.saved_tensors
+        dh = torch.nn.grad.conv1d_input(h.shape, w.flip(-1), dout, stride=ctx.stride, groups=w.shape[0])
+        dw = torch.nn.grad.conv1d_weight(h, w.shape, dout, stride=ctx.stride, groups=w.shape[0])
+        return dh, dw, None
+
+
+def forward(net, params, x, y, seed, step, training=True, state=None, dropout='oracle', batch_stats=None, mutation=None):
     """The network of oracle/net.py:TimeSlicedAttentionNet.forward written with torch ops (channels-first inside).
 
     net: the NumPy oracle object (layer table only); params: {Keras name: torch tensor}; x [B, 16000], y one-hot.
@@ -41,7 +89,7 @@ def forward(net, params, x, y, seed, step, training=True, state=None, dropout='o
             if batch_stats is not None:
                 with torch.no_grad():
                     batch_stats[idx] = (h.mean(dim=(0, 2)), h.var(dim=(0, 2), unbiased=False))
-            h = F.batch_norm(h, None, None, g, b, training=True, eps=1e-3)
+            h = _BNNoC2.apply(h, g, b) if mutation == 'bn_c2' else F.batch_norm(h, None, None, g, b, training=True, eps=1e-3)
         else:
             mm = state['batch_normalization_%d/moving_mean' % idx]
             mv = state['batch_normalization_%d/moving_variance' % idx]
@@ -50,7 +98,10 @@ def forward(net, params, x, y, seed, step, training=True, state=None, dropout='o
     h = bn_relu6(h, 1)
     for i, blk in enumerate(net.blocks):
         w = params['depthwise_conv2d_%d/depthwise_kernel' % (i + 1)].reshape(3, blk['cin'])
-        h = F.conv1d(F.pad(h, blk['pad']), w.t().unsqueeze(1), stride=blk['stride'], groups=blk['cin'])
+        if mutation == 'dw_flip' and training:
+            h = _DWFlip.apply(F.pad(h, blk['pad']), w.t().unsqueeze(1), blk['stride'])
+        else:
+            h = F.conv1d(F.pad(h, blk['pad']), w.t().unsqueeze(1), stride=blk['stride'], groups=blk['cin'])
         Wp = params['conv1d_%d/kernel' % (i + 2)].reshape(blk['cin'], blk['cout'])
         h = F.conv1d(h, Wp.t().unsqueeze(2))
         h = bn_relu6(h, i + 2)
@@ -83,8 +134,10 @@ def forward(net, params, x, y, seed, step, training=True, state=None, dropout='o
 class TorchTimeSlicedNet(object):
     """Trainable torch-CPU twin: Keras RMSprop / SGD-momentum (oracle/layers.py rules) and BN moving averages."""
 
-    def __init__(self, num_classes=12, dtype=torch.float32, numpy_net=None, threads=None):
+    def __init__(self, num_classes=12, dtype=torch.float32, numpy_net=None, threads=None, mutation=None):
         from .net import TimeSlicedAttentionNet
+        assert mutation is None or mutation in MUTATIONS, mutation
+        self.mutation = mutation            # a NEGATIVE CONTROL (see MUTATIONS): a deliberately wrong backward pass
         if threads:
             torch.set_num_threads(int(threads))
         self.np_net = numpy_net if numpy_net is not None else TimeSlicedAttentionNet(num_classes=num_classes,
@@ -115,8 +168,10 @@ class TorchTimeSlicedNet(object):
             v.grad = None
         stats = {}
         p, loss, reg = forward(self.np_net, self.params, xt, yt, seed, step, training=True, dropout=dropout,
-                               batch_stats=stats)
-        (loss + reg).backward()
+                               batch_stats=stats, mutation=self.mutation)
+        (loss if self.mutation == 'l2_off' else loss + reg).backward()
+        if self.mutation == 'pw_half':
+            self.params['conv1d_6/kernel'].grad.mul_(0.5)
         with torch.no_grad():
             for k, v in self.params.items():
                 g, a = v.grad, self.slots[k]

@@ -50,6 +50,31 @@ TOL_VAL_ACC = 0.05      # per seed: |settled val_acc(device) - settled val_acc(c
 TOL_SETTLED = 0.02      # mean over the seeds of the same difference
 TONE_AMP, TONE_STEP_HZ, LABEL_NOISE = 0.010, 25.0, 0.10
 SEEDS = (4321, 97)
+# the bars tests/test_val_acc_gpu.py asserts on every seed (one place, so that the negative controls are judged by the SAME bars)
+BAR_TRAIN_CURVE = (0.05, 0.03)   # |train_acc(device) - train_acc(cpu)| per epoch: the steep first three epochs, then the rest
+BAR_VAL_LOSS = 0.06              # |median of the last three epochs' validation loss, device - cpu|
+
+
+def tripped_bars(dev, cpu, n_epochs=None, settled=True):
+    """Which of the parity bars a (device series, CPU series) pair breaks; series = {"train_acc", "val_acc", "val_loss"} per epoch.
+    n_epochs: compare the first n epochs only (a negative control's short run against the head of the device run);
+    settled=False leaves out the two bars on the settled epochs (validation runs on the BatchNorm MOVING statistics, which sit at
+    chance for the first ~4 epochs on both sides: a 4-epoch run has no settled epochs to compare)."""
+    n = n_epochs or min(len(dev["train_acc"]), len(cpu["train_acc"]))
+    out = []
+    for e in range(n):
+        d = abs(dev["train_acc"][e] - cpu["train_acc"][e])
+        if not d < (BAR_TRAIN_CURVE[0] if e < 3 else BAR_TRAIN_CURVE[1]):
+            out.append({"bar": "train_curve", "epoch": e, "difference": d, "allowed": BAR_TRAIN_CURVE[0] if e < 3 else BAR_TRAIN_CURVE[1]})
+    if settled:
+        med = lambda a: float(np.median(a[n - 3:n]))
+        d = abs(med(dev["val_acc"]) - med(cpu["val_acc"]))
+        if not d <= TOL_SETTLED:
+            out.append({"bar": "settled_val_acc", "difference": d, "allowed": TOL_SETTLED})
+        d = abs(med(dev["val_loss"]) - med(cpu["val_loss"]))
+        if not d < BAR_VAL_LOSS:
+            out.append({"bar": "val_loss", "difference": d, "allowed": BAR_VAL_LOSS})
+    return out
 
 
 class Recorder(object):
@@ -101,7 +126,8 @@ def replay_reduce_lr(series, patience=2, factor=0.5, base_lr=1e-3, min_lr=1e-5):
     return {"fired_after_epochs": fired, "lr": lrs}
 
 
-def run_one(device, proc, settings, words, seed, epochs, steps, batch, val_batches, quiet, cpu_threads):
+def run_one(device, proc, settings, words, seed, epochs, steps, batch, val_batches, quiet, cpu_threads, negative_controls=(),
+            nc_epochs=4):
     import bench
     from speech_recognition_amd.keras_api import Callback
     from oracle.net import TimeSlicedAttentionNet
@@ -138,43 +164,71 @@ def run_one(device, proc, settings, words, seed, epochs, steps, batch, val_batch
     dev_acc = [float(v) for v in hist.history['val_categorical_accuracy']]
     dev_loss = [float(v) for v in hist.history['val_loss']]
     dev_train_acc = [float(v) for v in hist.history['categorical_accuracy']]
+    dev_train_loss = [float(v) for v in hist.history['loss']]
     # the enqueuer thread may have pulled batches past the last step: the twin trains on the first epochs*steps only
     batches = train.batches[:epochs * steps]
     # the validation generator keeps advancing from epoch to epoch (callbacks.py:63-66 calls next() validation_steps
     # times per epoch): the twin scores, epoch by epoch, the very batches the device callback consumed
-    twin = TorchTimeSlicedNet(numpy_net=ora, threads=cpu_threads or min(os.cpu_count() or 1, 16))
-    twin.init_optimizer('rmsprop')
-    cpu_acc, cpu_loss, cpu_train_acc = [], [], []
+    def run_twin(n_epochs, mutation=None, stop_when_tripped=None):
+        """the CPU twin over the first n_epochs of the recorded batches (the lr schedule of the FULL run); a NEGATIVE CONTROL
+        (mutation != None: a deliberately wrong backward pass, oracle/torch_net.py MUTATIONS) stops at the first epoch whose
+        series breaks one of the bars against `stop_when_tripped` (the device's series)"""
+        twin = TorchTimeSlicedNet(numpy_net=ora, threads=cpu_threads or min(os.cpu_count() or 1, 16), mutation=mutation)
+        twin.init_optimizer('rmsprop')
+        ser = {"val_acc": [], "val_loss": [], "train_acc": [], "train_loss": []}
+        for e in range(n_epochs):
+            accs, losses = [], []
+            for s in range(steps):
+                k = e * steps + s
+                X, y = batches[k]
+                l, a = twin.train_step(X, y, float(np.float32(lr_of_epoch(e, epochs))), seed=model.seed, step=k)
+                accs.append(a)
+                losses.append(l)
+            ser["train_acc"].append(float(np.mean(accs)))
+            ser["train_loss"].append(float(np.mean(losses)))       # data loss (label smoothing 0.1) + L2, as Keras logs it
+            vb = val.batches[e * val_batches:(e + 1) * val_batches]
+            assert len(vb) == val_batches, "the device callback consumed fewer validation batches than expected"
+            p = np.concatenate([twin.predict(X) for X, _ in vb])
+            yt = np.concatenate([y for _, y in vb])
+            ser["val_acc"].append(float((p.argmax(1) == yt.argmax(1)).mean()))
+            ser["val_loss"].append(float(-(yt * np.log(np.clip(p, 1e-12, 1 - 1e-12))).sum(axis=1).mean()))
+            if stop_when_tripped is not None and tripped_bars(stop_when_tripped, ser, n_epochs=e + 1, settled=False):
+                break
+        return ser
     t0 = time.time()
-    for e in range(epochs):
-        accs = []
-        for s in range(steps):
-            k = e * steps + s
-            X, y = batches[k]
-            _, a = twin.train_step(X, y, float(np.float32(lr_of_epoch(e, epochs))), seed=model.seed, step=k)
-            accs.append(a)
-        cpu_train_acc.append(float(np.mean(accs)))
-        vb = val.batches[e * val_batches:(e + 1) * val_batches]
-        assert len(vb) == val_batches, "the device callback consumed fewer validation batches than expected"
-        p = np.concatenate([twin.predict(X) for X, _ in vb])
-        yt = np.concatenate([y for _, y in vb])
-        cpu_acc.append(float((p.argmax(1) == yt.argmax(1)).mean()))
-        cpu_loss.append(float(-(yt * np.log(np.clip(p, 1e-12, 1 - 1e-12))).sum(axis=1).mean()))
+    cpu_ser = run_twin(epochs)
+    cpu_acc, cpu_loss, cpu_train_acc = cpu_ser["val_acc"], cpu_ser["val_loss"], cpu_ser["train_acc"]
     t_cpu = time.time() - t0
+    # NEGATIVE CONTROLS (VERDICT r5 item 2): the same twin with a deliberately wrong backward pass, on the same batches, judged against
+    # the DEVICE's series by the same bars the parity test asserts - a suite whose bars no wrong gradient can break proves nothing
+    dev_ser = {"val_acc": dev_acc, "val_loss": dev_loss, "train_acc": dev_train_acc, "train_loss": dev_train_loss}
+    controls = {}
+    for mut in negative_controls:
+        t0 = time.time()
+        ser = run_twin(min(nc_epochs, epochs), mutation=mut, stop_when_tripped=dev_ser)
+        n = len(ser["train_acc"])
+        controls[mut] = {"epochs_run": n, "tripped": tripped_bars(dev_ser, ser, n_epochs=n, settled=False), "train_acc": ser["train_acc"],
+                         "train_loss": ser["train_loss"], "device_train_loss": dev_train_loss[:n], "unmutated_twin_train_loss": cpu_ser["train_loss"][:n],
+                         "val_loss": ser["val_loss"], "device_train_acc": dev_train_acc[:n],
+                         "unmutated_twin_train_acc": cpu_train_acc[:n], "seconds": time.time() - t0}
     # "settled" = the median of the last three epochs: with Keras' BatchNorm momentum of 0.99 the inference-mode accuracy of
     # either side can sit lower for a single late epoch (and torch-CPU's threaded reductions are not run-to-run deterministic)
     settled = lambda a: float(np.median(a[-3:]))
     return {"seed": int(seed), "val_acc_settled": settled(dev_acc), "val_acc_cpu_settled": settled(cpu_acc),
             "val_acc_best": max(dev_acc), "val_acc_cpu_best": max(cpu_acc), "val_acc_last": dev_acc[-1], "val_acc_cpu_last": cpu_acc[-1],
-            "device": {"val_acc": dev_acc, "val_loss": dev_loss, "train_acc": dev_train_acc, "seconds": t_dev,
+            "device": {"val_acc": dev_acc, "val_loss": dev_loss, "train_acc": dev_train_acc, "train_loss": dev_train_loss, "seconds": t_dev,
                        "lr_replay": replay_reduce_lr(dev_acc)},
-            "cpu": {"val_acc": cpu_acc, "val_loss": cpu_loss, "train_acc": cpu_train_acc, "seconds": t_cpu,
+            "cpu": {"val_acc": cpu_acc, "val_loss": cpu_loss, "train_acc": cpu_train_acc, "train_loss": cpu_ser["train_loss"], "seconds": t_cpu,
                     "lr_replay": replay_reduce_lr(cpu_acc),
-                    "what": "oracle/torch_net.py (torch-CPU f32), same batches, same dropout masks, same RMSprop"}}
+                    "what": "oracle/torch_net.py (torch-CPU f32), same batches, same dropout masks, same RMSprop"},
+            "tripped": tripped_bars(dev_ser, cpu_ser),
+            "negative_controls": controls}
 
 
 def run(device=None, epochs=10, steps=100, batch=64, val_batches=None, bank=16384, quiet=False, cpu_threads=None, seeds=SEEDS,
-        tone_amp=TONE_AMP, tone_step_hz=TONE_STEP_HZ, label_noise=LABEL_NOISE):
+        tone_amp=TONE_AMP, tone_step_hz=TONE_STEP_HZ, label_noise=LABEL_NOISE, negative_controls=(), nc_epochs=4):
+    """negative_controls: mutations of oracle/torch_net.py MUTATIONS run on the FIRST seed only (nc_epochs epochs each, stopping at
+    the first epoch that breaks a bar)"""
     import bench
     device = device if device is not None else torch.device("cuda", 0)
     spec = bench.build_synthetic(device, bank, seed=59185, tone_amp=tone_amp, tone_step_hz=tone_step_hz, label_noise=label_noise)
@@ -191,7 +245,9 @@ def run(device=None, epochs=10, steps=100, batch=64, val_batches=None, bank=1638
                                       num_log_mel_features=60, output_representation='raw')
     # ONE processor (clip bank, generator stream) for all seeds: a seed is the sampler's RNG state and fresh generators
     proc = AudioProcessor(spec, 13.0, 60.0, bench.WANTED, 10.0, 0.0, settings, output_representation='raw', device=device)
-    per_seed = [run_one(device, proc, settings, words, sd, epochs, steps, batch, val_batches, quiet, cpu_threads) for sd in seeds]
+    per_seed = [run_one(device, proc, settings, words, sd, epochs, steps, batch, val_batches, quiet, cpu_threads,
+                        negative_controls=negative_controls if (i == 0 or os.environ.get("KWS_NC_ALL_SEEDS")) else (), nc_epochs=nc_epochs)
+                for i, sd in enumerate(seeds)]
     mean = lambda k: float(np.mean([r[k] for r in per_seed]))
     d_settled = [r["val_acc_settled"] - r["val_acc_cpu_settled"] for r in per_seed]
     res = {"val_acc": mean("val_acc_last"), "val_acc_cpu": mean("val_acc_cpu_last"), "val_acc_best": mean("val_acc_best"),
@@ -208,6 +264,13 @@ def run(device=None, epochs=10, steps=100, batch=64, val_batches=None, bank=1638
                               "ok_best": bool(abs(mean("val_acc_best") - mean("val_acc_cpu_best")) <= TOL_VAL_ACC),
                               "lr_replay_same_epochs": [r["device"]["lr_replay"]["fired_after_epochs"] == r["cpu"]["lr_replay"]["fired_after_epochs"]
                                                         for r in per_seed],
+                              "negative_controls": {
+                                  "what": "the CPU twin with a deliberately WRONG backward pass (oracle/torch_net.py MUTATIONS) on the first "
+                                          "seed's batches, judged against the device's series by the bars of the parity test "
+                                          "(train-curve %g / %g per epoch; validation sits at chance for the first ~4 epochs on both sides, "
+                                          "so a short control has no settled epochs)" % BAR_TRAIN_CURVE,
+                                  "tripped": {m: [t["bar"] + "@%d" % t.get("epoch", -1) for t in c["tripped"]]
+                                              for m, c in per_seed[0]["negative_controls"].items()}},
                               "epochs": epochs, "steps_per_epoch": steps, "batch": batch,
                               "validation_clips": val_batches * batch,
                               "validation_rows_disjoint_from_training": not (
@@ -226,11 +289,15 @@ def main():
     ap.add_argument("--tone-amp", type=float, default=TONE_AMP)
     ap.add_argument("--seeds", default=",".join(str(v) for v in SEEDS))
     ap.add_argument("--json", default=None)
+    ap.add_argument("--negative-controls", default="", help="comma list of oracle/torch_net.py MUTATIONS (or 'all')")
+    ap.add_argument("--nc-epochs", type=int, default=4)
     a = ap.parse_args()
+    from oracle.torch_net import MUTATIONS
+    ncs = MUTATIONS if a.negative_controls == "all" else tuple(m for m in a.negative_controls.split(",") if m)
     if not torch.cuda.is_available():
         raise SystemExit("val_acc_parity needs an MI355X for the device side")
     res = run(epochs=a.epochs, steps=a.steps, batch=a.batch, val_batches=a.val_batches, tone_amp=a.tone_amp,
-              seeds=tuple(int(v) for v in a.seeds.split(",")))
+              seeds=tuple(int(v) for v in a.seeds.split(",")), negative_controls=ncs, nc_epochs=a.nc_epochs)
     txt = json.dumps(res, indent=1)
     print(txt)
     if a.json:

@@ -1517,8 +1517,14 @@ int launch_nn(const NNArgs& a0, hipStream_t st) {
       if (stats) hipLaunchKernelGGL((gemm_nn_ws_kernel<64, 64, 2, 2, true>), gp, bp, 0, st, a);
       else hipLaunchKernelGGL((gemm_nn_ws_kernel<64, 64, 2, 2, false>), gp, bp, 0, st, a);
     } else {
+#ifdef KWS_NN_NLW_K32     // experiment (round 6): more loader waves for the 32-deep slabs of the 64-wide tiles (K = 64: C3's first blocks)
+      const dim3 bq((4 + KWS_NN_NLW_K32 + 2) * 64);
+      if (stats) hipLaunchKernelGGL((gemm_nn_ws_kernel<64, 32, KWS_NN_NLW_K32, 2, true>), gp, bq, 0, st, a);
+      else hipLaunchKernelGGL((gemm_nn_ws_kernel<64, 32, KWS_NN_NLW_K32, 2, false>), gp, bq, 0, st, a);
+#else
       if (stats) hipLaunchKernelGGL((gemm_nn_ws_kernel<64, 32, 2, 2, true>), gp, bp, 0, st, a);
       else hipLaunchKernelGGL((gemm_nn_ws_kernel<64, 32, 2, 2, false>), gp, bp, 0, st, a);
+#endif
     }
     KWS_LAUNCH_CHECK("gemm_nn_ws_kernel");
     return KWS_OK;

