@@ -292,6 +292,29 @@ ROOFLINE_KERNELS = [
 ]
 
 
+# configs[2] (C3: conv_1d_log_mfcc at batch 2048): (profiler family, device kernels pooled in it, bound, what)
+C3_ROOFLINE_KERNELS = [
+    ("gemm_bwd_pair", "gemm_dgrad_wgrad_kernel", "mfma", "pointwise 1x1 convolutions: input gradient + weight gradient of a layer in one launch"),
+    ("gemm_nn", ("gemm_nn_ws_kernel", "gemm_nn_persist_kernel"), "mfma", "pointwise forward, the three shortcut convolutions' input gradients, and the gathered "
+                                                                          "first / shortcut convolutions (persistent kernel)"),
+    ("gemm_tn", ("gemm_tn_kernel", "gemm_tn_ws_kernel"), "mfma", "weight gradients of the gathered convolutions (first, shortcuts)"),
+    ("block_out_fwd", "block_out_fwd_kernel", "hbm", "residual join forward: max-pool(relu6(bn(y2))) + shortcut"),
+    ("block_join_bwd", "block_join_bwd_kernel", "hbm", "residual join backward + BatchNorm backward, two passes (reductions, then dY)"),
+    ("dwconv_fwd", "dwconv_fwd_kernel", "hbm", "depthwise k3 forward, BN + ReLU6 on load"),
+    ("dwconv_bwd", "dwconv_bwd_kernel", "hbm", "depthwise k3 backward (+ BatchNorm backward of its input, two passes, where the input is a BN output)"),
+    ("bn_finalize", ("bn_stats_finalize_kernel", "dw_bwd_finalize_kernel", "dw_grad_finalize_batch_kernel", "slice_reduce_kernel"), "hbm",
+     "fixed-order folds of partial rows: 49 launches on the dependency chain (latency, not bandwidth)"),
+    ("stft_mel", "stft4_kernel", "hbm", "STFT 480/160/512 -> |X| -> mel 40 -> log (40 x 98 per clip)"),
+    ("slab_sum", "reduce_slabs_batch_kernel", "hbm", "batched slab sums of the weight gradients"),
+    ("add", "add_strided_kernel", "hbm", "shortcut gradient added into the strided rows of the block input's gradient"),
+]
+# configs[4] (C5) plain inference
+C5_ROOFLINE_KERNELS = [
+    ("conv1_fwd", "conv1_fwd_kernel", "mfma", "first convolution"),
+    ("dwconv_fwd", "dwconv_fwd_kernel", "hbm", "depthwise k3 forward, BN + ReLU6 on load"),
+]
+
+
 def load_pmc_traffic(pattern="r*_pmc_traffic.json"):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (scripts/pmc_traffic.py), newest round first.
     An entry is used only while the kernel's source file still hashes to what was profiled: a changed kernel reports
@@ -317,7 +340,55 @@ def load_pmc_traffic(pattern="r*_pmc_traffic.json"):
     return None
 
 
-def roofline_entry(prof, family, kernel, bound, what, pmc):
+def _source_hashes(names):
+    import hashlib
+    cur = {}
+    for src in names:
+        try:
+            with open(os.path.join(ROOT, "speech_recognition_amd", "csrc", src), "rb") as f:
+                cur[src] = hashlib.sha256(f.read()).hexdigest()[:16]
+        except Exception:
+            cur[src] = None
+    return cur
+
+
+def load_rocprof_stats(pattern="r*_kernel_stats_bench_b1024.csv"):
+    """Average launch duration per device kernel from the newest committed `rocprofv3 --kernel-trace --stats` summary of the bench
+    command (profiles/r0N_kernel_stats_bench_b1024.csv) - the SECOND clock next to this run's HIP events (the two
+    differ by ~3 % across boxes; the line carries both).  Template instantiations of one kernel are pooled (total time / launches).
+    Gated like the PMC traffic: the sidecar <csv>.sources.json (scripts/profile_round.sh) holds the hashes of the kernel sources at
+    profiling time, and a kernel whose source file has changed since reports null."""
+    import csv
+    import re
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
+        if "f16x2" in os.path.basename(path):
+            continue
+        try:
+            agg = {}
+            with open(path) as f:
+                for r in csv.DictReader(f):
+                    name = r["Name"].replace("void ", "").replace("(anonymous namespace)::", "")
+                    m = re.match(r"(\w+)", name)
+                    if not m:
+                        continue
+                    a = agg.setdefault(m.group(1), [0, 0.0])
+                    a[0] += int(r["Calls"])
+                    a[1] += float(r["TotalDurationNs"])
+            side = path[:-4] + ".sources.json"
+            sources = {}
+            if os.path.exists(side):
+                with open(side) as f:
+                    sources = json.load(f)
+            cur = _source_hashes(sources.get("sources", {}))
+            return {"_file": os.path.basename(path), "kernels": {k: {"launches": c, "avg_us": t / c / 1e3} for k, (c, t) in agg.items() if c > 0},
+                    "source_of": sources.get("source_of", {}),
+                    "_fresh": {src: cur.get(src) == h for src, h in sources.get("sources", {}).items()}}
+        except Exception:
+            continue
+    return None
+
+
+def roofline_entry(prof, family, kernel, bound, what, pmc, rocprof=None):
     k = prof.get(family)
     if not k or k["ms"] <= 0 or k["count"] <= 0:
         return None
@@ -325,14 +396,20 @@ def roofline_entry(prof, family, kernel, bound, what, pmc):
     tflops = k["flops"] / sec / 1e12
     gbs = k["bytes"] / sec / 1e9
     traffic, src = None, None
+    # a family may pool several device kernels (C3: the wave-specialised and the persistent NN kernel are both "gemm_nn"): traffic and
+    # the rocprofv3 duration are then launch-weighted means over the kernels listed
+    kernels = (kernel,) if isinstance(kernel, str) else tuple(kernel)
+    kernel = kernels[0]
     if pmc is not None:
-        rec = pmc.get("kernels", {}).get(kernel)
-        if rec is not None:
-            fresh = pmc["_fresh"].get(rec.get("source"), False)
-            if fresh:
-                traffic = rec["hbm_bytes_per_launch"]
-            src = "%s%s" % (pmc["_file"], "" if fresh else " (not used: %s changed since that PMC pass, or the pass predates source hashes)" % rec.get("source"))
-    e = {"family": family, "kernel": kernel, "what": what, "bound": bound,
+        recs = [pmc.get("kernels", {}).get(kn) for kn in kernels]
+        recs = [r for r in recs if r is not None and r.get("launches_seen", 0) > 0]
+        if recs:
+            stale = sorted(set(r.get("source") for r in recs if not pmc["_fresh"].get(r.get("source"), False)))
+            if not stale:
+                n = sum(r["launches_seen"] for r in recs)
+                traffic = sum(r.get("hbm_bytes_total", r["hbm_bytes_per_launch"] * r["launches_seen"]) for r in recs) / n
+            src = "%s%s" % (pmc["_file"], "" if not stale else " (not used: %s changed since that PMC pass, or the pass predates source hashes)" % ", ".join(str(v) for v in stale))
+    e = {"family": family, "kernel": kernel if len(kernels) == 1 else " + ".join(kernels), "what": what, "bound": bound,
          "launches": k["count"], "avg_launch_us": 1e3 * k["ms"] / k["count"],
          "algorithmic_bytes_per_launch": k["bytes"] / k["count"], "algorithmic_flops_per_launch": k["flops"] / k["count"],
          "traffic": traffic, "traffic_source": src,
@@ -341,6 +418,21 @@ def roofline_entry(prof, family, kernel, bound, what, pmc):
         e.update({"achieved": tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tflops / PEAK_F32_MFMA_TFLOPS})
     else:
         e.update({"achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS})
+    # the same fraction by the OTHER clock: the committed rocprofv3 summary's average duration of this kernel (another box, another
+    # run: `frac` above is this run's HIP events)
+    e["frac_rocprof"], e["rocprof_avg_launch_us"], e["rocprof_source"] = None, None, None
+    if rocprof is not None:
+        recs = [(kn, rocprof["kernels"].get(kn)) for kn in kernels]
+        recs = [(kn, r) for kn, r in recs if r is not None]
+        if recs:
+            stale = sorted(set(str(rocprof["source_of"].get(kn)) for kn, _ in recs if not rocprof["_fresh"].get(rocprof["source_of"].get(kn), False)))
+            fresh = not stale
+            e["rocprof_source"] = "%s%s" % (rocprof["_file"], "" if fresh else " (not used: %s changed since that profile, or it has no source hashes)" % ", ".join(stale))
+            if fresh:
+                us = sum(r["avg_us"] * r["launches"] for _, r in recs) / sum(r["launches"] for _, r in recs)
+                per = (e["algorithmic_flops_per_launch"] / 1e12 / PEAK_F32_MFMA_TFLOPS) if bound == "mfma" else (e["algorithmic_bytes_per_launch"] / 1e9 / PEAK_HBM_GBS)
+                e["rocprof_avg_launch_us"] = us
+                e["frac_rocprof"] = per / (us * 1e-6)
     return e
 
 
@@ -762,8 +854,9 @@ def main():
             profiler.detach()
             prof = profiler.collect()
             pmc = load_pmc_traffic()
+            rocprof = load_rocprof_stats()
             for family, kernel, bound, what in ROOFLINE_KERNELS:
-                e = roofline_entry(prof, family, kernel, bound, what, pmc)
+                e = roofline_entry(prof, family, kernel, bound, what, pmc, rocprof)
                 if e is not None:
                     stages.append(e)
             # the line's `roofline` = the dominant kernel of the step: the GEMM family with the largest summed HIP-event time
@@ -1000,8 +1093,35 @@ def main():
                     e["alone_avg_launch_us"] = us
                     e["alone_frac_hbm"] = e["algorithmic_bytes_per_launch"] / (us * 1e-6) / 1e9 / PEAK_HBM_GBS
                     e["alone_frac_flops"] = e["algorithmic_flops_per_launch"] / (us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS
+            # the augment stage ALONE, the same way (its in-situ 0.44 of HBM is measured beside the training step on a low-priority
+            # stream: this says whether the kernel or the contention is short of the roof): the last batch's own draw parameters,
+            # 20 back-to-back launches
+            di, df, do = proc._keep
+            Bk = int(di.numel() // 2)
+            bank = proc.bank
+            fn = "kws_augment_i16" if bank.clips.dtype == torch.int16 else "kws_augment_f32"
+            out_t = torch.empty((Bk, 16000), dtype=torch.float32, device=device)
+
+            def aug():
+                _lib.call(fn, _lib.ptr(bank.clips), bank.n_clips, 16000, _lib.ptr(di[:Bk]), _lib.ptr(df[:Bk]), _lib.ptr(di[Bk:]),
+                          _lib.ptr(bank.noise), 0 if bank.noise is None else bank.noise.numel(),
+                          _lib.ptr(do) if bank.noise is not None else None, _lib.ptr(df[Bk:]), _lib.ptr(out_t), Bk, _lib.stream_ptr(st))
+            with torch.cuda.stream(st):
+                for _ in range(3):
+                    aug()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(st)
+                for _ in range(20):
+                    aug()
+                e1.record(st)
+            e1.synchronize()
+            us_a = 1e3 * e0.elapsed_time(e1) / 20
+            for e in stages:
+                if e["family"] == "augment":
+                    e["alone_avg_launch_us"] = us_a
+                    e["alone_frac_hbm"] = e["algorithmic_bytes_per_launch"] / (us_a * 1e-6) / 1e9 / PEAK_HBM_GBS
         except Exception as ex:
-            sys.stderr.write("standalone STFT timing skipped: %r\n" % (ex,))
+            sys.stderr.write("standalone STFT / augment timing skipped: %r\n" % (ex,))
 
     # ---- the other single-GPU BASELINE configurations on the record (N = 1 only; < 2 s each): configs[2] = C3, the 32-class
     # conv_1d_log_mfcc net at batch 2048 (freeze_graph_32_classes.py:55-69), configs[4] = C5 on this one GPU, TTA inference
@@ -1020,14 +1140,37 @@ def main():
             c3 = bench_configs.c3(steps=30, warm=5, profile_steps=3)
             kern = c3.pop("kernels", None) or {}
             fams = sorted([f for f in kern if kern[f]["ms"] > 0], key=lambda f: -kern[f]["ms"])
-            c3["kernel_ms_per_step"] = {f: kern[f]["ms"] / 3 for f in fams[:8]}
-            if fams:
-                dom = fams[0]
-                bound = "mfma" if dom.startswith("gemm") or dom.startswith("conv1") else "hbm"
-                c3["roofline"] = roofline_entry(kern, dom, {"gemm_nn": "gemm_nn_ws_kernel", "gemm_tn": "gemm_tn_ws_kernel", "gemm_bwd_pair": "gemm_dgrad_wgrad_kernel"}.get(dom, dom + "_kernel"),
-                                                bound, "dominant kernel family of the C3 step by summed HIP-event time", None)
+            c3["kernel_ms_per_step"] = {f: kern[f]["ms"] / 3 for f in fams[:10]}
+            c3["launches_per_step"] = sum(kern[f]["count"] for f in kern) / 3.0
+            # every family of the C3 step against both roofs, with the PMC traffic and the rocprofv3 durations of scripts/profile_c3.sh
+            # (profiles/r0N_pmc_traffic_c3.json, r0N_kernel_stats_c3.csv: the DEFAULT schedule only) while the kernels' sources are unchanged
+            pmc3, roc3 = load_pmc_traffic("r*_pmc_traffic_c3.json"), load_rocprof_stats("r*_kernel_stats_c3.csv")
+            c3_stages = []
+            for family, kernel, bound, what in C3_ROOFLINE_KERNELS:
+                e = roofline_entry(kern, family, kernel, bound, what, pmc3, roc3)
+                if e is not None:
+                    e["ms_per_step"] = kern[family]["ms"] / 3
+                    c3_stages.append(e)
+            gemm3 = [e for e in c3_stages if e["family"] in ("gemm_bwd_pair", "gemm_nn")]
+            c3["roofline"] = max(gemm3, key=lambda e: e["ms_per_step"]) if gemm3 else None
+            c3["roofline_stages"] = [e for e in c3_stages if e is not c3["roofline"]]
+            gflop = sum(kern[f]["flops"] for f in kern if f.startswith("gemm")) / 3.0
+            c3["end_to_end"] = {"gemm_flops_per_step": gflop, "frac_of_f32_mfma_peak": gflop / (c3["ms_per_step"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                "algorithmic_bytes_per_step": sum(kern[f]["bytes"] for f in kern) / 3.0,
+                                "frac_of_hbm_peak": sum(kern[f]["bytes"] for f in kern) / 3.0 / (c3["ms_per_step"] * 1e-3) / 1e9 / PEAK_HBM_GBS}
             configs["C3"] = c3
-            configs["C5"] = bench_configs.c5(speed_tta=True, n=10, warm=3)   # x3 AND the six-term speed TTA BASELINE configs[4] names
+            c5 = bench_configs.c5(speed_tta=True, n=10, warm=3)   # x3 AND the six-term speed TTA BASELINE configs[4] names
+            k5 = c5.pop("kernels", None) or {}
+            if k5:      # plain inference (one forward of 4096 clips): the dominant family + the end-to-end MFMA fraction
+                n5 = float(c5.get("profiled_batches", 1))
+                roc5 = load_rocprof_stats("r*_kernel_stats_c5.csv")
+                e5 = roofline_entry(k5, "gemm_nn", "gemm_nn_ws_kernel", "mfma", "pointwise 1x1 convolutions, forward (plain inference, batch 4096)", None, roc5)
+                gf5 = sum(k5[f]["flops"] for f in k5 if f.startswith("gemm") or f.startswith("conv1")) / n5
+                c5["roofline"] = e5
+                c5["roofline_stages"] = [e for e in (roofline_entry(k5, f, kn, b, w, None, roc5) for f, kn, b, w in C5_ROOFLINE_KERNELS) if e is not None]
+                c5["end_to_end"] = {"gemm_flops_per_batch": gf5,
+                                    "frac_of_f32_mfma_peak": gf5 / (c5["plain_inference_ms_per_batch"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}
+            configs["C5"] = c5
         except Exception as ex:
             configs["error"] = repr(ex)
             sys.stderr.write("configs legs failed: %r\n" % (ex,))
@@ -1099,7 +1242,7 @@ def main():
                 try:
                     sys.path.insert(0, os.path.join(ROOT, "scripts"))
                     import val_acc_parity
-                    out.update(val_acc_parity.run(device, quiet=True, negative_controls=("bn_c2",)))
+                    out.update(val_acc_parity.run(device, quiet=True, negative_controls=("dw_flip",)))
                 except Exception as e:
                     out["val_acc_error"] = repr(e)
             else:

@@ -185,4 +185,5 @@ class TorchTimeSlicedNet(object):
                 self.state['batch_normalization_%d/moving_mean' % idx].mul_(0.99).add_(0.01 * mean)
                 self.state['batch_normalization_%d/moving_variance' % idx].mul_(0.99).add_(0.01 * var)
             acc = float((p.argmax(dim=1) == yt.argmax(dim=1)).float().mean())
+        self.last_data_loss = float(loss.detach())      # the batch's data loss alone (what the device's metrics row holds)
         return float((loss + reg).detach()), acc

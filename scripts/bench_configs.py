@@ -105,6 +105,16 @@ def c5(speed_tta=True, n=10, warm=3):
            "batch": B, "ms_per_batch": ms_tta, "clips_per_s": B / ms_tta * 1e3, "plain_inference_ms_per_batch": ms_plain,
            "plain_inference_clips_per_s": B / ms_plain * 1e3, "n_gpus": 1, "dtype": "f32", "gemm_arm": ARM[net.gemm_mode],
            "data": "synthetic"}
+    # per-family HIP-event times of PLAIN inference (the caller builds C5's roofline object from them)
+    prof = _lib.Profiler()
+    prof.attach()
+    for _ in range(3):
+        net.predict(x)
+    torch.cuda.synchronize()
+    out["kernels"] = prof.collect()
+    out["profiled_batches"] = 3
+    prof.detach()
+    prof.close()
     if speed_tta:
         # make_submission.py use_speed_tta: three more passes over the 0.9x time-stretched clips, stretched on the
         # device inside the timed region (the reference reads them from the offline set of create_tta_set.py)

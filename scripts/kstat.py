@@ -2,4 +2,5 @@
 import csv, sys
 for r in csv.DictReader(open(sys.argv[1])):
     if sys.argv[2] in r['Name']:
-        print("%s calls %s avg %.1f us" % (r['Name'].split('(')[0].replace('void ', '').replace('(anonymous namespace)::', ''), r['Calls'], float(r['AverageNs']) / 1e3))
+        name = r['Name'].replace('void ', '').replace('(anonymous namespace)::', '').split('(')[0]
+        print("%s calls %s avg %.1f us" % (name, r['Calls'], float(r['AverageNs']) / 1e3))

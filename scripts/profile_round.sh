@@ -16,7 +16,7 @@ BENCH="python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-val-acc --n
 mkdir -p gpurun_out
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats -- $BENCH > gpurun_out/${tag}_stats.log 2>&1
 f=$(find gpurun_out/${tag}_stats -name "*kernel_stats.csv" | head -1)
-[ -n "$f" ] && cp "$f" gpurun_out/${tag}_kernel_stats_bench_b1024.csv
+[ -n "$f" ] && cp "$f" gpurun_out/${tag}_kernel_stats_bench_b1024.csv && python3 scripts/stats_sources.py gpurun_out/${tag}_kernel_stats_bench_b1024.csv
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/${tag}_pmc_$c -- python3 bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-val-acc --no-ab --no-configs --profile-steps 0 > gpurun_out/${tag}_pmc_$c.log 2>&1
 done

@@ -153,8 +153,18 @@ def run_one(device, proc, settings, words, seed, epochs, steps, batch, val_batch
         class Schedule(Callback):
             def on_epoch_begin(self, epoch, logs=None):
                 self.model.optimizer.lr.value = np.float32(lr_of_epoch(epoch, epochs))
+
+        class FirstEpochSteps(Callback):          # the per-step data loss of epoch 0 (the device's metrics ring, read once at epoch end)
+            def __init__(self):
+                Callback.__init__(self)
+                self.loss = []
+
+            def on_epoch_end(self, epoch, logs=None):
+                if epoch == 0:
+                    self.loss = [float(v) / batch for v in self.model._ring[:steps, 0].cpu().numpy()]
+        first = FirstEpochSteps()
         t0 = time.time()
-        hist = model.fit_generator(train, steps_per_epoch=steps, epochs=epochs, verbose=0, callbacks=[Schedule(), cb],
+        hist = model.fit_generator(train, steps_per_epoch=steps, epochs=epochs, verbose=0, callbacks=[Schedule(), first, cb],
                                    max_queue_size=1)
         torch.cuda.synchronize()
         t_dev = time.time() - t0
@@ -175,7 +185,7 @@ def run_one(device, proc, settings, words, seed, epochs, steps, batch, val_batch
         series breaks one of the bars against `stop_when_tripped` (the device's series)"""
         twin = TorchTimeSlicedNet(numpy_net=ora, threads=cpu_threads or min(os.cpu_count() or 1, 16), mutation=mutation)
         twin.init_optimizer('rmsprop')
-        ser = {"val_acc": [], "val_loss": [], "train_acc": [], "train_loss": []}
+        ser = {"val_acc": [], "val_loss": [], "train_acc": [], "train_loss": [], "first_steps_data_loss": []}
         for e in range(n_epochs):
             accs, losses = [], []
             for s in range(steps):
@@ -184,6 +194,8 @@ def run_one(device, proc, settings, words, seed, epochs, steps, batch, val_batch
                 l, a = twin.train_step(X, y, float(np.float32(lr_of_epoch(e, epochs))), seed=model.seed, step=k)
                 accs.append(a)
                 losses.append(l)
+                if e == 0:
+                    ser["first_steps_data_loss"].append(twin.last_data_loss)
             ser["train_acc"].append(float(np.mean(accs)))
             ser["train_loss"].append(float(np.mean(losses)))       # data loss (label smoothing 0.1) + L2, as Keras logs it
             vb = val.batches[e * val_batches:(e + 1) * val_batches]
@@ -201,14 +213,15 @@ def run_one(device, proc, settings, words, seed, epochs, steps, batch, val_batch
     t_cpu = time.time() - t0
     # NEGATIVE CONTROLS: the same twin with a deliberately wrong backward pass, on the same batches, judged against
     # the DEVICE's series by the same bars the parity test asserts - a suite whose bars no wrong gradient can break proves nothing
-    dev_ser = {"val_acc": dev_acc, "val_loss": dev_loss, "train_acc": dev_train_acc, "train_loss": dev_train_loss}
+    dev_ser = {"val_acc": dev_acc, "val_loss": dev_loss, "train_acc": dev_train_acc, "train_loss": dev_train_loss,
+               "first_steps_data_loss": first.loss}
     controls = {}
     for mut in negative_controls:
         t0 = time.time()
         ser = run_twin(min(nc_epochs, epochs), mutation=mut, stop_when_tripped=dev_ser)
         n = len(ser["train_acc"])
         controls[mut] = {"epochs_run": n, "tripped": tripped_bars(dev_ser, ser, n_epochs=n, settled=False), "train_acc": ser["train_acc"],
-                         "train_loss": ser["train_loss"], "device_train_loss": dev_train_loss[:n], "unmutated_twin_train_loss": cpu_ser["train_loss"][:n],
+                         "train_loss": ser["train_loss"], "device_train_loss": dev_train_loss[:n], "first_steps_data_loss": ser["first_steps_data_loss"], "unmutated_twin_train_loss": cpu_ser["train_loss"][:n],
                          "val_loss": ser["val_loss"], "device_train_acc": dev_train_acc[:n],
                          "unmutated_twin_train_acc": cpu_train_acc[:n], "seconds": time.time() - t0}
     # "settled" = the median of the last three epochs: with Keras' BatchNorm momentum of 0.99 the inference-mode accuracy of
@@ -216,9 +229,11 @@ def run_one(device, proc, settings, words, seed, epochs, steps, batch, val_batch
     settled = lambda a: float(np.median(a[-3:]))
     return {"seed": int(seed), "val_acc_settled": settled(dev_acc), "val_acc_cpu_settled": settled(cpu_acc),
             "val_acc_best": max(dev_acc), "val_acc_cpu_best": max(cpu_acc), "val_acc_last": dev_acc[-1], "val_acc_cpu_last": cpu_acc[-1],
-            "device": {"val_acc": dev_acc, "val_loss": dev_loss, "train_acc": dev_train_acc, "train_loss": dev_train_loss, "seconds": t_dev,
+            "device": {"val_acc": dev_acc, "val_loss": dev_loss, "train_acc": dev_train_acc, "train_loss": dev_train_loss,
+                       "first_steps_data_loss": first.loss, "seconds": t_dev,
                        "lr_replay": replay_reduce_lr(dev_acc)},
-            "cpu": {"val_acc": cpu_acc, "val_loss": cpu_loss, "train_acc": cpu_train_acc, "train_loss": cpu_ser["train_loss"], "seconds": t_cpu,
+            "cpu": {"val_acc": cpu_acc, "val_loss": cpu_loss, "train_acc": cpu_train_acc, "train_loss": cpu_ser["train_loss"],
+                    "first_steps_data_loss": cpu_ser["first_steps_data_loss"], "seconds": t_cpu,
                     "lr_replay": replay_reduce_lr(cpu_acc),
                     "what": "oracle/torch_net.py (torch-CPU f32), same batches, same dropout masks, same RMSprop"},
             "tripped": tripped_bars(dev_ser, cpu_ser),

@@ -57,7 +57,7 @@ struct Conv1Args {
 // Rows that lie fully inside their clip (all but the first row of a clip) are read with unconditional 8-byte loads; the
 // others - and the rows past M - read this zero buffer instead, and only a row that straddles the clip start is patched
 // element by element.  (A per-load `inside ? load : 0` compiles to a branch and a vmcnt(0) per load.)
-__device__ __attribute__((aligned(16))) float g_zero64[64] = {0.f};   // not const: a constant-address-space operand turns the selected loads into flat loads
+__device__ __attribute__((aligned(16))) float g_zero64[128] = {0.f};   // (>= one whole 80-sample row) not const: a constant-address-space operand turns the selected loads into flat loads
 
 __device__ __forceinline__ float2 load2_or_zero(const float* xb, int pos, int x_len) {
   if (pos >= 0 && pos + 1 < x_len) return *reinterpret_cast<const float2*>(xb + pos);
@@ -219,6 +219,208 @@ __global__ __launch_bounds__(256, 3) void conv1_fwd_kernel(Conv1Args p) {
     __syncthreads();
     const int q = tid >> 7, c = tid & 127;
     p.stats[((int64_t)blockIdx.x * 2 + q) * NOUT + c] = sRed[q][0][c] + sRed[q][1][c];
+  }
+}
+
+// Round 6: the forward kernel with the pointwise GEMMs' WAVE ROLES (gemm.hip gemm_nn_ws_kernel).  Round 5's ablations of the
+// kernel above (profiles/r05_conv1_fwd_ablation.txt): the MFMA loop with its LDS reads alone 75.3 us, the shipped kernel 94.5 - every
+// non-MFMA instruction in an MFMA wave's stream (32 output stores, 64 statistics operations, 10 row loads and LDS writes per tile) costs
+// matrix cycles, and software-pipelining them inside the same four waves ran out of registers at three workgroups per CU.  Here ONE
+// 8-wave workgroup per CU:
+//   waves 0-3  MFMA only: the same (wr, wc) blocks, the same folded kernel in registers, the same k order - with the two MFMA
+//              operands SWAPPED (D = W^T-fragment x row-fragment: the products and their order are unchanged, every output element
+//              is bit-identical) so that a lane's four consecutive accumulator registers are four consecutive COLUMNS of one output
+//              row: a finished tile leaves as 8 ds_write_b128 per lane into an LDS staging tile.  Two accumulator sets: tile t's set
+//              is staged after the first K group of tile t + 1 has been issued, so the matrix pipe never drains;
+//   waves 4-5  loaders: wave w stages the rows of its tiles t = w (mod 2) - lane = row, 40 8-byte loads, issued two iterations
+//              before they are written to LDS;
+//   waves 6-7  storers: the staging tile of iteration t - 2 to global memory as 16-byte row stores (a wave instruction = two whole
+//              512-byte rows) and the BatchNorm column sums on the way (running sums per thread over all tiles, folded in a fixed
+//              order at the end: ONE statistics row per workgroup, as before - the same sums in another fixed order).
+// One barrier per tile.  LDS: 2 x 21.5 KB rows + 2 x 33.8 KB staging.
+template <int KF, bool STATS>
+__global__ __launch_bounds__(512, 1) void conv1_fwd_ws_kernel(Conv1Args p) {
+  constexpr int PA = KF + 4;        // LDS row pitch of the staged rows
+  constexpr int NQ = KF / 8;
+  constexpr int NL = KF / 2;        // 8-byte loads per loader lane (one whole row)
+  constexpr int SLD = NOUT + 4;     // staging row pitch: conflict-free b128 writes
+  __shared__ __attribute__((aligned(16))) float sA[2][FM * PA];
+  __shared__ __attribute__((aligned(16))) float sC[2][FM * SLD];
+  __shared__ float sRed[2][4][NOUT];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int n_my = (p.m_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // >= 1: the grid is at most m_tiles
+  // iterations it = 0 .. n_my + 1: MFMA waves multiply local tile it (it < n_my) and stage tile it - 1 (1 <= it <= n_my); the
+  // storers move tile it - 2 (it >= 2); a loader writes tile it + 1 (its own) and re-issues.  Barriers per wave: 1 + n_my + 2 (+ 1)
+  if (wave < 4) {
+    // ---------------------------------------------------------------- MFMA waves
+    const int li = lane & 31, lh = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
+    float wreg[NQ][4][2];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {                  // fold on load: as conv1_fwd_kernel (same candidates, same order of the adds)
+      float wv[3][4][2];
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            const int sidx = q * 8 + lh * 4 + r, n = wc * 64 + jj * 32 + li;
+            const int c = sidx - p.hop * j;
+            const bool ok = j < p.taps && c >= 0 && c < p.cin;
+            const float* src = ok ? p.W + ((int64_t)j * p.cin + c) * NOUT + n : g_zero64;
+            wv[j][r][jj] = *src;
+          }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          wreg[q][r][jj] = ((0.f + wv[0][r][jj]) + wv[1][r][jj]) + wv[2][r][jj];
+          asm volatile("" : "+v"(wreg[q][r][jj]));
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    f32x16 accA[2], accB[2];
+    // stage a finished set: register group vq of block jj = columns 64 wc + 32 jj + 8 vq + 4 lh .. + 3 of row 32 wr + li
+    auto stage = [&](const f32x16 (&acc)[2], int buf) {
+      float* dst = &sC[buf][(wr * 32 + li) * SLD + wc * 64 + 4 * lh];
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int vq = 0; vq < 4; ++vq)
+          *reinterpret_cast<float4*>(dst + jj * 32 + 8 * vq) =
+              make_float4(acc[jj][4 * vq], acc[jj][4 * vq + 1], acc[jj][4 * vq + 2], acc[jj][4 * vq + 3]);
+    };
+    auto iteration = [&](int it, f32x16 (&cur)[2], const f32x16 (&prev)[2]) {
+      if (it < n_my) {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+          for (int v = 0; v < 16; ++v) cur[jj][v] = 0.f;
+        const float* cA = &sA[it & 1][(wr * 32 + li) * PA + lh * 4];
+        float4 av[3];
+        av[0] = *reinterpret_cast<const float4*>(cA);
+        av[1] = *reinterpret_cast<const float4*>(cA + 8);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          if (q + 2 < NQ) av[(q + 2) % 3] = *reinterpret_cast<const float4*>(cA + (q + 2) * 8);
+          __builtin_amdgcn_sched_barrier(0);
+          const float4 ac = av[q % 3];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float a = r == 0 ? ac.x : (r == 1 ? ac.y : (r == 2 ? ac.z : ac.w));
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) cur[jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[q][r][jj], a, cur[jj], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (q == 0 && it >= 1) {                  // the previous tile's set, under the MFMAs just issued
+            stage(prev, (it - 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      } else if (it == n_my) {
+        stage(prev, (it - 1) & 1);
+      }
+      __syncthreads();
+    };
+    __syncthreads();                                // prologue: tile 0 staged by loader 0
+    for (int it = 0; it <= n_my + 1; it += 2) {
+      iteration(it, accA, accB);
+      if (it + 1 <= n_my + 1) iteration(it + 1, accB, accA);
+    }
+    if (STATS) __syncthreads();
+  } else if (wave < 6) {
+    // ---------------------------------------------------------------- loader waves: lane = row of my tiles
+    // Branch-free: ONE buffer descriptor over the whole input, 40 8-byte buffer loads per row at immediate offsets.  A row that hangs
+    // over its clip's start (the first row of every clip: 10 samples) reads the previous clip's tail - or, before the first clip and
+    // for the rows past M, nothing: the descriptor's range check returns zeros - and the samples outside the clip are zeroed in LDS
+    // afterwards by the one lane that owns the row.  (The element-by-element patch of conv1_fwd_kernel is 80 loads behind branches:
+    // a loader wave that runs it holds the whole workgroup at the barrier.)
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    const int lw = wave - 4;
+    const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x), 0, (unsigned)((int64_t)p.B * p.g.x_batch_stride * 4), 0x00020000);
+    float2 ra[NL];
+    int e0_cur = 0;                                 // first sample of my row inside its clip (of the tile held in ra)
+    bool ok_cur = false;
+    auto issue = [&](int loc) {                     // local tile loc (>= n_my: nothing to load)
+      if (loc >= n_my) return;
+      const int tile = (int)blockIdx.x + loc * (int)gridDim.x;
+      const unsigned m = (unsigned)tile * FM + lane;
+      ok_cur = (int64_t)m < p.M;
+      const unsigned b = m / (unsigned)p.g.L_out;
+      const int t = (int)(m - b * (unsigned)p.g.L_out);
+      e0_cur = t * p.g.stride_t + p.g.base_off;
+      // byte offset of the row's first sample; a row past M (or in front of the buffer) points past the descriptor's range
+      const unsigned voff = ok_cur ? (b * (unsigned)p.g.x_batch_stride + (unsigned)e0_cur) * 4u : 0xFFFFF000u;
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(xres, voff + 8 * i, 0, 0);
+        ra[i] = make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+      }
+    };
+    auto write_lds = [&](int loc) {
+      if (loc >= n_my) return;
+      float* dst = &sA[loc & 1][lane * PA];
+#pragma unroll
+      for (int i = 0; i < NL; ++i) *reinterpret_cast<float2*>(dst + 2 * i) = ra[i];
+      if (ok_cur && (e0_cur < 0 || e0_cur + KF > p.g.x_len)) {     // rare: the samples of this row that lie outside its clip are zeros
+        for (int k = 0; k < KF; ++k)
+          if (e0_cur + k < 0 || e0_cur + k >= p.g.x_len) dst[k] = 0.f;
+      }
+    };
+    int mine = lw;                                  // my next tile
+    issue(mine);
+    if (lw == 0) {
+      write_lds(0);
+      mine += 2;
+      issue(mine);
+    }
+    __syncthreads();
+    for (int it = 0; it <= n_my + 1; ++it) {
+      if (mine == it + 1) {                         // slot (it + 1) & 1 was last read in iteration it - 1
+        write_lds(mine);
+        mine += 2;
+        issue(mine);
+      }
+      __syncthreads();
+    }
+    if (STATS) __syncthreads();
+  } else {
+    // ---------------------------------------------------------------- storer waves
+    const int st = tid - 384;                       // 0 .. 127
+    const int c4 = st & 31, rg = st >> 5;           // columns 4 c4 .. 4 c4 + 3; rows rg, rg + 4, ...
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f), ss = s;
+    __syncthreads();
+    for (int it = 0; it <= n_my + 1; ++it) {
+      if (it >= 2) {
+        const int loc = it - 2;
+        const int tile = (int)blockIdx.x + loc * (int)gridDim.x;
+        const float* src = &sC[loc & 1][rg * SLD + 4 * c4];
+        const int64_t m0 = (int64_t)tile * FM + rg;
+        float* dst = p.y + m0 * NOUT + 4 * c4;
+        const bool whole = (int64_t)(tile + 1) * FM <= p.M;
+#pragma unroll
+        for (int i = 0; i < FM / 4; ++i) {
+          const float4 v = *reinterpret_cast<const float4*>(src + 4 * i * SLD);
+          if (whole || m0 + 4 * i < p.M) *reinterpret_cast<float4*>(dst + (int64_t)4 * i * NOUT) = v;
+          if (STATS) {                              // rows past M were staged as zeros: they add nothing
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            ss.x = fmaf(v.x, v.x, ss.x); ss.y = fmaf(v.y, v.y, ss.y); ss.z = fmaf(v.z, v.z, ss.z); ss.w = fmaf(v.w, v.w, ss.w);
+          }
+        }
+      }
+      __syncthreads();
+    }
+    if (STATS) {
+      *reinterpret_cast<float4*>(&sRed[0][rg][4 * c4]) = s;
+      *reinterpret_cast<float4*>(&sRed[1][rg][4 * c4]) = ss;
+      __syncthreads();
+    }
+  }
+  if (STATS && tid < 2 * NOUT) {                    // (every wave has passed the barrier above)
+    const int q = tid >> 7, c = tid & 127;
+    p.stats[((int64_t)blockIdx.x * 2 + q) * NOUT + c] = ((sRed[q][0][c] + sRed[q][1][c]) + sRed[q][2][c]) + sRed[q][3][c];
   }
 }
 
@@ -387,10 +589,15 @@ WgradPlan wgrad_plan(int64_t M) {
 
 }  // namespace
 
-// statistics rows the forward kernel writes = its grid: three persistent 43 KB workgroups per CU
+// statistics rows the forward kernel writes = its grid: ONE persistent 8-wave workgroup per CU (round 6; -DKWS_C1_WS=0 builds the
+// four-wave kernel of rounds 2 - 5: three 43 KB workgroups per CU)
+#ifndef KWS_C1_WS
+#define KWS_C1_WS 1
+#endif
 int kws_conv1_stats_rows(int64_t M) {
   const int64_t tiles = ceil_div64(M, FM);
-  return (int)(tiles < 768 ? tiles : 768);
+  const int64_t cap = KWS_C1_WS ? 256 : 768;
+  return (int)(tiles < cap ? tiles : cap);
 }
 
 bool kws_conv1_supported(const kws_gather_t* g, const kws_gather_t* unfolded, int N) {
@@ -409,8 +616,18 @@ int kws_conv1_fwd(const float* x, const kws_gather_t* g, const kws_gather_t* unf
   a.m_tiles = (int)ceil_div64(a.M, FM);
   KwsProfScope prof("conv1_fwd", 2.0 * a.M * 80 * N, 4.0 * ((double)B * g->x_len + (double)a.M * N + 80.0 * N), st);
   const int grid = kws_conv1_stats_rows(a.M);
+#if KWS_C1_WS
+  // the wave-role kernel addresses the whole input through ONE buffer descriptor with 32-bit byte offsets; a batch beyond that
+  // (> 4 GB of clips) takes the four-wave kernel on the same grid (persistent: any grid; one statistics row per workgroup)
+  if ((int64_t)B * g->x_batch_stride * 4 < 0xFFFFF000ll && a.M < (1ll << 31)) {
+    if (stats) hipLaunchKernelGGL((conv1_fwd_ws_kernel<80, true>), dim3(grid), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((conv1_fwd_ws_kernel<80, false>), dim3(grid), dim3(512), 0, st, a);
+  } else if (stats) hipLaunchKernelGGL((conv1_fwd_kernel<80, true>), dim3(grid), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((conv1_fwd_kernel<80, false>), dim3(grid), dim3(256), 0, st, a);
+#else
   if (stats) hipLaunchKernelGGL((conv1_fwd_kernel<80, true>), dim3(grid), dim3(256), 0, st, a);
   else hipLaunchKernelGGL((conv1_fwd_kernel<80, false>), dim3(grid), dim3(256), 0, st, a);
+#endif
   KWS_LAUNCH_CHECK("conv1_fwd_kernel");
   return KWS_OK;
 }

@@ -48,15 +48,28 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
   p[i] = p[i] + v;
 }
 
-__global__ __launch_bounds__(256) void l2_loss_kernel(const float* __restrict__ p, const float* __restrict__ l2,
-                                                      int64_t n, float* out) {
-  // single workgroup, fixed-order: the buffer is ~1.2M floats (4.8 MB), this is a metric only
-  __shared__ double red[256];
-  double s = 0.0;
-  for (int64_t i = threadIdx.x; i < n; i += 256) s += (double)l2[i] * (double)p[i] * (double)p[i];
-  red[threadIdx.x] = s;
+__global__ __launch_bounds__(1024) void l2_loss_kernel(const float* __restrict__ p, const float* __restrict__ l2,
+                                                       int64_t n, float* out) {
+  // single workgroup (no scratch buffer in the call, re-entrant), fixed order: the buffer is ~1.2 M floats (2 x 4.8 MB), a metric only.
+  // Round 6: 16 waves, 16-byte loads, four independent double accumulators per thread - the 256-thread scalar loop of rounds 1 - 5
+  // took ~1.5 ms per call, and fit_generator reads this value every 16 steps (bench.py ab_fit_generator: 0.1 ms per step)
+  __shared__ double red[1024];
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  const bool aligned = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(l2)) & 15) == 0;
+  const int64_t n4 = aligned ? n / 4 : 0;            // unaligned views take the scalar loop below
+  const float4* p4 = reinterpret_cast<const float4*>(p);
+  const float4* l4 = reinterpret_cast<const float4*>(l2);
+  for (int64_t i = threadIdx.x; i < n4; i += 1024) {
+    const float4 a = p4[i], c = l4[i];
+    s0 += (double)c.x * (double)a.x * (double)a.x;
+    s1 += (double)c.y * (double)a.y * (double)a.y;
+    s2 += (double)c.z * (double)a.z * (double)a.z;
+    s3 += (double)c.w * (double)a.w * (double)a.w;
+  }
+  for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += 1024) s0 += (double)l2[i] * (double)p[i] * (double)p[i];
+  red[threadIdx.x] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
+  for (int o = 512; o > 0; o >>= 1) {
     if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
@@ -91,7 +104,7 @@ int kws_sgd_momentum_step(float* p, const float* grad, float* vel, const float* 
 int kws_l2_loss(const float* p, const float* l2, int64_t n, float* out, void* stream) {
   KWS_REQUIRE(p && l2 && out && n > 0, "l2_loss: bad arguments");
   KwsProfScope prof("l2_loss", 3.0 * n, 8.0 * n, (hipStream_t)stream);
-  hipLaunchKernelGGL(l2_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, p, l2, n, out);
+  hipLaunchKernelGGL(l2_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, p, l2, n, out);
   KWS_LAUNCH_CHECK("l2_loss_kernel");
   return KWS_OK;
 }

@@ -125,15 +125,18 @@ __global__ __launch_bounds__(256) void block_out_bwd_kernel(const float* __restr
 //           the same operation order: bit-identical to "store g, then kws_bn_bwd_apply").
 // 5 tensor passes per join instead of 6, and no launch between the finalise and the next GEMM but this one.  All loads of a
 // unit (TT steps x {dO, y0, y1}) are issued before the first is used - from clamped addresses - as in dwconv.hip.
-template <int P, bool RELU, int PASS>
+#ifndef KWS_JOIN1_THREADS
+#define KWS_JOIN1_THREADS 512          // threads of a PASS 1 workgroup (one workgroup per CU: 512 = 2 waves per SIMD)
+#endif
+template <int P, bool RELU, int PASS, int NT>
 // (dO and out carry no __restrict__: the shortcut BatchNorm's pass 2 runs in place, out == dO with P == 1 - every thread loads its
 // own rows of a unit before it stores them, which is only defined behaviour while the compiler may not assume the two apart)
-__global__ __launch_bounds__(512) void block_join_bwd_kernel(const float* dO, const float* __restrict__ y,
+__global__ __launch_bounds__(NT) void block_join_bwd_kernel(const float* dO, const float* __restrict__ y,
                                                              const float* __restrict__ bn, const float* __restrict__ gamma,
                                                              const float* __restrict__ coef, float* out,
                                                              float* __restrict__ part, int L, int Lo, int C, int nchunks, int R,
                                                              int Cb, int64_t units) {
-  __shared__ float red[2][512 * 4];
+  __shared__ float red[2][NT * 4];
   const int C4 = Cb >> 2;
   const int tid = threadIdx.x;
   const int r = tid / C4, c4 = tid - r * C4;
@@ -838,7 +841,7 @@ int kws_block_out_fwd(const float* y, const float* bn, const float* res, const f
               "block_out_fwd: bad arguments (L=%d C=%d pool=%d)", L, C, pool);
   const int Lo = (L + pool - 1) / pool;             // 'same' pooling: ceil
   const int64_t n4 = (int64_t)B * Lo * C / 4;
-  KwsProfScope prof("block_join", 4.0 * B * L * C, 4.0 * ((double)B * L * C + 2.0 * B * Lo * C), st);
+  KwsProfScope prof("block_out_fwd", 4.0 * B * L * C, 4.0 * ((double)B * L * C + 2.0 * B * Lo * C), st);
   dim3 g((unsigned)ceil_div64(n4, 256)), b(256);
   if (pool == 1) {
     if (res_bn) hipLaunchKernelGGL((block_out_fwd_kernel<1, true>), g, b, 0, st, y, bn, res, res_bn, o, n4, L, Lo, C);
@@ -863,7 +866,7 @@ int kws_block_out_bwd(const float* dO, const float* y, const float* bn, float* g
               "block_out_bwd: bad arguments (L=%d C=%d pool=%d relu=%d)", L, C, pool, relu);
   const int Lo = (L + pool - 1) / pool;
   const Geom ge = geom(B, Lo, C);
-  KwsProfScope prof("block_join", 6.0 * B * L * C, 4.0 * (2.0 * B * L * C + (double)B * Lo * C), st);
+  KwsProfScope prof("block_join_bwd", 6.0 * B * L * C, 4.0 * (2.0 * B * L * C + (double)B * Lo * C), st);
   dim3 gr((unsigned)ge.grid, (unsigned)ge.ny), b((unsigned)ge.block);
   if (pool == 2) hipLaunchKernelGGL((block_out_bwd_kernel<2, true>), gr, b, 0, st, dO, y, bn, g, part, B, L, Lo, C, ge.nchunks, ge.R, ge.Cb);
   else if (relu) hipLaunchKernelGGL((block_out_bwd_kernel<1, true>), gr, b, 0, st, dO, y, bn, g, part, B, L, Lo, C, ge.nchunks, ge.R, ge.Cb);
@@ -878,13 +881,13 @@ struct JoinGeom {
   int nchunks, R, block, ny, Cb, grid;
   int64_t units;
 };
-static JoinGeom join_geom(int B, int Lo, int C) {
+static JoinGeom join_geom(int B, int Lo, int C, int threads = 512) {
   JoinGeom g;
   g.ny = ceil_div(C / 4, 256);
   g.Cb = C / g.ny;
   const int C4 = g.Cb / 4;
   g.nchunks = ceil_div(Lo, TT);
-  g.R = 512 / C4 < 1 ? 1 : 512 / C4;
+  g.R = threads / C4 < 1 ? 1 : threads / C4;
   g.block = g.R * C4;
   g.units = (int64_t)B * g.nchunks;
   const int64_t wgs = ceil_div64(g.units, g.R);
@@ -893,7 +896,7 @@ static JoinGeom join_geom(int B, int Lo, int C) {
 }
 int kws_block_join_bwd_parts(int B, int L, int C, int pool) {
   if (B <= 0 || L <= 0 || !geom_ok(C) || pool < 1) return 0;
-  return join_geom(B, (L + pool - 1) / pool, C).grid;
+  return join_geom(B, (L + pool - 1) / pool, C, KWS_JOIN1_THREADS).grid;
 }
 int kws_block_join_bwd(const float* dO, const float* y, const float* bn, const float* gamma, const float* coef, float* out,
                        float* part, int pass, int B, int L, int C, int pool, int relu, hipStream_t st) {
@@ -901,16 +904,16 @@ int kws_block_join_bwd(const float* dO, const float* y, const float* bn, const f
                   ((pass == 1 && part) || (pass == 2 && gamma && coef && out)),
               "block_join_bwd: bad arguments (L=%d C=%d pool=%d relu=%d pass=%d)", L, C, pool, relu, pass);
   const int Lo = (L + pool - 1) / pool;
-  const JoinGeom ge = join_geom(B, Lo, C);
-  KwsProfScope prof("block_join", 6.0 * B * L * C, 4.0 * ((pass == 1 ? 1.0 : 2.0) * B * L * C + (double)B * Lo * C), st);
+  const JoinGeom ge = join_geom(B, Lo, C, pass == 1 ? KWS_JOIN1_THREADS : 512);
+  KwsProfScope prof("block_join_bwd", 6.0 * B * L * C, 4.0 * ((pass == 1 ? 1.0 : 2.0) * B * L * C + (double)B * Lo * C), st);
   dim3 gr((unsigned)ge.grid, (unsigned)ge.ny), b((unsigned)ge.block);
 #define KWS_JOIN_LAUNCH(P_, RELU_)                                                                                              \
   do {                                                                                                                          \
     if (pass == 1)                                                                                                              \
-      hipLaunchKernelGGL((block_join_bwd_kernel<P_, RELU_, 1>), gr, b, 0, st, dO, y, bn, gamma, coef, out, part, L, Lo, C,       \
+      hipLaunchKernelGGL((block_join_bwd_kernel<P_, RELU_, 1, KWS_JOIN1_THREADS>), gr, b, 0, st, dO, y, bn, gamma, coef, out, part, L, Lo, C, \
                          ge.nchunks, ge.R, ge.Cb, ge.units);                                                                    \
     else                                                                                                                        \
-      hipLaunchKernelGGL((block_join_bwd_kernel<P_, RELU_, 2>), gr, b, 0, st, dO, y, bn, gamma, coef, out, part, L, Lo, C,       \
+      hipLaunchKernelGGL((block_join_bwd_kernel<P_, RELU_, 2, 512>), gr, b, 0, st, dO, y, bn, gamma, coef, out, part, L, Lo, C,  \
                          ge.nchunks, ge.R, ge.Cb, ge.units);                                                                    \
   } while (0)
   if (pool == 2) KWS_JOIN_LAUNCH(2, true);
@@ -927,7 +930,7 @@ int kws_block_out3_fwd(const float* y, const float* bn, const float* res, const 
                   pad_l >= 0 && pad_l <= 1 && (Lo - 1) * stride - pad_l < L,
               "block_out3_fwd: bad arguments (L=%d Lo=%d C=%d stride=%d pad_l=%d)", L, Lo, C, stride, pad_l);
   const int64_t n4 = (int64_t)B * Lo * C / 4;
-  KwsProfScope prof("block_join", 6.0 * B * L * C, 4.0 * ((double)B * L * C + 2.0 * B * Lo * C), st);
+  KwsProfScope prof("block_out_fwd", 6.0 * B * L * C, 4.0 * ((double)B * L * C + 2.0 * B * Lo * C), st);
   dim3 g((unsigned)ceil_div64(n4, 256)), b(256);
   if (res_bn) hipLaunchKernelGGL((block_out3_fwd_kernel<true>), g, b, 0, st, y, bn, res, res_bn, o, n4, L, Lo, C, stride, pad_l);
   else hipLaunchKernelGGL((block_out3_fwd_kernel<false>), g, b, 0, st, y, bn, res, res_bn, o, n4, L, Lo, C, stride, pad_l);
@@ -946,7 +949,7 @@ int kws_block_out3_bwd(const float* dO, const float* y, const float* bn, float* 
                   pad_l >= 0 && pad_l <= 1,
               "block_out3_bwd: bad arguments (L=%d Lo=%d C=%d stride=%d pad_l=%d)", L, Lo, C, stride, pad_l);
   const Geom ge = geom(B, L, C);
-  KwsProfScope prof("block_join", 12.0 * B * L * C, 4.0 * (2.0 * B * L * C + (double)B * Lo * C), st);
+  KwsProfScope prof("block_join_bwd", 12.0 * B * L * C, 4.0 * (2.0 * B * L * C + (double)B * Lo * C), st);
   dim3 gr((unsigned)ge.grid, (unsigned)ge.ny), b((unsigned)ge.block);
   hipLaunchKernelGGL(block_out3_bwd_kernel, gr, b, 0, st, dO, y, bn, g, part, B, L, Lo, C, stride, pad_l, ge.nchunks, ge.R,
                      ge.Cb);

@@ -306,7 +306,15 @@ class GeneratorEnqueuer(object):
     def stop(self):
         self._stop.set()
         if self._thread is not None:
-            self._thread.join(timeout=10)
+            # the producer may sit in queue.put() on a full queue (it polls the stop flag every 50 ms): free a slot so that it
+            # returns at once - a fit_generator call otherwise pays up to 50 ms here (measured: 0.5 ms per step of a 100-step fit)
+            deadline = time.time() + 10.0
+            while self._thread.is_alive() and time.time() < deadline:
+                try:
+                    self.queue.get_nowait()
+                except queue.Empty:
+                    pass
+                self._thread.join(timeout=0.002)
 
 
 # ------------------------------------------------------------------------------------------------

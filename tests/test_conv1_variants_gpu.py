@@ -1,0 +1,43 @@
+"""Round 6: the first convolution's forward kernel was rebuilt with the pointwise GEMMs' wave roles (csrc/conv1.hip
+conv1_fwd_ws_kernel: loader / MFMA / storer waves, the two MFMA operands swapped).  Every OUTPUT element must keep its bits: the
+same products in the same k order.  The four-wave kernel of rounds 2 - 5 still builds with -DKWS_C1_WS=0 (scripts/build_variant.sh);
+this test builds that variant on the box and compares the two libraries' first-convolution outputs bit for bit at awkward batch
+sizes (1, 3, 70, 200, 1024: single tile, ragged last tile, more tiles than workgroups).  The BatchNorm statistics are the same sums
+folded in another fixed order (256 rows instead of 768): equal to 1e-6, not bitwise."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_wave_role_forward_kernel_keeps_every_output_bit(repo_root, tmp_path):
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc on this box: the reference variant cannot be built")
+    r = subprocess.run(["bash", os.path.join(repo_root, "scripts", "build_variant.sh"), "c1old", "-DKWS_C1_WS=0", "conv1"], cwd=repo_root,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    outs = {}
+    for tag, lib in (("new", None), ("old", os.path.join(repo_root, "variants", "libkws_c1old.so"))):
+        env = dict(os.environ)
+        env.pop("KWS_LIB_PATH", None)
+        if lib:
+            env["KWS_LIB_PATH"] = lib
+        f = str(tmp_path / (tag + ".npz"))
+        r = subprocess.run([sys.executable, os.path.join(repo_root, "scripts", "dump_conv1_y.py"), f], cwd=repo_root, env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert ("libkws_c1old" in r.stdout) == (lib is not None), r.stdout
+        outs[tag] = np.load(f)
+    for k in outs["new"].files:
+        a, b = outs["new"][k], outs["old"][k]
+        if k.startswith("y0_") or k.startswith("pred_"):
+            assert a.shape == b.shape and np.array_equal(a, b), k          # outputs: bit for bit (pred: inference, no statistics at all)
+        elif k.startswith("bn0_"):
+            np.testing.assert_allclose(a, b, rtol=2e-6, atol=1e-7, err_msg=k)      # scale | shift | mean | rstd from re-ordered sums
+        else:
+            np.testing.assert_allclose(a, b, rtol=0, atol=2e-6, err_msg=k)
+    assert float(np.abs(outs["new"]["y0_1024"]).max()) > 0

@@ -14,8 +14,19 @@ pytestmark = pytest.mark.gpu
 def test_val_acc_parity_device_vs_cpu_oracle(repo_root):
     sys.path.insert(0, os.path.join(repo_root, "scripts"))
     import val_acc_parity
-    res = val_acc_parity.run(epochs=9, steps=100, batch=64, quiet=True)      # (9 x 100 steps x 2 seeds: ~ 170 s, the CPU twin is 150 of them)
+    # (9 x 100 steps x 2 seeds: ~ 110 s, the CPU twin is 100 of them; + 2 epochs of the negative control on the first seed)
+    res = val_acc_parity.run(epochs=9, steps=100, batch=64, quiet=True, negative_controls=("dw_flip",))
     par = res["val_acc_parity"]
+    # NEGATIVE CONTROL (round 6): the same twin with a deliberately wrong backward pass (depthwise input gradient with reversed taps) on
+    # the first seed's batches must BREAK the training-curve bar asserted below - a bar no wrong gradient can break proves nothing.
+    # What this run can and cannot see is measured in profiles/r06_negative_controls.txt: structural errors like this one show within
+    # two epochs (0.14 against 0.05); scale-class errors (a BatchNorm backward without its c2 term: 18 % of a gradient) stay inside the
+    # band by which two CORRECT implementations drift apart under RMSprop and ReLU6 kinks - those are caught by the step-level bars,
+    # tests/test_negative_controls_gpu.py
+    nc = par["per_seed"][0]["negative_controls"]["dw_flip"]
+    print("negative control dw_flip:", nc["train_acc"], nc["device_train_acc"], nc["tripped"])
+    assert any(t["bar"] == "train_curve" for t in nc["tripped"]), nc
+    print("bars broken by the unmutated twin (per seed):", [r["tripped"] for r in par["per_seed"]])
     for r in par["per_seed"]:
         print(r["seed"], r["device"]["val_acc"], r["cpu"]["val_acc"], r["device"]["val_loss"], r["cpu"]["val_loss"])
     assert par["validation_rows_disjoint_from_training"] and len(par["per_seed"]) >= 2
@@ -32,6 +43,7 @@ def test_val_acc_parity_device_vs_cpu_oracle(repo_root):
         # the LEARNING CURVES track each other: training accuracy per epoch under the same batches and dropout masks (it climbs
         # 0.51 -> 0.95 over the run: a gradient that is off would bend this curve long before it shows in the settled accuracy;
         # measured differences <= 0.021 in the first three epochs, <= 0.009 after)
+        assert val_acc_parity.BAR_TRAIN_CURVE == (0.05, 0.03) and val_acc_parity.BAR_VAL_LOSS == 0.06
         for e, (a, b) in enumerate(zip(r["device"]["train_acc"], r["cpu"]["train_acc"])):
             assert abs(a - b) < (0.05 if e < 3 else 0.03), (e, a, b)      # (the steep first epochs: 0.51 -> 0.79 -> 0.85)
         assert r["device"]["train_acc"][1] - r["device"]["train_acc"][0] > 0.1 and r["device"]["train_acc"][-1] > 0.9
