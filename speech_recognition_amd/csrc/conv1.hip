@@ -21,8 +21,13 @@
 // __builtin_amdgcn_sched_barrier (168 -> 157 us).
 #include "internal.h"
 
-// -DKWS_C1_ABL=<bits> builds (timing only, wrong results) of conv1_fwd_kernel: without 1 the output stores, 2 the BN statistics
-// sums, 4 the MFMAs, 8 the global row loads
+// -DKWS_C1_WS=1 builds the forward kernel with the pointwise GEMMs' wave roles (round 6's experiment, conv1_fwd_ws_kernel below: bit-identical
+// outputs, measured SLOWER - profiles/r06_conv1_ws.txt - so the shipped library keeps the four-wave kernel)
+#ifndef KWS_C1_WS
+#define KWS_C1_WS 0
+#endif
+// -DKWS_C1_ABL=<bits> builds (timing only, wrong results) of the forward kernels: without 1 the output stores, 2 the BN statistics
+// sums, 4 the MFMAs, 8 the global row loads, 16 (wave-role kernel) the MFMA waves' staging writes
 #ifndef KWS_C1_ABL
 #define KWS_C1_ABL 0
 #endif
@@ -222,7 +227,9 @@ __global__ __launch_bounds__(256, 3) void conv1_fwd_kernel(Conv1Args p) {
   }
 }
 
-// Round 6: the forward kernel with the pointwise GEMMs' WAVE ROLES (gemm.hip gemm_nn_ws_kernel).  Round 5's ablations of the
+#if KWS_C1_WS
+// Round 6 EXPERIMENT (variant builds only, -DKWS_C1_WS=1; measured a LOSS: 104.5 - 106 us against the 92 - 94 us of conv1_fwd_kernel,
+// profiles/r06_conv1_ws.txt): the forward kernel with the pointwise GEMMs' WAVE ROLES (gemm.hip gemm_nn_ws_kernel).  Round 5's ablations of the
 // kernel above (profiles/r05_conv1_fwd_ablation.txt): the MFMA loop with its LDS reads alone 75.3 us, the shipped kernel 94.5 - every
 // non-MFMA instruction in an MFMA wave's stream (32 output stores, 64 statistics operations, 10 row loads and LDS writes per tile) costs
 // matrix cycles, and software-pipelining them inside the same four waves ran out of registers at three workgroups per CU.  Here ONE
@@ -283,6 +290,7 @@ __global__ __launch_bounds__(512, 1) void conv1_fwd_ws_kernel(Conv1Args p) {
     f32x16 accA[2], accB[2];
     // stage a finished set: register group vq of block jj = columns 64 wc + 32 jj + 8 vq + 4 lh .. + 3 of row 32 wr + li
     auto stage = [&](const f32x16 (&acc)[2], int buf) {
+      if (KWS_C1_ABL & 16) { asm volatile("" :: "v"(acc[0][0]), "v"(acc[1][5])); return; }
       float* dst = &sC[buf][(wr * 32 + li) * SLD + wc * 64 + 4 * lh];
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj)
@@ -310,7 +318,10 @@ __global__ __launch_bounds__(512, 1) void conv1_fwd_ws_kernel(Conv1Args p) {
           for (int r = 0; r < 4; ++r) {
             const float a = r == 0 ? ac.x : (r == 1 ? ac.y : (r == 2 ? ac.z : ac.w));
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj) cur[jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[q][r][jj], a, cur[jj], 0, 0, 0);
+            for (int jj = 0; jj < 2; ++jj) {
+              if (KWS_C1_ABL & 4) { cur[jj][(q * 4 + r) & 15] += a * wreg[q][r][jj]; continue; }
+              cur[jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[q][r][jj], a, cur[jj], 0, 0, 0);
+            }
           }
           __builtin_amdgcn_sched_barrier(0);
           if (q == 0 && it >= 1) {                  // the previous tile's set, under the MFMAs just issued
@@ -351,12 +362,24 @@ __global__ __launch_bounds__(512, 1) void conv1_fwd_ws_kernel(Conv1Args p) {
       const unsigned b = m / (unsigned)p.g.L_out;
       const int t = (int)(m - b * (unsigned)p.g.L_out);
       e0_cur = t * p.g.stride_t + p.g.base_off;
-      // byte offset of the row's first sample; a row past M (or in front of the buffer) points past the descriptor's range
-      const unsigned voff = ok_cur ? (b * (unsigned)p.g.x_batch_stride + (unsigned)e0_cur) * 4u : 0xFFFFF000u;
+      // byte offset of the row's first sample; a row past M points past the descriptor's range.  ONE row of the whole batch starts
+      // in front of the buffer (the first row of the first clip): a negative offset does not wrap inside the address unit (offset +
+      // immediate is range-checked unwrapped: the row would read as all zeros), so that lane alone loads element by element
+      const bool front = ok_cur && b == 0 && e0_cur < 0;
+      const unsigned voff = ok_cur && !front ? (b * (unsigned)p.g.x_batch_stride + (unsigned)e0_cur) * 4u : 0xFFFFF000u;
+      if (KWS_C1_ABL & 8) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) ra[i] = make_float2((float)voff, (float)i);
+        return;
+      }
 #pragma unroll
       for (int i = 0; i < NL; ++i) {
         const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(xres, voff + 8 * i, 0, 0);
         ra[i] = make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+      }
+      if (front) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) ra[i] = load2_or_zero(p.x, e0_cur + 2 * i, p.g.x_len);
       }
     };
     auto write_lds = [&](int loc) {
@@ -403,8 +426,9 @@ __global__ __launch_bounds__(512, 1) void conv1_fwd_ws_kernel(Conv1Args p) {
 #pragma unroll
         for (int i = 0; i < FM / 4; ++i) {
           const float4 v = *reinterpret_cast<const float4*>(src + 4 * i * SLD);
-          if (whole || m0 + 4 * i < p.M) *reinterpret_cast<float4*>(dst + (int64_t)4 * i * NOUT) = v;
-          if (STATS) {                              // rows past M were staged as zeros: they add nothing
+          if (KWS_C1_ABL & 1) { asm volatile("" :: "v"(v.x)); }
+          else if (whole || m0 + 4 * i < p.M) *reinterpret_cast<float4*>(dst + (int64_t)4 * i * NOUT) = v;
+          if (STATS && !(KWS_C1_ABL & 2)) {         // rows past M were staged as zeros: they add nothing
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
             ss.x = fmaf(v.x, v.x, ss.x); ss.y = fmaf(v.y, v.y, ss.y); ss.z = fmaf(v.z, v.z, ss.z); ss.w = fmaf(v.w, v.w, ss.w);
           }
@@ -423,6 +447,7 @@ __global__ __launch_bounds__(512, 1) void conv1_fwd_ws_kernel(Conv1Args p) {
     p.stats[((int64_t)blockIdx.x * 2 + q) * NOUT + c] = ((sRed[q][0][c] + sRed[q][1][c]) + sRed[q][2][c]) + sRed[q][3][c];
   }
 }
+#endif  // KWS_C1_WS
 
 // Weight gradient.  dy goes from global memory STRAIGHT into the MFMA operand registers and only the Toeplitz rows of x pass
 // through LDS (20.5 KB double buffered -> three workgroups per CU).  Round 3: v_mfma_f32_16x16x4_f32 instead of 32x32x2 - the
@@ -589,11 +614,8 @@ WgradPlan wgrad_plan(int64_t M) {
 
 }  // namespace
 
-// statistics rows the forward kernel writes = its grid: ONE persistent 8-wave workgroup per CU (round 6; -DKWS_C1_WS=0 builds the
-// four-wave kernel of rounds 2 - 5: three 43 KB workgroups per CU)
-#ifndef KWS_C1_WS
-#define KWS_C1_WS 1
-#endif
+// statistics rows the forward kernel writes = its grid: three persistent 43 KB workgroups per CU (-DKWS_C1_WS=1, round 6's
+// wave-role experiment: ONE 8-wave workgroup per CU)
 int kws_conv1_stats_rows(int64_t M) {
   const int64_t tiles = ceil_div64(M, FM);
   const int64_t cap = KWS_C1_WS ? 256 : 768;

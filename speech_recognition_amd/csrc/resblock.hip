@@ -128,7 +128,10 @@ __global__ __launch_bounds__(256) void block_out_bwd_kernel(const float* __restr
 #ifndef KWS_JOIN1_THREADS
 #define KWS_JOIN1_THREADS 512          // threads of a PASS 1 workgroup (one workgroup per CU: 512 = 2 waves per SIMD)
 #endif
-template <int P, bool RELU, int PASS, int NT>
+#ifndef KWS_JOIN1_TT
+#define KWS_JOIN1_TT 8                 // output steps per thread and unit in PASS 1 (all loads of a unit are issued before the first is used)
+#endif
+template <int P, bool RELU, int PASS, int NT, int TTJ>
 // (dO and out carry no __restrict__: the shortcut BatchNorm's pass 2 runs in place, out == dO with P == 1 - every thread loads its
 // own rows of a unit before it stores them, which is only defined behaviour while the compiler may not assume the two apart)
 __global__ __launch_bounds__(NT) void block_join_bwd_kernel(const float* dO, const float* __restrict__ y,
@@ -152,10 +155,10 @@ __global__ __launch_bounds__(NT) void block_join_bwd_kernel(const float* dO, con
   for (int64_t unit = (int64_t)blockIdx.x * R + r; unit < units; unit += (int64_t)gridDim.x * R) {
     const int64_t b = unit / nchunks;
     const int chunk = (int)(unit - b * nchunks);
-    float4 d[TT], y0[TT], y1[P == 2 ? TT : 1];
+    float4 d[TTJ], y0[TTJ], y1[P == 2 ? TTJ : 1];
 #pragma unroll
-    for (int i = 0; i < TT; ++i) {
-      const int t = chunk * TT + i;
+    for (int i = 0; i < TTJ; ++i) {
+      const int t = chunk * TTJ + i;
       const int tc = t < Lo ? t : Lo - 1;
       d[i] = ld4(dO + (b * Lo + tc) * (int64_t)C + c);
       y0[i] = ld4(y + (b * L + (int64_t)tc * P) * C + c);
@@ -165,9 +168,9 @@ __global__ __launch_bounds__(NT) void block_join_bwd_kernel(const float* dO, con
       }
     }
 #pragma unroll
-    for (int i = 0; i < TT; ++i) {
-      const int t = chunk * TT + i;
-      if (t >= Lo) break;
+    for (int i = 0; i < TTJ; ++i) {
+      const int t = chunk * TTJ + i;
+      if (t >= Lo) continue;
       const int64_t u0 = b * L + (int64_t)t * P;
       const bool two = P == 2 && 2 * t + 1 < L;     // an odd L: the last window has one element
       const float4 dd = d[i], a0 = y0[i];
@@ -881,12 +884,12 @@ struct JoinGeom {
   int nchunks, R, block, ny, Cb, grid;
   int64_t units;
 };
-static JoinGeom join_geom(int B, int Lo, int C, int threads = 512) {
+static JoinGeom join_geom(int B, int Lo, int C, int threads = 512, int tt = TT) {
   JoinGeom g;
   g.ny = ceil_div(C / 4, 256);
   g.Cb = C / g.ny;
   const int C4 = g.Cb / 4;
-  g.nchunks = ceil_div(Lo, TT);
+  g.nchunks = ceil_div(Lo, tt);
   g.R = threads / C4 < 1 ? 1 : threads / C4;
   g.block = g.R * C4;
   g.units = (int64_t)B * g.nchunks;
@@ -896,7 +899,7 @@ static JoinGeom join_geom(int B, int Lo, int C, int threads = 512) {
 }
 int kws_block_join_bwd_parts(int B, int L, int C, int pool) {
   if (B <= 0 || L <= 0 || !geom_ok(C) || pool < 1) return 0;
-  return join_geom(B, (L + pool - 1) / pool, C, KWS_JOIN1_THREADS).grid;
+  return join_geom(B, (L + pool - 1) / pool, C, KWS_JOIN1_THREADS, KWS_JOIN1_TT).grid;
 }
 int kws_block_join_bwd(const float* dO, const float* y, const float* bn, const float* gamma, const float* coef, float* out,
                        float* part, int pass, int B, int L, int C, int pool, int relu, hipStream_t st) {
@@ -904,16 +907,16 @@ int kws_block_join_bwd(const float* dO, const float* y, const float* bn, const f
                   ((pass == 1 && part) || (pass == 2 && gamma && coef && out)),
               "block_join_bwd: bad arguments (L=%d C=%d pool=%d relu=%d pass=%d)", L, C, pool, relu, pass);
   const int Lo = (L + pool - 1) / pool;
-  const JoinGeom ge = join_geom(B, Lo, C, pass == 1 ? KWS_JOIN1_THREADS : 512);
+  const JoinGeom ge = join_geom(B, Lo, C, pass == 1 ? KWS_JOIN1_THREADS : 512, pass == 1 ? KWS_JOIN1_TT : TT);
   KwsProfScope prof("block_join_bwd", 6.0 * B * L * C, 4.0 * ((pass == 1 ? 1.0 : 2.0) * B * L * C + (double)B * Lo * C), st);
   dim3 gr((unsigned)ge.grid, (unsigned)ge.ny), b((unsigned)ge.block);
 #define KWS_JOIN_LAUNCH(P_, RELU_)                                                                                              \
   do {                                                                                                                          \
     if (pass == 1)                                                                                                              \
-      hipLaunchKernelGGL((block_join_bwd_kernel<P_, RELU_, 1, KWS_JOIN1_THREADS>), gr, b, 0, st, dO, y, bn, gamma, coef, out, part, L, Lo, C, \
+      hipLaunchKernelGGL((block_join_bwd_kernel<P_, RELU_, 1, KWS_JOIN1_THREADS, KWS_JOIN1_TT>), gr, b, 0, st, dO, y, bn, gamma, coef, out, part, L, Lo, C, \
                          ge.nchunks, ge.R, ge.Cb, ge.units);                                                                    \
     else                                                                                                                        \
-      hipLaunchKernelGGL((block_join_bwd_kernel<P_, RELU_, 2, 512>), gr, b, 0, st, dO, y, bn, gamma, coef, out, part, L, Lo, C,  \
+      hipLaunchKernelGGL((block_join_bwd_kernel<P_, RELU_, 2, 512, TT>), gr, b, 0, st, dO, y, bn, gamma, coef, out, part, L, Lo, C,  \
                          ge.nchunks, ge.R, ge.Cb, ge.units);                                                                    \
   } while (0)
   if (pool == 2) KWS_JOIN_LAUNCH(2, true);
