@@ -1,6 +1,7 @@
-// The depthwise-backward pass (reference model.py:34-51) as a device function of a block id,
-// shared by dwconv.hip's own kernels and by gemm.hip's dwbwd_wgrad_kernel (round 5: a layer's weight-gradient work items
-// beside its depthwise-backward pass in ONE grid, the CUs partitioned between the two).
+// The depthwise-backward pass (reference model.py:34-51) as a device function of a block id:
+// dwconv.hip's kernels run it on their own grids.  (Round 5 also ran it on the first blocks of a grid that held weight-gradient
+// work items - a measured loss, retired in round 6: scripts/probes/wgrad_beside_dwbwd/ - which is why it takes (bid, nblk, by)
+// instead of reading blockIdx.)
 #pragma once
 #include "internal.h"
 
@@ -30,7 +31,10 @@ __device__ __forceinline__ void st4_stream(float* p, float4 o) {
   *reinterpret_cast<float4*>(p) = o;
 }
 
-constexpr int TT = 8;  // time steps per thread
+#ifndef KWS_DW_TT
+#define KWS_DW_TT 8
+#endif
+constexpr int TT = KWS_DW_TT;  // time steps per thread
 
 __device__ __forceinline__ float4 f4_fma(float4 a, float4 b, float4 c) {
   return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));

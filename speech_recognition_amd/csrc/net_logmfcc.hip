@@ -1033,9 +1033,7 @@ int lm_train(const kws_net* n, const float* params, float* state, const float* x
       float* gw = ws + lo.gwpad;
       KWS_TRY(kws_gemm_tn_gather_f32(x, &p.g0, G, gw, B, p.C0, ws + lo.tn, st));
       KWS_HIP(hipMemcpyAsync(grads + p.conv1, gw, (size_t)p.K0 * p.C0 * 4, hipMemcpyDeviceToDevice, st));
-    } else if (p.Fp == p.F) {
-      KWS_TRY(kws_gemm_tn_gather_f32(x, &p.g0, G, grads + p.conv1, B, p.C0, ws + lo.tn, st));
-    } else {  // the forward of this step left the padded input in xpad
+    } else {  // (Fp != F here: the unpadded case left above) the forward of this step left the padded input in xpad
       float* gw = ws + lo.gwpad;
       KWS_TRY(kws_gemm_tn_gather_f32(ws + lo.xpad, &p.g0, G, gw, B, p.C0, ws + lo.tn, st));
       KWS_HIP(hipMemcpy2DAsync(grads + p.conv1, (size_t)p.F * p.C0 * 4, gw, (size_t)p.Fp * p.C0 * 4, (size_t)p.F * p.C0 * 4, 3,

@@ -129,7 +129,10 @@ __global__ __launch_bounds__(256) void block_out_bwd_kernel(const float* __restr
 #define KWS_JOIN1_THREADS 512          // threads of a PASS 1 workgroup (one workgroup per CU: 512 = 2 waves per SIMD)
 #endif
 #ifndef KWS_JOIN1_TT
-#define KWS_JOIN1_TT 8                 // output steps per thread and unit in PASS 1 (all loads of a unit are issued before the first is used)
+#define KWS_JOIN1_TT 4                 // output steps per thread and unit in PASS 1 (all loads of a unit are issued before the first is used; measured 16: 21.1, 8: 18.5, 4: 17.1 us on the 64-channel joins of C3 - profiles/r06_c3_joins_vs_copy_rate.txt)
+#endif
+#ifndef KWS_JOIN2_TT
+#define KWS_JOIN2_TT 4                 // the same for PASS 2 (which also writes dy): 8 -> 4 = 21.3 -> 20.1 us on the same joins
 #endif
 template <int P, bool RELU, int PASS, int NT, int TTJ>
 // (dO and out carry no __restrict__: the shortcut BatchNorm's pass 2 runs in place, out == dO with P == 1 - every thread loads its
@@ -407,9 +410,12 @@ __global__ __launch_bounds__(256) void lm_att_logits_kernel(LmArgs p) {
   if (tid < T) a.u[(int64_t)b * T + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
 }
 
-// BatchNorm statistics of the 1-channel attention logits over all B*T values (fixed-order, one workgroup)
-__global__ __launch_bounds__(256) void lm_att_bn_kernel(LmArgs p, int training) {
-  __shared__ double red[2][256];
+// BatchNorm statistics of the 1-channel attention logits over all B*T values (fixed-order, one workgroup).
+// Round 6: 16 waves and four independent loads in flight per thread - the 256-thread loop of one dependent load per iteration took
+// 26 us for the 24,576 values of config C3 (96 round trips), 31 us in the backward twin below: 1 % of that step between them.
+constexpr int LM_BN_NT = 1024;
+__global__ __launch_bounds__(LM_BN_NT) void lm_att_bn_kernel(LmArgs p, int training) {
+  __shared__ double red[2][LM_BN_NT];
   const kws_lm_tail_args& a = p.a;
   const int n = a.B * a.T, tid = threadIdx.x;
   float gamma = a.bn_gamma[0], beta = a.bn_beta[0];
@@ -420,16 +426,27 @@ __global__ __launch_bounds__(256) void lm_att_bn_kernel(LmArgs p, int training) 
     }
     return;
   }
-  double s = 0.0, ss = 0.0;
-  for (int i = tid; i < n; i += 256) {
-    const double v = a.u[i];
-    s += v;
-    ss += v * v;
+  double s[4] = {0.0, 0.0, 0.0, 0.0}, ss[4] = {0.0, 0.0, 0.0, 0.0};
+  int i = tid;
+  for (; i + 3 * LM_BN_NT < n; i += 4 * LM_BN_NT) {
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = a.u[i + k * LM_BN_NT];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      s[k] += (double)v[k];
+      ss[k] += (double)v[k] * (double)v[k];
+    }
   }
-  red[0][tid] = s;
-  red[1][tid] = ss;
+  for (; i < n; i += LM_BN_NT) {
+    const double v = a.u[i];
+    s[0] += v;
+    ss[0] += v * v;
+  }
+  red[0][tid] = (s[0] + s[1]) + (s[2] + s[3]);
+  red[1][tid] = (ss[0] + ss[1]) + (ss[2] + ss[3]);
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
+  for (int o = LM_BN_NT / 2; o > 0; o >>= 1) {
     if (tid < o) {
       red[0][tid] += red[0][tid + o];
       red[1][tid] += red[1][tid + o];
@@ -583,21 +600,35 @@ __global__ __launch_bounds__(256) void lm_tail_kernel(LmArgs p) {
 }
 
 // BN backward of the attention logits (1 channel): sums over all B*T, then coef / dgamma / dbeta
-__global__ __launch_bounds__(256) void lm_att_bn_bwd_kernel(LmArgs p) {
-  __shared__ double red[2][256];
+__global__ __launch_bounds__(LM_BN_NT) void lm_att_bn_bwd_kernel(LmArgs p) {
+  __shared__ double red[2][LM_BN_NT];
   const kws_lm_tail_args& a = p.a;
   const int n = a.B * a.T, tid = threadIdx.x;
   const float mean = a.bn[2], rstd = a.bn[3];
-  double s = 0.0, sx = 0.0;
-  for (int i = tid; i < n; i += 256) {
-    const double g = a.gu[i];
-    s += g;
-    sx += g * (double)((a.u[i] - mean) * rstd);
+  double s[4] = {0.0, 0.0, 0.0, 0.0}, sx[4] = {0.0, 0.0, 0.0, 0.0};
+  int i = tid;
+  for (; i + 3 * LM_BN_NT < n; i += 4 * LM_BN_NT) {
+    float g[4], u[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      g[k] = a.gu[i + k * LM_BN_NT];
+      u[k] = a.u[i + k * LM_BN_NT];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      s[k] += (double)g[k];
+      sx[k] += (double)g[k] * (double)((u[k] - mean) * rstd);
+    }
   }
-  red[0][tid] = s;
-  red[1][tid] = sx;
+  for (; i < n; i += LM_BN_NT) {
+    const double g = a.gu[i];
+    s[0] += g;
+    sx[0] += g * (double)((a.u[i] - mean) * rstd);
+  }
+  red[0][tid] = (s[0] + s[1]) + (s[2] + s[3]);
+  red[1][tid] = (sx[0] + sx[1]) + (sx[2] + sx[3]);
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
+  for (int o = LM_BN_NT / 2; o > 0; o >>= 1) {
     if (tid < o) {
       red[0][tid] += red[0][tid + o];
       red[1][tid] += red[1][tid + o];
@@ -907,7 +938,7 @@ int kws_block_join_bwd(const float* dO, const float* y, const float* bn, const f
                   ((pass == 1 && part) || (pass == 2 && gamma && coef && out)),
               "block_join_bwd: bad arguments (L=%d C=%d pool=%d relu=%d pass=%d)", L, C, pool, relu, pass);
   const int Lo = (L + pool - 1) / pool;
-  const JoinGeom ge = join_geom(B, Lo, C, pass == 1 ? KWS_JOIN1_THREADS : 512, pass == 1 ? KWS_JOIN1_TT : TT);
+  const JoinGeom ge = join_geom(B, Lo, C, pass == 1 ? KWS_JOIN1_THREADS : 512, pass == 1 ? KWS_JOIN1_TT : KWS_JOIN2_TT);
   KwsProfScope prof("block_join_bwd", 6.0 * B * L * C, 4.0 * ((pass == 1 ? 1.0 : 2.0) * B * L * C + (double)B * Lo * C), st);
   dim3 gr((unsigned)ge.grid, (unsigned)ge.ny), b((unsigned)ge.block);
 #define KWS_JOIN_LAUNCH(P_, RELU_)                                                                                              \
@@ -916,7 +947,7 @@ int kws_block_join_bwd(const float* dO, const float* y, const float* bn, const f
       hipLaunchKernelGGL((block_join_bwd_kernel<P_, RELU_, 1, KWS_JOIN1_THREADS, KWS_JOIN1_TT>), gr, b, 0, st, dO, y, bn, gamma, coef, out, part, L, Lo, C, \
                          ge.nchunks, ge.R, ge.Cb, ge.units);                                                                    \
     else                                                                                                                        \
-      hipLaunchKernelGGL((block_join_bwd_kernel<P_, RELU_, 2, 512, TT>), gr, b, 0, st, dO, y, bn, gamma, coef, out, part, L, Lo, C,  \
+      hipLaunchKernelGGL((block_join_bwd_kernel<P_, RELU_, 2, 512, KWS_JOIN2_TT>), gr, b, 0, st, dO, y, bn, gamma, coef, out, part, L, Lo, C,  \
                          ge.nchunks, ge.R, ge.Cb, ge.units);                                                                    \
   } while (0)
   if (pool == 2) KWS_JOIN_LAUNCH(2, true);
@@ -985,7 +1016,7 @@ int kws_lm_tail_fwd(const kws_lm_tail_args* a, int training, hipStream_t st) {
   KwsProfScope prof(training ? "tail_train" : "tail_infer", 8.0 * a->B * a->T * a->C, 8.0 * a->B * a->T * a->C, st);
   hipLaunchKernelGGL(lm_att_logits_kernel, dim3((unsigned)a->B), dim3(256), 0, st, p);
   KWS_LAUNCH_CHECK("lm_att_logits_kernel");
-  hipLaunchKernelGGL(lm_att_bn_kernel, dim3(1), dim3(256), 0, st, p, training);
+  hipLaunchKernelGGL(lm_att_bn_kernel, dim3(1), dim3(LM_BN_NT), 0, st, p, training);
   KWS_LAUNCH_CHECK("lm_att_bn_kernel");
   if (training) hipLaunchKernelGGL((lm_tail_kernel<true>), dim3((unsigned)a->B), dim3(256), 0, st, p);
   else hipLaunchKernelGGL((lm_tail_kernel<false>), dim3((unsigned)a->B), dim3(256), 0, st, p);
@@ -996,7 +1027,7 @@ int kws_lm_tail_fwd(const kws_lm_tail_args* a, int training, hipStream_t st) {
 int kws_lm_tail_bwd(const kws_lm_tail_args* a, hipStream_t st) {
   const LmArgs p = make_args(a);
   KwsProfScope prof("tail_train", 12.0 * a->B * a->T * a->C, 12.0 * a->B * a->T * a->C, st);
-  hipLaunchKernelGGL(lm_att_bn_bwd_kernel, dim3(1), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(lm_att_bn_bwd_kernel, dim3(1), dim3(LM_BN_NT), 0, st, p);
   KWS_LAUNCH_CHECK("lm_att_bn_bwd_kernel");
   hipLaunchKernelGGL(lm_att_bwd_kernel, dim3((unsigned)a->B), dim3(256), 0, st, p);
   KWS_LAUNCH_CHECK("lm_att_bwd_kernel");

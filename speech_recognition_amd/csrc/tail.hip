@@ -542,33 +542,38 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__
   for (int k = 1; k < S; ++k) s += in[(int64_t)k * n + i];
   out[i] = s;
 }
-// out[k] = sum_b D[b, k]: KP columns x 256/KP row groups, each group sums its rows b = g, g+G, ... in
-// ascending order, the groups are combined in ascending order (fixed order, one workgroup).
-template <int KP>
+// out[k] = sum_b D[b, k]: KP columns x NT/KP row groups, each group sums its rows b = g, g+G, ... in ascending order over four
+// interleaved accumulators, the groups are combined in ascending order (fixed order, one workgroup).  Round 6: 1024 threads and
+// KP = the narrowest of 16 / 32 / 64 that holds N - the 256-thread form gave config C3's 32-column bias 4 row groups of 512 rows
+// each: 27 us of dependent loads.
+template <int KP, int NT>
 __device__ __forceinline__ void colsum_body(const float* __restrict__ D, float* __restrict__ out, int B, int N) {
-  constexpr int G = 256 / KP;
+  constexpr int G = NT / KP;
   __shared__ float red[G][KP];
   const int k = threadIdx.x % KP, g = threadIdx.x / KP;
-  float s0 = 0.f, s1 = 0.f;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
   if (k < N) {
     int b = g;
-    for (; b + G < B; b += 2 * G) {
-      s0 += D[(int64_t)b * N + k];
-      s1 += D[(int64_t)(b + G) * N + k];
+    for (; b + 3 * G < B; b += 4 * G) {
+      float v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = D[(int64_t)(b + q * G) * N + k];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) s[q] += v[q];
     }
-    if (b < B) s0 += D[(int64_t)b * N + k];
+    for (; b < B; b += G) s[0] += D[(int64_t)b * N + k];
   }
-  red[g][k] = s0 + s1;
+  red[g][k] = (s[0] + s[1]) + (s[2] + s[3]);
   __syncthreads();
   if (g == 0 && k < N) {
-    float s = red[0][k];
-    for (int q = 1; q < G; ++q) s += red[q][k];
-    out[k] = s;
+    float t = red[0][k];
+    for (int q = 1; q < G; ++q) t += red[q][k];
+    out[k] = t;
   }
 }
-template <int KP>
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ D, float* __restrict__ out, int B, int N) {
-  colsum_body<KP>(D, out, B, N);
+template <int KP, int NT>
+__global__ __launch_bounds__(NT) void colsum_kernel(const float* __restrict__ D, float* __restrict__ out, int B, int N) {
+  colsum_body<KP, NT>(D, out, B, N);
 }
 // metrics[0] = sum per_loss (double accumulation), metrics[1] = sum per_correct: thread t sums elements
 // t, t+256, ... and the 256 partials are combined in ascending order (fixed order, one workgroup).
@@ -623,7 +628,7 @@ __global__ __launch_bounds__(256) void tail_post_kernel(TailPost p) {
   }
   b -= p.gx1 * p.S;
   if (b == 0) metrics_body(p.a.per_loss, p.a.per_correct, p.a.B, p.a.metrics);
-  else colsum_body<16>(p.a.D1, p.a.bias1, p.a.B, p.a.N1);
+  else colsum_body<16, 256>(p.a.D1, p.a.bias1, p.a.B, p.a.N1);
 }
 
 }  // namespace
@@ -694,8 +699,10 @@ int kws_small_wgrad_launch(const float* X, const float* D, float* out, float* ou
   }
   if (out_bias) {
     KWS_REQUIRE(N <= 64, "small_wgrad: N=%d > 64", N);
-    if (N <= 16) hipLaunchKernelGGL(colsum_kernel<16>, dim3(1), dim3(256), 0, st, D, out_bias, B, N);
-    else hipLaunchKernelGGL(colsum_kernel<64>, dim3(1), dim3(256), 0, st, D, out_bias, B, N);
+    // (N <= 16 keeps the 256-thread geometry: tail_post_kernel runs the same body in its 256-thread grid, bit for bit)
+    if (N <= 16) hipLaunchKernelGGL((colsum_kernel<16, 256>), dim3(1), dim3(256), 0, st, D, out_bias, B, N);
+    else if (N <= 32) hipLaunchKernelGGL((colsum_kernel<32, 1024>), dim3(1), dim3(1024), 0, st, D, out_bias, B, N);
+    else hipLaunchKernelGGL((colsum_kernel<64, 1024>), dim3(1), dim3(1024), 0, st, D, out_bias, B, N);
     KWS_LAUNCH_CHECK("colsum_kernel");
   }
   return KWS_OK;

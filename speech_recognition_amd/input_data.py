@@ -168,14 +168,21 @@ class AudioProcessor(object):
         own = getattr(self, '_own_stream', None)
         if own is not None and own.stream is not None:
             try:
+                import torch
                 own.stream.synchronize()
                 # torch's pinned-memory cache holds events recorded on this stream (the non_blocking parameter uploads of
-                # _augment): let it retire them while the stream still exists - a later query of an event whose stream is gone,
-                # or whose handle a NEW stream got, fails ("event last recorded in a capturing stream", round 5)
-                import torch
-                torch.empty(16).pin_memory()
-            except Exception:
-                pass
+                # _augment): they must be retired while the stream still exists - a later query of an event whose stream is gone,
+                # or whose handle a NEW stream got, fails ("event last recorded in a capturing stream", round 5).  Explicitly:
+                # the device is drained (every such event has completed) and the pinned cache is emptied (it processes and
+                # frees its events); an allocation through the cache is the fallback on a torch without that entry point.
+                torch.cuda.synchronize(self.device)
+                empty = getattr(torch._C, "_host_emptyCache", None)
+                if empty is not None:
+                    empty()
+                else:
+                    torch.empty(16).pin_memory()
+            except Exception as ex:       # closing must not raise - but a failure here is the round-5 bug coming back: say so
+                sys.stderr.write("AudioProcessor.close(): retiring the generator stream's pinned-memory events failed: %r\n" % (ex,))
         if getattr(self, '_plan', None):
             self.lib.kws_stft_plan_destroy(self._plan)
             self._plan = None
