@@ -387,11 +387,15 @@ __global__ __launch_bounds__(256) void lm_att_logits_kernel(LmArgs p) {
   for (int t = 0; t < LM_MAXT; ++t) acc[t] = 0.f;
   for (int c = tid; c < C; c += 256) {
     const float w0 = a.wa[c], w1 = a.wa[C + c], w2 = a.wa[2 * C + c], wp = a.Wa[c];
-    float xm = 0.f, x0 = xb[c];
+    float xv[LM_MAXT + 1];                            // the column's T values in flight at once, from clamped addresses (a load behind
+#pragma unroll                                        // "t + 1 < T ? .. : 0" is a branch and a wait per step)
+    for (int t = 0; t < LM_MAXT; ++t) xv[t] = xb[(t < T ? t : 0) * C + c];
+    xv[LM_MAXT] = 0.f;
+    float xm = 0.f, x0 = xv[0];
 #pragma unroll
     for (int t = 0; t < LM_MAXT; ++t) {
       if (t < T) {
-        const float xp = (t + 1 < T) ? xb[(t + 1) * C + c] : 0.f;
+        const float xp = (t + 1 < T) ? xv[t + 1] : 0.f;
         acc[t] = fmaf(wp, fmaf(w2, xp, fmaf(w1, x0, w0 * xm)), acc[t]);
         xm = x0;
         x0 = xp;
@@ -468,18 +472,27 @@ __global__ __launch_bounds__(LM_BN_NT) void lm_att_bn_kernel(LmArgs p, int train
 
 // per clip: att = softmax_t(relu6(bn(u))), feat = mean_t(x * att), dropout, dense + softmax, CCE loss and the
 // backward down to (dX partial, masked gradient of the attention logits)
+// (256, 8): eight waves per SIMD = 64 registers - with 69 the 2,048 workgroups of config C3's batch needed a second, quarter-full round
 template <bool TRAIN>
-__global__ __launch_bounds__(256) void lm_tail_kernel(LmArgs p) {
+__global__ __launch_bounds__(256, 8) void lm_tail_kernel(LmArgs p) {
   __shared__ float s_att[LM_MAXT], s_pre[LM_MAXT], s_datt[LM_MAXT], s_p[LM_MAXNC], s_dl[LM_MAXNC];
   __shared__ float s_feat[1024], s_red[4][LM_MAXNC];
   const kws_lm_tail_args& a = p.a;
   const int T = a.T, C = a.C, NC = a.NC, b = blockIdx.x, tid = threadIdx.x;
   const float* xb = a.x + (int64_t)b * T * C;
   const uint32_t row = (uint32_t)(a.row_offset + b);
+  // Round 6: the clip's logits and labels are fetched by T + NC threads at once; the serial sections below (thread 0: two softmaxes and
+  // the loss, kept serial so that every sum keeps its order) read them from LDS.  They used to load them one by one from global memory
+  // - 12 + 32 dependent round trips per clip on a chip running 2,048 such workgroups at once: 87 us for the batch, now see profiles/.
+  __shared__ float s_u[LM_MAXT], s_y[LM_MAXNC];
+  if (tid < T) s_u[tid] = a.u[(int64_t)b * T + tid];
+  if (TRAIN && tid >= 64 && tid < 64 + NC) s_y[tid - 64] = a.labels[(int64_t)b * NC + tid - 64];
+  __syncthreads();
   if (tid == 0) {
     float m = -INFINITY;
+    const float bn0 = a.bn[0], bn1 = a.bn[1];
     for (int t = 0; t < T; ++t) {
-      const float pre = fmaf(a.u[(int64_t)b * T + t], a.bn[0], a.bn[1]);
+      const float pre = fmaf(s_u[t], bn0, bn1);
       s_pre[t] = pre;
       s_att[t] = relu6f(pre);
       m = fmaxf(m, s_att[t]);
@@ -495,7 +508,12 @@ __global__ __launch_bounds__(256) void lm_tail_kernel(LmArgs p) {
   if (TRAIN && a.att != nullptr && tid < T) a.att[(int64_t)b * T + tid] = s_att[tid];
   for (int c = tid; c < C; c += 256) {
     float f = 0.f;
-    for (int t = 0; t < T; ++t) f = fmaf(xb[t * C + c], s_att[t], f);
+    float xv[LM_MAXT];                                // all T loads of the column in flight at once (T is a run-time bound: the plain
+#pragma unroll                                        // loop waited for one load per iteration)
+    for (int t = 0; t < LM_MAXT; ++t) xv[t] = xb[(t < T ? t : 0) * C + c];
+#pragma unroll
+    for (int t = 0; t < LM_MAXT; ++t)
+      if (t < T) f = fmaf(xv[t], s_att[t], f);
     f = f / (float)T;
     if (TRAIN) {
       f = kws_keep(row * (uint32_t)C + (uint32_t)c, p.key, p.thresh) ? f * p.inv_keep : 0.f;
@@ -507,8 +525,22 @@ __global__ __launch_bounds__(256) void lm_tail_kernel(LmArgs p) {
   {
     const int k = tid & 63, sl = tid >> 6;
     float s = 0.f;
-    if (k < NC)
-      for (int c = sl; c < C; c += 4) s = fmaf(s_feat[c], a.Wd[(int64_t)c * NC + k], s);
+    if (k < NC) {
+      // eight weight loads in flight per thread, consumed in the loop's own order (round 6: one dependent load per iteration before)
+      for (int c0 = sl; c0 < C; c0 += 32) {
+        float w[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int c = c0 + 4 * j;
+          w[j] = a.Wd[(int64_t)(c < C ? c : sl) * NC + k];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int c = c0 + 4 * j;
+          if (c < C) s = fmaf(s_feat[c], w[j], s);
+        }
+      }
+    }
     s_red[sl][k] = s;
     __syncthreads();
     if (tid < NC) s_p[tid] = (((s_red[0][tid] + s_red[1][tid]) + s_red[2][tid]) + s_red[3][tid]) + a.bd[tid];
@@ -530,7 +562,7 @@ __global__ __launch_bounds__(256) void lm_tail_kernel(LmArgs p) {
   if (tid == 0) {
     // keras categorical_crossentropy: p /= sum(p); clip(eps, 1-eps); -sum(y log p)
     const float eps = 1e-7f;
-    const float* yl = a.labels + (int64_t)b * NC;
+    const float* yl = s_y;
     float S = 0.f;
     for (int q = 0; q < NC; ++q) S += s_p[q];
     float loss = 0.f, dotp = 0.f;
@@ -565,14 +597,24 @@ __global__ __launch_bounds__(256) void lm_tail_kernel(LmArgs p) {
   float* dxb = a.dX + (int64_t)b * T * C;
   for (int c = tid; c < C; c += 256) {
     float s = 0.f;
-    for (int q = 0; q < NC; ++q) s = fmaf(a.Wd[(int64_t)c * NC + q], s_dl[q], s);
+    for (int q0 = 0; q0 < NC; q0 += 8) {            // the row of Wd: eight loads in flight, the products in index order
+      float w[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) w[j] = a.Wd[(int64_t)c * NC + (q0 + j < NC ? q0 + j : NC - 1)];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (q0 + j < NC) s = fmaf(w[j], s_dl[q0 + j], s);
+    }
     const bool keep = kws_keep(row * (uint32_t)C + (uint32_t)c, p.key, p.thresh);
     const float dprod = (keep ? s * p.inv_keep : 0.f) / (float)T;
+    float xv[LM_MAXT];
+#pragma unroll
+    for (int t = 0; t < LM_MAXT; ++t) xv[t] = xb[(t < T ? t : 0) * C + c];
 #pragma unroll
     for (int t = 0; t < LM_MAXT; ++t) {
       if (t < T) {
         dxb[t * C + c] = dprod * s_att[t];
-        dattl[t] = fmaf(dprod, xb[t * C + c], dattl[t]);
+        dattl[t] = fmaf(dprod, xv[t], dattl[t]);
       }
     }
   }
