@@ -55,10 +55,12 @@ def test_stft_full_batch_sampled_rows_shift_and_linearity():
     feat = torch.full((B_FULL, F, 60), float("nan"), device="cuda")
     _lib.call("kws_stft_mel_f32", plan, _lib.ptr(x), B_FULL, L, _lib.ptr(feat), 0, S())
     assert torch.isfinite(feat).all()
-    # (1) sampled rows against the oracle (tolerance as in test_kernels_gpu: 2e-3 on DCT outputs)
+    # (1) sampled rows against the float64 oracle: 1.1e-4 on the DCT outputs = 2 x the measured 5e-5 (the fp16-split MFMA DCT), the bar of
+    # tests/test_kernels_gpu.py::test_stft_mel_features (round 6: this line still carried round 1's 2e-3)
     rows = [0, 1, 255, 256, 511, 777, 1023]
     ref = OF.features(x[rows].cpu().numpy(), tables, 160, dtype=np.float64)
-    assert np.abs(feat[rows].cpu().numpy() - ref.reshape(len(rows), F, 60)).max() < 2e-3
+    err = np.abs(feat[rows].cpu().numpy() - ref.reshape(len(rows), F, 60)).max()
+    assert err < 1.1e-4, err
     # (2) frame-shift equivariance: dropping the first 160 samples moves every frame up by one, bit for bit
     xs = torch.zeros_like(x)
     xs[:, :L - 160] = x[:, 160:]
