@@ -16,7 +16,9 @@ SOURCE_OF = {"gemm_nn_ws_kernel": "gemm.hip", "gemm_dgrad_wgrad_kernel": "gemm.h
              "block_out_fwd_kernel": "resblock.hip", "block_out_bwd_kernel": "resblock.hip", "block_join_bwd_kernel": "resblock.hip",
              "add_strided_kernel": "resblock.hip", "lm_tail_kernel": "resblock.hip", "lm_att_bn_kernel": "resblock.hip",
              "lm_att_bn_bwd_kernel": "resblock.hip", "lm_att_logits_kernel": "resblock.hip", "lm_att_bwd_kernel": "resblock.hip",
-             "colsum_kernel": "tail.hip", "small_wgrad_kernel": "tail.hip", "bn_relu6_apply_kernel": "bn.hip"}
+             "colsum_kernel": "tail.hip", "small_wgrad_kernel": "tail.hip", "bn_relu6_apply_kernel": "bn.hip",
+             "bn_stats_finalize_kernel": "bn.hip", "dw_bwd_finalize_kernel": "bn.hip", "dw_grad_finalize_batch_kernel": "bn.hip",
+             "slice_reduce_kernel": "bn.hip", "bn_bwd_apply_kernel": "bn.hip", "rmsprop_kernel": "optim.hip"}
 
 
 def load(path, counter):

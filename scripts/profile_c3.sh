@@ -12,7 +12,7 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats_c3 -- python3 scripts/prof_c3.py 30 > gpurun_out/${tag}_stats_c3.log 2>&1
 f=$(find gpurun_out/${tag}_stats_c3 -name "*kernel_stats.csv" | head -1)
-[ -n "$f" ] && cp "$f" gpurun_out/${tag}_kernel_stats_c3.csv
+[ -n "$f" ] && cp "$f" gpurun_out/${tag}_kernel_stats_c3.csv && python3 scripts/stats_sources.py gpurun_out/${tag}_kernel_stats_c3.csv
 t=$(find gpurun_out/${tag}_stats_c3 -name "*kernel_trace.csv" | head -1)
 [ -n "$t" ] && python3 scripts/step_trace.py "$t" gpurun_out/${tag}_step_trace_c3.txt
 for c in FETCH_SIZE WRITE_SIZE; do

@@ -45,7 +45,7 @@ fi
 for c in c3 c5; do
   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats_$c -- python3 scripts/prof_$c.py > gpurun_out/${tag}_stats_$c.log 2>&1
   f=$(find gpurun_out/${tag}_stats_$c -name "*kernel_stats.csv" | head -1)
-  [ -n "$f" ] && cp "$f" gpurun_out/${tag}_kernel_stats_$c.csv
+  [ -n "$f" ] && cp "$f" gpurun_out/${tag}_kernel_stats_$c.csv && python3 scripts/stats_sources.py gpurun_out/${tag}_kernel_stats_$c.csv
   rm -rf gpurun_out/${tag}_stats_$c
 done
 # the raw traces are large: keep the summaries only

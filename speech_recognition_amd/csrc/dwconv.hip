@@ -76,8 +76,16 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict
 }
 
 // The backward passes: kws_dw::bwd_body (dw_bwd_body.h) as a kernel of its own.
+// -DKWS_DW_BWD2_MINW=<waves per SIMD> / -DKWS_DW_BWD1_MINW: register caps of pass 2 / of the row-writing modes (experiment, round 6: at the
+// default the compiler takes 130 - 184 registers, i.e. ONE 512-thread workgroup per CU; 4 = 128 registers = two)
+#ifndef KWS_DW_BWD2_MINW
+#define KWS_DW_BWD2_MINW 1
+#endif
+#ifndef KWS_DW_BWD1_MINW
+#define KWS_DW_BWD1_MINW 1
+#endif
 template <int S, bool HAS_BN, int MODE>
-__global__ __launch_bounds__(MODE == 2 ? DW_BWD2_THREADS : DW_BWD_THREADS) void dwconv_bwd_kernel(BwdArgs p) {
+__global__ __launch_bounds__(MODE == 2 ? DW_BWD2_THREADS : DW_BWD_THREADS, MODE == 2 ? KWS_DW_BWD2_MINW : KWS_DW_BWD1_MINW) void dwconv_bwd_kernel(BwdArgs p) {
   __shared__ float red[bwd_smem_floats(MODE, DW_BWD_THREADS)];
   bwd_body<S, HAS_BN, MODE, false>(p, red, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y);
 }
