@@ -50,6 +50,8 @@ struct NNArgs {
   int half_tail;  // wave-specialised kernel: the tiles of a short last round are walked as 64-row halves
   int last_rows;  // rows of the last row tile: M - 128 (m_tiles - 1)
   unsigned inv_n_tiles;   // ceil(2^32 / n_tiles) (0 for n_tiles = 1): tile / n_tiles as one s_mul_hi_u32
+  int lda;        // wave-specialised kernel only: row pitch of A in floats (0 = K).  Round 6: a 1 x 1 convolution with stride s over an
+                  // even-length input is a plain GEMM over every s-th row - the shortcut convolutions of the residual nets
 };
 
 // 16 bytes of zeros that masked-out lanes load from instead of branching around their load.
@@ -662,7 +664,8 @@ __device__ __forceinline__ void nn_ws_body(const NNArgs& p, float* const smem, c
     const int brow = lane / BN4;                    // + BROWS r
     const int bcol = (lane % BN4) * 4;
     constexpr int BROWS = 64 / BN4;                 // B rows covered by one wave instruction
-    const int a_voff = (arow * K + acol) * 4;       // byte offsets inside the tile's buffer views
+    const int lda = p.lda ? p.lda : K;              // row pitch of A (a strided row view: every s-th row of a wider matrix)
+    const int a_voff = (arow * lda + acol) * 4;     // byte offsets inside the tile's buffer views
     const int b_voff = (brow * N + bcol) * 4;
     int ld_i = lw / nk, ld_kt = lw % nk;            // my next slab: tile ordinal, K-slab
     float4 ra[A_F4], rb[B_F4];
@@ -673,13 +676,13 @@ __device__ __forceinline__ void nn_ws_body(const NNArgs& p, float* const smem, c
       const int64_t m0 = (int64_t)tile_m * BM + row0;
       const int rows = tile_ok ? rows_t : 0;
       const __amdgpu_buffer_rsrc_t ares = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<float*>(p.A + m0 * K), 0, rows * K * 4, KWS_BUFFER_RSRC_FLAGS);
+          const_cast<float*>(p.A + m0 * lda), 0, rows > 0 ? ((rows - 1) * lda + K) * 4 : 0, KWS_BUFFER_RSRC_FLAGS);
       const __amdgpu_buffer_rsrc_t bres = __builtin_amdgcn_make_buffer_rsrc(
           const_cast<float*>(p.W + n0), 0, tile_ok ? (K * N - n0) * 4 : 0, KWS_BUFFER_RSRC_FLAGS);
       const int k0 = ld_kt * PBK;
       if (!(KWS_WS_ABL & 4)) {
 #pragma unroll
-      for (int r = 0; r < A_F4; ++r) ra[r] = buf_ld4(ares, a_voff, (k0 + AROWS * r * K) * 4);
+      for (int r = 0; r < A_F4; ++r) ra[r] = buf_ld4(ares, a_voff, (k0 + AROWS * r * lda) * 4);
 #pragma unroll
       for (int r = 0; r < B_F4; ++r) rb[r] = buf_ld4(bres, b_voff, (k0 + BROWS * r) * N * 4);
       }
@@ -837,6 +840,7 @@ struct TNArgs {
   int64_t chunk;    // rows per split (multiple of 32)
   int k_tiles, n_tiles, S;
   kws_gather_t g;
+  int lda = 0;      // wave-specialised kernel only: row pitch of A in floats (0 = K), as NNArgs::lda
 };
 
 constexpr int MS = 32;  // rows of M per LDS stage
@@ -1166,16 +1170,17 @@ __device__ __forceinline__ void tn_ws_body(const TNArgs& p, float* const smem, c
     constexpr int Z_F4 = 32 / RZ, G_F4 = 32 / RG;   // instructions per unit: 16 or 8 each
     const int zrow = lane / ZC4, zc = (lane % ZC4) * 4;
     const int grow = lane / GC4, gc = (lane % GC4) * 4;
-    const int z_voff = (zrow * K + k0 + zc) * 4, g_voff = (grow * N + n0 + gc) * 4;
+    const int lda = p.lda ? p.lda : K;              // row pitch of A (a strided row view, NNArgs::lda)
+    const int z_voff = (zrow * lda + k0 + zc) * 4, g_voff = (grow * N + n0 + gc) * 4;
     const __amdgpu_buffer_rsrc_t zres = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.A + m_begin * K), 0, rows * K * 4, KWS_BUFFER_RSRC_FLAGS);
+        const_cast<float*>(p.A + m_begin * lda), 0, rows > 0 ? ((rows - 1) * lda + K) * 4 : 0, KWS_BUFFER_RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t gres = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.G + m_begin * N), 0, rows * N * 4, KWS_BUFFER_RSRC_FLAGS);
     float4 rz[Z_F4], rg[G_F4];
     auto issue = [&](int x) {                       // unit x = rows [32 x, 32 x + 32) of my split
       if (KWS_WS_ABL & 4) return;
 #pragma unroll
-      for (int r = 0; r < Z_F4; ++r) rz[r] = buf_ld4(zres, z_voff, (x * 32 + RZ * r) * K * 4);
+      for (int r = 0; r < Z_F4; ++r) rz[r] = buf_ld4(zres, z_voff, (x * 32 + RZ * r) * lda * 4);
 #pragma unroll
       for (int r = 0; r < G_F4; ++r) rg[r] = buf_ld4(gres, g_voff, (x * 32 + RG * r) * N * 4);
     };
@@ -1716,6 +1721,44 @@ int kws_gemm_dgrad_wgrad_f32(const float* dY, const float* WT, float* dZ, const 
   const double fl = 2.0 * M * cin * cout;
   KwsProfScope prof("gemm_bwd_pair", 2.0 * fl, 4.0 * (3.0 * M * cout + 2.0 * M * cin + 2.0 * (double)cin * cout) , stream);
   return launch_dgrad_wgrad(a, t, np, tp, tn_grid, stream, S);
+}
+
+// internal (net_logmfcc.hip, round 6): a gather that is nothing but every stride_t / cin-th ROW of a row-major matrix - a 1 x 1 convolution
+// with stride s over inputs whose length is a multiple of s (the shortcut convolutions of the residual nets: row (b, t) reads input row
+// s (b L_out + t)) - is a plain GEMM with a row pitch.  *lda = that pitch in floats.
+bool kws_gather_strided_rows(const kws_gather_t* g, int* lda) {
+  if (!g || g->taps != 1 || g->base_off != 0 || g->cin <= 0 || g->stride_t < g->cin || g->stride_t % 4 != 0) return false;
+  if (g->x_batch_stride != (int64_t)g->L_out * g->stride_t) return false;          // uniform row pitch across clip borders
+  if ((int64_t)(g->L_out - 1) * g->stride_t + g->cin > g->x_len) return false;     // every row inside its clip
+  *lda = g->stride_t;
+  return true;
+}
+// C[M, N] = A'[M, K] W[K, N] with A' = rows of pitch lda (the wave-specialised kernel; BN statistics rows as kws_gemm_nn_stats_rows).
+// Returns 1 (nothing launched) when the shape does not take that kernel: the caller then makes the gathered call.
+int kws_gemm_nn_strided_f32(const float* A, int lda, const float* W, float* C, int64_t M, int K, int N, float* stats_part, hipStream_t stream) {
+  KWS_REQUIRE(A && W && C, "gemm_nn_strided: NULL pointer");
+  KWS_REQUIRE(M > 0 && K > 0 && N > 0 && K % 4 == 0 && N % 4 == 0 && lda >= K && lda % 4 == 0, "gemm_nn_strided: M=%lld K=%d N=%d lda=%d",
+              (long long)M, K, N, lda);
+  const NNPlan pl = nn_plan(M, K, N, false);
+  if (!pl.ws || 128ll * lda * 4 >= (1ll << 31)) return 1;
+  NNArgs a{};
+  a.A = A; a.W = W; a.C = C; a.M = M; a.K = K; a.N = N; a.stats = stats_part; a.lda = lda;
+  KwsProfScope prof("gemm_nn", 2.0 * M * K * N, 4.0 * ((double)M * K + (double)K * N + (double)M * N), stream);
+  return launch_nn<false>(a, stream);
+}
+// the slabs of dW[K, N] = A'^T G with A' = rows of pitch lda (the wave-specialised kernel; workspace / *S as kws_gemm_tn_slabs_f32).
+// Returns 1 (nothing launched) when the shape does not take that kernel.
+int kws_gemm_tn_slabs_strided_f32(const float* A, int lda, const float* G, int64_t M, int K, int N, float* workspace, int* S, hipStream_t stream) {
+  KWS_REQUIRE(A && G && workspace && S, "gemm_tn_slabs_strided: NULL pointer");
+  KWS_REQUIRE(M > 0 && K > 0 && N > 0 && K % 4 == 0 && N % 4 == 0 && lda >= K && lda % 4 == 0, "gemm_tn_slabs_strided: M=%lld K=%d N=%d lda=%d",
+              (long long)M, K, N, lda);
+  if (!tn_ws_eligible(K, N, false)) return 1;
+  const TNPlan pl = tn_plan(M, K, N, true);
+  if (pl.chunk * (int64_t)(lda > N ? lda : N) * 4 >= (1ll << 31)) return 1;       // 32-bit offsets inside a split
+  TNArgs a{};
+  a.A = A; a.G = G; a.ws = workspace; a.M = M; a.K = K; a.N = N; a.lda = lda;
+  KwsProfScope prof("gemm_tn", 2.0 * M * K * N, 4.0 * ((double)M * K + (double)M * N + (double)K * N), stream);
+  return launch_tn<false>(a, nullptr, stream, S);
 }
 
 int kws_slab_batch_fill(SlabBatch* b, const float* const* ws, float* const* out, const int64_t* n, const int* S, int count, int* blocks_out,

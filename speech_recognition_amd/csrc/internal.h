@@ -55,6 +55,13 @@ extern "C" int kws_gemm_tn_slabs_f32(const float* A, const float* G, int64_t M, 
 // gemm.hip: a layer's input-gradient GEMM and the slabs of its weight-gradient GEMM in one launch (returns 1 = not eligible, nothing launched)
 extern "C" int kws_gemm_dgrad_wgrad_f32(const float* dY, const float* WT, float* dZ, const float* Z, int64_t M, int cin, int cout,
                                         float* workspace, int* S, hipStream_t stream);
+// gemm.hip (round 6): a gather that is every s-th ROW of a matrix (1 x 1 convolution with stride s over an even-length input) as a
+// plain GEMM with a row pitch on the wave-specialised kernels; both return 1 (nothing launched) for shapes those do not take
+extern "C" bool kws_gather_strided_rows(const kws_gather_t* g, int* lda);
+extern "C" int kws_gemm_nn_strided_f32(const float* A, int lda, const float* W, float* C, int64_t M, int K, int N, float* stats_part,
+                                       hipStream_t stream);
+extern "C" int kws_gemm_tn_slabs_strided_f32(const float* A, int lda, const float* G, int64_t M, int K, int N, float* workspace, int* S,
+                                             hipStream_t stream);
 // gemm.hip (round 5): the gathered weight-gradient GEMM without its slab sum (queue the slabs with a NEGATIVE count)
 extern "C" int kws_gemm_tn_gather_slabs_f32(const float* X, const kws_gather_t* g, const float* G, int B, int N, float* workspace, int* S,
                                             hipStream_t stream);
@@ -160,7 +167,17 @@ struct KwsSlabQueue {
     }
     if (need > cap) return KWS_E_WORKSPACE;
     ws[count] = base + used; out[count] = dW; n[count] = (int64_t)K * N;
-    int S_ = 0;
+    int S_ = 0, lda = 0;
+    if (kws_gather_strided_rows(g, &lda)) {     // every s-th row of a matrix: the wave-specialised kernel with a row pitch (round 6)
+      const int rs = kws_gemm_tn_slabs_strided_f32(X, lda, G, M, K, N, base + used, &S_, st);
+      if (rs < 0) return rs;
+      if (rs == 0) {
+        S[count] = S_;                          // that kernel's slabs: the plain summation order
+        used += need;
+        ++count;
+        return 0;
+      }
+    }
     const int rc = kws_gemm_tn_gather_slabs_f32(X, g, G, B, N, base + used, &S_, st);
     if (rc) return rc;
     S[count] = -S_;

@@ -347,8 +347,18 @@ int forward(const Ctx& c, const float* x, kws_lm_tail_args* t) {
     const LmBlock& b = p.blocks[i];
     const int64_t M = (int64_t)B * b.Lmid;
     if (b.has_short) {
-      KWS_TRY(kws_gemm_gather_f32(xin, &b.gs, c.params + b.ws, ws + lo.ys[i], B, b.nf, stats, c.st));
-      KWS_TRY(bn_table(c, b.bns, b.bns_idx, (int64_t)B * b.Lout, kws_gemm_gather_stats_rows((int64_t)B * b.Lout)));
+      // the shortcut convolution (1 x 1, stride s): over an even-length input it is every s-th ROW of the block input - a plain GEMM
+      // with a row pitch on the wave-specialised kernel (round 6); the gathered kernel otherwise
+      const int64_t Ms = (int64_t)B * b.Lout;
+      int lda = 0, srows = kws_gemm_gather_stats_rows(Ms);
+      int rs = 1;
+      if (kws_gather_strided_rows(&b.gs, &lda)) {
+        rs = kws_gemm_nn_strided_f32(xin, lda, c.params + b.ws, ws + lo.ys[i], Ms, b.gs.cin, b.nf, stats, c.st);
+        if (rs < 0) return rs;
+        if (rs == 0 && stats) srows = kws_gemm_nn_stats_rows(Ms, b.gs.cin, b.nf);
+      }
+      if (rs != 0) KWS_TRY(kws_gemm_gather_f32(xin, &b.gs, c.params + b.ws, ws + lo.ys[i], B, b.nf, stats, c.st));
+      KWS_TRY(bn_table(c, b.bns, b.bns_idx, Ms, srows));
     }
     KWS_TRY(kws_dwconv_fwd_f32(xin, nullptr, c.params + b.dw1, ws + lo.z1[i], B, b.Lin, b.Lmid, b.cin, b.s1, b.pad1, c.st));
     KWS_TRY(kws_gemm_nn_f32(ws + lo.z1[i], c.params + b.pw1, ws + lo.y1[i], M, b.cin, b.nf, stats, c.st));
