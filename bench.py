@@ -1242,7 +1242,9 @@ def main():
                 try:
                     sys.path.insert(0, os.path.join(ROOT, "scripts"))
                     import val_acc_parity
-                    out.update(val_acc_parity.run(device, quiet=True, negative_controls=("dw_flip",)))
+                    # ONE sampler seed here (the CPU twin is 50 - 75 s per seed on the box's host cores, the longest leg of the run by far); the
+                    # two-seed form is tests/test_val_acc_gpu.py and the script's own default
+                    out.update(val_acc_parity.run(device, quiet=True, seeds=(val_acc_parity.SEEDS[0],), negative_controls=("dw_flip",)))
                 except Exception as e:
                     out["val_acc_error"] = repr(e)
             else:
