@@ -273,8 +273,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ g
 }
 
 // Folds n partial rows of width W into at most KWS_REDUCE_SLICES rows in `scratch` when that pays.
+#ifndef KWS_PRE_REDUCE_MIN
+#define KWS_PRE_REDUCE_MIN (8 * KWS_REDUCE_SLICES)   // 256
+#endif
 int pre_reduce(const float* part, int n, int W, float* scratch, hipStream_t st, const float** out_part, int* out_n) {
-  if (scratch == nullptr || n <= 8 * KWS_REDUCE_SLICES) {   // up to 256 rows: the finalise kernels sum them directly
+  if (scratch == nullptr || n <= KWS_PRE_REDUCE_MIN) {      // up to this many rows the finalise kernels sum them directly
     *out_part = part;
     *out_n = n;
     return KWS_OK;
