@@ -123,3 +123,63 @@ def test_l2_term_dropped_trips_the_loss_and_update_bars():
         worst_without = max(worst_without, float(np.abs(w1[k] - ref_without).max()))
     assert worst_with < 2e-6, worst_with
     assert worst_without > 2e-6, worst_without
+
+
+# ---- the residual family (conv_1d_log_mfcc, BASELINE configs[2]): the same idea against tests/test_logmfcc_gpu.py's gradient bar (1e-4) ----
+def _lm_device_step(B=19, nc=32):
+    import test_logmfcc_gpu as T
+    ora, net = T._pair(nc)
+    x, y = T._batch(B, nc, B)
+    net.train_fwd_bwd(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(), seed=77, step=2)
+    torch.cuda.synchronize()
+    masks, args = T._decisions(net, ora, B)
+    return ora, net, x, y, masks, args
+
+
+def _lm_worst_gradient_error(ora, net, x, y, masks, args):
+    loss, p, grads, cache = ora.loss_and_grads(x.astype(np.float64), y.astype(np.float64), seed=77, step=2, relu_masks=masks, pool_args=args)
+    g = net.grads_dict()
+    worst = 0.0
+    for k, ref in grads.items():
+        if k in ora.l2_names:
+            ref = ref - 2e-5 * ora.params[k].astype(np.float64)
+        ref = ref.reshape(g[k].shape)
+        worst = max(worst, float(np.abs(g[k] - ref).max() / max(np.abs(ref).max(), 1e-7)))
+    return worst
+
+
+def test_residual_net_unmutated_oracle_passes_and_mutations_trip_the_gradient_bar(monkeypatch):
+    """Three wrong backward passes of the ORACLE's residual program must break the 1e-4 bar the unmutated one passes: the max-pool
+    join routing the gradient to the LAST maximum of a window instead of the first (MaxPoolGrad's rule; the device kernels'
+    `w1 > w0` test), the BatchNorm backward without its c2 term, and the last block's MAIN branch cut out of the join (only the
+    shortcut path carries gradient upstream)."""
+    import oracle.net as ON
+    ora, net, x, y, masks, args = _lm_device_step()
+    assert _lm_worst_gradient_error(ora, net, x, y, masks, args) < 1e-4          # the positive control
+    # (1) pool routing: the winners handed over by the device, inverted
+    flipped = {i: 1 - a for i, a in args.items()}
+    assert _lm_worst_gradient_error(ora, net, x, y, masks, flipped) > 1e-2
+    # (2) BatchNorm backward without the xhat * mean(g xhat) term
+    real_bn = OL.bn_train_bwd
+
+    def bn_bwd_no_c2(dout, yv, gamma, stats):
+        mean, var, rstd = stats
+        n = yv.shape[0] * yv.shape[1]
+        xhat = (yv - mean) * rstd
+        dbeta = dout.sum(axis=(0, 1))
+        dgamma = (dout * xhat).sum(axis=(0, 1))
+        return (gamma * rstd) * (dout - dbeta / n), dgamma, dbeta
+    monkeypatch.setattr(OL, "bn_train_bwd", bn_bwd_no_c2)
+    assert _lm_worst_gradient_error(ora, net, x, y, masks, args) > 1e-3
+    monkeypatch.setattr(OL, "bn_train_bwd", real_bn)
+    # (3) the residual join: the gradient that flows through the MAIN branch of the last block zeroed (the first max-pool backward of
+    # the pass) - everything upstream of that block then sees the shortcut path alone
+    real_pool = ON.maxpool_same_bwd
+    calls = {"n": 0}
+
+    def pool_bwd_first_call_zeroed(do, arg, pool, L):
+        calls["n"] += 1
+        out = real_pool(do, arg, pool, L)
+        return out * 0.0 if calls["n"] == 1 else out
+    monkeypatch.setattr(ON, "maxpool_same_bwd", pool_bwd_first_call_zeroed)
+    assert _lm_worst_gradient_error(ora, net, x, y, masks, args) > 1e-2
