@@ -298,7 +298,8 @@ C3_ROOFLINE_KERNELS = [
     ("gemm_nn", ("gemm_nn_ws_kernel", "gemm_nn_persist_kernel"), "mfma", "pointwise forward, the three shortcut convolutions' input gradients, and the gathered "
                                                                           "first / shortcut convolutions (persistent kernel)"),
     ("gemm_tn", ("gemm_tn_kernel", "gemm_tn_ws_kernel"), "mfma", "weight gradients of the gathered convolutions (first, shortcuts)"),
-    ("block_out_fwd", "block_out_fwd_kernel", "hbm", "residual join forward: max-pool(relu6(bn(y2))) + shortcut"),
+    ("block_out_fwd", ("block_out_dw_fwd_kernel", "block_out_fwd_kernel"), "hbm",
+     "residual join forward: max-pool(relu6(bn(y2))) + shortcut, and (round 6) the next block's first depthwise convolution in the same pass"),
     ("block_join_bwd", "block_join_bwd_kernel", "hbm", "residual join backward + BatchNorm backward, two passes (reductions, then dY)"),
     ("dwconv_fwd", "dwconv_fwd_kernel", "hbm", "depthwise k3 forward, BN + ReLU6 on load"),
     ("dwconv_bwd", "dwconv_bwd_kernel", "hbm", "depthwise k3 backward (+ BatchNorm backward of its input, two passes, where the input is a BN output)"),

@@ -13,7 +13,7 @@ SOURCE_OF = {"gemm_nn_ws_kernel": "gemm.hip", "gemm_dgrad_wgrad_kernel": "gemm.h
              "dwconv_bwd_kernel": "dwconv.hip", "dwconv_bwd_bn_kernel": "dwconv.hip", "ts_tail_kernel": "tail.hip",
              "gemm_nn_f16x2_kernel": "gemm_f16x2.hip", "gemm_tn_f16x2_kernel": "gemm_f16x2.hip",
              # C3 (conv_1d_log_mfcc) families
-             "block_out_fwd_kernel": "resblock.hip", "block_out_bwd_kernel": "resblock.hip", "block_join_bwd_kernel": "resblock.hip",
+             "block_out_fwd_kernel": "resblock.hip", "block_out_dw_fwd_kernel": "resblock.hip", "block_out_bwd_kernel": "resblock.hip", "block_join_bwd_kernel": "resblock.hip",
              "add_strided_kernel": "resblock.hip", "lm_tail_kernel": "resblock.hip", "lm_att_bn_kernel": "resblock.hip",
              "lm_att_bn_bwd_kernel": "resblock.hip", "lm_att_logits_kernel": "resblock.hip", "lm_att_bwd_kernel": "resblock.hip",
              "colsum_kernel": "tail.hip", "small_wgrad_kernel": "tail.hip", "bn_relu6_apply_kernel": "bn.hip",

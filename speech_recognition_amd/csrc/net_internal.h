@@ -80,6 +80,9 @@ int lm_train(const kws_net* n, const float* params, float* state, const float* x
 // o = maxpool_P(relu6(bn(y))) + (res_bn ? res_bn.scale*res + res_bn.shift : res)
 int kws_block_out_fwd(const float* y, const float* bn, const float* res, const float* res_bn, float* o, int B,
                       int L, int C, int pool, hipStream_t st);
+// resblock.hip (round 6): that join and the NEXT block's first depthwise convolution (k 3, stride 1, pad (1, 1); kernel w [3, C]) in one pass
+int kws_block_out_dw_fwd(const float* y, const float* bn, const float* res, const float* res_bn, const float* w, float* o, float* z, int B,
+                         int L, int C, int pool, hipStream_t st);
 // g[b,u,c] = [u wins its pool window] * dO[b,u/P,c] * (relu ? relu6'(bn(y)) : 1); part = [blocks][5][C] sums of
 // (g, g*xhat, 0, 0, 0)
 // two-pass join backward + BatchNorm backward (resblock.hip block_join_bwd_kernel): pass 1 leaves kws_block_join_bwd_parts()

@@ -343,6 +343,8 @@ int forward(const Ctx& c, const float* x, kws_lm_tail_args* t) {
     KWS_TRY(kws_bn_relu6_apply(ws + lo.yc, c.bn_at(p.ctx_bn_idx), ws + lo.ac, M, p.C0, 1, c.st));
     xin = ws + lo.ac;
   }
+  bool z1_ready = false;
+  const bool fuse_join_dw = kws_net_get_gemm_mode(c.n) != 1;
   for (size_t i = 0; i < p.blocks.size(); ++i) {
     const LmBlock& b = p.blocks[i];
     const int64_t M = (int64_t)B * b.Lmid;
@@ -360,7 +362,9 @@ int forward(const Ctx& c, const float* x, kws_lm_tail_args* t) {
       if (rs != 0) KWS_TRY(kws_gemm_gather_f32(xin, &b.gs, c.params + b.ws, ws + lo.ys[i], B, b.nf, stats, c.st));
       KWS_TRY(bn_table(c, b.bns, b.bns_idx, Ms, srows));
     }
-    KWS_TRY(kws_dwconv_fwd_f32(xin, nullptr, c.params + b.dw1, ws + lo.z1[i], B, b.Lin, b.Lmid, b.cin, b.s1, b.pad1, c.st));
+    if (!z1_ready)      // (else: written by the previous block's join, kws_block_out_dw_fwd below)
+      KWS_TRY(kws_dwconv_fwd_f32(xin, nullptr, c.params + b.dw1, ws + lo.z1[i], B, b.Lin, b.Lmid, b.cin, b.s1, b.pad1, c.st));
+    z1_ready = false;
     KWS_TRY(kws_gemm_nn_f32(ws + lo.z1[i], c.params + b.pw1, ws + lo.y1[i], M, b.cin, b.nf, stats, c.st));
     KWS_TRY(bn_table(c, b.bn1, b.bn1_idx, M, kws_gemm_nn_stats_rows(M, b.cin, b.nf)));
     KWS_TRY(kws_dwconv_fwd_f32(ws + lo.y1[i], c.bn_at(b.bn1_idx), c.params + b.dw2, ws + lo.z2[i], B, b.Lmid, b.Lmid,
@@ -371,9 +375,22 @@ int forward(const Ctx& c, const float* x, kws_lm_tail_args* t) {
       KWS_TRY(kws_block_out3_fwd(ws + lo.y2[i], c.bn_at(b.bn2_idx), b.has_short ? ws + lo.ys[i] : xin,
                                  b.has_short ? c.bn_at(b.bns_idx) : nullptr, ws + lo.o[i], B, b.Lmid, b.Lout, b.nf, b.stride,
                                  b.ppad, c.st));
-    else
-      KWS_TRY(kws_block_out_fwd(ws + lo.y2[i], c.bn_at(b.bn2_idx), b.has_short ? ws + lo.ys[i] : xin,
-                                b.has_short ? c.bn_at(b.bns_idx) : nullptr, ws + lo.o[i], B, b.Lmid, b.nf, b.pool, c.st));
+    else {
+      // round 6: the join writes the NEXT block's first depthwise output too where that is a k 3 / stride 1 / 'same' convolution over
+      // this block's output (every log-mfcc block): one tensor pass and one launch less per block, bit-identical (gemm mode 1, the A/B
+      // reference schedule, keeps the two launches)
+      const LmBlock* nx = i + 1 < p.blocks.size() ? &p.blocks[i + 1] : nullptr;
+      const bool fuse = nx && fuse_join_dw && nx->s1 == 1 && nx->pad1 == 1 && nx->Lmid == nx->Lin && nx->Lin == b.Lout && nx->cin == b.nf;
+      if (fuse) {
+        KWS_TRY(kws_block_out_dw_fwd(ws + lo.y2[i], c.bn_at(b.bn2_idx), b.has_short ? ws + lo.ys[i] : xin,
+                                     b.has_short ? c.bn_at(b.bns_idx) : nullptr, c.params + nx->dw1, ws + lo.o[i], ws + lo.z1[i + 1], B,
+                                     b.Lmid, b.nf, b.pool, c.st));
+        z1_ready = true;
+      } else {
+        KWS_TRY(kws_block_out_fwd(ws + lo.y2[i], c.bn_at(b.bn2_idx), b.has_short ? ws + lo.ys[i] : xin,
+                                  b.has_short ? c.bn_at(b.bns_idx) : nullptr, ws + lo.o[i], B, b.Lmid, b.nf, b.pool, c.st));
+      }
+    }
     xin = ws + lo.o[i];
   }
   if (!p.plain.empty()) {  // _reduce_block: depthwise -> pointwise -> BN -> ReLU6, twice; the last activation is materialised

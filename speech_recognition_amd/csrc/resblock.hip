@@ -44,6 +44,78 @@ __global__ __launch_bounds__(256) void block_out_fwd_kernel(const float* __restr
   *reinterpret_cast<float4*>(o + bt * C + c) = make_float4(v.x + r.x, v.y + r.y, v.z + r.z, v.w + r.w);
 }
 
+// Round 6: the join of block i AND the first depthwise convolution of block i + 1 (k = 3, stride 1, 'same': every log-mfcc block starts
+// with one) in ONE pass.  A thread computes o = maxpool_P(relu6(bn(y2))) + res for the TT steps of its unit plus one halo step on each
+// side, writes its own TT once, and writes z[t] = w0 o[t-1] + w1 o[t] + w2 o[t+1] from registers - the two launches wrote o and read it
+// again (one tensor pass of eleven per block, and a launch).  Every value is computed by the expressions of block_out_fwd_kernel and
+// dwconv_fwd_kernel<1, false> in their order: o and z are bit-identical to the two launches' (gemm mode 1 keeps those).
+template <int P, bool RES_BN>
+__global__ __launch_bounds__(256) void block_out_dw_fwd_kernel(const float* __restrict__ y, const float* __restrict__ bn,
+                                                               const float* __restrict__ res, const float* __restrict__ res_bn,
+                                                               const float* __restrict__ w, float* __restrict__ o,
+                                                               float* __restrict__ z, int B, int L, int Lo, int C, int nchunks) {
+  constexpr int NK = TT + 2;
+  const int C4 = C >> 2;
+  const int64_t total = (int64_t)B * nchunks * C4;
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+    const int c = (int)(id % C4) * 4;
+    const int64_t rest = id / C4;
+    const int chunk = (int)(rest % nchunks);
+    const int64_t b = rest / nchunks;
+    const float4 sc = ld4(bn + c), sh = ld4(bn + C + c);
+    float4 rsc = sc, rsh = sh;
+    if (RES_BN) {
+      rsc = ld4(res_bn + c);
+      rsh = ld4(res_bn + C + c);
+    }
+    const float4 w0 = ld4(w + c), w1 = ld4(w + C + c), w2 = ld4(w + 2 * C + c);
+    const int t0 = chunk * TT;
+    const float* yb = y + b * (int64_t)L * C + c;
+    const float* rb = res + b * (int64_t)Lo * C + c;
+    float4 a0[NK], a1[P == 2 ? NK : 1], rv[NK];
+    // all loads of the unit first, from clamped rows (a step outside [0, Lo) becomes a zero below: the convolution's 'same' padding)
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      const int t = t0 - 1 + k;
+      const int tc = t < 0 ? 0 : (t < Lo ? t : Lo - 1);
+      a0[k] = ld4(yb + (int64_t)tc * P * C);
+      if (P == 2) {
+        const int u1 = 2 * tc + 1 < L ? 2 * tc + 1 : L - 1;
+        a1[k] = ld4(yb + (int64_t)u1 * C);
+      }
+      rv[k] = ld4(rb + (int64_t)tc * C);
+    }
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      const int t = t0 - 1 + k;
+      const int tc = t < 0 ? 0 : (t < Lo ? t : Lo - 1);
+      float4 v = relu6_4(bn4(a0[k], sc, sh));
+      if (P == 2 && 2 * tc + 1 < L) {               // an odd L leaves the last window with one element
+        const float4 u = relu6_4(bn4(a1[k], sc, sh));
+        v = make_float4(fmaxf(v.x, u.x), fmaxf(v.y, u.y), fmaxf(v.z, u.z), fmaxf(v.w, u.w));
+      }
+      float4 r = rv[k];
+      if (RES_BN) r = bn4(r, rsc, rsh);
+      const float4 ov = make_float4(v.x + r.x, v.y + r.y, v.z + r.z, v.w + r.w);
+      a0[k] = (t >= 0 && t < Lo) ? ov : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float* ob = o + b * (int64_t)Lo * C + c;
+    float* zb = z + b * (int64_t)Lo * C + c;
+#pragma unroll
+    for (int i = 0; i < TT; ++i) {
+      const int t = t0 + i;
+      if (t >= Lo) continue;
+      *reinterpret_cast<float4*>(ob + (int64_t)t * C) = a0[i + 1];
+      float4 q = make_float4(w0.x * a0[i].x, w0.y * a0[i].y, w0.z * a0[i].z, w0.w * a0[i].w);
+      q = bn4(a0[i + 1], w1, q);                    // fmaf(w1, o[t], q), the depthwise kernel's order
+      q = bn4(a0[i + 2], w2, q);
+      typedef float v4f __attribute__((ext_vector_type(4)));
+      const v4f qv = {q.x, q.y, q.z, q.w};          // streamed once: a non-temporal 16-byte store, as dwconv_fwd_kernel's
+      __builtin_nontemporal_store(qv, reinterpret_cast<v4f*>(zb + (int64_t)t * C));
+    }
+  }
+}
+
 // Backward of the join's main branch.  One thread: float4 of channels x TT output steps.
 // part[block][5][C]: sums of (g, g*xhat, 0, 0, 0).
 template <int P, bool RELU>
@@ -927,6 +999,30 @@ int kws_block_out_fwd(const float* y, const float* bn, const float* res, const f
     else hipLaunchKernelGGL((block_out_fwd_kernel<2, false>), g, b, 0, st, y, bn, res, res_bn, o, n4, L, Lo, C);
   }
   KWS_LAUNCH_CHECK("block_out_fwd_kernel");
+  return KWS_OK;
+}
+
+// internal (net_logmfcc.hip): kws_block_out_fwd and the next block's first depthwise convolution (k = 3, stride 1, pad (1, 1)) in one pass:
+// o [B, Lo, C] and z [B, Lo, C]; w = that convolution's kernel [3, C]
+int kws_block_out_dw_fwd(const float* y, const float* bn, const float* res, const float* res_bn, const float* w, float* o, float* z, int B,
+                         int L, int C, int pool, hipStream_t st) {
+  KWS_REQUIRE(y && bn && res && w && o && z && B > 0 && L > 0 && C % 4 == 0 && (pool == 1 || pool == 2),
+              "block_out_dw_fwd: bad arguments (L=%d C=%d pool=%d)", L, C, pool);
+  const int Lo = (L + pool - 1) / pool;
+  const int nchunks = ceil_div(Lo, TT);
+  const int64_t threads = (int64_t)B * nchunks * (C / 4);
+  int64_t grid = ceil_div64(threads, 256);
+  if (grid > 4096) grid = 4096;                     // grid-stride, as the depthwise forward kernel
+  KwsProfScope prof("block_out_fwd", 10.0 * B * Lo * C, 4.0 * ((double)B * L * C + 3.0 * B * Lo * C), st);
+  dim3 g((unsigned)grid), b(256);
+  if (pool == 1) {
+    if (res_bn) hipLaunchKernelGGL((block_out_dw_fwd_kernel<1, true>), g, b, 0, st, y, bn, res, res_bn, w, o, z, B, L, Lo, C, nchunks);
+    else hipLaunchKernelGGL((block_out_dw_fwd_kernel<1, false>), g, b, 0, st, y, bn, res, res_bn, w, o, z, B, L, Lo, C, nchunks);
+  } else {
+    if (res_bn) hipLaunchKernelGGL((block_out_dw_fwd_kernel<2, true>), g, b, 0, st, y, bn, res, res_bn, w, o, z, B, L, Lo, C, nchunks);
+    else hipLaunchKernelGGL((block_out_dw_fwd_kernel<2, false>), g, b, 0, st, y, bn, res, res_bn, w, o, z, B, L, Lo, C, nchunks);
+  }
+  KWS_LAUNCH_CHECK("block_out_dw_fwd_kernel");
   return KWS_OK;
 }
 
