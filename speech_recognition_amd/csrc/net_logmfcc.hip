@@ -315,6 +315,7 @@ int forward(const Ctx& c, const float* x, kws_lm_tail_args* t) {
   float* ws = c.ws;
   const int B = c.B;
   float* stats = c.training ? ws + lo.part : nullptr;
+  bool z1_first = false;      // the first block's first depthwise output already written (see below)
   if (p.style == 3) {  // two stems on the packed [mfcc | raw] rows, concatenated after BN + ReLU6
     const int64_t M = (int64_t)B * p.L0;
     float* y0m = ws + lo.y0;
@@ -332,7 +333,16 @@ int forward(const Ctx& c, const float* x, kws_lm_tail_args* t) {
   KWS_TRY(pad_first_conv(c, x, &x0, &w0));
   KWS_TRY(kws_gemm_gather_f32(x0, &p.g0, w0, ws + lo.y0, B, p.C0, stats, c.st));
   KWS_TRY(bn_table(c, p.bn0, 1, (int64_t)B * p.L0, kws_gemm_gather_stats_rows((int64_t)B * p.L0)));
-  KWS_TRY(kws_bn_relu6_apply(ws + lo.y0, c.bn_at(1), ws + lo.a0, (int64_t)B * p.L0, p.C0, 1, c.st));
+  // the first convolution's activation - and, where the first block starts with a k 3 / stride 1 / 'same' depthwise convolution over it
+  // (conv_1d_log_mfcc), that convolution's output in the same pass (round 6, kws_block_out_dw_fwd without a residual: bit-identical)
+  if (p.style == 0 && !p.blocks.empty() && kws_net_get_gemm_mode(c.n) != 1) {
+    const LmBlock& b0 = p.blocks[0];
+    if (b0.s1 == 1 && b0.pad1 == 1 && b0.Lmid == b0.Lin && b0.Lin == p.L0 && b0.cin == p.C0) {
+      KWS_TRY(kws_block_out_dw_fwd(ws + lo.y0, c.bn_at(1), nullptr, nullptr, c.params + b0.dw1, ws + lo.a0, ws + lo.z1[0], B, p.L0, p.C0, 1, c.st));
+      z1_first = true;
+    }
+  }
+  if (!z1_first) KWS_TRY(kws_bn_relu6_apply(ws + lo.y0, c.bn_at(1), ws + lo.a0, (int64_t)B * p.L0, p.C0, 1, c.st));
   }
   const float* xin = ws + lo.a0;
   if (p.style == 1) {  // _context_conv(x, 256, 3, 'same'): depthwise -> pointwise -> BN -> ReLU6, materialised
@@ -343,7 +353,7 @@ int forward(const Ctx& c, const float* x, kws_lm_tail_args* t) {
     KWS_TRY(kws_bn_relu6_apply(ws + lo.yc, c.bn_at(p.ctx_bn_idx), ws + lo.ac, M, p.C0, 1, c.st));
     xin = ws + lo.ac;
   }
-  bool z1_ready = false;
+  bool z1_ready = z1_first;
   const bool fuse_join_dw = kws_net_get_gemm_mode(c.n) != 1;
   for (size_t i = 0; i < p.blocks.size(); ++i) {
     const LmBlock& b = p.blocks[i];

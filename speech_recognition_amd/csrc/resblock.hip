@@ -49,7 +49,9 @@ __global__ __launch_bounds__(256) void block_out_fwd_kernel(const float* __restr
 // side, writes its own TT once, and writes z[t] = w0 o[t-1] + w1 o[t] + w2 o[t+1] from registers - the two launches wrote o and read it
 // again (one tensor pass of eleven per block, and a launch).  Every value is computed by the expressions of block_out_fwd_kernel and
 // dwconv_fwd_kernel<1, false> in their order: o and z are bit-identical to the two launches' (gemm mode 1 keeps those).
-template <int P, bool RES_BN>
+// HAS_RES = false: no residual (o = relu6(bn(y)), bn_relu6_apply_kernel's expression): the first convolution's activation and the first
+// block's depthwise convolution in one pass.
+template <int P, bool RES_BN, bool HAS_RES = true>
 __global__ __launch_bounds__(256) void block_out_dw_fwd_kernel(const float* __restrict__ y, const float* __restrict__ bn,
                                                                const float* __restrict__ res, const float* __restrict__ res_bn,
                                                                const float* __restrict__ w, float* __restrict__ o,
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(256) void block_out_dw_fwd_kernel(const float* __re
     const int t0 = chunk * TT;
     const float* yb = y + b * (int64_t)L * C + c;
     const float* rb = res + b * (int64_t)Lo * C + c;
-    float4 a0[NK], a1[P == 2 ? NK : 1], rv[NK];
+    float4 a0[NK], a1[P == 2 ? NK : 1], rv[HAS_RES ? NK : 1];
     // all loads of the unit first, from clamped rows (a step outside [0, Lo) becomes a zero below: the convolution's 'same' padding)
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(256) void block_out_dw_fwd_kernel(const float* __re
         const int u1 = 2 * tc + 1 < L ? 2 * tc + 1 : L - 1;
         a1[k] = ld4(yb + (int64_t)u1 * C);
       }
-      rv[k] = ld4(rb + (int64_t)tc * C);
+      if (HAS_RES) rv[k] = ld4(rb + (int64_t)tc * C);
     }
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
@@ -94,9 +96,12 @@ __global__ __launch_bounds__(256) void block_out_dw_fwd_kernel(const float* __re
         const float4 u = relu6_4(bn4(a1[k], sc, sh));
         v = make_float4(fmaxf(v.x, u.x), fmaxf(v.y, u.y), fmaxf(v.z, u.z), fmaxf(v.w, u.w));
       }
-      float4 r = rv[k];
-      if (RES_BN) r = bn4(r, rsc, rsh);
-      const float4 ov = make_float4(v.x + r.x, v.y + r.y, v.z + r.z, v.w + r.w);
+      float4 ov = v;
+      if (HAS_RES) {
+        float4 r = rv[k];
+        if (RES_BN) r = bn4(r, rsc, rsh);
+        ov = make_float4(v.x + r.x, v.y + r.y, v.z + r.z, v.w + r.w);
+      }
       a0[k] = (t >= 0 && t < Lo) ? ov : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     float* ob = o + b * (int64_t)Lo * C + c;
@@ -1006,16 +1011,19 @@ int kws_block_out_fwd(const float* y, const float* bn, const float* res, const f
 // o [B, Lo, C] and z [B, Lo, C]; w = that convolution's kernel [3, C]
 int kws_block_out_dw_fwd(const float* y, const float* bn, const float* res, const float* res_bn, const float* w, float* o, float* z, int B,
                          int L, int C, int pool, hipStream_t st) {
-  KWS_REQUIRE(y && bn && res && w && o && z && B > 0 && L > 0 && C % 4 == 0 && (pool == 1 || pool == 2),
+  // res == NULL (pool 1 only): no residual - o = relu6(bn(y)), the activation kws_bn_relu6_apply materialises
+  KWS_REQUIRE(y && bn && w && o && z && B > 0 && L > 0 && C % 4 == 0 && (pool == 1 || pool == 2) && (res || (pool == 1 && !res_bn)),
               "block_out_dw_fwd: bad arguments (L=%d C=%d pool=%d)", L, C, pool);
   const int Lo = (L + pool - 1) / pool;
   const int nchunks = ceil_div(Lo, TT);
   const int64_t threads = (int64_t)B * nchunks * (C / 4);
   int64_t grid = ceil_div64(threads, 256);
   if (grid > 4096) grid = 4096;                     // grid-stride, as the depthwise forward kernel
-  KwsProfScope prof("block_out_fwd", 10.0 * B * Lo * C, 4.0 * ((double)B * L * C + 3.0 * B * Lo * C), st);
+  KwsProfScope prof("block_out_fwd", 10.0 * B * Lo * C, 4.0 * ((double)B * L * C + (res ? 3.0 : 2.0) * B * Lo * C), st);
   dim3 g((unsigned)grid), b(256);
-  if (pool == 1) {
+  if (!res) {
+    hipLaunchKernelGGL((block_out_dw_fwd_kernel<1, false, false>), g, b, 0, st, y, bn, y, res_bn, w, o, z, B, L, Lo, C, nchunks);
+  } else if (pool == 1) {
     if (res_bn) hipLaunchKernelGGL((block_out_dw_fwd_kernel<1, true>), g, b, 0, st, y, bn, res, res_bn, w, o, z, B, L, Lo, C, nchunks);
     else hipLaunchKernelGGL((block_out_dw_fwd_kernel<1, false>), g, b, 0, st, y, bn, res, res_bn, w, o, z, B, L, Lo, C, nchunks);
   } else {
