@@ -67,6 +67,9 @@ struct BwdArgs {
   float* g; float* part;
   int B, Lin, Lout, C, pad_l, nchunks, R, Cb;
   unsigned* amax;
+  // MODE 0's added tensor (`coef`): add_stride <= 1: the shape of g, added everywhere; s > 1: [B, add_len, C], row q added at position s q
+  // (the input gradient of a stride-s shortcut convolution joining the depthwise input gradient: round 6, instead of an add_strided pass)
+  int add_stride = 0, add_len = 0;
 };
 // LDS floats a workgroup of `threads` threads needs for one pass (pass 2 reduces nothing)
 constexpr int bwd_smem_floats(int mode, int threads) { return mode == 2 ? 4 : 5 * threads * 4; }
@@ -83,7 +86,8 @@ constexpr int bwd_smem_floats(int mode, int threads) { return mode == 2 ? 4 : 5 
 // walk several block ids one after the other (a barrier between them): block `bid` of `nblk` does exactly what the
 // workgroup with that index of a `nblk`-workgroup launch does, down to the order of every sum.
 // GUARD: the launching workgroup may be wider than the R * C4 threads this shape uses; the extra threads only keep the barrier.
-template <int S, bool HAS_BN, int MODE, bool GUARD>
+// ADDS (MODE 0): the added tensor is the coarser one (add_stride > 1) - a compile-time form, so that the plain add keeps its code
+template <int S, bool HAS_BN, int MODE, bool GUARD, bool ADDS = false>
 __device__ __forceinline__ void bwd_body(const BwdArgs& p, float* const red, const int bid, const int nblk, const int by) {
   const float* __restrict__ dz = p.dz;
   const float* __restrict__ y = p.y;
@@ -201,8 +205,15 @@ __device__ __forceinline__ void bwd_body(const BwdArgs& p, float* const red, con
         if (MODE == 0) {
           float4 o = gv;
           if (coef != nullptr) {   // MODE 0 reuses `coef` as an optional tensor added to the input gradient (residual join)
-            const float4 ad = *reinterpret_cast<const float4*>(coef + (b * (int64_t)Lin + u) * C + c);
-            o = make_float4(o.x + ad.x, o.y + ad.y, o.z + ad.z, o.w + ad.w);
+            if (!ADDS) {
+              const float4 ad = *reinterpret_cast<const float4*>(coef + (b * (int64_t)Lin + u) * C + c);
+              o = make_float4(o.x + ad.x, o.y + ad.y, o.z + ad.z, o.w + ad.w);
+            } else {               // every add_stride-th position receives a row of the coarser tensor (address selected, not branched)
+              const int q = u / p.add_stride;
+              const bool on = q * p.add_stride == u && q < p.add_len;
+              const float4 ad = *reinterpret_cast<const float4*>(coef + (b * (int64_t)p.add_len + (on ? q : 0)) * C + c);
+              o = make_float4(on ? o.x + ad.x : o.x, on ? o.y + ad.y : o.y, on ? o.z + ad.z : o.z, on ? o.w + ad.w : o.w);
+            }
           }
           st4_stream(gb + (int64_t)u * C, o);
         }

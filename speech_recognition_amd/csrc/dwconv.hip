@@ -84,10 +84,10 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict
 #ifndef KWS_DW_BWD1_MINW
 #define KWS_DW_BWD1_MINW 1
 #endif
-template <int S, bool HAS_BN, int MODE>
+template <int S, bool HAS_BN, int MODE, bool ADDS = false>
 __global__ __launch_bounds__(MODE == 2 ? DW_BWD2_THREADS : DW_BWD_THREADS, MODE == 2 ? KWS_DW_BWD2_MINW : KWS_DW_BWD1_MINW) void dwconv_bwd_kernel(BwdArgs p) {
   __shared__ float red[bwd_smem_floats(MODE, DW_BWD_THREADS)];
-  bwd_body<S, HAS_BN, MODE, false>(p, red, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y);
+  bwd_body<S, HAS_BN, MODE, false, ADDS>(p, red, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y);
 }
 
 }  // namespace
@@ -97,13 +97,20 @@ namespace {
 template <int MODE>
 int launch_dw_bwd(const float* dz, const float* y, const float* bn, const float* w, const float* coef, float* g,
                   float* part, int B, int L_in, int L_out, int C, int stride, int pad_l, hipStream_t st,
-                  unsigned* amax = nullptr) {
+                  unsigned* amax = nullptr, int add_stride = 0, int add_len = 0) {
   const BwdGeom ge = bwd_geom(B, L_in, C, MODE != 2);
   KWS_REQUIRE(ge.grid < 0x7FFFFFFF, "dwconv_bwd: grid too large");
   dim3 gr((unsigned)ge.grid, (unsigned)ge.ny), b((unsigned)ge.block);
   BwdArgs a;
   a.dz = dz; a.y = y; a.bn = bn; a.w = w; a.coef = coef; a.g = g; a.part = part;
   a.B = B; a.Lin = L_in; a.Lout = L_out; a.C = C; a.pad_l = pad_l; a.nchunks = ge.nchunks; a.R = ge.R; a.Cb = ge.Cb; a.amax = amax;
+  a.add_stride = add_stride; a.add_len = add_len;
+  if (MODE == 0 && add_stride > 1) {               // the strided-add form (no BatchNorm on the input: the residual programs' first depthwise layers)
+    if (stride == 1) hipLaunchKernelGGL((dwconv_bwd_kernel<1, false, MODE, true>), gr, b, 0, st, a);
+    else hipLaunchKernelGGL((dwconv_bwd_kernel<2, false, MODE, true>), gr, b, 0, st, a);
+    KWS_LAUNCH_CHECK("dwconv_bwd_kernel");
+    return KWS_OK;
+  }
   if (stride == 1) {
     if (bn) hipLaunchKernelGGL((dwconv_bwd_kernel<1, true, MODE>), gr, b, 0, st, a);
     else hipLaunchKernelGGL((dwconv_bwd_kernel<1, false, MODE>), gr, b, 0, st, a);
@@ -175,6 +182,19 @@ int kws_dwconv_bwd_acc_f32(const float* dz, const float* y, const float* w, cons
               "dwconv_bwd_acc: bad shape B=%d L=%d->%d C=%d stride=%d", B, L_in, L_out, C, stride);
   KwsProfScope prof("dwconv_bwd", 13.0 * B * L_in * C, 4.0 * (3.0 * B * L_in * C + (double)B * L_out * C), st);
   return launch_dw_bwd<0>(dz, y, nullptr, w, add, g, part, B, L_in, L_out, C, stride, pad_l, st);
+}
+
+// internal (residual-family programs, round 6): g = dgrad, and row q of add [B, add_len, C] added at position add_stride q - the input
+// gradient of the block's stride-s shortcut convolution joins the depthwise input gradient without an add_strided pass (the same single
+// addition per element: bit-identical to the two launches)
+int kws_dwconv_bwd_acc_strided_f32(const float* dz, const float* y, const float* w, const float* add, int add_stride, int add_len,
+                                   float* g, float* part, int B, int L_in, int L_out, int C, int stride, int pad_l, hipStream_t st) {
+  KWS_REQUIRE(dz && y && w && add && g && part && add != g, "dwconv_bwd_acc_strided: bad pointers");
+  KWS_REQUIRE(B > 0 && L_in > 0 && L_out > 0 && bwd_geom_ok(C) && (stride == 1 || stride == 2) && add_stride >= 2 && add_len > 0 &&
+                  (int64_t)(add_len - 1) * add_stride < L_in,
+              "dwconv_bwd_acc_strided: bad shape B=%d L=%d->%d C=%d stride=%d add %d x %d", B, L_in, L_out, C, stride, add_len, add_stride);
+  KwsProfScope prof("dwconv_bwd", 13.0 * B * L_in * C, 4.0 * (2.0 * B * L_in * C + (double)B * L_out * C + (double)B * add_len * C), st);
+  return launch_dw_bwd<0>(dz, y, nullptr, w, add, g, part, B, L_in, L_out, C, stride, pad_l, st, nullptr, add_stride, add_len);
 }
 
 int kws_dwconv_bwd_bn_f32(const float* dz, const float* y, const float* bn, const float* w, const float* coef,

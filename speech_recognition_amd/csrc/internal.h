@@ -48,6 +48,9 @@ extern "C" int kws_reduce_slabs_f32(const float* ws, float* out, int64_t n, int 
 // (the |x|-maximum producers kws_dwconv_fwd_amax_f32 / kws_dwconv_bwd_bn_amax_f32 / kws_bn_bwd_apply_amax are public: include/kws_hip.h)
 extern "C" int kws_dwconv_bwd_acc_f32(const float* dz, const float* y, const float* w, const float* add, float* g, float* part,
                                       int B, int L_in, int L_out, int C, int stride, int pad_l, hipStream_t st);
+// dwconv.hip (round 6): as above with row q of add [B, add_len, C] added at position add_stride q (a strided shortcut's input gradient)
+extern "C" int kws_dwconv_bwd_acc_strided_f32(const float* dz, const float* y, const float* w, const float* add, int add_stride, int add_len,
+                                              float* g, float* part, int B, int L_in, int L_out, int C, int stride, int pad_l, hipStream_t st);
 // gemm.hip: the weight-gradient GEMM without its slab sum, and the slab sums of several of them in one launch
 constexpr int KWS_SLAB_BATCH = 16;
 extern "C" int kws_gemm_tn_slabs_f32(const float* A, const float* G, int64_t M, int K, int N, float* workspace, int* S,

@@ -1017,12 +1017,22 @@ int lm_train(const kws_net* n, const float* params, float* state, const float* x
     // depthwise 1 on the (materialised) block input
     float* dpart;      // only a weight gradient comes out of these rows: folded with the other blocks' at the end of the pass
     KWS_TRY(dq.take(kws_dwconv_bwd_part_floats(B, b.Lin, b.cin), b.cin, grads + b.dw1, &dpart));
-    if (!b.has_short)   // identity shortcut: the join's other gradient is added while the depthwise input gradient is written
+    // round 6: with a strided shortcut whose rows sit at whole multiples of the stride, the shortcut branch runs FIRST and its input
+    // gradient joins the depthwise input gradient inside that kernel (same single addition per element: bit-identical) instead of an
+    // add_strided pass afterwards; gemm mode 1 (the A/B reference schedule) keeps the order and the launches of rounds 3 - 5
+    const bool short_first = b.has_short && sq.allow_pair && b.stride >= 2 && (int64_t)(b.Lout - 1) * b.stride < b.Lin;
+    if (b.has_short && short_first) {
+      const int64_t Mo = (int64_t)B * b.Lout;
+      KWS_TRY(join_bwd(dO, ws + lo.ys[i], b.bns, b.bns_idx, dO, b.Lout, b.nf, 1, 0));   // the shortcut's BN: no mask, in place
+      KWS_TRY(sq.gemm_gather(xin, &b.gs, dO, grads + b.ws, B, b.nf, st));
+      KWS_TRY(kws_gemm_nn_f32(dO, ws + lo.wt_ws[i], ws + lo.DXS, Mo, b.nf, b.cin, nullptr, st));
+      KWS_TRY(kws_dwconv_bwd_acc_strided_f32(DZ, xin, params + b.dw1, ws + lo.DXS, b.stride, b.Lout, dX, dpart, B, b.Lin, b.Lmid, b.cin,
+                                             b.s1, b.pad1, st));
+    } else if (!b.has_short) {   // identity shortcut: the join's other gradient is added while the depthwise input gradient is written
       KWS_TRY(kws_dwconv_bwd_acc_f32(DZ, xin, params + b.dw1, dO, dX, dpart, B, b.Lin, b.Lmid, b.cin, b.s1, b.pad1, st));
-    else
+    } else {
       KWS_TRY(kws_dwconv_bwd_f32(DZ, xin, nullptr, params + b.dw1, dX, dpart, B, b.Lin, b.Lmid, b.cin, b.s1, b.pad1, st));
-    // residual branch
-    if (b.has_short) {
+      // residual branch
       const int64_t Mo = (int64_t)B * b.Lout;
       KWS_TRY(join_bwd(dO, ws + lo.ys[i], b.bns, b.bns_idx, dO, b.Lout, b.nf, 1, 0));   // the shortcut's BN: no mask, in place
       KWS_TRY(sq.gemm_gather(xin, &b.gs, dO, grads + b.ws, B, b.nf, st));   // slabs queued: summed with the pass's other weight gradients
